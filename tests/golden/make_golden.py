@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REAL REFERENCE.
+
+Runs only in the build container (needs oracle/_ref/libsela_ref.so, i.e. `make -C oracle ref`,
+which compiles the unmodified reference from /root/reference).  The fixtures are pure data:
+inputs and the reference's outputs.  Commit the resulting .npz / .json files; the GPU box
+and CI only ever read them.
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle_lib import reference  # noqa: E402
+from sela_amd.synth import synth_frames  # noqa: E402
+
+
+def edge_blocks():
+    """The reference's own test signals (test/lpctests.cpp:16-18, test/frametests.cpp:14-24)
+    plus the degenerate blocks of SURVEY.md App. C / App. E."""
+    n = 2048
+    rng = np.random.default_rng(1)
+    i = np.arange(n)
+    blocks = {
+        "sine_deg": np.array([int(32767 * math.sin(j * (math.pi / 180))) for j in range(n)], np.int32),
+        "silence": np.zeros(n, np.int32),
+        "const_1234": np.full(n, 1234, np.int32),
+        "white_fullscale": rng.integers(-32768, 32768, n).astype(np.int32),
+        "square_p64": np.where((i // 32) % 2 == 0, 32767, -32768).astype(np.int32),
+        "impulse": np.concatenate([[32767], np.zeros(n - 1)]).astype(np.int32),
+        "ramp": (i - 1024).astype(np.int32),
+        "alternating": np.where(i % 2 == 0, 20000, -20000).astype(np.int32),
+        "min_value": np.full(n, -32768, np.int32),
+        "white_small": rng.integers(-3, 4, n).astype(np.int32),
+        "diff_extreme": (np.where(i % 3 == 0, 32767, -32768) - np.where(i % 5 == 0, -32768, 32767)).astype(np.int32),
+    }
+    return blocks
+
+
+def main():
+    ref = reference()
+    assert ref is not None, "build oracle/_ref first: make -C oracle ref"
+    out = {}
+
+    # ---- per-stage KATs on single blocks --------------------------------------------------
+    names = []
+    for name, s in edge_blocks().items():
+        order, q, r = ref.lpc_analyze(s)
+        a = ref.lpc_coeffs(order, q)
+        ck, cw = ref.rice_encode(q)
+        rk, rw = ref.rice_encode(r)
+        back = ref.lpc_synth(order, q, r)
+        names.append(name)
+        out[f"blk/{name}/samples"] = s
+        out[f"blk/{name}/order"] = np.int32(order)
+        out[f"blk/{name}/q"] = q
+        out[f"blk/{name}/a"] = a
+        out[f"blk/{name}/residues"] = r
+        out[f"blk/{name}/coef_k"] = np.uint32(ck)
+        out[f"blk/{name}/coef_words"] = cw
+        out[f"blk/{name}/res_k"] = np.uint32(rk)
+        out[f"blk/{name}/res_words"] = rw
+        out[f"blk/{name}/synth"] = back
+    out["blk_names"] = np.array(names)
+
+    # ---- Rice KATs (SURVEY.md App. C + test/ricetests.cpp-style values) ---------------------
+    rng = np.random.default_rng(7)
+    rice_cases = {
+        "small": np.array([0, -1, 1, -2, 2, 100, -100, 5], np.int32),
+        "ricetest_like": (200 + rng.integers(0, 201, 100)).astype(np.int32),
+        "zeros": np.zeros(64, np.int32),
+        "single": np.array([-7], np.int32),
+        "long_unary": np.array([0, 0, 5000, 0, -4000, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], np.int32),
+        "wide": rng.integers(-(1 << 20), 1 << 20, 257).astype(np.int32),
+    }
+    out["rice_names"] = np.array(list(rice_cases))
+    for name, v in rice_cases.items():
+        k, w = ref.rice_encode(v)
+        assert np.array_equal(ref.rice_decode(w, len(v), k), v)
+        out[f"rice/{name}/values"] = v
+        out[f"rice/{name}/k"] = np.uint32(k)
+        out[f"rice/{name}/words"] = w
+
+    # ---- frame KATs: on-disk bytes of whole frames ----------------------------------------------
+    sine = edge_blocks()["sine_deg"].astype(np.int16)
+    frames = {
+        "stereo_same_sine": np.stack([sine, sine], axis=1),  # test/frametests.cpp:40-70
+        "mono_sine": sine[:, None],
+        "stereo_synth0": synth_frames(9, 2, 0)[8],   # w == 2 region
+        "stereo_synth_diff": synth_frames(20, 2, 0)[17],  # fully common noise -> difference coding
+        "stereo_synth_indep": synth_frames(2, 2, 0)[1],
+        "mono_synth": synth_frames(3, 1, 3)[2],
+        "three_channel": synth_frames(2, 3, 5)[1],
+        "stereo_silence": np.zeros((2048, 2), np.int16),
+    }
+    out["frame_names"] = np.array(list(frames))
+    for name, pcm in frames.items():
+        blob = ref.frame_encode(pcm)
+        dec, used = ref.frame_decode(blob, pcm.shape[1])
+        assert used == len(blob)
+        out[f"frame/{name}/pcm"] = pcm.astype(np.int16)
+        out[f"frame/{name}/bytes"] = np.frombuffer(blob, np.uint8)
+        out[f"frame/{name}/decoded"] = dec
+
+    np.savez_compressed(os.path.join(HERE, "kats.npz"), **out)
+
+    # ---- whole-config digests (BASELINE.json configs; inputs are regenerated from synth) -------
+    digests = {}
+    for label, nf, ch, track in [("config0_mono_10s", 215, 1, 0), ("config1_stereo_3min", 3875, 2, 0),
+                                 ("config2_1000_frames", 1000, 2, 1)]:
+        pcm = synth_frames(nf, ch, track)
+        blob, offs, _ = ref.encode_frames(pcm, threads=8)
+        dec, _ = ref.decode_frames(blob, offs, ch, threads=8)
+        digests[label] = {
+            "n_frames": nf, "channels": ch, "track": track,
+            "pcm_sha256": hashlib.sha256(pcm.tobytes()).hexdigest(),
+            "frames_blob_sha256": hashlib.sha256(blob.tobytes()).hexdigest(),
+            "frames_blob_bytes": int(len(blob)),
+            "offsets_sha256": hashlib.sha256(offs.astype("<u8").tobytes()).hexdigest(),
+            "decoded_sha256": hashlib.sha256(dec.tobytes()).hexdigest(),
+            "lossless": bool(np.array_equal(dec, pcm)),
+        }
+        print(label, digests[label])
+    with open(os.path.join(HERE, "digests.json"), "w") as f:
+        json.dump(digests, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
