@@ -29,7 +29,12 @@
 #include "sela_tables.inc"
 
 /* On-disk size of one frame given the per-subframe word counts. */
-static inline uint32_t sela_frame_bytes(uint32_t channels, uint32_t total_words)
+#if defined(__HIPCC__)
+#define SELA_HOST_DEVICE __host__ __device__
+#else
+#define SELA_HOST_DEVICE
+#endif
+SELA_HOST_DEVICE static inline uint32_t sela_frame_bytes(uint32_t channels, uint32_t total_words)
 {
     return 4u + channels * SELA_SUBFRAME_HEADER_BYTES + 4u * total_words;
 }

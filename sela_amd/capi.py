@@ -1,0 +1,98 @@
+"""ctypes bindings of libsela_hip.so (the C ABI declared in include/sela_hip.h).
+
+Importing this module does not need a GPU; calling into it does.  If the shared library has not
+been built, `lib()` raises -- there is no fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsela_hip.so")
+
+OK = 0
+ERRORS = {-1: "ENODEV", -2: "EINVAL", -3: "ENOMEM", -4: "ECAPACITY", -5: "EFORMAT", -6: "ERANGE"}
+SAMPLES_PER_FRAME = 2048
+
+FLAG_Q_RANGE, FLAG_COEF_OVERFLOW, FLAG_RICE_RANGE, FLAG_RICE_OVERRUN, FLAG_WORDS_CAP, FLAG_BAD_FRAME = 1, 2, 4, 8, 16, 32
+
+# every symbol include/sela_hip.h declares
+EXPORTS = [
+    "sela_hip_init", "sela_hip_shutdown", "sela_hip_last_error", "sela_hip_device_count",
+    "sela_hip_signals_per_frame", "sela_hip_encode_workspace_bytes", "sela_hip_decode_workspace_bytes",
+    "sela_hip_encode_bound_bytes", "sela_hip_encode_device", "sela_hip_decode_device",
+    "sela_hip_encode", "sela_hip_decode", "sela_hip_index_frames",
+    "sela_hip_enable_kernel_timing", "sela_hip_kernel_times",
+]
+
+
+class Trace(C.Structure):
+    """sela_hip_trace"""
+    _fields_ = [
+        ("mean", C.c_double), ("ac", C.c_double * 101), ("k", C.c_double * 100), ("a", C.c_int64 * 101),
+        ("q", C.c_int32 * 100), ("order", C.c_int32), ("coef_k", C.c_uint32), ("coef_words", C.c_uint32),
+        ("res_k", C.c_uint32), ("res_words", C.c_uint32), ("flags", C.c_uint32),
+    ]
+
+
+class SelaHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libsela_hip: {ERRORS.get(code, code)}: {message}")
+        self.code = code
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The SELA MI355X path has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64p, sz = C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t
+    L.sela_hip_init.argtypes = [C.c_int]
+    L.sela_hip_init.restype = C.c_int
+    L.sela_hip_shutdown.argtypes = []
+    L.sela_hip_shutdown.restype = None
+    L.sela_hip_last_error.argtypes = []
+    L.sela_hip_last_error.restype = C.c_char_p
+    L.sela_hip_device_count.argtypes = []
+    L.sela_hip_device_count.restype = C.c_int
+    L.sela_hip_signals_per_frame.argtypes = [u32]
+    L.sela_hip_signals_per_frame.restype = u32
+    for name in ("sela_hip_encode_workspace_bytes", "sela_hip_decode_workspace_bytes", "sela_hip_encode_bound_bytes"):
+        getattr(L, name).argtypes = [u32, u32]
+        getattr(L, name).restype = sz
+    L.sela_hip_encode_device.argtypes = [vp, u32, u32, vp, sz, u64p, vp, vp, sz, vp, vp]
+    L.sela_hip_encode_device.restype = C.c_int
+    L.sela_hip_decode_device.argtypes = [vp, u64p, u32, u32, vp, vp, vp, sz, vp]
+    L.sela_hip_decode_device.restype = C.c_int
+    L.sela_hip_encode.argtypes = [vp, u32, u32, u32, vp, sz, vp]
+    L.sela_hip_encode.restype = C.c_int
+    L.sela_hip_decode.argtypes = [vp, vp, u32, u32, vp]
+    L.sela_hip_decode.restype = C.c_int
+    L.sela_hip_index_frames.argtypes = [vp, sz, u32, u32, vp]
+    L.sela_hip_index_frames.restype = u32
+    L.sela_hip_enable_kernel_timing.argtypes = [C.c_int]
+    L.sela_hip_enable_kernel_timing.restype = None
+    L.sela_hip_kernel_times.argtypes = [C.POINTER(C.c_float), C.c_int]
+    L.sela_hip_kernel_times.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def kernel_times(capacity: int = 4):
+    """Durations (ms) of the kernels of the calling thread's last *_device call (timing must be enabled)."""
+    buf = (C.c_float * capacity)()
+    n = lib().sela_hip_kernel_times(buf, capacity)
+    return [float(buf[i]) for i in range(n)]
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise SelaHipError(rc, lib().sela_hip_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,139 @@
+"""Torch/numpy wrappers over the C ABI.  PyTorch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+BLOCK = capi.SAMPLES_PER_FRAME
+
+
+@dataclass
+class EncodedFrames:
+    """Device-resident result of an encode: the .sela frame byte stream + per-frame offsets."""
+    frames: "torch.Tensor"       # uint8 [capacity]; the first offsets[-1] bytes are valid
+    offsets: "torch.Tensor"      # int64 [n_frames + 1] (bit pattern of the library's uint64)
+    status: "torch.Tensor"       # int32 [4]
+    n_frames: int
+    channels: int
+
+    def total_bytes(self) -> int:
+        return int(self.offsets[-1].item())
+
+    def check(self) -> None:
+        st = self.status.cpu().numpy().view(np.uint32)
+        bad = int(st[0]) & (capi.FLAG_WORDS_CAP | capi.FLAG_RICE_RANGE | capi.FLAG_COEF_OVERFLOW)
+        if bad:
+            raise capi.SelaHipError(-6, f"a block left the range the .sela format can carry (flags 0x{int(st[0]):x})")
+        if int(st[1]):
+            raise capi.SelaHipError(-4, "frame buffer too small")
+
+    def to_host(self):
+        self.check()
+        n = self.total_bytes()
+        return self.frames[:n].cpu().numpy(), self.offsets.cpu().numpy().view(np.uint64)
+
+
+class Encoder:
+    """Reusable device buffers for encoding batches of up to `max_frames` frames on the current device."""
+
+    def __init__(self, max_frames: int, channels: int, device=None, with_trace: bool = False):
+        import torch
+
+        self.torch = torch
+        self.lib = capi.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.max_frames, self.channels = max_frames, channels
+        self.n_sig = int(self.lib.sela_hip_signals_per_frame(channels))
+        ws = int(self.lib.sela_hip_encode_workspace_bytes(max_frames, channels))
+        # the algorithmic output never exceeds the input for audio; keep the certain bound small by
+        # default (2x PCM) and let callers who want certainty pass frames_capacity explicitly
+        self.capacity = max(2 * max_frames * BLOCK * channels * 2, 4096)
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(ws, dtype=torch.uint8, device=self.device)
+            self.frames = torch.empty(self.capacity, dtype=torch.uint8, device=self.device)
+            self.offsets = torch.empty(max_frames + 1, dtype=torch.int64, device=self.device)
+            self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self.trace = (torch.zeros(max_frames * self.n_sig * C.sizeof(capi.Trace), dtype=torch.uint8, device=self.device)
+                          if with_trace else None)
+
+    def encode(self, pcm) -> EncodedFrames:
+        """pcm: int16 cuda tensor [n_frames, 2048, channels] (contiguous).  Asynchronous on the current stream."""
+        torch = self.torch
+        assert pcm.dtype == torch.int16 and pcm.is_cuda and pcm.is_contiguous()
+        n_frames = pcm.shape[0]
+        assert pcm.shape[1] == BLOCK and pcm.shape[2] == self.channels and n_frames <= self.max_frames
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        capi.check(self.lib.sela_hip_encode_device(
+            pcm.data_ptr(), n_frames, self.channels, self.frames.data_ptr(), self.capacity, self.offsets.data_ptr(),
+            self.status.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            self.trace.data_ptr() if self.trace is not None else None, stream))
+        return EncodedFrames(self.frames, self.offsets[: n_frames + 1], self.status, n_frames, self.channels)
+
+    def traces(self, n_frames: int):
+        raw = self.trace[: n_frames * self.n_sig * C.sizeof(capi.Trace)].cpu().numpy().tobytes()
+        return (capi.Trace * (n_frames * self.n_sig)).from_buffer_copy(raw)
+
+
+class Decoder:
+    def __init__(self, max_frames: int, channels: int, device=None):
+        import torch
+
+        self.torch = torch
+        self.lib = capi.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.max_frames, self.channels = max_frames, channels
+        with torch.cuda.device(self.device):
+            self.pcm = torch.empty((max_frames, BLOCK, channels), dtype=torch.int16, device=self.device)
+            self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
+
+    def decode(self, frames, offsets, n_frames: int):
+        """frames: uint8 cuda tensor, offsets: int64 cuda tensor [n_frames+1].  Asynchronous."""
+        torch = self.torch
+        assert frames.is_cuda and offsets.is_cuda and offsets.dtype == torch.int64 and n_frames <= self.max_frames
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        capi.check(self.lib.sela_hip_decode_device(
+            frames.data_ptr(), offsets.data_ptr(), n_frames, self.channels, self.pcm.data_ptr(), self.status.data_ptr(),
+            None, 0, stream))
+        return self.pcm[:n_frames]
+
+    def check(self) -> None:
+        st = self.status.cpu().numpy().view(np.uint32)
+        if int(st[0]) & capi.FLAG_BAD_FRAME:
+            raise capi.SelaHipError(-5, f"malformed frame stream ({int(st[1])} bad frames)")
+        if int(st[0]) & capi.FLAG_RICE_OVERRUN:
+            raise capi.SelaHipError(-5, "a Rice stream ended before all its values were read")
+
+
+# ---- host-pointer API on numpy arrays (what the C++ host calls) --------------------------------------
+def encode_host(pcm: np.ndarray):
+    """pcm: int16 [n_frames, 2048, channels] -> (frames uint8[...], offsets uint64[n_frames+1])."""
+    lib = capi.lib()
+    p = np.ascontiguousarray(pcm, dtype=np.int16)
+    n_frames, n, ch = p.shape
+    cap = max(2 * p.nbytes, 4096)
+    frames = np.empty(cap, np.uint8)
+    offs = np.zeros(n_frames + 1, np.uint64)
+    capi.check(lib.sela_hip_encode(p.ctypes.data, n_frames, ch, n, frames.ctypes.data, cap, offs.ctypes.data))
+    return frames[: int(offs[n_frames])].copy(), offs
+
+
+def decode_host(frames: np.ndarray, offsets: np.ndarray, channels: int) -> np.ndarray:
+    lib = capi.lib()
+    fr = np.ascontiguousarray(frames, dtype=np.uint8)
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n_frames = len(offs) - 1
+    pcm = np.empty((n_frames, BLOCK, channels), np.int16)
+    capi.check(lib.sela_hip_decode(fr.ctypes.data, offs.ctypes.data, n_frames, channels, pcm.ctypes.data))
+    return pcm
+
+
+def index_frames(frames: np.ndarray, n_frames: int, channels: int) -> np.ndarray:
+    lib = capi.lib()
+    fr = np.ascontiguousarray(frames, dtype=np.uint8)
+    offs = np.zeros(n_frames + 1, np.uint64)
+    found = lib.sela_hip_index_frames(fr.ctypes.data, fr.nbytes, n_frames, channels, offs.ctypes.data)
+    return offs[: found + 1]

@@ -1,0 +1,635 @@
+// sela_encode.hip -- MI355X (gfx950) encoder kernels of the SELA frame path.
+//
+// Pipeline for a batch of frames (three launches on one stream):
+//
+//   k_encode_blocks   one WAVE per (frame, signal): the whole of lpc::ResidueGenerator +
+//                     rice::RiceEncoder x2 for that signal (reference src/lpc/residue_generator.cpp:
+//                     121-134, src/rice/rice_encoder.cpp:73-81).  A stereo frame has three signals
+//                     (ch0, ch1, ch0-ch1; src/frame/frame_encoder.cpp:18-60); all three are coded and
+//                     the loser is simply not copied out.  Output: a fixed-stride slot of Rice
+//                     words + an 8-byte BlockMeta per signal.
+//   k_plan_frames     one workgroup: per frame, the stereo decision of src/frame/frame_encoder.cpp:
+//                     64-72 (strict < on u32 word counts) and the frame's on-disk size, then an
+//                     exclusive scan of the sizes -> frame_offsets[].
+//   k_assemble_frames one workgroup per frame: writes the exact byte stream that
+//                     file::SelaFile::writeToFile emits for the frame (src/file/sela_file.cpp:115-135).
+//
+// Arithmetic contract: this file must be compiled with -ffp-contract=off.  Every
+// FP64 accumulator is updated in the reference's order: the lanes of a wave carry *independent*
+// accumulators (autocorrelation lags, Schur columns, step-up elements), never a split of one sum.
+#include "sela_device.h"
+
+namespace sela {
+
+// ---- LDS plan of k_encode_blocks (one 64-lane workgroup) -----------------------------------------
+// Phase A (analysis):  centred samples c[] as FP64, split by index parity so that the per-lane
+//                      operand of the lag-pair autocorrelation is a conflict-free ds_read_b64:
+//                        E[m] = c[2m], O[m] = c[2m+1], each with kPadC zeros in front (lags reach
+//                        back before the block start; x + (+-0) is exact) and 2 behind.
+// Phase B (after the autocorrelation c[] is dead): the same bytes hold
+//                        [0, 8704)      biased samples s' = s + 2^17 with 128 words of bias in front
+//                                       (FIR warm-up: "no sample" == 0), later the transposed residues
+//                        [8704, ...)    first the small analysis arrays (ac, k, t, a, q), later the
+//                                       packed residue words
+constexpr int kPadC = 64;
+constexpr int kParityLen = kPadC + kBlock / 2 + 2;   // 1090 doubles
+constexpr int kBigBytes = 17664;                      // >= 2 * 1090 * 8 = 17440
+constexpr int kPadS = 128;
+constexpr int kSBufWords = kPadS + kBlock;            // 2176 words = 8704 bytes
+constexpr int kSmallBase = kSBufWords * 4;            // 8704
+constexpr uint32_t kBias = 1u << 17;                  // |ch0 - ch1| <= 65535 < 2^17
+static_assert(kSmallBase + kResWordsCap * 4 <= kBigBytes, "packed residue words must fit behind the sample buffer");
+static_assert((kBlock + kBlock / 32) * 4 <= kSmallBase, "transposed residues must fit in the sample buffer");
+
+struct SmallArrays { // lives at kSmallBase during analysis; dead before the residue words are packed
+    double ac[104];
+    double k[104];   // reflection coefficients, later the dequantised ones
+    double t[104];   // step-up scratch
+    int64_t a[104];  // Q35 predictor
+    int32_t q[128];
+};
+static_assert(sizeof(SmallArrays) + kSmallBase <= kBigBytes, "analysis arrays overflow the LDS plan");
+
+// OR `nbits` (1..32) low bits of v into the LDS bit buffer at bit position pos (buffer pre-zeroed;
+// neighbouring lanes share boundary words, hence the atomic).
+__device__ __forceinline__ void or_bits(uint32_t* buf, uint32_t pos, uint32_t v, uint32_t nbits)
+{
+    const uint32_t w = pos >> 5, sh = pos & 31;
+    atomicOr(&buf[w], v << sh);
+    if (sh + nbits > 32)
+        atomicOr(&buf[w + 1], v >> (32 - sh));
+}
+
+// Append one Golomb-Rice codeword (src/rice/rice_encoder.cpp:41-53): u >> k ones, a zero, then the
+// low k bits MSB first.  Stream bit t lives at bit t%32 of word t/32, so the MSB-first remainder is
+// the bit-reversed remainder in stream order.
+__device__ __forceinline__ uint32_t put_codeword(uint32_t* buf, uint32_t pos, uint32_t u, uint32_t k)
+{
+    uint32_t ones = u >> k;
+    const uint32_t rem = k ? (__brev(u << (32 - k))) : 0u; // low k bits of u, reversed
+    while (ones >= 32) {
+        or_bits(buf, pos, 0xFFFFFFFFu, 32);
+        pos += 32;
+        ones -= 32;
+    }
+    if (ones + 1 + k <= 32) {
+        or_bits(buf, pos, ((1u << ones) - 1u) | (rem << (ones + 1)), ones + 1 + k);
+        return pos + ones + 1 + k;
+    }
+    or_bits(buf, pos, (1u << ones) - 1u, ones + 1);
+    pos += ones + 1;
+    if (k) {
+        or_bits(buf, pos, rem, k);
+        pos += k;
+    }
+    return pos;
+}
+
+// rice::RiceEncoder::calculateOptimumRiceParam (src/rice/rice_encoder.cpp:20-33) for the values
+// u[0..V) of every lane (invalid slots hold 0 and are not counted in n).  Exact 64-bit sums;
+// first minimum wins.
+template <int V>
+__device__ __forceinline__ void rice_plan(const uint32_t (&u)[V], uint32_t n, uint32_t& best_k, uint64_t& best_bits)
+{
+    best_k = 0;
+    best_bits = 0;
+#pragma unroll 1
+    for (uint32_t k = 0; k < SELA_MAX_RICE_PARAM; k++) {
+        uint64_t part = 0;
+#pragma unroll
+        for (int t = 0; t < V; t++)
+            part += u[t] >> k;
+        const uint64_t bits = wave_sum(part) + (uint64_t)n * (1 + k);
+        if (k == 0 || bits < best_bits) {
+            best_bits = bits;
+            best_k = k;
+        }
+    }
+}
+
+template <bool kTrace>
+__global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
+    uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
+    sela_hip_trace* __restrict__ trace)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char big[kBigBytes];
+    __shared__ uint32_t cw_buf[kCoefWordsCap];
+
+    const int lane = threadIdx.x;
+
+    // XCD-aware block -> (frame, signal): hardware places workgroup b on XCD b % 8, so the signals
+    // of one frame are given ids that are equal mod 8 and share that XCD's L2 copy of the PCM.
+    const uint32_t per_group = 8 * n_sig;
+    const uint32_t grp = blockIdx.x / per_group, rem = blockIdx.x % per_group;
+    const uint32_t sig = rem / 8;
+    const uint32_t frame = grp * 8 + (rem % 8);
+    if (frame >= n_frames)
+        return;
+    const uint32_t block_id = frame * n_sig + sig;
+    uint32_t flags = 0;
+
+    double* const E = reinterpret_cast<double*>(big) + kPadC;             // E[-64 .. 1025]
+    double* const O = reinterpret_cast<double*>(big) + kParityLen + kPadC; // O[-64 .. 1025]
+    SmallArrays* const sm = reinterpret_cast<SmallArrays*>(big + kSmallBase);
+
+    // ---- load this signal: s[t] = sample lane + 64 t  (coalesced) ---------------------------------
+    int32_t s[kPerLane];
+    {
+        const int16_t* fp = pcm + (size_t)frame * kBlock * channels;
+        if (channels == 2) {
+            const uint32_t* fp2 = reinterpret_cast<const uint32_t*>(fp);
+#pragma unroll
+            for (int t = 0; t < kPerLane; t++) {
+                const uint32_t w = fp2[lane + 64 * t];
+                const int32_t l = (int16_t)(w & 0xFFFFu), r = (int16_t)(w >> 16);
+                s[t] = sig == 0 ? l : (sig == 1 ? r : l - r); // src/frame/frame_encoder.cpp:22-24
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < kPerLane; t++)
+                s[t] = fp[(size_t)(lane + 64 * t) * channels + sig];
+        }
+    }
+
+    // ---- quantizeSamples (src/lpc/residue_generator.cpp:12-18): x = s / 32767 ----------------------
+    // sample i = lane + 64 t has parity lane & 1 and half-index (lane >> 1) + 32 t.
+    double* const mine = (lane & 1) ? O : E;
+    const int half = lane >> 1;
+    for (int m = lane; m < kPadC; m += 64) { // zero pads in front of both parity arrays
+        E[m - kPadC] = 0.0;
+        O[m - kPadC] = 0.0;
+    }
+    if (lane < 2) {
+        E[kBlock / 2 + lane] = 0.0;
+        O[kBlock / 2 + lane] = 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < kPerLane; t++)
+        mine[half + 32 * t] = (double)s[t] / SELA_SAMPLE_SCALE;
+    wave_sync();
+
+    // ---- mean (src/lpc/residue_generator.cpp:27-30): one strictly sequential sum -----------------
+    // Every lane walks the same chain from broadcast LDS reads, so the result is wave-uniform.
+    double sum = 0.0;
+#pragma unroll 8
+    for (int m = 0; m < kBlock / 2; m++) {
+        sum += E[m];
+        sum += O[m];
+    }
+    const double mean = sum / (double)kBlock;
+
+    // c[j] = x[j] - mean, in place (same value at every use)
+#pragma unroll
+    for (int t = 0; t < kPerLane; t++)
+        mine[half + 32 * t] = mine[half + 32 * t] - mean;
+    wave_sync();
+
+    // ---- autocorrelation (src/lpc/residue_generator.cpp:33-38) -------------------------------------
+    // Lane L owns lags 2L and 2L+1 (lanes 0..50 matter).  At step j it needs
+    //     A = c[j - 2L]      (lag 2L)       B = c[j - 2L - 1]   (lag 2L+1)
+    // and the wave-uniform c[j], which is lane 0's A.  Going to j+1: B' = A, A' = c[j+1-2L], whose
+    // parity is that of j+1 for every lane -> one conflict-free ds_read_b64 per step.  Each
+    // accumulator sees its products in ascending j exactly like the reference loop; the extra
+    // leading terms c[j]*0 (j < lag) leave an accumulator at +0.0.
+    double acc_e = 0.0, acc_o = 0.0;
+    {
+        const double* pe = E - lane; // E[m - L]
+        const double* po = O - lane;
+        double A = pe[0]; // c[0 - 2L]
+        double B = 0.0;   // c[-2L - 1]
+#pragma unroll 4
+        for (int m = 0; m < kBlock / 2; m++) {
+            // j = 2m (even)
+            double cj = read_first_lane(A);
+            acc_e += cj * A;
+            acc_o += cj * B;
+            B = A;
+            A = po[m]; // c[2m + 1 - 2L]
+            // j = 2m + 1 (odd)
+            cj = read_first_lane(A);
+            acc_e += cj * A;
+            acc_o += cj * B;
+            B = A;
+            A = pe[m + 1]; // c[2m + 2 - 2L]
+        }
+    }
+    wave_sync(); // c[] is dead from here on
+
+    // normalise (src/lpc/residue_generator.cpp:41-44)
+    {
+        const double ac0 = read_first_lane(acc_e);
+        if (lane <= 50) {
+            sm->ac[2 * lane] = lane == 0 ? 1.0 : acc_e / ac0;
+            sm->ac[2 * lane + 1] = acc_o / ac0;
+        }
+    }
+    wave_sync();
+
+    // ---- Schur recursion (src/lpc/residue_generator.cpp:47-68), always 100 stages -------------------
+    // Column j of gen[0]/gen[1] lives in lane j (j < 64) and lane j - 64 of a second register.
+    // Stage i reads gen1[j+1] (old) -> a one-lane shift; all columns update from old values.
+    double k_lo = 0.0, k_hi = 0.0; // k[lane], k[lane + 64]
+    {
+        double g0a = sm->ac[lane + 1], g1a = g0a;
+        double g0b = lane < 36 ? sm->ac[lane + 65] : 0.0, g1b = g0b;
+        double err = 1.0; // ac[0]
+        double g = read_first_lane(g1a);
+        double ki = -g / err;
+        err += g * ki;
+        if (lane == 0)
+            k_lo = ki;
+#pragma unroll 1
+        for (int i = 1; i < kMaxOrder; i++) {
+            const double sa = wave_shl1(read_first_lane(g1b), g1a); // gen1[j+1], j = lane
+            const double sb = wave_shl1(0.0, g1b);                  // gen1[j+1], j = lane + 64
+            g1a = sa + ki * g0a;
+            g0a = sa * ki + g0a;
+            g1b = sb + ki * g0b;
+            g0b = sb * ki + g0b;
+            g = read_first_lane(g1a);
+            ki = -g / err;
+            err += g * ki;
+            if (lane == i)
+                k_lo = ki;
+            if (lane + 64 == i)
+                k_hi = ki;
+        }
+    }
+
+    // ---- order (src/lpc/residue_generator.cpp:70-78): 1 + last i with |k[i]| > 0.05 ----------------
+    int order;
+    {
+        const unsigned long long b_lo = __ballot(fabs(k_lo) > SELA_ORDER_THRESHOLD);
+        const unsigned long long b_hi = __ballot(lane < 36 && fabs(k_hi) > SELA_ORDER_THRESHOLD);
+        order = b_hi ? 128 - __clzll(b_hi) : (b_lo ? 64 - __clzll(b_lo) : 1);
+    }
+
+    // ---- quantise (src/lpc/residue_generator.cpp:80-96), dequantise (linear_predictor.cpp:16-28) ----
+    {
+        const double sqrt2 = SELA_SQRT2;
+        double v_lo;
+        if (lane == 0)
+            v_lo = floor(64 * (-1 + (sqrt2 * sqrt(k_lo + 1))));
+        else if (lane == 1)
+            v_lo = floor(64 * (-1 + (sqrt2 * sqrt(-k_lo + 1))));
+        else
+            v_lo = floor(64 * k_lo);
+        const double v_hi = floor(64 * k_hi);
+        const int32_t q_lo = isnan(v_lo) ? 0 : (int32_t)v_lo;
+        const int32_t q_hi = isnan(v_hi) ? 0 : (int32_t)v_hi;
+        if (lane < order) {
+            sm->q[lane] = q_lo;
+            sm->k[lane] = order <= 1 ? 0.0 : dequant(lane, q_lo, flags);
+        }
+        if (lane + 64 < order) {
+            sm->q[lane + 64] = q_hi;
+            sm->k[lane + 64] = dequant(lane + 64, q_hi, flags);
+        }
+        if (kTrace) {
+            sela_hip_trace* tr = trace + block_id;
+            if (lane == 0) {
+                tr->mean = mean;
+                tr->order = order;
+            }
+            for (int i = lane; i <= kMaxOrder; i += 64)
+                tr->ac[i] = sm->ac[i];
+            tr->k[lane] = k_lo;
+            if (lane < 36)
+                tr->k[lane + 64] = k_hi;
+        }
+    }
+    wave_sync();
+
+    // ---- step-up to the Q35 predictor (src/lpc/linear_predictor.cpp:30-61) ---------------------------
+    step_up(sm->k, sm->t, sm->a, order, lane, flags);
+    if (kTrace) {
+        sela_hip_trace* tr = trace + block_id;
+        for (int i = lane; i <= order; i += 64)
+            tr->a[i] = sm->a[i];
+        for (int i = lane; i < order; i += 64)
+            tr->q[i] = sm->q[i];
+    }
+
+    // ---- residues (src/lpc/residue_generator.cpp:98-119) -----------------------------------------------
+    // r[i] = s[i] - (int32)((2^34 + sum_{j=1..order} a[j] s[i-j]) >> 35), samples before the block
+    // count as absent.  Integer wrap-around arithmetic is associative, so the taps are accumulated
+    // per sample in any order.  To keep the multiplier operand unsigned the samples are biased,
+    // s' = s + 2^17 >= 0 (pad = 2^17 == "sample 0"), and 2^17 * sum(a) is removed at the end:
+    //   a * s' mod 2^64 = lo32(a) * s'  +  (hi32(a) * s' mod 2^32) << 32      (two v_mad_u64_u32).
+    uint32_t* const sbuf = reinterpret_cast<uint32_t*>(big);
+    for (int m = lane; m < kPadS; m += 64)
+        sbuf[m] = kBias;
+#pragma unroll
+    for (int t = 0; t < kPerLane; t++)
+        sbuf[kPadS + lane + 64 * t] = (uint32_t)(s[t] + (int32_t)kBias);
+    wave_sync();
+
+    int32_t r[kPerLane];
+    {
+        uint64_t acc[kPerLane], hi[kPerLane];
+#pragma unroll
+        for (int t = 0; t < kPerLane; t++)
+            acc[t] = 0, hi[t] = 0;
+        uint64_t sum_a = 0;
+        const uint32_t* base = sbuf + kPadS + lane;
+#pragma unroll 1
+        for (int j = 1; j <= order; j++) {
+            const uint64_t aj = read_first_lane((uint64_t)sm->a[j]);
+            const uint32_t a_lo = (uint32_t)aj, a_hi = (uint32_t)(aj >> 32);
+            sum_a += aj;
+            const uint32_t* p = base - j;
+#pragma unroll
+            for (int t = 0; t < kPerLane; t++) {
+                const uint32_t sp = p[64 * t];
+                acc[t] += (uint64_t)a_lo * sp;
+                hi[t] += (uint64_t)a_hi * sp;
+            }
+        }
+        const uint64_t corr = ((uint64_t)1 << (SELA_Q_SHIFT - 1)) - (sum_a << 17);
+#pragma unroll
+        for (int t = 0; t < kPerLane; t++) {
+            const uint64_t total = acc[t] + (hi[t] << 32) + corr;
+            r[t] = (int32_t)((uint32_t)s[t] - (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT));
+        }
+    }
+    wave_sync(); // sbuf is dead
+
+    // ---- Rice parameters -----------------------------------------------------------------------------
+    // coefficients: value i of q[] sits in lane i / 2 slot i % 2 (lane-contiguous for packing)
+    uint32_t cu[2];
+    cu[0] = 2 * lane < order ? zigzag32(sm->q[2 * lane]) : 0u;
+    cu[1] = 2 * lane + 1 < order ? zigzag32(sm->q[2 * lane + 1]) : 0u;
+    uint32_t coef_k;
+    uint64_t coef_bits;
+    rice_plan<2>(cu, (uint32_t)order, coef_k, coef_bits);
+    const uint32_t coef_words = words_for_bits(coef_bits);
+
+    uint32_t ru[kPerLane];
+    bool wide = false;
+#pragma unroll
+    for (int t = 0; t < kPerLane; t++) {
+        ru[t] = zigzag32(r[t]);
+        wide |= (r[t] >= (1 << 30)) || (r[t] < -(1 << 30)); // zig-zag would not fit 32 bits
+    }
+    if (__any(wide))
+        flags |= SELA_HIP_FLAG_RICE_RANGE;
+    uint32_t res_k;
+    uint64_t res_bits;
+    rice_plan<kPerLane>(ru, (uint32_t)kBlock, res_k, res_bits);
+    uint32_t res_words = words_for_bits(res_bits);
+    if (res_words > (uint32_t)kResWordsCap || coef_words > (uint32_t)kCoefWordsCap) {
+        flags |= SELA_HIP_FLAG_WORDS_CAP;
+        res_words = 0;
+    }
+
+    // ---- pack the coefficient stream (<= 100 values) ----------------------------------------------
+    if (lane < kCoefWordsCap)
+        cw_buf[lane] = 0;
+    wave_sync();
+    if (!(flags & SELA_HIP_FLAG_WORDS_CAP)) {
+        const uint32_t n0 = 2 * lane < order ? (cu[0] >> coef_k) + 1 + coef_k : 0u;
+        const uint32_t n1 = 2 * lane + 1 < order ? (cu[1] >> coef_k) + 1 + coef_k : 0u;
+        uint32_t pos = wave_exclusive_scan(n0 + n1, lane);
+        if (n0)
+            pos = put_codeword(cw_buf, pos, cu[0], coef_k);
+        if (n1)
+            pos = put_codeword(cw_buf, pos, cu[1], coef_k);
+    }
+
+    // ---- pack the residue stream ----------------------------------------------------------------------
+    // Transpose through LDS so that lane l owns the 32 consecutive residues 32l .. 32l+31 (index
+    // i stored at i + i/32: both sides conflict-free), scan the per-lane bit counts, then every lane
+    // appends its codewords.  The analysis arrays die here: out_words overlays them.
+    uint32_t* const rT = reinterpret_cast<uint32_t*>(big);
+    uint32_t* const out_words = reinterpret_cast<uint32_t*>(big + kSmallBase);
+#pragma unroll
+    for (int t = 0; t < kPerLane; t++) {
+        const int i = lane + 64 * t;
+        rT[i + (i >> 5)] = ru[t];
+    }
+    wave_sync();
+    for (uint32_t w = lane; w < res_words; w += 64)
+        out_words[w] = 0;
+    uint32_t lu[kPerLane];
+    uint32_t lane_bits = 0;
+#pragma unroll
+    for (int t = 0; t < kPerLane; t++) {
+        lu[t] = rT[33 * lane + t];
+        lane_bits += (lu[t] >> res_k) + 1 + res_k;
+    }
+    wave_sync();
+    if (res_words) {
+        uint32_t pos = wave_exclusive_scan(lane_bits, lane);
+#pragma unroll 4
+        for (int t = 0; t < kPerLane; t++)
+            pos = put_codeword(out_words, pos, lu[t], res_k);
+    }
+    wave_sync();
+
+    // ---- slot + meta -------------------------------------------------------------------------------------
+    uint32_t* slot = slots + (size_t)block_id * kSlotWords;
+    if (lane < (int)coef_words && lane < kCoefWordsCap)
+        slot[lane] = cw_buf[lane];
+    for (uint32_t w = lane; w < res_words; w += 64)
+        slot[kCoefWordsCap + w] = out_words[w];
+    uint32_t all_flags = flags; // OR over the wave
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        all_flags |= (uint32_t)__shfl_xor((int)all_flags, m, 64);
+    if (lane == 0) {
+        BlockMeta bm;
+        bm.order = (uint8_t)order;
+        bm.coef_k = (uint8_t)coef_k;
+        bm.res_k = (uint8_t)res_k;
+        bm.flags = (uint8_t)all_flags;
+        bm.coef_words = (uint16_t)coef_words;
+        bm.res_words = (uint16_t)res_words;
+        meta[block_id] = bm;
+        if (kTrace) {
+            sela_hip_trace* tr = trace + block_id;
+            tr->coef_k = coef_k;
+            tr->coef_words = coef_words;
+            tr->res_k = res_k;
+            tr->res_words = res_words;
+            tr->flags = all_flags;
+        }
+    }
+}
+
+// ---- plan: stereo decision + frame sizes + exclusive scan (one workgroup of 1024) -------------------
+// choice[f] = 1 when the second channel of an exactly-stereo frame is stored as the difference
+// signal (src/frame/frame_encoder.cpp:64-72).
+constexpr int kPlanThreads = 1024;
+
+__device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t channels, uint32_t n_sig, uint32_t& choice,
+    uint32_t& flags)
+{
+    uint32_t words = 0;
+    choice = 0;
+    for (uint32_t c = 0; c < channels; c++) {
+        BlockMeta b = m[c];
+        if (c == 1 && n_sig == 3) {
+            const BlockMeta d = m[2];
+            const uint32_t dsz = (uint32_t)d.coef_words + d.res_words, asz = (uint32_t)b.coef_words + b.res_words;
+            flags |= d.flags;
+            if (dsz < asz) {
+                choice = 1;
+                b = d;
+            }
+        }
+        flags |= b.flags;
+        words += (uint32_t)b.coef_words + b.res_words;
+    }
+    return words;
+}
+
+__global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
+    uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* __restrict__ frame_offsets,
+    uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status)
+{
+    __shared__ uint64_t part[kPlanThreads];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_frames + kPlanThreads - 1) / kPlanThreads;
+    const uint32_t begin = tid * per, end = min(begin + per, n_frames);
+    uint64_t bytes = 0;
+    uint32_t flags = 0;
+    for (uint32_t f = begin; f < end; f++) {
+        uint32_t choice;
+        const uint32_t words = frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, flags);
+        choice_out[f] = (uint8_t)choice;
+        bytes += sela_frame_bytes(channels, words);
+    }
+    part[tid] = bytes;
+    __syncthreads();
+    for (uint32_t d = 1; d < kPlanThreads; d <<= 1) { // Hillis-Steele inclusive scan
+        const uint64_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint64_t off = part[tid] - bytes;
+    uint32_t overflow = 0;
+    for (uint32_t f = begin; f < end; f++) {
+        uint32_t choice;
+        uint32_t dummy = 0;
+        const uint32_t words = frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, dummy);
+        frame_offsets[f] = off;
+        off += sela_frame_bytes(channels, words);
+        if (off > frames_cap)
+            overflow++;
+    }
+    if (tid == kPlanThreads - 1)
+        frame_offsets[n_frames] = part[tid];
+    if (flags)
+        atomicOr(&status[0], flags);
+    if (overflow)
+        atomicAdd(&status[1], overflow);
+}
+
+// ---- assemble: the on-disk bytes of each frame (src/file/sela_file.cpp:115-135) ------------------------
+// Frame sizes are multiples of 4 and the stream base is 4-byte aligned, so everything is written as
+// aligned u32.  Within a subframe the 7 header bytes push the coefficient words 3 bytes off word
+// alignment (funnel shift below); the 5 bytes of the residue header realign the residue words.
+constexpr int kAsmThreads = 256;
+
+__global__ __launch_bounds__(kAsmThreads) void k_assemble_frames(const BlockMeta* __restrict__ meta,
+    const uint32_t* __restrict__ slots, const uint8_t* __restrict__ choice, const uint64_t* __restrict__ frame_offsets,
+    uint32_t n_frames, uint32_t channels, uint32_t n_sig, size_t frames_cap, uint8_t* __restrict__ frames)
+{
+    const uint32_t f = blockIdx.x;
+    if (f >= n_frames)
+        return;
+    const uint64_t begin = frame_offsets[f], end = frame_offsets[f + 1];
+    if (end > frames_cap)
+        return; // reported through status[1] by k_plan_frames
+    uint32_t* out = reinterpret_cast<uint32_t*>(frames + begin);
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0)
+        out[0] = SELA_SYNC_WORD;
+    uint32_t p = 1; // word cursor inside the frame
+    for (uint32_t c = 0; c < channels; c++) {
+        uint32_t sig = c, type = 0, parent = c;
+        if (c == 1 && n_sig == 3 && choice[f]) {
+            sig = 2;
+            type = 1;
+            parent = 0;
+        }
+        const BlockMeta b = meta[(size_t)f * n_sig + sig];
+        const uint32_t* slot = slots + ((size_t)f * n_sig + sig) * kSlotWords;
+        const uint32_t cw = b.coef_words, rw = b.res_words;
+        if (tid == 0)
+            out[p] = c | (type << 8) | (parent << 16) | ((uint32_t)b.coef_k << 24);
+        // words p+1 .. p+1+cw: [cw:16 | order:8] then the coefficient words shifted by 3 bytes, then res_k
+        for (uint32_t i = tid; i <= cw; i += kAsmThreads) {
+            const uint32_t low = i == 0 ? (cw | ((uint32_t)b.order << 16)) : (slot[i - 1] >> 8);
+            const uint32_t top = i < cw ? slot[i] : (uint32_t)b.res_k;
+            out[p + 1 + i] = (low & 0x00FFFFFFu) | (top << 24);
+        }
+        if (tid == 0)
+            out[p + 2 + cw] = rw | ((uint32_t)kBlock << 16);
+        const uint32_t* rs = slot + kCoefWordsCap;
+        uint32_t* ro = out + p + 3 + cw;
+        for (uint32_t i = tid; i < rw; i += kAsmThreads)
+            ro[i] = rs[i];
+        p += 3 + cw + rw;
+    }
+}
+
+} // namespace sela
+
+// ---- host-side launchers (called from sela_capi.hip) ---------------------------------------------------
+namespace sela {
+
+size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
+{
+    const uint32_t n_sig = sela_hip_signals_per_frame(channels);
+    const size_t blocks = (size_t)n_frames * n_sig;
+    size_t bytes = 0;
+    bytes += (blocks * sizeof(BlockMeta) + 255) & ~(size_t)255;
+    bytes += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
+    bytes += ((size_t)n_frames + 255) & ~(size_t)255; // choice
+    return bytes + 256;
+}
+
+hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames,
+    size_t frames_cap, uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace,
+    hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */)
+{
+    const uint32_t n_sig = sela_hip_signals_per_frame(channels);
+    const size_t blocks = (size_t)n_frames * n_sig;
+    unsigned char* ws = static_cast<unsigned char*>(d_workspace);
+    ws = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    BlockMeta* meta = reinterpret_cast<BlockMeta*>(ws);
+    ws += (blocks * sizeof(BlockMeta) + 255) & ~(size_t)255;
+    uint32_t* slots = reinterpret_cast<uint32_t*>(ws);
+    ws += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
+    uint8_t* choice = ws;
+
+    hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
+    if (err != hipSuccess)
+        return err;
+    if (n_frames == 0) {
+        return hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), stream);
+    }
+    const uint32_t groups = (n_frames + 7) / 8;
+    const dim3 grid(groups * 8 * n_sig), wg(64);
+    if (ev)
+        (void)hipEventRecord(ev[0], stream);
+    if (d_trace)
+        hipLaunchKernelGGL(k_encode_blocks<true>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace);
+    else
+        hipLaunchKernelGGL(k_encode_blocks<false>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace);
+    if (ev)
+        (void)hipEventRecord(ev[1], stream);
+    hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap,
+        d_frame_offsets, choice, d_status);
+    if (ev)
+        (void)hipEventRecord(ev[2], stream);
+    hipLaunchKernelGGL(k_assemble_frames, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets,
+        n_frames, channels, n_sig, frames_cap, d_frames);
+    if (ev)
+        (void)hipEventRecord(ev[3], stream);
+    return hipGetLastError();
+}
+
+} // namespace sela

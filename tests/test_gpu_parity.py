@@ -1,0 +1,223 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bit-exact everywhere: .sela frame bytes, frame offsets, decoded PCM, and -- stage by stage -- the
+FP64 intermediates of the analysis (compared as bit patterns, tolerance zero).
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle_lib import oracle, reference
+from sela_amd.synth import synth_frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    from sela_amd import capi
+
+    capi.lib()  # raises if the HIP library is missing: no fallback
+    return torch
+
+
+def _encode(gpu, pcm, with_trace=False):
+    from sela_amd import codec
+
+    enc = codec.Encoder(pcm.shape[0], pcm.shape[2], with_trace=with_trace)
+    out = enc.encode(gpu.from_numpy(np.ascontiguousarray(pcm)).cuda())
+    gpu.cuda.synchronize()
+    frames, offsets = out.to_host()
+    return (frames, offsets, enc, out)
+
+
+def _decode(gpu, frames, offsets, channels):
+    from sela_amd import codec
+
+    n = len(offsets) - 1
+    dec = codec.Decoder(n, channels)
+    f = gpu.from_numpy(np.ascontiguousarray(frames)).cuda()
+    o = gpu.from_numpy(np.ascontiguousarray(offsets).view(np.int64)).cuda()
+    pcm = dec.decode(f, o, n)
+    gpu.cuda.synchronize()
+    dec.check()
+    return pcm.cpu().numpy()
+
+
+def _bits(x):
+    return np.asarray(x, dtype=np.float64).view(np.uint64)
+
+
+def _kat_block_frames(kats):
+    """The single-block KAT signals as mono frames (those that fit int16)."""
+    names, frames = [], []
+    for name in kats["blk_names"]:
+        s = kats[f"blk/{name}/samples"]
+        if s.min() >= -32768 and s.max() <= 32767:
+            names.append(str(name))
+            frames.append(s.astype(np.int16)[:, None])
+    return names, np.stack(frames)
+
+
+def test_analysis_stages_bit_exact(gpu, kats):
+    """mean / autocorrelation / reflection coefficients / order / q / a against the oracle's trace."""
+    o = oracle()
+    names, mono = _kat_block_frames(kats)
+    pcm_sets = [mono, synth_frames(24, 2, 3), synth_frames(5, 3, 4)]
+    for pcm in pcm_sets:
+        frames, offsets, enc, out = _encode(gpu, pcm, with_trace=True)
+        traces = enc.traces(pcm.shape[0])
+        ch = pcm.shape[2]
+        n_sig = 3 if ch == 2 else ch
+        for f in range(pcm.shape[0]):
+            for sig in range(n_sig):
+                s = (pcm[f, :, 0].astype(np.int32) - pcm[f, :, 1]) if (ch == 2 and sig == 2) else pcm[f, :, sig].astype(np.int32)
+                order, q, r, a, tr, _ = o.lpc_analyze(s, with_trace=True)
+                g = traces[f * n_sig + sig]
+                ctx = (f, sig)
+                assert _bits(g.mean) == _bits(tr.mean), ctx
+                assert np.array_equal(_bits(list(g.ac)), _bits(list(tr.ac))), ctx
+                assert np.array_equal(_bits(list(g.k)), _bits(list(tr.k))), ctx
+                assert g.order == order, ctx
+                assert list(g.q)[:order] == q.tolist(), ctx
+                assert list(g.a)[: order + 1] == a.tolist(), ctx
+                ck, cw = o.rice_encode(q)
+                rk, rw = o.rice_encode(r)
+                assert (g.coef_k, g.coef_words, g.res_k, g.res_words) == (ck, len(cw), rk, len(rw)), ctx
+                assert g.flags == 0
+
+
+def test_all_int16_sample_values(gpu):
+    """Every int16 value goes through the x/32767 division and the FP64 sums at least once."""
+    o = oracle()
+    vals = np.arange(-32768, 32768, dtype=np.int32)
+    rng = np.random.default_rng(3)
+    rng.shuffle(vals)
+    pcm = vals.astype(np.int16).reshape(32, 2048, 1)
+    frames, offsets, enc, out = _encode(gpu, pcm, with_trace=True)
+    traces = enc.traces(32)
+    for f in range(32):
+        _, _, _, _, tr, _ = o.lpc_analyze(pcm[f, :, 0].astype(np.int32), with_trace=True)
+        assert _bits(traces[f].mean) == _bits(tr.mean)
+        assert np.array_equal(_bits(list(traces[f].ac)), _bits(list(tr.ac)))
+    ref_frames, ref_offsets, _ = o.encode_frames(pcm, threads=4)
+    assert np.array_equal(frames, ref_frames) and np.array_equal(offsets, ref_offsets)
+
+
+def test_frame_kats_encode_and_decode(gpu, kats):
+    """Golden on-disk frames produced by the reference (tests/golden/make_golden.py)."""
+    for name in kats["frame_names"]:
+        pcm = kats[f"frame/{name}/pcm"][None]
+        golden = kats[f"frame/{name}/bytes"]
+        frames, offsets, _, _ = _encode(gpu, pcm)
+        assert offsets.tolist() == [0, len(golden)], name
+        assert np.array_equal(frames, golden), name
+        back = _decode(gpu, golden, np.array([0, len(golden)], np.uint64), pcm.shape[2])
+        assert np.array_equal(back[0], kats[f"frame/{name}/decoded"]), name
+
+
+def test_block_kats_as_frames(gpu, kats):
+    """Edge blocks (silence, constant, full-scale noise, square, impulse, ramp, ...) as mono frames."""
+    o = oracle()
+    names, mono = _kat_block_frames(kats)
+    frames, offsets, _, _ = _encode(gpu, mono)
+    ref_frames, ref_offsets, _ = o.encode_frames(mono, threads=2)
+    assert np.array_equal(offsets, ref_offsets)
+    assert np.array_equal(frames, ref_frames)
+    for i, name in enumerate(names):  # per-block check against the reference's own numbers
+        b = frames[int(offsets[i]): int(offsets[i + 1])]
+        assert b[10] == int(kats[f"blk/{name}/order"]), name
+        cw = int(b[8]) | int(b[9]) << 8
+        assert np.array_equal(b[11: 11 + 4 * cw].view(np.uint32), kats[f"blk/{name}/coef_words"]), name
+    back = _decode(gpu, frames, offsets, 1)
+    assert np.array_equal(back, mono)
+
+
+@pytest.mark.parametrize("channels,track,n_frames", [(1, 11, 70), (2, 12, 150), (3, 13, 40), (6, 14, 20)])
+def test_random_batches_match_oracle(gpu, channels, track, n_frames):
+    o = oracle()
+    pcm = synth_frames(n_frames, channels, track)
+    frames, offsets, _, _ = _encode(gpu, pcm)
+    ref_frames, ref_offsets, _ = o.encode_frames(pcm, threads=8)
+    assert np.array_equal(offsets, ref_offsets)
+    assert np.array_equal(frames, ref_frames)
+    back = _decode(gpu, frames, offsets, channels)
+    ref_back, _ = o.decode_frames(ref_frames, ref_offsets, channels, threads=8)
+    assert np.array_equal(back, ref_back) and np.array_equal(back, pcm)
+
+
+def test_extreme_stereo(gpu):
+    """Full-scale anti-correlated channels: the difference signal uses all 17 bits."""
+    o = oracle()
+    rng = np.random.default_rng(21)
+    l = rng.integers(-32768, 32768, (6, 2048)).astype(np.int16)
+    pcm = np.stack([l, (-l.astype(np.int32)).clip(-32768, 32767).astype(np.int16)], axis=2)
+    pcm[3] = np.stack([np.full(2048, 32767, np.int16), np.full(2048, -32768, np.int16)], axis=1)
+    pcm[4, :, 1] = pcm[4, :, 0]
+    frames, offsets, _, _ = _encode(gpu, pcm)
+    ref_frames, ref_offsets, _ = o.encode_frames(pcm, threads=4)
+    assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames)
+    assert np.array_equal(_decode(gpu, frames, offsets, 2), pcm)
+
+
+@pytest.mark.parametrize("label", ["config0_mono_10s", "config1_stereo_3min", "config2_1000_frames"])
+def test_baseline_configs_by_digest(gpu, digests, label):
+    """BASELINE.json configs 0-2 at full size: SHA-256 of the frame stream / offsets / decoded PCM
+    against digests computed with the unmodified reference."""
+    d = digests[label]
+    pcm = synth_frames(d["n_frames"], d["channels"], d["track"])
+    assert hashlib.sha256(pcm.tobytes()).hexdigest() == d["pcm_sha256"]
+    frames, offsets, _, out = _encode(gpu, pcm)
+    assert len(frames) == d["frames_blob_bytes"]
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == d["frames_blob_sha256"]
+    assert hashlib.sha256(offsets.astype("<u8").tobytes()).hexdigest() == d["offsets_sha256"]
+    back = _decode(gpu, frames, offsets, d["channels"])
+    assert hashlib.sha256(back.tobytes()).hexdigest() == d["decoded_sha256"]
+    assert np.array_equal(back, pcm)  # encode -> decode round trip is lossless
+
+
+def test_host_pointer_api(gpu):
+    """The synchronous host-pointer entry points used by the C++ host."""
+    from sela_amd import codec
+
+    o = oracle()
+    pcm = synth_frames(9, 2, 30)
+    frames, offsets = codec.encode_host(pcm)
+    ref_frames, ref_offsets, _ = o.encode_frames(pcm, threads=2)
+    assert np.array_equal(frames, ref_frames) and np.array_equal(offsets, ref_offsets)
+    assert np.array_equal(codec.index_frames(frames, 9, 2), offsets)
+    assert np.array_equal(codec.decode_host(frames, offsets, 2), pcm)
+    # empty batch
+    f0, o0 = codec.encode_host(np.zeros((0, 2048, 2), np.int16))
+    assert len(f0) == 0 and o0.tolist() == [0]
+
+
+def test_decoder_rejects_corrupt_frames(gpu):
+    from sela_amd import capi, codec
+
+    pcm = synth_frames(4, 2, 31)
+    frames, offsets = codec.encode_host(pcm)
+    bad = frames.copy()
+    bad[int(offsets[2])] ^= 0x01  # sync word of frame 2
+    with pytest.raises(capi.SelaHipError) as e:
+        codec.decode_host(bad, offsets, 2)
+    assert e.value.code == -5
+
+
+def test_reference_library_agrees_when_present(gpu):
+    """If the real reference travelled with the repo (oracle/_ref), compare against it directly."""
+    ref = reference()
+    if ref is None:
+        pytest.skip("oracle/_ref/libsela_ref.so not present")
+    pcm = synth_frames(64, 2, 40)
+    frames, offsets, _, _ = _encode(gpu, pcm)
+    ref_frames, ref_offsets, _ = ref.encode_frames(pcm, threads=8)
+    assert np.array_equal(frames, ref_frames) and np.array_equal(offsets, ref_offsets)
+    ref_back, _ = ref.decode_frames(ref_frames, ref_offsets, 2, threads=8)
+    assert np.array_equal(_decode(gpu, frames, offsets, 2), ref_back)
