@@ -468,7 +468,7 @@ __device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t cha
     choice = 0;
     for (uint32_t c = 0; c < channels; c++) {
         BlockMeta b = m[c];
-        if (c == 1 && n_sig == 3) {
+        if (c == 1 && channels == 2) { // exactly-stereo only, src/frame/frame_encoder.cpp:18
             const BlockMeta d = m[2];
             const uint32_t dsz = (uint32_t)d.coef_words + d.res_words, asz = (uint32_t)b.coef_words + b.res_words;
             flags |= d.flags;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_frames(const BlockMeta
     uint32_t p = 1; // word cursor inside the frame
     for (uint32_t c = 0; c < channels; c++) {
         uint32_t sig = c, type = 0, parent = c;
-        if (c == 1 && n_sig == 3 && choice[f]) {
+        if (c == 1 && channels == 2 && choice[f]) {
             sig = 2;
             type = 1;
             parent = 0;
