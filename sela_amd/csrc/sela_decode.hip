@@ -19,7 +19,7 @@
 namespace sela {
 
 constexpr int kDecMaxWaves = 8;
-constexpr int kStageWords = kCoefWordsCap * 2 + kResWordsCap + 8; // staged Rice words of one subframe
+constexpr int kStageWords = kCoefWordsCap * 2 + kResWordsCap + 72; // + zero tail for the chunked parser // staged Rice words of one subframe
 
 struct DecodeWaveLds {
     uint32_t words[kStageWords]; // [0,64) coefficient words, [64, ...) residue words
@@ -29,76 +29,222 @@ struct DecodeWaveLds {
     int32_t q[256];
 };
 
-// Serial Rice parse by lane 0 (src/rice/rice_decoder.cpp:21-44); `out` is in LDS.
-__device__ inline void rice_decode_serial(const uint32_t* words, uint32_t nwords, uint32_t n, uint32_t k, int32_t* out,
-    int lane, uint32_t& flags)
+// ---- wave-parallel Golomb-Rice decoder ---------------------------------------------------------
+// rice::RiceDecoder::generateDecodedUnsignedInts (src/rice/rice_decoder.cpp:21-44) is a serial bit
+// parse: where codeword i+1 starts depends on codeword i.  The wave cuts the stream into 64
+// word-aligned chunks (one per lane) and resolves the dependency with a scan over *parser states*:
+//
+//   state at a chunk boundary:  R_m (m = 0..k)  "m more remainder bits to skip, then a codeword
+//                                                starts"  (R_0 = a codeword starts right here)
+//                               M   (= k+1)     "inside a unary run: skip to the first zero, skip
+//                                                k remainder bits, then a codeword starts"
+//   phase 1  every lane parses its chunk once for EVERY entry state (k+2 parses in lockstep, all
+//            independent -> the LDS latency of one hides behind the others) and records
+//            map[entry] = (exit state, number of codewords that START in the chunk)
+//   walk     the 64 maps are composed from lane 0 (entry R_0, value index 0): 64 dependent LDS
+//            reads give every lane its true entry state and the index of its first codeword
+//   phase 2  every lane decodes the codewords that start in its chunk (the last one may run past
+//            the chunk end) straight to their final positions.
+//
+// Bit t of the stream is bit t%32 of word t/32 (LSB first); the k remainder bits are MSB first,
+// i.e. bit-reversed in stream order.  `words` must be readable (zero) for 3 words past its end.
+__device__ __forceinline__ uint64_t bit_window(const uint32_t* words, uint32_t pos)
 {
-    if (lane == 0) {
-        const uint64_t total = (uint64_t)nwords * 32;
-        uint64_t pos = 0;
-        bool overrun = false;
-        for (uint32_t c = 0; c < n; c++) {
-            uint32_t ones = 0;
-            for (;;) { // count ones up to the terminating zero
-                if (pos >= total) {
-                    overrun = true;
-                    break;
-                }
-                const uint32_t w = words[pos >> 5] >> (pos & 31);
-                const uint32_t avail = 32 - (uint32_t)(pos & 31);
-                const uint32_t run = (uint32_t)__builtin_ctzll((uint64_t)(~w) | (1ull << 32)); // trailing ones of w, <= 32
-                const uint32_t take = run < avail ? run : avail;
-                ones += take;
-                pos += take;
-                if (take < avail)
-                    break;
-            }
-            pos++; // the zero
-            uint64_t u = (uint64_t)(uint32_t)(ones << k); // uint32 shift, src/rice/rice_decoder.cpp:35
-            for (uint32_t i = 1; i <= k; i++) {
-                uint32_t bit = 0;
-                if (pos < total)
-                    bit = (words[pos >> 5] >> (pos & 31)) & 1u;
-                else
-                    overrun = true;
-                u |= (uint64_t)bit << (k - i);
-                pos++;
-            }
-            out[c] = unzigzag(u);
+    const uint32_t w = pos >> 5;
+    return (((uint64_t)words[w + 1] << 32) | words[w]) >> (pos & 31); // >= 33 valid bits
+}
+
+// first zero bit at or after pos, capped at `limit` (a multiple of 32 inside the zero padding)
+__device__ __forceinline__ uint32_t next_zero(const uint32_t* words, uint32_t pos, uint32_t limit)
+{
+    for (;;) {
+        const uint32_t lo = (uint32_t)bit_window(words, pos);
+        if (lo != 0xFFFFFFFFu)
+            return pos + (uint32_t)__builtin_ctz(~lo);
+        pos += 32;
+        if (pos >= limit)
+            return limit;
+    }
+}
+
+constexpr int kMaxStates = SELA_MAX_RICE_PARAM + 2; // R_0..R_k, M with k <= 19 (header values >= 20 are rejected)
+
+__device__ inline void rice_decode_wave(const uint32_t* words, uint32_t nwords, uint32_t n, uint32_t k, int32_t* out,
+    uint32_t* maps /* 64 * kMaxStates words of LDS scratch */, int lane, uint32_t& flags)
+{
+    if (n == 0)
+        return;
+    const uint32_t chunk_words = (nwords + 63) / 64 ? (nwords + 63) / 64 : 1;
+    const uint32_t chunk_bits = chunk_words * 32;
+    const uint32_t limit = 64 * chunk_bits; // every lane's chunk lies below this; words are zero beyond nwords
+    const uint32_t c0 = (uint32_t)lane * chunk_bits, c1 = c0 + chunk_bits;
+    const uint32_t n_states = k + 2, state_m = k + 1;
+
+    // ---- phase 1: (exit state, starts) for every entry state ------------------------------------
+    {
+        uint32_t pos[kMaxStates], cnt[kMaxStates];
+        uint32_t active = 0; // bit e set while parse e is still inside the chunk
+#pragma unroll
+        for (int e = 0; e < kMaxStates; e++) {
+            pos[e] = c0 + (uint32_t)e; // R_e: the first codeword starts e bits in
+            cnt[e] = 0;
+            if ((uint32_t)e < n_states)
+                active |= 1u << e;
         }
-        if (overrun)
-            flags |= SELA_HIP_FLAG_RICE_OVERRUN;
+        {   // M: resynchronise after the first zero
+            const uint32_t z = next_zero(words, c0, limit);
+            uint32_t ex = 0xFFFFFFFFu;
+            if (z >= c1)
+                ex = state_m; // the run swallows the whole chunk
+            else
+                pos[0] = pos[0]; // (keeps the array in registers)
+#pragma unroll
+            for (int e = 0; e < kMaxStates; e++)
+                if ((uint32_t)e == state_m) {
+                    if (ex == state_m) {
+                        maps[lane * kMaxStates + e] = state_m; // exit M, 0 starts
+                        active &= ~(1u << e);
+                    } else {
+                        pos[e] = z + 1 + k;
+                    }
+                }
+        }
+        while (__any(active != 0)) {
+#pragma unroll
+            for (int e = 0; e < kMaxStates; e++) {
+                if (active & (1u << e)) {
+                    uint32_t p = pos[e];
+                    if (p >= c1) { // the next codeword starts in a later chunk: p - c1 bits into it
+                        maps[lane * kMaxStates + e] = (p - c1) | (cnt[e] << 8);
+                        active &= ~(1u << e);
+                    } else {
+                        const uint32_t z = next_zero(words, p, limit);
+                        cnt[e]++;
+                        if (z >= c1) { // its unary run crosses the boundary
+                            maps[lane * kMaxStates + e] = state_m | (cnt[e] << 8);
+                            active &= ~(1u << e);
+                        } else {
+                            pos[e] = z + 1 + k;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    wave_sync();
+
+    // ---- walk: compose the maps from the stream start --------------------------------------------------
+    uint32_t my_state = 0, my_first = 0;
+    {
+        uint32_t state = 0, first = 0; // R_0 at bit 0, value index 0
+        for (int l = 0; l < 64; l++) {
+            if (l == lane) {
+                my_state = state;
+                my_first = first;
+            }
+            const uint32_t m = maps[l * kMaxStates + state];
+            state = m & 0xFFu;
+            first += m >> 8;
+        }
+        if (first < n)
+            flags |= SELA_HIP_FLAG_RICE_OVERRUN; // the words hold fewer than n codewords
+    }
+    wave_sync(); // maps may alias `out`
+
+    // ---- phase 2: decode the codewords that start in this lane's chunk -------------------------------
+    {
+        uint32_t p;
+        if (my_state <= k) {
+            p = c0 + my_state;
+        } else {
+            const uint32_t z = next_zero(words, c0, limit);
+            p = z >= c1 ? c1 : z + 1 + k;
+        }
+        uint32_t idx = my_first;
+        const uint32_t kmask = k ? (0xFFFFFFFFu >> (32 - k)) : 0u;
+        while (p < c1 && idx < n) {
+            uint64_t win = bit_window(words, p);
+            uint32_t ones = 0;
+            while ((uint32_t)win == 0xFFFFFFFFu) { // long unary run
+                ones += 32;
+                if (p + ones >= limit)
+                    break;
+                win = bit_window(words, p + ones);
+            }
+            const uint32_t t = (uint32_t)win == 0xFFFFFFFFu ? 0u : (uint32_t)__builtin_ctz(~(uint32_t)win);
+            ones += t;
+            uint32_t field; // the k bits after the zero, in stream order
+            if (t + 1 + k <= 32)
+                field = (uint32_t)(win >> (t + 1)) & kmask;
+            else
+                field = (uint32_t)bit_window(words, p + ones + 1) & kmask;
+            const uint32_t rem = k ? (__brev(field) >> (32 - k)) : 0u; // MSB first (src/rice/rice_decoder.cpp:37-40)
+            const uint64_t u = (uint64_t)(uint32_t)(ones << k) | rem;  // uint32 shift as src/rice/rice_decoder.cpp:35
+            out[idx++] = unzigzag(u);
+            p += ones + 1 + k;
+        }
     }
     wave_sync();
 }
 
+// ---- synthesis filter ----------------------------------------------------------------------------------
 // lpc::SampleGenerator::generateSamples (src/lpc/sample_generator.cpp:11-30), in place over the
-// residues in LDS.  Transposed direct form: after sample s_i is known every tap p adds a[p+1]*s_i to
-// the partial sum that will be complete p+1 steps later:
-//     z_p <- z_{p+1} + a[p+1] * s_i ,        P_{i+1} = z_0
+// residues in LDS.  Transposed direct form: once sample s_i is known every tap position p adds
+// a[p+1]*s_i to the partial sum that completes p+1 steps later and the partial sums move down one
+// position:
+//     z_p <- z_{p+1} + a[p+1] * s_i ,        P_{i+1} = z_0 ,
 //     s_{i+1} = r_{i+1} - (int32)((2^34 - P_{i+1}) >> 35)
-// which reproduces both reference loops (warm-up: taps beyond the block start simply have not
-// received anything yet).  Lane L holds taps p = 2L (even) and 2L+1 (odd); 50 lanes cover order 100.
+// which reproduces both reference loops (during warm-up the higher positions simply have not
+// received anything yet).  Lane L owns positions P*L .. P*L+P-1 (P = 1 for order <= 64, else 2); the
+// one-position move between lanes is a DPP wave shift.  The recurrence itself (z_0 -> s_i) runs on
+// the scalar unit: s_i stays in an SGPR and feeds the multiply-adds as a scalar operand.
+//
+// 64x32-bit products in two instructions: a = ah*2^32 + al with al = (int32)a, so
+//     a*s mod 2^64 = al*s (v_mad_i64_i32, exact) + ((ah*s mod 2^32) << 32) (v_mad_u64_u32, low half)
+// and a position carries the pair (acc1, acc2) with z = acc1 + (acc2 << 32).
+template <int P>
 __device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int lane)
 {
-    const uint64_t a_odd = (2 * lane + 1 <= order) ? (uint64_t)a[2 * lane + 1] : 0;  // multiplies into z_{2L}
-    const uint64_t a_even = (2 * lane + 2 <= order) ? (uint64_t)a[2 * lane + 2] : 0; // multiplies into z_{2L+1}
-    uint64_t z_even = 0, z_odd = 0;
+    int32_t al[P];
+    uint32_t ah[P];
+#pragma unroll
+    for (int h = 0; h < P; h++) {
+        const int idx = P * lane + h + 1;
+        const int64_t av = idx <= order ? a[idx] : 0;
+        al[h] = (int32_t)(uint32_t)(uint64_t)av;
+        ah[h] = (uint32_t)((uint64_t)(av - (int64_t)al[h]) >> 32);
+    }
+    uint64_t acc1[P];
+    uint32_t acc2[P];
+#pragma unroll
+    for (int h = 0; h < P; h++)
+        acc1[h] = 0, acc2[h] = 0;
     const uint64_t half = (uint64_t)1 << (SELA_Q_SHIFT - 1);
+#pragma unroll 1
     for (int base = 0; base < kBlock; base += 64) {
         const int32_t r_chunk = rs[base + lane];
         int32_t s_chunk = 0;
-#pragma unroll 8
+#pragma unroll
         for (int m = 0; m < 64; m++) {
+            // scalar side: P_i sits in lane 0, position 0
+            const uint32_t p_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc1[0]);
+            const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(acc1[0] >> 32))
+                + (uint32_t)__builtin_amdgcn_readfirstlane((int)acc2[0]);
+            const uint64_t pv = ((uint64_t)p_hi << 32) | p_lo;
+            const int32_t pred = (int32_t)((int64_t)(half - pv) >> SELA_Q_SHIFT);
             const int32_t r_i = __builtin_amdgcn_readlane(r_chunk, m);
-            // lane 0: z_even == P_i
-            const int32_t pred = (int32_t)((int64_t)(half - z_even) >> SELA_Q_SHIFT);
-            const int32_t s_i = __builtin_amdgcn_readfirstlane((int32_t)((uint32_t)r_i - (uint32_t)pred));
-            s_chunk = lane == m ? s_i : s_chunk;
-            const uint64_t sx = (uint64_t)(int64_t)s_i;
-            const uint64_t from_next = wave_shl1((uint64_t)0, z_even); // z_{2L+2} (old)
-            z_even = z_odd + a_odd * sx;
-            z_odd = from_next + a_even * sx;
+            const int32_t s_i = (int32_t)((uint32_t)r_i - (uint32_t)pred);
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(s_chunk) : "s"(s_i), "n"(m));
+            // vector side: move every partial sum down one position and add this sample's products
+            const uint64_t in1 = wave_shl1_zero(acc1[0]);
+            const uint32_t in2 = wave_shl1_zero(acc2[0]);
+#pragma unroll
+            for (int h = 0; h < P; h++) {
+                const uint64_t up1 = h + 1 < P ? acc1[h + 1 < P ? h + 1 : h] : in1;
+                const uint32_t up2 = h + 1 < P ? acc2[h + 1 < P ? h + 1 : h] : in2;
+                acc1[h] = (uint64_t)((int64_t)up1 + (int64_t)al[h] * (int64_t)s_i);
+                acc2[h] = (uint32_t)((uint64_t)up2 + (uint64_t)ah[h] * (uint32_t)s_i);
+            }
         }
         rs[base + lane] = s_chunk;
     }
@@ -153,7 +299,7 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
         const uint32_t rw = (uint32_t)h2[1] | ((uint32_t)h2[2] << 8), n = (uint32_t)h2[3] | ((uint32_t)h2[4] << 8);
         const uint64_t next = p + 12 + 4 * ((uint64_t)cw + rw);
         const bool ok = next <= fbytes && channel < channels && order <= (uint32_t)kMaxOrder && n == (uint32_t)kBlock
-            && cw <= 2u * kCoefWordsCap && rw <= (uint32_t)kResWordsCap && ck < 32 && rk < 32 && type <= 1
+            && cw <= 2u * kCoefWordsCap && rw <= (uint32_t)kResWordsCap && ck < SELA_MAX_RICE_PARAM && rk < SELA_MAX_RICE_PARAM && type <= 1
             && (type == 0 || parent < channels);
         if (!ok) {
             flags |= SELA_HIP_FLAG_BAD_FRAME;
@@ -163,23 +309,29 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
             // stage the Rice words: coefficient words sit 3 bytes off alignment (funnel shift),
             // residue words are aligned again.
             const uint32_t* al = reinterpret_cast<const uint32_t*>(h + 4); // bytes 4..7 of the subframe
-            for (uint32_t i = lane; i < cw; i += 64)
-                wl->words[i] = (al[i] >> 24) | (al[i + 1] << 8);
+            for (uint32_t i = lane; i < 2u * kCoefWordsCap; i += 64)
+                wl->words[i] = i < cw ? (al[i] >> 24) | (al[i + 1] << 8) : 0u;
             const uint32_t* rwp = reinterpret_cast<const uint32_t*>(h2 + 5);
-            for (uint32_t i = lane; i < rw; i += 64)
-                wl->words[2 * kCoefWordsCap + i] = rwp[i];
+            const uint32_t rw_pad = ((rw + 63) / 64) * 64 + 4; // zero tail: chunks are word-aligned, windows read 1 word ahead
+            for (uint32_t i = lane; i < rw_pad; i += 64)
+                wl->words[2 * kCoefWordsCap + i] = i < rw ? rwp[i] : 0u;
             wave_sync();
 
             int32_t* dst = samples + (size_t)channel * kBlock;
-            rice_decode_serial(wl->words, cw, order, ck, wl->q, lane, flags);
-            rice_decode_serial(wl->words + 2 * kCoefWordsCap, rw, n, rk, dst, lane, flags);
+            // the parser-state maps of both Rice streams borrow the output buffer of this channel
+            uint32_t* maps = reinterpret_cast<uint32_t*>(dst);
+            rice_decode_wave(wl->words, cw, order, ck, wl->q, maps, lane, flags);
+            rice_decode_wave(wl->words + 2 * kCoefWordsCap, rw, n, rk, dst, maps, lane, flags);
 
             // dequantise (src/lpc/linear_predictor.cpp:16-28)
             for (uint32_t i = lane; i < order; i += 64)
                 wl->k[i] = order <= 1 ? 0.0 : dequant((int)i, wl->q[i], flags);
             wave_sync();
             step_up(wl->k, wl->t, wl->a, (int)order, lane, flags);
-            synthesize(dst, wl->a, (int)order, lane);
+            if (order <= 64)
+                synthesize<1>(dst, wl->a, (int)order, lane);
+            else
+                synthesize<2>(dst, wl->a, (int)order, lane);
             if (lane == 0)
                 sub_info[channel] = type | (parent << 8);
         }

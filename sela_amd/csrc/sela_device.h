@@ -56,6 +56,19 @@ __device__ __forceinline__ int wave_shl1(int fill, int v)
 {
     return __builtin_amdgcn_update_dpp(fill, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
+// lane l <- lane l+1 ; lane 63 receives 0 (bound_ctrl: no register has to be pre-set)
+__device__ __forceinline__ uint32_t wave_shl1_zero(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint64_t wave_shl1_zero(uint64_t x)
+{
+    return ((uint64_t)wave_shl1_zero((uint32_t)(x >> 32)) << 32) | wave_shl1_zero((uint32_t)x);
+}
+__device__ __forceinline__ double wave_shl1_zero(double v)
+{
+    return __builtin_bit_cast(double, wave_shl1_zero(__builtin_bit_cast(uint64_t, v)));
+}
 __device__ __forceinline__ double wave_shl1(double fill, double v)
 {
     const uint64_t f = __builtin_bit_cast(uint64_t, fill), x = __builtin_bit_cast(uint64_t, v);

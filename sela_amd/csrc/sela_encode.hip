@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
 #pragma unroll 1
         for (int i = 1; i < kMaxOrder; i++) {
             const double sa = wave_shl1(read_first_lane(g1b), g1a); // gen1[j+1], j = lane
-            const double sb = wave_shl1(0.0, g1b);                  // gen1[j+1], j = lane + 64
+            const double sb = wave_shl1_zero(g1b);                  // gen1[j+1], j = lane + 64
             g1a = sa + ki * g0a;
             g0a = sa * ki + g0a;
             g1b = sb + ki * g0b;
