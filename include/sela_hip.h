@@ -129,6 +129,12 @@ uint32_t sela_hip_index_frames(const uint8_t* frames, size_t frames_bytes, uint3
 void sela_hip_enable_kernel_timing(int enable);
 int sela_hip_kernel_times(float* ms_out, int capacity);
 
+/* Debug hook: while a non-NULL device buffer is set, the *_device calls of the calling thread run an
+ * instrumented build of the kernels that stores s_memtime deltas per phase: 16 uint64 per
+ * (frame, signal) for the encoder and per (frame, subframe) for the decoder.  Slower; never set
+ * in the timed path. */
+void sela_hip_debug_phase_buffer(uint64_t* d_cycles);
+
 /* ---- flag bits reported through d_status[0] / sela_hip_trace.flags --------------------------------- */
 #define SELA_HIP_FLAG_Q_RANGE 1u       /* quantised reflection coefficient outside [-64,63] (clamped) */
 #define SELA_HIP_FLAG_COEF_OVERFLOW 2u /* |2^35 * coefficient| >= 2^63 */

@@ -23,7 +23,7 @@ EXPORTS = [
     "sela_hip_signals_per_frame", "sela_hip_encode_workspace_bytes", "sela_hip_decode_workspace_bytes",
     "sela_hip_encode_bound_bytes", "sela_hip_encode_device", "sela_hip_decode_device",
     "sela_hip_encode", "sela_hip_decode", "sela_hip_index_frames",
-    "sela_hip_enable_kernel_timing", "sela_hip_kernel_times",
+    "sela_hip_enable_kernel_timing", "sela_hip_kernel_times", "sela_hip_debug_phase_buffer",
 ]
 
 
@@ -82,6 +82,8 @@ def lib() -> C.CDLL:
     L.sela_hip_enable_kernel_timing.restype = None
     L.sela_hip_kernel_times.argtypes = [C.POINTER(C.c_float), C.c_int]
     L.sela_hip_kernel_times.restype = C.c_int
+    L.sela_hip_debug_phase_buffer.argtypes = [C.c_void_p]
+    L.sela_hip_debug_phase_buffer.restype = None
     _LIB = L
     return L
 

@@ -15,9 +15,9 @@ namespace sela {
 size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
-    hipEvent_t* ev);
+    hipEvent_t* ev, uint64_t* d_phase_cycles);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, hipStream_t stream, hipEvent_t* ev);
+    int16_t* d_pcm_out, uint32_t* d_status, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles);
 size_t decode_lds_bytes(uint32_t channels, int n_waves);
 int decode_waves(uint32_t channels);
 } // namespace sela
@@ -93,6 +93,7 @@ struct KernelTiming {
     }
 };
 thread_local KernelTiming g_timing;
+thread_local uint64_t* g_phase_cycles = nullptr; // debug: per-block phase cycle counts (sela_hip_debug_phase_buffer)
 
 uint32_t flags_to_error(uint32_t flags)
 {
@@ -131,6 +132,8 @@ int sela_hip_init(int device)
 
 void sela_hip_shutdown(void) { g_ctx.release(); }
 
+void sela_hip_debug_phase_buffer(uint64_t* d_cycles) { g_phase_cycles = d_cycles; }
+
 void sela_hip_enable_kernel_timing(int enable) { g_timing.enabled = enable != 0; }
 
 int sela_hip_kernel_times(float* ms_out, int capacity)
@@ -168,7 +171,7 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 3 : 0;
     hipError_t e = sela::launch_encode(d_pcm, n_frames, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace,
-        d_trace, static_cast<hipStream_t>(stream), ev);
+        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles);
     if (e != hipSuccess)
         return fail_hip(e, "encode launch");
     return SELA_HIP_OK;
@@ -187,7 +190,7 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
         return fail(SELA_HIP_EINVAL, "d_frames must be 4-byte aligned");
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 1 : 0;
-    hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, static_cast<hipStream_t>(stream), ev);
+    hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, static_cast<hipStream_t>(stream), ev, g_phase_cycles);
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
     return SELA_HIP_OK;

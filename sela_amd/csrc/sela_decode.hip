@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t next_zero(const uint32_t* words, uint32_t po
 constexpr int kMaxStates = SELA_MAX_RICE_PARAM + 2; // R_0..R_k, M with k <= 19 (header values >= 20 are rejected)
 
 __device__ inline void rice_decode_wave(const uint32_t* words, uint32_t nwords, uint32_t n, uint32_t k, int32_t* out,
-    uint32_t* maps /* 64 * kMaxStates words of LDS scratch */, int lane, uint32_t& flags)
+    uint32_t* maps /* 64 * kMaxStates words of LDS scratch */, int lane, uint32_t& flags, long long* tm = nullptr)
 {
     if (n == 0)
         return;
@@ -81,50 +81,64 @@ __device__ inline void rice_decode_wave(const uint32_t* words, uint32_t nwords, 
     const uint32_t n_states = k + 2, state_m = k + 1;
 
     // ---- phase 1: (exit state, starts) for every entry state ------------------------------------
+    // An entry state is only possible if the bits in front of the chunk agree with it: R_m needs the
+    // terminating zero at bit c0-k-1+m, M needs a one at bit c0-1 -- about half of the parses are
+    // never started.  Each round first issues the LDS window reads of ALL live parses, then advances
+    // every parse by one codeword (or by 32 bits of a long unary run), so the read latencies overlap.
     {
         uint32_t pos[kMaxStates], cnt[kMaxStates];
-        uint32_t active = 0; // bit e set while parse e is still inside the chunk
-#pragma unroll
-        for (int e = 0; e < kMaxStates; e++) {
-            pos[e] = c0 + (uint32_t)e; // R_e: the first codeword starts e bits in
-            cnt[e] = 0;
-            if ((uint32_t)e < n_states)
-                active |= 1u << e;
-        }
-        {   // M: resynchronise after the first zero
-            const uint32_t z = next_zero(words, c0, limit);
-            uint32_t ex = 0xFFFFFFFFu;
-            if (z >= c1)
-                ex = state_m; // the run swallows the whole chunk
-            else
-                pos[0] = pos[0]; // (keeps the array in registers)
-#pragma unroll
-            for (int e = 0; e < kMaxStates; e++)
-                if ((uint32_t)e == state_m) {
-                    if (ex == state_m) {
-                        maps[lane * kMaxStates + e] = state_m; // exit M, 0 starts
-                        active &= ~(1u << e);
-                    } else {
-                        pos[e] = z + 1 + k;
-                    }
-                }
-        }
-        while (__any(active != 0)) {
+        uint32_t active = 0; // bit e: parse e still inside the chunk
+        uint32_t fresh = 0;  // bit e: pos[e] is the first bit of a codeword (else: inside a unary run)
+        {
+            uint32_t feasible;
+            if (c0 == 0) {
+                feasible = 1u; // the stream starts with a codeword
+            } else {
+                const uint32_t pre = (uint32_t)bit_window(words, c0 - k - 1); // bit m = stream bit c0-k-1+m
+                feasible = ~pre & ((1u << (k + 1)) - 1u);
+                if ((pre >> k) & 1u)
+                    feasible |= 1u << state_m;
+            }
 #pragma unroll
             for (int e = 0; e < kMaxStates; e++) {
-                if (active & (1u << e)) {
-                    uint32_t p = pos[e];
-                    if (p >= c1) { // the next codeword starts in a later chunk: p - c1 bits into it
-                        maps[lane * kMaxStates + e] = (p - c1) | (cnt[e] << 8);
+                pos[e] = (uint32_t)e == state_m ? c0 : c0 + (uint32_t)e;
+                cnt[e] = 0;
+                if ((uint32_t)e < n_states)
+                    maps[lane * kMaxStates + e] = 0;
+            }
+            active = feasible;
+            fresh = feasible & ~(1u << state_m);
+        }
+        while (__any(active != 0)) {
+            uint64_t win[kMaxStates];
+#pragma unroll
+            for (int e = 0; e < kMaxStates; e++)
+                if ((uint32_t)e < n_states && (active & (1u << e)))
+                    win[e] = bit_window(words, pos[e] < limit ? pos[e] : limit);
+#pragma unroll
+            for (int e = 0; e < kMaxStates; e++) {
+                if ((uint32_t)e < n_states && (active & (1u << e))) {
+                    const uint32_t p = pos[e];
+                    const bool is_fresh = (fresh >> e) & 1u;
+                    if (p >= c1) { // next codeword starts p - c1 bits into a later chunk / the run goes on
+                        maps[lane * kMaxStates + e] = (is_fresh ? p - c1 : state_m) | (cnt[e] << 8);
                         active &= ~(1u << e);
                     } else {
-                        const uint32_t z = next_zero(words, p, limit);
-                        cnt[e]++;
-                        if (z >= c1) { // its unary run crosses the boundary
-                            maps[lane * kMaxStates + e] = state_m | (cnt[e] << 8);
-                            active &= ~(1u << e);
+                        if (is_fresh)
+                            cnt[e]++;
+                        const uint32_t lo = (uint32_t)win[e];
+                        if (lo == 0xFFFFFFFFu) { // 32 more ones
+                            pos[e] = p + 32;
+                            fresh &= ~(1u << e);
                         } else {
-                            pos[e] = z + 1 + k;
+                            const uint32_t z = p + (uint32_t)__builtin_ctz(~lo);
+                            if (z >= c1) { // the terminating zero belongs to a later chunk
+                                maps[lane * kMaxStates + e] = state_m | (cnt[e] << 8);
+                                active &= ~(1u << e);
+                            } else {
+                                pos[e] = z + 1 + k;
+                                fresh |= 1u << e;
+                            }
                         }
                     }
                 }
@@ -132,6 +146,8 @@ __device__ inline void rice_decode_wave(const uint32_t* words, uint32_t nwords, 
         }
     }
     wave_sync();
+    if (tm)
+        tm[0] = clock64();
 
     // ---- walk: compose the maps from the stream start --------------------------------------------------
     uint32_t my_state = 0, my_first = 0;
@@ -150,6 +166,8 @@ __device__ inline void rice_decode_wave(const uint32_t* words, uint32_t nwords, 
             flags |= SELA_HIP_FLAG_RICE_OVERRUN; // the words hold fewer than n codewords
     }
     wave_sync(); // maps may alias `out`
+    if (tm)
+        tm[1] = clock64();
 
     // ---- phase 2: decode the codewords that start in this lane's chunk -------------------------------
     {
@@ -251,10 +269,18 @@ __device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int 
     wave_sync();
 }
 
+// kProf: also write per-phase cycle counts (debug hook sela_hip_debug_phase_buffer; 16 uint64 per subframe).
+template <bool kProf>
 __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* __restrict__ pcm_out,
-    uint32_t* __restrict__ status)
+    uint32_t* __restrict__ status, uint64_t* __restrict__ phase_cycles)
 {
+    long long stamp[8], tm[2] = { 0, 0 };
+    for (int i = 0; i < 8; i++)
+        stamp[i] = 0;
+    uint32_t prof_sub = 0xFFFFFFFFu;
+    if (kProf)
+        stamp[0] = clock64();
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     // [channels][2048] int32 samples, then one DecodeWaveLds per wave, then per-channel type/parent
     int32_t* const samples = reinterpret_cast<int32_t*>(dyn);
@@ -316,28 +342,40 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
             for (uint32_t i = lane; i < rw_pad; i += 64)
                 wl->words[2 * kCoefWordsCap + i] = i < rw ? rwp[i] : 0u;
             wave_sync();
+            if (kProf)
+                stamp[1] = clock64(), prof_sub = c;
 
             int32_t* dst = samples + (size_t)channel * kBlock;
             // the parser-state maps of both Rice streams borrow the output buffer of this channel
             uint32_t* maps = reinterpret_cast<uint32_t*>(dst);
             rice_decode_wave(wl->words, cw, order, ck, wl->q, maps, lane, flags);
-            rice_decode_wave(wl->words + 2 * kCoefWordsCap, rw, n, rk, dst, maps, lane, flags);
+            if (kProf)
+                stamp[2] = clock64();
+            rice_decode_wave(wl->words + 2 * kCoefWordsCap, rw, n, rk, dst, maps, lane, flags, kProf ? tm : nullptr);
+            if (kProf)
+                stamp[3] = clock64();
 
             // dequantise (src/lpc/linear_predictor.cpp:16-28)
             for (uint32_t i = lane; i < order; i += 64)
                 wl->k[i] = order <= 1 ? 0.0 : dequant((int)i, wl->q[i], flags);
             wave_sync();
             step_up(wl->k, wl->t, wl->a, (int)order, lane, flags);
+            if (kProf)
+                stamp[4] = clock64();
             if (order <= 64)
                 synthesize<1>(dst, wl->a, (int)order, lane);
             else
                 synthesize<2>(dst, wl->a, (int)order, lane);
+            if (kProf)
+                stamp[5] = clock64();
             if (lane == 0)
                 sub_info[channel] = type | (parent << 8);
         }
         p = next;
     }
     __syncthreads();
+    if (kProf)
+        stamp[6] = clock64();
 
     // ---- second pass of frame::FrameDecoder + interleave to int16 ------------------------------------
     // dependent channels become parent - difference (parents are independent subframes).
@@ -369,6 +407,15 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
         if (wave == 0 && (flags & SELA_HIP_FLAG_BAD_FRAME))
             atomicAdd(&status[1], 1u);
     }
+    if (kProf && lane == 0 && prof_sub != 0xFFFFFFFFu) { // (one subframe per wave is reported)
+        stamp[7] = clock64();
+        for (int i = 0; i < 7; i++)
+            phase_cycles[((size_t)f * channels + prof_sub) * 16 + i] = (uint64_t)(stamp[i + 1] - stamp[i]);
+        // residue Rice parse split: phase 1 / walk / phase 2
+        phase_cycles[((size_t)f * channels + prof_sub) * 16 + 8] = (uint64_t)(tm[0] - stamp[2]);
+        phase_cycles[((size_t)f * channels + prof_sub) * 16 + 9] = (uint64_t)(tm[1] - tm[0]);
+        phase_cycles[((size_t)f * channels + prof_sub) * 16 + 10] = (uint64_t)(stamp[3] - tm[1]);
+    }
 }
 
 size_t decode_lds_bytes(uint32_t channels, int n_waves)
@@ -382,7 +429,7 @@ int decode_waves(uint32_t channels)
 }
 
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, hipStream_t stream, hipEvent_t* ev /* 2 events or nullptr */)
+    int16_t* d_pcm_out, uint32_t* d_status, hipStream_t stream, hipEvent_t* ev /* 2 events or nullptr */, uint64_t* d_phase_cycles)
 {
     hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
     if (err != hipSuccess || n_frames == 0)
@@ -391,13 +438,19 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
     const size_t lds = decode_lds_bytes(channels, n_waves);
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess)
         return err;
     if (ev)
         (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL(k_decode_frames, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames,
-        channels, d_pcm_out, d_status);
+    if (d_phase_cycles)
+        hipLaunchKernelGGL(k_decode_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames,
+            channels, d_pcm_out, d_status, d_phase_cycles);
+    else
+        hipLaunchKernelGGL(k_decode_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames,
+            channels, d_pcm_out, d_status, d_phase_cycles);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     return hipGetLastError();

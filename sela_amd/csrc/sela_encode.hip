@@ -107,11 +107,22 @@ __device__ __forceinline__ void rice_plan(const uint32_t (&u)[V], uint32_t n, ui
     }
 }
 
-template <bool kTrace>
+// kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts
+// (debug hook sela_hip_debug_phase_buffer; 16 uint64 per block).
+#define SELA_STAMP(n)                 \
+    do {                              \
+        if (kMode == 2)               \
+            stamp[n] = clock64();     \
+    } while (0)
+
+template <int kMode>
 __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
-    sela_hip_trace* __restrict__ trace)
+    sela_hip_trace* __restrict__ trace, uint64_t* __restrict__ phase_cycles)
 {
+    constexpr bool kTrace = kMode == 1;
+    long long stamp[14];
+    SELA_STAMP(0);
     __shared__ __attribute__((aligned(16))) unsigned char big[kBigBytes];
     __shared__ uint32_t cw_buf[kCoefWordsCap];
 
@@ -168,6 +179,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
         mine[half + 32 * t] = (double)s[t] / SELA_SAMPLE_SCALE;
     wave_sync();
 
+    SELA_STAMP(1);
     // ---- mean (src/lpc/residue_generator.cpp:27-30): one strictly sequential sum -----------------
     // Every lane walks the same chain from broadcast LDS reads, so the result is wave-uniform.
     double sum = 0.0;
@@ -178,12 +190,14 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     }
     const double mean = sum / (double)kBlock;
 
+    SELA_STAMP(2);
     // c[j] = x[j] - mean, in place (same value at every use)
 #pragma unroll
     for (int t = 0; t < kPerLane; t++)
         mine[half + 32 * t] = mine[half + 32 * t] - mean;
     wave_sync();
 
+    SELA_STAMP(3);
     // ---- autocorrelation (src/lpc/residue_generator.cpp:33-38) -------------------------------------
     // Lane L owns lags 2L and 2L+1 (lanes 0..50 matter).  At step j it needs
     //     A = c[j - 2L]      (lag 2L)       B = c[j - 2L - 1]   (lag 2L+1)
@@ -215,6 +229,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     }
     wave_sync(); // c[] is dead from here on
 
+    SELA_STAMP(4);
     // normalise (src/lpc/residue_generator.cpp:41-44)
     {
         const double ac0 = read_first_lane(acc_e);
@@ -256,6 +271,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
         }
     }
 
+    SELA_STAMP(5);
     // ---- order (src/lpc/residue_generator.cpp:70-78): 1 + last i with |k[i]| > 0.05 ----------------
     int order;
     {
@@ -300,6 +316,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     }
     wave_sync();
 
+    SELA_STAMP(6);
     // ---- step-up to the Q35 predictor (src/lpc/linear_predictor.cpp:30-61) ---------------------------
     step_up(sm->k, sm->t, sm->a, order, lane, flags);
     if (kTrace) {
@@ -310,6 +327,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
             tr->q[i] = sm->q[i];
     }
 
+    SELA_STAMP(7);
     // ---- residues (src/lpc/residue_generator.cpp:98-119) -----------------------------------------------
     // r[i] = s[i] - (int32)((2^34 + sum_{j=1..order} a[j] s[i-j]) >> 35), samples before the block
     // count as absent.  Integer wrap-around arithmetic is associative, so the taps are accumulated
@@ -354,6 +372,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     }
     wave_sync(); // sbuf is dead
 
+    SELA_STAMP(8);
     // ---- Rice parameters -----------------------------------------------------------------------------
     // coefficients: value i of q[] sits in lane i / 2 slot i % 2 (lane-contiguous for packing)
     uint32_t cu[2];
@@ -382,6 +401,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
         res_words = 0;
     }
 
+    SELA_STAMP(9);
     // ---- pack the coefficient stream (<= 100 values) ----------------------------------------------
     if (lane < kCoefWordsCap)
         cw_buf[lane] = 0;
@@ -396,6 +416,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
             pos = put_codeword(cw_buf, pos, cu[1], coef_k);
     }
 
+    SELA_STAMP(10);
     // ---- pack the residue stream ----------------------------------------------------------------------
     // Transpose through LDS so that lane l owns the 32 consecutive residues 32l .. 32l+31 (index
     // i stored at i + i/32: both sides conflict-free), scan the per-lane bit counts, then every lane
@@ -426,6 +447,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     }
     wave_sync();
 
+    SELA_STAMP(11);
     // ---- slot + meta -------------------------------------------------------------------------------------
     uint32_t* slot = slots + (size_t)block_id * kSlotWords;
     if (lane < (int)coef_words && lane < kCoefWordsCap)
@@ -454,6 +476,10 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
             tr->flags = all_flags;
         }
     }
+    SELA_STAMP(12);
+    if (kMode == 2 && lane == 0)
+        for (int i = 0; i < 12; i++)
+            phase_cycles[(size_t)block_id * 16 + i] = (uint64_t)(stamp[i + 1] - stamp[i]);
 }
 
 // ---- plan: stereo decision + frame sizes + exclusive scan (one workgroup of 1024) -------------------
@@ -593,7 +619,7 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
 
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames,
     size_t frames_cap, uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace,
-    hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */)
+    hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles)
 {
     const uint32_t n_sig = sela_hip_signals_per_frame(channels);
     const size_t blocks = (size_t)n_frames * n_sig;
@@ -615,10 +641,12 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     const dim3 grid(groups * 8 * n_sig), wg(64);
     if (ev)
         (void)hipEventRecord(ev[0], stream);
-    if (d_trace)
-        hipLaunchKernelGGL(k_encode_blocks<true>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace);
+    if (d_phase_cycles)
+        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, d_phase_cycles);
+    else if (d_trace)
+        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, d_phase_cycles);
     else
-        hipLaunchKernelGGL(k_encode_blocks<false>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace);
+        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, d_phase_cycles);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap,

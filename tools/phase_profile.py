@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the encode/decode kernels on the bench workload (debug hook).
+
+    python tools/phase_profile.py [n_frames]
+
+Prints the mean s_memtime cycles each phase takes per block (encoder: per (frame, signal);
+decoder: per subframe).  Quoted in DESIGN.md; not part of the timed path.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sela_amd import capi, codec  # noqa: E402
+from sela_amd.synth import synth_frames  # noqa: E402
+
+ENC = ["load+x/32767", "mean chain", "centre", "autocorr", "normalise+Schur", "order/quant/dequant", "step-up",
+       "FIR residues", "Rice k search", "pack coefs", "transpose+pack residues", "store slot/meta"]
+DEC = ["header walk+stage", "Rice coefs", "Rice residues", "dequant+step-up", "synthesis", "wait barrier", "combine+store"]
+
+
+def main():
+    n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3875
+    lib = capi.lib()
+    pcm = torch.from_numpy(synth_frames(n_frames, 2, 0)).cuda()
+    enc, dec = codec.Encoder(n_frames, 2), codec.Decoder(n_frames, 2)
+    out = enc.encode(pcm)
+    torch.cuda.synchronize()
+    buf = torch.zeros(n_frames * 3 * 16, dtype=torch.int64, device="cuda")
+    lib.sela_hip_debug_phase_buffer(buf.data_ptr())
+    enc.encode(pcm)
+    torch.cuda.synchronize()
+    e = buf.cpu().numpy().reshape(-1, 16)[:, :12].astype(np.float64)
+    buf.zero_()
+    dec.decode(out.frames, out.offsets, n_frames)
+    torch.cuda.synchronize()
+    lib.sela_hip_debug_phase_buffer(None)
+    dd = buf.cpu().numpy().reshape(-1, 16)[: n_frames * 2].astype(np.float64)
+    d = dd[:, :7]
+    print(f"encoder, mean cycles per (frame, signal) block over {len(e)} blocks (total {e.sum(1).mean():.0f}):")
+    for name, v in zip(ENC, e.mean(0)):
+        print(f"  {name:28s} {v:10.0f}  {100 * v / e.sum(1).mean():5.1f}%")
+    print(f"decoder, mean cycles per subframe over {len(d)} subframes (total {d.sum(1).mean():.0f}):")
+    for name, v in zip(DEC, d.mean(0)):
+        print(f"  {name:28s} {v:10.0f}  {100 * v / d.sum(1).mean():5.1f}%")
+    print("  residue Rice split: phase1 %.0f  walk %.0f  phase2 %.0f" % tuple(dd[:, 8:11].mean(0)))
+
+
+if __name__ == "__main__":
+    main()
