@@ -144,11 +144,11 @@ def main():
         o2 = enc.encode(pcm)
         k_enc.append(capi.kernel_times(3))
         dec.decode(o2.frames, o2.offsets, n_frames)
-        k_dec.append(capi.kernel_times(1))
+        k_dec.append(capi.kernel_times(2))
     lib.sela_hip_enable_kernel_timing(0)
     torch.cuda.synchronize()
     k_enc = np.array(k_enc)  # [reps, 3] ms: blocks, plan, assemble
-    k_dec = np.array(k_dec)  # [reps, 1] ms
+    k_dec = np.array(k_dec)  # [reps, 2] ms: parse, synthesize
     enc_blocks_ms = float(k_enc[:, 0].mean())
     pcm_bytes = pcm_host.nbytes
     algo_bytes = pcm_bytes + payload_bytes  # PCM16 read + .sela frame bytes written
@@ -181,7 +181,8 @@ def main():
             "encode_msps_kernels": samples / (enc_ms * 1e-3) / 1e6,
             "decode_msps_kernels": samples / (dec_ms * 1e-3) / 1e6,
             "kernel_ms": {"encode_blocks": enc_blocks_ms, "encode_plan": float(k_enc[:, 1].mean()),
-                          "encode_assemble": float(k_enc[:, 2].mean()), "decode_frames": float(k_dec[:, 0].mean())},
+                          "encode_assemble": float(k_enc[:, 2].mean()), "decode_parse": float(k_dec[:, 0].mean()),
+                          "decode_synthesize": float(k_dec[:, 1].mean())},
             "roofline": {
                 "kernel": "k_encode_blocks", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -103,7 +103,8 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
 /*
  * Decode n_frames frames.  d_frames / d_frame_offsets as produced above (or by parsing a .sela
  * file).  d_pcm_out: int16 [n_frames][2048][channels].  d_status: uint32[4], [0] = OR of flag
- * bits, [1] = number of malformed frames.
+ * bits, [1] = number of malformed frames.  Launches 2 kernels on `stream`; d_workspace holds the parsed
+ * residues between them (sela_hip_decode_workspace_bytes()).
  */
 int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames,
     uint32_t channels, int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, size_t workspace_bytes,
@@ -124,7 +125,7 @@ uint32_t sela_hip_index_frames(const uint8_t* frames, size_t frames_bytes, uint3
 /* ---- per-kernel timing (measurement hook used by bench.py) ------------------------------------------
  * When enabled, the *_device calls of the calling thread bracket each kernel launch with HIP events
  * recorded on the caller's stream.  sela_hip_kernel_times() waits for the events of the most recent
- * encode (3 kernels: blocks, plan, assemble) or decode (1 kernel) call and returns their durations
+ * encode (3 kernels: blocks, plan, assemble) or decode (2 kernels: parse, synthesize) call and returns their durations
  * in milliseconds; it returns the number of kernels reported (0 if timing was off). */
 void sela_hip_enable_kernel_timing(int enable);
 int sela_hip_kernel_times(float* ms_out, int capacity);

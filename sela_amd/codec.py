@@ -89,6 +89,8 @@ class Decoder:
         with torch.cuda.device(self.device):
             self.pcm = torch.empty((max_frames, BLOCK, channels), dtype=torch.int16, device=self.device)
             self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
+            ws = int(self.lib.sela_hip_decode_workspace_bytes(max_frames, channels))
+            self.workspace = torch.empty(ws, dtype=torch.uint8, device=self.device)
 
     def decode(self, frames, offsets, n_frames: int):
         """frames: uint8 cuda tensor, offsets: int64 cuda tensor [n_frames+1].  Asynchronous."""
@@ -97,7 +99,7 @@ class Decoder:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         capi.check(self.lib.sela_hip_decode_device(
             frames.data_ptr(), offsets.data_ptr(), n_frames, self.channels, self.pcm.data_ptr(), self.status.data_ptr(),
-            None, 0, stream))
+            self.workspace.data_ptr(), self.workspace.numel(), stream))
         return self.pcm[:n_frames]
 
     def check(self) -> None:

@@ -17,7 +17,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
     hipEvent_t* ev, uint64_t* d_phase_cycles);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles);
+    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles);
+size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 size_t decode_lds_bytes(uint32_t channels, int n_waves);
 int decode_waves(uint32_t channels);
 } // namespace sela
@@ -150,7 +151,7 @@ uint32_t sela_hip_signals_per_frame(uint32_t channels) { return channels == 2 ? 
 
 size_t sela_hip_encode_workspace_bytes(uint32_t n_frames, uint32_t channels) { return sela::encode_workspace_bytes(n_frames, channels); }
 
-size_t sela_hip_decode_workspace_bytes(uint32_t, uint32_t) { return 0; }
+size_t sela_hip_decode_workspace_bytes(uint32_t n_frames, uint32_t channels) { return sela::decode_workspace_bytes(n_frames, channels); }
 
 size_t sela_hip_encode_bound_bytes(uint32_t n_frames, uint32_t channels)
 {
@@ -178,19 +179,22 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
 }
 
 int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, void*, size_t, void* stream)
+    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream)
 {
     if (channels == 0 || channels > 255)
         return fail(SELA_HIP_EINVAL, "channels must be in 1..255");
     if (sela::decode_lds_bytes(channels, sela::decode_waves(channels)) > 160 * 1024)
         return fail(SELA_HIP_EINVAL, "too many channels for the on-chip decoder (LDS budget)");
-    if (!d_status || (n_frames && (!d_frames || !d_frame_offsets || !d_pcm_out)))
+    if (!d_status || (n_frames && (!d_frames || !d_frame_offsets || !d_pcm_out || !d_workspace)))
         return fail(SELA_HIP_EINVAL, "null device pointer");
     if ((uintptr_t)d_frames & 3)
         return fail(SELA_HIP_EINVAL, "d_frames must be 4-byte aligned");
+    if (workspace_bytes < sela::decode_workspace_bytes(n_frames, channels))
+        return fail(SELA_HIP_ECAPACITY, "workspace smaller than sela_hip_decode_workspace_bytes()");
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
-    g_timing.recorded = ev ? 1 : 0;
-    hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, static_cast<hipStream_t>(stream), ev, g_phase_cycles);
+    g_timing.recorded = ev ? 2 : 0;
+    hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, d_workspace,
+        static_cast<hipStream_t>(stream), ev, g_phase_cycles);
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
     return SELA_HIP_OK;
@@ -255,13 +259,15 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
     const size_t pcm_bytes = (size_t)n_frames * sela::kBlock * channels * sizeof(int16_t);
     hipError_t e;
     if ((e = g_ctx.pcm.reserve(pcm_bytes + 4)) != hipSuccess || (e = g_ctx.frames.reserve(total + 8)) != hipSuccess
-        || (e = g_ctx.offsets.reserve(((size_t)n_frames + 1) * 8)) != hipSuccess || (e = g_ctx.status.reserve(16)) != hipSuccess)
+        || (e = g_ctx.offsets.reserve(((size_t)n_frames + 1) * 8)) != hipSuccess || (e = g_ctx.status.reserve(16)) != hipSuccess
+        || (e = g_ctx.workspace.reserve(sela::decode_workspace_bytes(n_frames, channels))) != hipSuccess)
         return fail_hip(e, "hipMalloc");
     if ((e = hipMemcpyAsync(g_ctx.frames.ptr, frames, total, hipMemcpyHostToDevice, nullptr)) != hipSuccess
         || (e = hipMemcpyAsync(g_ctx.offsets.ptr, frame_offsets, ((size_t)n_frames + 1) * 8, hipMemcpyHostToDevice, nullptr)) != hipSuccess)
         return fail_hip(e, "H2D frames");
     rc = sela_hip_decode_device(static_cast<const uint8_t*>(g_ctx.frames.ptr), static_cast<const uint64_t*>(g_ctx.offsets.ptr), n_frames,
-        channels, static_cast<int16_t*>(g_ctx.pcm.ptr), static_cast<uint32_t*>(g_ctx.status.ptr), nullptr, 0, nullptr);
+        channels, static_cast<int16_t*>(g_ctx.pcm.ptr), static_cast<uint32_t*>(g_ctx.status.ptr), g_ctx.workspace.ptr, g_ctx.workspace.cap,
+        nullptr);
     if (rc != SELA_HIP_OK)
         return rc;
     uint32_t status[4];

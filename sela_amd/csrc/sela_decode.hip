@@ -1,208 +1,185 @@
-// sela_decode.hip -- MI355X (gfx950) decoder kernel of the SELA frame path.
+// sela_decode.hip -- MI355X (gfx950) decoder kernels of the SELA frame path.
 //
-//   k_decode_frames   one WORKGROUP per frame, one WAVE per subframe (channel):
-//       parse the subframe header               (layout of src/file/sela_file.cpp:58-91)
-//       rice::RiceDecoder x2                    (src/rice/rice_decoder.cpp:11-61)
+// Two launches on one stream:
+//
+//   k_parse_subframes      one LANE per subframe (64 independent bitstreams per wave).
+//       rice::RiceDecoder x2 (src/rice/rice_decoder.cpp:11-61) is a serial bit parse -- where
+//       codeword i+1 starts depends on codeword i -- so the parallelism used is ACROSS streams:
+//       every lane walks to its subframe header (layout of src/file/sela_file.cpp:58-91), then
+//       parses its coefficient stream and its 2048-value residue stream out of a 64-bit register
+//       bit window.  Residues / quantised coefficients / a descriptor go to a per-subframe slot in
+//       the workspace (HBM; L2/MALL-resident at these sizes).
+//   k_synthesize_frames    one WORKGROUP per frame, one WAVE per subframe:
 //       dequantise + step-up                    (src/lpc/linear_predictor.cpp:16-61)
 //       lpc::SampleGenerator::generateSamples   (src/lpc/sample_generator.cpp:11-30)
 //     then, after a workgroup barrier, frame::FrameDecoder's second pass
 //       out[ch] = parent - difference           (src/frame/frame_decoder.cpp:40-69)
-//     and the int16 interleave of               (src/file/wav_file.cpp:244-257)
-//     written coalesced to HBM.
+//     and the int16 interleave of               (src/file/wav_file.cpp:244-257), stored coalesced.
 //
 // The synthesis filter is a true serial recurrence (every sample is rounded before it feeds the
-// next one), so the wave runs it as a transposed-form systolic array: lane L carries the partial
-// sums of taps 2L+1 and 2L+2, the new sample is broadcast from lane 0, and the partial sums move one
-// tap per step with a single DPP shift -- integer wrap-around arithmetic, any evaluation order exact.
+// next one), so a wave runs it as a transposed-form systolic array: the lanes carry the partial
+// sums of the taps, the new sample is computed on the scalar unit and broadcast as an SGPR operand,
+// and the partial sums move one tap per step with a DPP wave shift -- integer wrap-around
+// arithmetic, exact under any evaluation order.
 #include "sela_device.h"
 
 namespace sela {
 
 constexpr int kDecMaxWaves = 8;
-constexpr int kStageWords = kCoefWordsCap * 2 + kResWordsCap + 72; // + zero tail for the chunked parser // staged Rice words of one subframe
+constexpr int kQStride = 128; // int32 slots per subframe for the quantised coefficients
 
-struct DecodeWaveLds {
-    uint32_t words[kStageWords]; // [0,64) coefficient words, [64, ...) residue words
-    double k[104];
-    double t[104];
-    int64_t a[104];
-    int32_t q[256];
+// per-subframe record written by k_parse_subframes
+struct SubDesc {
+    uint32_t info;  // channel | type << 8 | parent << 16 | order << 24
+    uint32_t flags; // SELA_HIP_FLAG_* bits; BAD_FRAME means "do not synthesise"
 };
 
-// ---- wave-parallel Golomb-Rice decoder ---------------------------------------------------------
-// rice::RiceDecoder::generateDecodedUnsignedInts (src/rice/rice_decoder.cpp:21-44) is a serial bit
-// parse: where codeword i+1 starts depends on codeword i.  The wave cuts the stream into 64
-// word-aligned chunks (one per lane) and resolves the dependency with a scan over *parser states*:
-//
-//   state at a chunk boundary:  R_m (m = 0..k)  "m more remainder bits to skip, then a codeword
-//                                                starts"  (R_0 = a codeword starts right here)
-//                               M   (= k+1)     "inside a unary run: skip to the first zero, skip
-//                                                k remainder bits, then a codeword starts"
-//   phase 1  every lane parses its chunk once for EVERY entry state (k+2 parses in lockstep, all
-//            independent -> the LDS latency of one hides behind the others) and records
-//            map[entry] = (exit state, number of codewords that START in the chunk)
-//   walk     the 64 maps are composed from lane 0 (entry R_0, value index 0): 64 dependent LDS
-//            reads give every lane its true entry state and the index of its first codeword
-//   phase 2  every lane decodes the codewords that start in its chunk (the last one may run past
-//            the chunk end) straight to their final positions.
-//
-// Bit t of the stream is bit t%32 of word t/32 (LSB first); the k remainder bits are MSB first,
-// i.e. bit-reversed in stream order.  `words` must be readable (zero) for 3 words past its end.
-__device__ __forceinline__ uint64_t bit_window(const uint32_t* words, uint32_t pos)
-{
-    const uint32_t w = pos >> 5;
-    return (((uint64_t)words[w + 1] << 32) | words[w]) >> (pos & 31); // >= 33 valid bits
-}
+// ---- per-lane bit reader over 32-bit words (stream bit t = bit t%32 of word t/32) -------------------
+struct BitReader {
+    const uint32_t* next; // next word to fetch
+    const uint32_t* end;  // one past the last word of the stream
+    uint64_t buf;         // bit 0 = next stream bit
+    uint32_t avail;       // valid bits in buf
+    uint32_t starved;     // number of words fetched past `end` (they read as zero)
 
-// first zero bit at or after pos, capped at `limit` (a multiple of 32 inside the zero padding)
-__device__ __forceinline__ uint32_t next_zero(const uint32_t* words, uint32_t pos, uint32_t limit)
-{
-    for (;;) {
-        const uint32_t lo = (uint32_t)bit_window(words, pos);
-        if (lo != 0xFFFFFFFFu)
-            return pos + (uint32_t)__builtin_ctz(~lo);
-        pos += 32;
-        if (pos >= limit)
-            return limit;
-    }
-}
-
-constexpr int kMaxStates = SELA_MAX_RICE_PARAM + 2; // R_0..R_k, M with k <= 19 (header values >= 20 are rejected)
-
-__device__ inline void rice_decode_wave(const uint32_t* words, uint32_t nwords, uint32_t n, uint32_t k, int32_t* out,
-    uint32_t* maps /* 64 * kMaxStates words of LDS scratch */, int lane, uint32_t& flags, long long* tm = nullptr)
-{
-    if (n == 0)
-        return;
-    const uint32_t chunk_words = (nwords + 63) / 64 ? (nwords + 63) / 64 : 1;
-    const uint32_t chunk_bits = chunk_words * 32;
-    const uint32_t limit = 64 * chunk_bits; // every lane's chunk lies below this; words are zero beyond nwords
-    const uint32_t c0 = (uint32_t)lane * chunk_bits, c1 = c0 + chunk_bits;
-    const uint32_t n_states = k + 2, state_m = k + 1;
-
-    // ---- phase 1: (exit state, starts) for every entry state ------------------------------------
-    // An entry state is only possible if the bits in front of the chunk agree with it: R_m needs the
-    // terminating zero at bit c0-k-1+m, M needs a one at bit c0-1 -- about half of the parses are
-    // never started.  Each round first issues the LDS window reads of ALL live parses, then advances
-    // every parse by one codeword (or by 32 bits of a long unary run), so the read latencies overlap.
+    __device__ __forceinline__ void init(const uint32_t* begin, const uint32_t* stop)
     {
-        uint32_t pos[kMaxStates], cnt[kMaxStates];
-        uint32_t active = 0; // bit e: parse e still inside the chunk
-        uint32_t fresh = 0;  // bit e: pos[e] is the first bit of a codeword (else: inside a unary run)
-        {
-            uint32_t feasible;
-            if (c0 == 0) {
-                feasible = 1u; // the stream starts with a codeword
-            } else {
-                const uint32_t pre = (uint32_t)bit_window(words, c0 - k - 1); // bit m = stream bit c0-k-1+m
-                feasible = ~pre & ((1u << (k + 1)) - 1u);
-                if ((pre >> k) & 1u)
-                    feasible |= 1u << state_m;
-            }
-#pragma unroll
-            for (int e = 0; e < kMaxStates; e++) {
-                pos[e] = (uint32_t)e == state_m ? c0 : c0 + (uint32_t)e;
-                cnt[e] = 0;
-                if ((uint32_t)e < n_states)
-                    maps[lane * kMaxStates + e] = 0;
-            }
-            active = feasible;
-            fresh = feasible & ~(1u << state_m);
-        }
-        while (__any(active != 0)) {
-            uint64_t win[kMaxStates];
-#pragma unroll
-            for (int e = 0; e < kMaxStates; e++)
-                if ((uint32_t)e < n_states && (active & (1u << e)))
-                    win[e] = bit_window(words, pos[e] < limit ? pos[e] : limit);
-#pragma unroll
-            for (int e = 0; e < kMaxStates; e++) {
-                if ((uint32_t)e < n_states && (active & (1u << e))) {
-                    const uint32_t p = pos[e];
-                    const bool is_fresh = (fresh >> e) & 1u;
-                    if (p >= c1) { // next codeword starts p - c1 bits into a later chunk / the run goes on
-                        maps[lane * kMaxStates + e] = (is_fresh ? p - c1 : state_m) | (cnt[e] << 8);
-                        active &= ~(1u << e);
-                    } else {
-                        if (is_fresh)
-                            cnt[e]++;
-                        const uint32_t lo = (uint32_t)win[e];
-                        if (lo == 0xFFFFFFFFu) { // 32 more ones
-                            pos[e] = p + 32;
-                            fresh &= ~(1u << e);
-                        } else {
-                            const uint32_t z = p + (uint32_t)__builtin_ctz(~lo);
-                            if (z >= c1) { // the terminating zero belongs to a later chunk
-                                maps[lane * kMaxStates + e] = state_m | (cnt[e] << 8);
-                                active &= ~(1u << e);
-                            } else {
-                                pos[e] = z + 1 + k;
-                                fresh |= 1u << e;
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        next = begin;
+        end = stop;
+        buf = 0;
+        avail = 0;
+        starved = 0;
     }
-    wave_sync();
-    if (tm)
-        tm[0] = clock64();
-
-    // ---- walk: compose the maps from the stream start --------------------------------------------------
-    uint32_t my_state = 0, my_first = 0;
+    // make at least 33 bits available
+    __device__ __forceinline__ void refill()
     {
-        uint32_t state = 0, first = 0; // R_0 at bit 0, value index 0
-        for (int l = 0; l < 64; l++) {
-            if (l == lane) {
-                my_state = state;
-                my_first = first;
-            }
-            const uint32_t m = maps[l * kMaxStates + state];
-            state = m & 0xFFu;
-            first += m >> 8;
-        }
-        if (first < n)
-            flags |= SELA_HIP_FLAG_RICE_OVERRUN; // the words hold fewer than n codewords
-    }
-    wave_sync(); // maps may alias `out`
-    if (tm)
-        tm[1] = clock64();
-
-    // ---- phase 2: decode the codewords that start in this lane's chunk -------------------------------
-    {
-        uint32_t p;
-        if (my_state <= k) {
-            p = c0 + my_state;
-        } else {
-            const uint32_t z = next_zero(words, c0, limit);
-            p = z >= c1 ? c1 : z + 1 + k;
-        }
-        uint32_t idx = my_first;
-        const uint32_t kmask = k ? (0xFFFFFFFFu >> (32 - k)) : 0u;
-        while (p < c1 && idx < n) {
-            uint64_t win = bit_window(words, p);
-            uint32_t ones = 0;
-            while ((uint32_t)win == 0xFFFFFFFFu) { // long unary run
-                ones += 32;
-                if (p + ones >= limit)
-                    break;
-                win = bit_window(words, p + ones);
-            }
-            const uint32_t t = (uint32_t)win == 0xFFFFFFFFu ? 0u : (uint32_t)__builtin_ctz(~(uint32_t)win);
-            ones += t;
-            uint32_t field; // the k bits after the zero, in stream order
-            if (t + 1 + k <= 32)
-                field = (uint32_t)(win >> (t + 1)) & kmask;
+        if (avail <= 32) {
+            uint32_t w = 0;
+            if (next < end)
+                w = *next;
             else
-                field = (uint32_t)bit_window(words, p + ones + 1) & kmask;
-            const uint32_t rem = k ? (__brev(field) >> (32 - k)) : 0u; // MSB first (src/rice/rice_decoder.cpp:37-40)
-            const uint64_t u = (uint64_t)(uint32_t)(ones << k) | rem;  // uint32 shift as src/rice/rice_decoder.cpp:35
-            out[idx++] = unzigzag(u);
-            p += ones + 1 + k;
+                starved++;
+            next++;
+            buf |= (uint64_t)w << avail;
+            avail += 32;
         }
     }
-    wave_sync();
+    __device__ __forceinline__ void skip(uint32_t n)
+    {
+        buf >>= n;
+        avail -= n;
+    }
+    // one Golomb-Rice codeword (src/rice/rice_decoder.cpp:27-42): ones up to a zero, then k bits MSB first
+    __device__ __forceinline__ int32_t codeword(uint32_t k, uint32_t kmask)
+    {
+        refill();
+        uint32_t ones = 0;
+        uint32_t lo = (uint32_t)buf;
+        while (lo == 0xFFFFFFFFu && starved < 4) { // long unary run (rare)
+            ones += 32;
+            skip(32);
+            refill();
+            lo = (uint32_t)buf;
+        }
+        const uint32_t t = lo == 0xFFFFFFFFu ? 0u : (uint32_t)__builtin_ctz(~lo);
+        ones += t;
+        skip(t + 1);
+        refill();
+        const uint32_t field = (uint32_t)buf & kmask; // stream order
+        skip(k);
+        const uint32_t rem = k ? (__brev(field) >> (32 - k)) : 0u;
+        const uint64_t u = (uint64_t)(uint32_t)(ones << k) | rem; // uint32 shift as src/rice/rice_decoder.cpp:35
+        return unzigzag(u);
+    }
+};
+
+__global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restrict__ frames,
+    const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, SubDesc* __restrict__ desc,
+    int32_t* __restrict__ q_out, int32_t* __restrict__ residues)
+{
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x; // subframe index = frame * channels + position
+    if (g >= n_frames * channels)
+        return;
+    const uint32_t f = g / channels, c = g % channels;
+    const uint8_t* fb = frames + frame_offsets[f];
+    const uint64_t fbytes = frame_offsets[f + 1] - frame_offsets[f];
+
+    SubDesc d;
+    d.info = 0;
+    d.flags = SELA_HIP_FLAG_BAD_FRAME;
+    bool ok = fbytes >= 4 && (fbytes & 3) == 0 && reinterpret_cast<const uint32_t*>(fb)[0] == SELA_SYNC_WORD;
+    uint64_t p = 4;
+    uint32_t channel = 0, type = 0, parent = 0, ck = 0, cw = 0, order = 0, rk = 0, rw = 0, n = 0;
+    for (uint32_t i = 0; ok && i <= c; i++) { // walk the headers up to this subframe
+        if (p + 12 > fbytes) {
+            ok = false;
+            break;
+        }
+        const uint32_t h0 = *reinterpret_cast<const uint32_t*>(fb + p);     // channel, type, parent, coefficient k
+        const uint32_t h1 = *reinterpret_cast<const uint32_t*>(fb + p + 4); // word count (u16), order (u8), first coefficient byte
+        channel = h0 & 0xFF, type = (h0 >> 8) & 0xFF, parent = (h0 >> 16) & 0xFF, ck = h0 >> 24;
+        cw = h1 & 0xFFFF, order = (h1 >> 16) & 0xFF;
+        const uint64_t p2 = p + 4 + 4 * (uint64_t)cw; // aligned word: last 3 coefficient bytes + residue k
+        if (p2 + 8 > fbytes) {
+            ok = false;
+            break;
+        }
+        const uint32_t h2 = *reinterpret_cast<const uint32_t*>(fb + p2);
+        const uint32_t h3 = *reinterpret_cast<const uint32_t*>(fb + p2 + 4);
+        rk = h2 >> 24, rw = h3 & 0xFFFF, n = h3 >> 16;
+        const uint64_t next = p + 12 + 4 * ((uint64_t)cw + rw);
+        if (next > fbytes) {
+            ok = false;
+            break;
+        }
+        if (i < c)
+            p = next;
+    }
+    ok = ok && channel < channels && order <= (uint32_t)kMaxOrder && n == (uint32_t)kBlock && ck < 32 && rk < 32 && type <= 1
+        && (type == 0 || parent < channels);
+    if (!ok) {
+        desc[g] = d;
+        return;
+    }
+    uint32_t flags = 0;
+
+    // coefficient stream: starts 3 bytes into the aligned word at p + 4 (behind word count + order);
+    // its last word shares an aligned word with the residue k, hence cw + 1 aligned words.
+    {
+        BitReader br;
+        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(fb + p + 4);
+        br.init(w0, w0 + cw + 1);
+        br.refill();
+        br.skip(24);
+        const uint32_t kmask = ck ? (0xFFFFFFFFu >> (32 - ck)) : 0u;
+        int32_t* qo = q_out + (size_t)g * kQStride;
+        for (uint32_t i = 0; i < order; i++)
+            qo[i] = br.codeword(ck, kmask);
+        if (br.starved > 2) // up to two look-ahead words past the end are normal
+            flags |= SELA_HIP_FLAG_RICE_OVERRUN;
+    }
+    // residue stream (aligned)
+    {
+        BitReader br;
+        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(fb + p + 12 + 4 * (uint64_t)cw);
+        br.init(w0, w0 + rw);
+        const uint32_t kmask = rk ? (0xFFFFFFFFu >> (32 - rk)) : 0u;
+        int4* ro = reinterpret_cast<int4*>(residues + (size_t)g * kBlock);
+#pragma unroll 1
+        for (uint32_t i = 0; i < (uint32_t)kBlock / 4; i++) {
+            int4 v;
+            v.x = br.codeword(rk, kmask);
+            v.y = br.codeword(rk, kmask);
+            v.z = br.codeword(rk, kmask);
+            v.w = br.codeword(rk, kmask);
+            ro[i] = v;
+        }
+        if (br.starved > 2)
+            flags |= SELA_HIP_FLAG_RICE_OVERRUN;
+    }
+    d.info = channel | (type << 8) | (parent << 16) | (order << 24);
+    d.flags = flags;
+    desc[g] = d;
 }
 
 // ---- synthesis filter ----------------------------------------------------------------------------------
@@ -218,7 +195,7 @@ __device__ inline void rice_decode_wave(const uint32_t* words, uint32_t nwords, 
 // the scalar unit: s_i stays in an SGPR and feeds the multiply-adds as a scalar operand.
 //
 // 64x32-bit products in two instructions: a = ah*2^32 + al with al = (int32)a, so
-//     a*s mod 2^64 = al*s (v_mad_i64_i32, exact) + ((ah*s mod 2^32) << 32) (v_mad_u64_u32, low half)
+//     a*s mod 2^64 = al*s (v_mad_i64_i32, exact) + ((ah*s mod 2^32) << 32)
 // and a position carries the pair (acc1, acc2) with z = acc1 + (acc2 << 32).
 template <int P>
 __device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int lane)
@@ -269,135 +246,98 @@ __device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int 
     wave_sync();
 }
 
+struct SynthWaveLds {
+    double k[104];
+    double t[104];
+    int64_t a[104];
+};
+
 // kProf: also write per-phase cycle counts (debug hook sela_hip_debug_phase_buffer; 16 uint64 per subframe).
 template <bool kProf>
-__global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8_t* __restrict__ frames,
-    const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* __restrict__ pcm_out,
-    uint32_t* __restrict__ status, uint64_t* __restrict__ phase_cycles)
+__global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const SubDesc* __restrict__ desc,
+    const int32_t* __restrict__ q_in, const int32_t* __restrict__ residues, uint32_t n_frames, uint32_t channels,
+    int16_t* __restrict__ pcm_out, uint32_t* __restrict__ status, uint64_t* __restrict__ phase_cycles)
 {
-    long long stamp[8], tm[2] = { 0, 0 };
-    for (int i = 0; i < 8; i++)
+    long long stamp[6];
+    for (int i = 0; i < 6; i++)
         stamp[i] = 0;
     uint32_t prof_sub = 0xFFFFFFFFu;
     if (kProf)
         stamp[0] = clock64();
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    // [channels][2048] int32 samples, then one DecodeWaveLds per wave, then per-channel type/parent
+    // [channels][2048] int32 samples, then one SynthWaveLds per wave, then per-channel type/parent
     int32_t* const samples = reinterpret_cast<int32_t*>(dyn);
     const int n_waves = blockDim.x / 64;
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    DecodeWaveLds* const wl = reinterpret_cast<DecodeWaveLds*>(dyn + (size_t)channels * kBlock * 4) + wave;
-    uint32_t* const sub_info = reinterpret_cast<uint32_t*>(dyn + (size_t)channels * kBlock * 4 + (size_t)n_waves * sizeof(DecodeWaveLds));
+    SynthWaveLds* const wl = reinterpret_cast<SynthWaveLds*>(dyn + (size_t)channels * kBlock * 4) + wave;
+    uint32_t* const sub_info = reinterpret_cast<uint32_t*>(dyn + (size_t)channels * kBlock * 4 + (size_t)n_waves * sizeof(SynthWaveLds));
 
     const uint32_t f = blockIdx.x;
     if (f >= n_frames)
         return;
-    const uint8_t* fb = frames + frame_offsets[f];
-    const uint64_t fbytes = frame_offsets[f + 1] - frame_offsets[f];
     uint32_t flags = 0;
-
     for (uint32_t c = threadIdx.x; c < channels; c += blockDim.x)
         sub_info[c] = 0xFFFFFFFFu; // "no subframe delivered this channel"
-    for (uint32_t i = threadIdx.x; i < channels * kBlock; i += blockDim.x)
-        samples[i] = 0;
     __syncthreads();
 
-    const bool sync_ok = fbytes >= 4 && reinterpret_cast<const uint32_t*>(fb)[0] == SELA_SYNC_WORD;
-    if (!sync_ok)
-        flags |= SELA_HIP_FLAG_BAD_FRAME;
-
-    // Every wave walks the subframe headers (wave-uniform scalar work) and decodes its share.
-    uint64_t p = 4;
-    for (uint32_t c = 0; sync_ok && c < channels; c++) {
-        if (p + 12 > fbytes) {
-            flags |= SELA_HIP_FLAG_BAD_FRAME;
-            break;
-        }
-        const uint8_t* h = fb + p;
-        const uint32_t channel = h[0], type = h[1], parent = h[2], ck = h[3];
-        const uint32_t cw = (uint32_t)h[4] | ((uint32_t)h[5] << 8), order = h[6];
-        const uint8_t* h2 = h + 7 + 4 * (size_t)cw;
-        if (p + 12 + 4 * (uint64_t)cw > fbytes) {
-            flags |= SELA_HIP_FLAG_BAD_FRAME;
-            break;
-        }
-        const uint32_t rk = h2[0];
-        const uint32_t rw = (uint32_t)h2[1] | ((uint32_t)h2[2] << 8), n = (uint32_t)h2[3] | ((uint32_t)h2[4] << 8);
-        const uint64_t next = p + 12 + 4 * ((uint64_t)cw + rw);
-        const bool ok = next <= fbytes && channel < channels && order <= (uint32_t)kMaxOrder && n == (uint32_t)kBlock
-            && cw <= 2u * kCoefWordsCap && rw <= (uint32_t)kResWordsCap && ck < SELA_MAX_RICE_PARAM && rk < SELA_MAX_RICE_PARAM && type <= 1
-            && (type == 0 || parent < channels);
-        if (!ok) {
-            flags |= SELA_HIP_FLAG_BAD_FRAME;
-            break;
-        }
-        if ((int)(c % (uint32_t)n_waves) == wave) {
-            // stage the Rice words: coefficient words sit 3 bytes off alignment (funnel shift),
-            // residue words are aligned again.
-            const uint32_t* al = reinterpret_cast<const uint32_t*>(h + 4); // bytes 4..7 of the subframe
-            for (uint32_t i = lane; i < 2u * kCoefWordsCap; i += 64)
-                wl->words[i] = i < cw ? (al[i] >> 24) | (al[i + 1] << 8) : 0u;
-            const uint32_t* rwp = reinterpret_cast<const uint32_t*>(h2 + 5);
-            const uint32_t rw_pad = ((rw + 63) / 64) * 64 + 4; // zero tail: chunks are word-aligned, windows read 1 word ahead
-            for (uint32_t i = lane; i < rw_pad; i += 64)
-                wl->words[2 * kCoefWordsCap + i] = i < rw ? rwp[i] : 0u;
-            wave_sync();
-            if (kProf)
-                stamp[1] = clock64(), prof_sub = c;
-
-            int32_t* dst = samples + (size_t)channel * kBlock;
-            // the parser-state maps of both Rice streams borrow the output buffer of this channel
-            uint32_t* maps = reinterpret_cast<uint32_t*>(dst);
-            rice_decode_wave(wl->words, cw, order, ck, wl->q, maps, lane, flags);
-            if (kProf)
-                stamp[2] = clock64();
-            rice_decode_wave(wl->words + 2 * kCoefWordsCap, rw, n, rk, dst, maps, lane, flags, kProf ? tm : nullptr);
-            if (kProf)
-                stamp[3] = clock64();
-
-            // dequantise (src/lpc/linear_predictor.cpp:16-28)
-            for (uint32_t i = lane; i < order; i += 64)
-                wl->k[i] = order <= 1 ? 0.0 : dequant((int)i, wl->q[i], flags);
-            wave_sync();
-            step_up(wl->k, wl->t, wl->a, (int)order, lane, flags);
-            if (kProf)
-                stamp[4] = clock64();
-            if (order <= 64)
-                synthesize<1>(dst, wl->a, (int)order, lane);
-            else
-                synthesize<2>(dst, wl->a, (int)order, lane);
-            if (kProf)
-                stamp[5] = clock64();
-            if (lane == 0)
-                sub_info[channel] = type | (parent << 8);
-        }
-        p = next;
+    for (uint32_t c = wave; c < channels; c += n_waves) {
+        const uint32_t g = f * channels + c;
+        const SubDesc d = desc[g];
+        flags |= d.flags;
+        if (d.flags & SELA_HIP_FLAG_BAD_FRAME)
+            continue;
+        const uint32_t channel = d.info & 0xFF, type = (d.info >> 8) & 0xFF, parent = (d.info >> 16) & 0xFF, order = d.info >> 24;
+        int32_t* dst = samples + (size_t)channel * kBlock;
+        // residues -> LDS (coalesced 16-byte loads)
+        const int4* rsrc = reinterpret_cast<const int4*>(residues + (size_t)g * kBlock);
+        int4* rdst = reinterpret_cast<int4*>(dst);
+#pragma unroll
+        for (int t = 0; t < kBlock / 4 / 64; t++)
+            rdst[lane + 64 * t] = rsrc[lane + 64 * t];
+        // dequantise (src/lpc/linear_predictor.cpp:16-28)
+        for (uint32_t i = lane; i < order; i += 64)
+            wl->k[i] = order <= 1 ? 0.0 : dequant((int)i, q_in[(size_t)g * kQStride + i], flags);
+        wave_sync();
+        if (kProf)
+            stamp[1] = clock64(), prof_sub = c;
+        step_up(wl->k, wl->t, wl->a, (int)order, lane, flags);
+        if (kProf)
+            stamp[2] = clock64();
+        if (order <= 64)
+            synthesize<1>(dst, wl->a, (int)order, lane);
+        else
+            synthesize<2>(dst, wl->a, (int)order, lane);
+        if (kProf)
+            stamp[3] = clock64();
+        if (lane == 0)
+            sub_info[channel] = type | (parent << 8);
     }
     __syncthreads();
     if (kProf)
-        stamp[6] = clock64();
+        stamp[4] = clock64();
 
     // ---- second pass of frame::FrameDecoder + interleave to int16 ------------------------------------
-    // dependent channels become parent - difference (parents are independent subframes).
+    // dependent channels become parent - difference (parents are independent subframes); a channel
+    // that no valid subframe delivered decodes to silence and raises BAD_FRAME.
     for (uint32_t i = threadIdx.x; i < (uint32_t)kBlock; i += blockDim.x) {
         for (uint32_t c = 0; c < channels; c++) {
             const uint32_t info = sub_info[c];
-            int32_t v = samples[(size_t)c * kBlock + i];
+            int32_t v = info == 0xFFFFFFFFu ? 0 : samples[(size_t)c * kBlock + i];
             if (info != 0xFFFFFFFFu && (info & 0xFF) == 1) {
                 const uint32_t par = info >> 8;
-                v = (int32_t)((uint32_t)samples[(size_t)par * kBlock + i] - (uint32_t)v);
+                const int32_t pv = sub_info[par] == 0xFFFFFFFFu ? 0 : samples[(size_t)par * kBlock + i];
+                v = (int32_t)((uint32_t)pv - (uint32_t)v);
             }
             pcm_out[((size_t)f * kBlock + i) * channels + c] = (int16_t)(uint16_t)v;
         }
     }
-    // a dependent subframe whose parent is itself dependent is outside what the reference defines
     if (threadIdx.x == 0) {
         for (uint32_t c = 0; c < channels; c++) {
             const uint32_t info = sub_info[c];
             if (info == 0xFFFFFFFFu)
                 flags |= SELA_HIP_FLAG_BAD_FRAME;
-            else if ((info & 0xFF) == 1 && (sub_info[info >> 8] & 0xFF) != 0)
-                flags |= SELA_HIP_FLAG_BAD_FRAME;
+            else if ((info & 0xFF) == 1 && (sub_info[info >> 8] == 0xFFFFFFFFu || (sub_info[info >> 8] & 0xFF) != 0))
+                flags |= SELA_HIP_FLAG_BAD_FRAME; // a parent that is itself dependent is outside what the reference defines
         }
     }
     for (int m = 32; m >= 1; m >>= 1)
@@ -408,19 +348,15 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
             atomicAdd(&status[1], 1u);
     }
     if (kProf && lane == 0 && prof_sub != 0xFFFFFFFFu) { // (one subframe per wave is reported)
-        stamp[7] = clock64();
-        for (int i = 0; i < 7; i++)
+        stamp[5] = clock64();
+        for (int i = 0; i < 5; i++)
             phase_cycles[((size_t)f * channels + prof_sub) * 16 + i] = (uint64_t)(stamp[i + 1] - stamp[i]);
-        // residue Rice parse split: phase 1 / walk / phase 2
-        phase_cycles[((size_t)f * channels + prof_sub) * 16 + 8] = (uint64_t)(tm[0] - stamp[2]);
-        phase_cycles[((size_t)f * channels + prof_sub) * 16 + 9] = (uint64_t)(tm[1] - tm[0]);
-        phase_cycles[((size_t)f * channels + prof_sub) * 16 + 10] = (uint64_t)(stamp[3] - tm[1]);
     }
 }
 
 size_t decode_lds_bytes(uint32_t channels, int n_waves)
 {
-    return (size_t)channels * kBlock * 4 + (size_t)n_waves * sizeof(DecodeWaveLds) + (size_t)channels * 4 + 16;
+    return (size_t)channels * kBlock * 4 + (size_t)n_waves * sizeof(SynthWaveLds) + (size_t)channels * 4 + 16;
 }
 
 int decode_waves(uint32_t channels)
@@ -428,31 +364,55 @@ int decode_waves(uint32_t channels)
     return channels < (uint32_t)kDecMaxWaves ? (int)channels : kDecMaxWaves;
 }
 
+size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels)
+{
+    const size_t subs = (size_t)n_frames * channels;
+    size_t bytes = 0;
+    bytes += (subs * sizeof(SubDesc) + 255) & ~(size_t)255;
+    bytes += (subs * kQStride * 4 + 255) & ~(size_t)255;
+    bytes += (subs * kBlock * 4 + 255) & ~(size_t)255;
+    return bytes + 256;
+}
+
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, hipStream_t stream, hipEvent_t* ev /* 2 events or nullptr */, uint64_t* d_phase_cycles)
+    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev /* 3 events or nullptr */,
+    uint64_t* d_phase_cycles)
 {
     hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
     if (err != hipSuccess || n_frames == 0)
         return err;
+    const size_t subs = (size_t)n_frames * channels;
+    unsigned char* ws = static_cast<unsigned char*>(d_workspace);
+    ws = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    SubDesc* desc = reinterpret_cast<SubDesc*>(ws);
+    ws += (subs * sizeof(SubDesc) + 255) & ~(size_t)255;
+    int32_t* q = reinterpret_cast<int32_t*>(ws);
+    ws += (subs * kQStride * 4 + 255) & ~(size_t)255;
+    int32_t* residues = reinterpret_cast<int32_t*>(ws);
+
     const int n_waves = decode_waves(channels);
     const size_t lds = decode_lds_bytes(channels, n_waves);
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_synthesize_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err == hipSuccess)
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_synthesize_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess)
         return err;
     if (ev)
         (void)hipEventRecord(ev[0], stream);
-    if (d_phase_cycles)
-        hipLaunchKernelGGL(k_decode_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames,
-            channels, d_pcm_out, d_status, d_phase_cycles);
-    else
-        hipLaunchKernelGGL(k_decode_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames,
-            channels, d_pcm_out, d_status, d_phase_cycles);
+    hipLaunchKernelGGL(k_parse_subframes, dim3((unsigned)((subs + 63) / 64)), dim3(64), 0, stream, d_frames, d_frame_offsets, n_frames,
+        channels, desc, q, residues);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
+    if (d_phase_cycles)
+        hipLaunchKernelGGL(k_synthesize_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, n_frames, channels,
+            d_pcm_out, d_status, d_phase_cycles);
+    else
+        hipLaunchKernelGGL(k_synthesize_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, n_frames, channels,
+            d_pcm_out, d_status, d_phase_cycles);
+    if (ev)
+        (void)hipEventRecord(ev[2], stream);
     return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ from sela_amd.synth import synth_frames  # noqa: E402
 
 ENC = ["load+x/32767", "mean chain", "centre", "autocorr", "normalise+Schur", "order/quant/dequant", "step-up",
        "FIR residues", "Rice k search", "pack coefs", "transpose+pack residues", "store slot/meta"]
-DEC = ["header walk+stage", "Rice coefs", "Rice residues", "dequant+step-up", "synthesis", "wait barrier", "combine+store"]
+DEC = ["load residues+dequant", "step-up", "synthesis", "wait barrier", "combine+store"]
 
 
 def main():
@@ -38,14 +38,13 @@ def main():
     torch.cuda.synchronize()
     lib.sela_hip_debug_phase_buffer(None)
     dd = buf.cpu().numpy().reshape(-1, 16)[: n_frames * 2].astype(np.float64)
-    d = dd[:, :7]
+    d = dd[:, :5]
     print(f"encoder, mean cycles per (frame, signal) block over {len(e)} blocks (total {e.sum(1).mean():.0f}):")
     for name, v in zip(ENC, e.mean(0)):
         print(f"  {name:28s} {v:10.0f}  {100 * v / e.sum(1).mean():5.1f}%")
     print(f"decoder, mean cycles per subframe over {len(d)} subframes (total {d.sum(1).mean():.0f}):")
     for name, v in zip(DEC, d.mean(0)):
         print(f"  {name:28s} {v:10.0f}  {100 * v / d.sum(1).mean():5.1f}%")
-    print("  residue Rice split: phase1 %.0f  walk %.0f  phase2 %.0f" % tuple(dd[:, 8:11].mean(0)))
 
 
 if __name__ == "__main__":
