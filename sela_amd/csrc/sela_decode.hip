@@ -34,79 +34,174 @@ struct SubDesc {
     uint32_t flags; // SELA_HIP_FLAG_* bits; BAD_FRAME means "do not synthesise"
 };
 
-// ---- per-lane bit reader over 32-bit words (stream bit t = bit t%32 of word t/32) -------------------
-struct BitReader {
-    const uint32_t* next; // next word to fetch
-    const uint32_t* end;  // one past the last word of the stream
-    uint64_t buf;         // bit 0 = next stream bit
-    uint32_t avail;       // valid bits in buf
-    uint32_t starved;     // number of words fetched past `end` (they read as zero)
+// ---- lane-per-stream Rice parser --------------------------------------------------------------------
+// Each of the 64 lanes parses its own bitstream (stream bit t = bit t%32 of word t/32) and only keeps
+// a bit position.  The words are staged through an LDS tile, one row of kTileWords words per lane,
+// that the whole wave refills cooperatively with coalesced 16-byte loads whenever ANY lane gets close
+// to the end of its row.  Control flow is wave-uniform throughout; only data is per lane.
+//
+// Codewords are decoded four at a time from a 128-bit register window read at the lane's bit
+// position (one LDS round trip per four values).  A group falls back to the bit-by-window slow path
+// when any lane meets a codeword longer than 31 bits (long unary run).
+constexpr int kTileWords = 96;
+constexpr int kTileStride = kTileWords + 1; // odd stride: lanes reading the same column hit different banks
+constexpr int kTileMargin = 12;             // re-tile when a lane is within this many words of its row end
+constexpr int kStageVals = 32;              // decoded values staged per lane before a coalesced store
+constexpr int kStageStride = kStageVals + 1;
 
-    __device__ __forceinline__ void init(const uint32_t* begin, const uint32_t* stop)
-    {
-        next = begin;
-        end = stop;
-        buf = 0;
-        avail = 0;
-        starved = 0;
-    }
-    // make at least 33 bits available
-    __device__ __forceinline__ void refill()
-    {
-        if (avail <= 32) {
-            uint32_t w = 0;
-            if (next < end)
-                w = *next;
-            else
-                starved++;
-            next++;
-            buf |= (uint64_t)w << avail;
-            avail += 32;
-        }
-    }
-    __device__ __forceinline__ void skip(uint32_t n)
-    {
-        buf >>= n;
-        avail -= n;
-    }
-    // one Golomb-Rice codeword (src/rice/rice_decoder.cpp:27-42): ones up to a zero, then k bits MSB first
-    __device__ __forceinline__ int32_t codeword(uint32_t k, uint32_t kmask)
-    {
-        refill();
-        uint32_t ones = 0;
-        uint32_t lo = (uint32_t)buf;
-        while (lo == 0xFFFFFFFFu && starved < 4) { // long unary run (rare)
-            ones += 32;
-            skip(32);
-            refill();
-            lo = (uint32_t)buf;
-        }
-        const uint32_t t = lo == 0xFFFFFFFFu ? 0u : (uint32_t)__builtin_ctz(~lo);
-        ones += t;
-        skip(t + 1);
-        refill();
-        const uint32_t field = (uint32_t)buf & kmask; // stream order
-        skip(k);
-        const uint32_t rem = k ? (__brev(field) >> (32 - k)) : 0u;
-        const uint64_t u = (uint64_t)(uint32_t)(ones << k) | rem; // uint32 shift as src/rice/rice_decoder.cpp:35
-        return unzigzag(u);
-    }
+struct StreamReader {
+    const uint32_t* base; // first aligned word of the stream (global)
+    uint32_t n_words;     // words in the stream; reads beyond are zero
+    uint32_t tile_first;  // stream index of tile column 0
+    uint32_t bp;          // bit position of the next unread bit
 };
+
+// Refill every lane's row so that it starts at the word holding the lane's next unread bit.
+__device__ inline void retile(StreamReader& r, uint32_t* tile, int lane)
+{
+    const uint32_t new_first = r.bp >> 5;
+    const uint64_t my_base = reinterpret_cast<uint64_t>(r.base);
+    wave_sync(); // earlier reads of the tile are done
+#pragma unroll 4
+    for (int i = 0; i < kTileWords / 4; i++) { // one wave-load = 16 bytes per lane; 64 rows x 24 loads in all
+        // 24 lanes cover one row of 96 words; rows are dealt out 64 lanes at a time
+        const int slot = i * 64 + lane; // 0 .. 64 * 24 - 1
+        const int row = slot / (kTileWords / 4);
+        const uint32_t c4 = (uint32_t)(slot % (kTileWords / 4)) * 4;
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)my_base, row, 64);
+        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(my_base >> 32), row, 64);
+        const uint32_t first = (uint32_t)__shfl((int)new_first, row, 64);
+        const uint32_t nw = (uint32_t)__shfl((int)r.n_words, row, 64);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(((uint64_t)hi << 32) | lo);
+        const uint32_t idx = first + c4;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (idx + 4 <= nw) {
+            v = *reinterpret_cast<const uint4*>(src + idx); // dword-aligned 16-byte load
+        } else { // row reaches the end of its stream: never touch memory past it
+            if (idx < nw)
+                v.x = src[idx];
+            if (idx + 1 < nw)
+                v.y = src[idx + 1];
+            if (idx + 2 < nw)
+                v.z = src[idx + 2];
+        }
+        uint32_t* dst = tile + row * kTileStride + c4;
+        dst[0] = v.x;
+        dst[1] = v.y;
+        dst[2] = v.z;
+        dst[3] = v.w;
+    }
+    r.tile_first = new_first;
+    wave_sync();
+}
+
+__device__ __forceinline__ bool reader_near_end(const StreamReader& r)
+{
+    return (r.bp >> 5) - r.tile_first >= (uint32_t)(kTileWords - kTileMargin);
+}
+
+// 64 stream bits starting at bit position bp (tile must cover them)
+__device__ __forceinline__ uint64_t reader_window(const StreamReader& r, const uint32_t* tile, int lane, uint32_t bp)
+{
+    const uint32_t col = (bp >> 5) - r.tile_first;
+    const uint32_t* w = tile + lane * kTileStride + (col < (uint32_t)kTileWords - 2 ? col : (uint32_t)kTileWords - 3);
+    const uint32_t sh = bp & 31;
+    const uint64_t lo = ((uint64_t)w[1] << 32) | w[0];
+    return sh ? (lo >> sh) | ((uint64_t)w[2] << (64 - sh)) : lo;
+}
+
+__device__ __forceinline__ int32_t rice_value(uint32_t ones, uint32_t field, uint32_t k)
+{
+    const uint32_t rem = k ? (__brev(field) >> (32 - k)) : 0u; // remainder is MSB first in the stream
+    const uint32_t u = (ones << k) | rem;                      // uint32 arithmetic as src/rice/rice_decoder.cpp:35
+    return (int32_t)((u >> 1) ^ (0u - (u & 1u)));               // un-zig-zag, src/rice/rice_decoder.cpp:49-50
+}
+
+// Slow path: one codeword per lane with no length limit (src/rice/rice_decoder.cpp:27-42).
+__device__ inline int32_t reader_codeword_slow(StreamReader& r, uint32_t* tile, int lane, uint32_t k, uint32_t kmask, bool live)
+{
+    uint32_t ones = 0;
+    uint32_t lo;
+    for (;;) {
+        if (__any(reader_near_end(r)))
+            retile(r, tile, lane);
+        lo = (uint32_t)reader_window(r, tile, lane, r.bp);
+        const bool in_run = live && lo == 0xFFFFFFFFu && (r.bp >> 5) <= r.n_words + 2; // zero padding ends any run
+        if (!__any(in_run))
+            break;
+        ones += in_run ? 32u : 0u;
+        r.bp += in_run ? 32u : 0u;
+    }
+    const uint32_t t = lo == 0xFFFFFFFFu ? 0u : (uint32_t)__builtin_ctz(~lo);
+    ones += t;
+    r.bp += live ? t + 1 : 0u;
+    const uint32_t field = (uint32_t)reader_window(r, tile, lane, r.bp) & kmask;
+    r.bp += live ? k : 0u;
+    return rice_value(ones, field, k);
+}
+
+// Four codewords per lane.  live_mask bit j: value j of this group exists for this lane.
+__device__ __forceinline__ void reader_codewords4(StreamReader& r, uint32_t* tile, int lane, uint32_t k, uint32_t kmask,
+    uint32_t live_mask, int32_t (&out)[4])
+{
+    if (__any(reader_near_end(r)))
+        retile(r, tile, lane);
+    // 128-bit window at bp
+    const uint32_t col = (r.bp >> 5) - r.tile_first;
+    const uint32_t* w = tile + lane * kTileStride + col;
+    const uint32_t sh = r.bp & 31;
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+    uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+    uint32_t x2 = __builtin_amdgcn_alignbit(w3, w2, sh), x3 = __builtin_amdgcn_alignbit(w4, w3, sh);
+    uint32_t used = 0;
+    bool slow = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool live = (live_mask >> j) & 1u;
+        const uint32_t t = (uint32_t)__builtin_ctz(~x0 | 0x80000000u); // <= 31
+        const uint32_t len = t + 1 + k;
+        slow |= live && (x0 == 0xFFFFFFFFu || len > 31);
+        const uint32_t field = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (t + 1)) & kmask;
+        out[j] = rice_value(t, field, k);
+        const uint32_t adv = live && len <= 31 ? len : 0u;
+        x0 = __builtin_amdgcn_alignbit(x1, x0, adv);
+        x1 = __builtin_amdgcn_alignbit(x2, x1, adv);
+        x2 = __builtin_amdgcn_alignbit(x3, x2, adv);
+        x3 >>= adv;
+        used += adv;
+    }
+    if (__any(slow)) { // some lane met a long codeword: redo the whole group bit-window by bit-window
+#pragma unroll 1
+        for (int j = 0; j < 4; j++)
+            out[j] = reader_codeword_slow(r, tile, lane, k, kmask, (live_mask >> j) & 1u);
+    } else {
+        r.bp += used;
+    }
+}
+
+__device__ __forceinline__ void reader_open(StreamReader& r, const uint32_t* base, uint32_t n_words, uint32_t start_bit, uint32_t* tile, int lane)
+{
+    r.base = base;
+    r.n_words = n_words;
+    r.bp = start_bit;
+    retile(r, tile, lane);
+}
 
 __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, SubDesc* __restrict__ desc,
     int32_t* __restrict__ q_out, int32_t* __restrict__ residues)
 {
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x; // subframe index = frame * channels + position
-    if (g >= n_frames * channels)
-        return;
+    __shared__ uint32_t tile[64 * kTileStride + 8];
+    __shared__ int32_t stage[64 * kStageStride];
+    const int lane = threadIdx.x;
+    const uint32_t n_subs = n_frames * channels;
+    const uint32_t g_raw = blockIdx.x * 64 + lane; // subframe index = frame * channels + position
+    const bool in_range = g_raw < n_subs;
+    const uint32_t g = in_range ? g_raw : n_subs - 1; // idle lanes shadow a valid subframe, never store
     const uint32_t f = g / channels, c = g % channels;
     const uint8_t* fb = frames + frame_offsets[f];
     const uint64_t fbytes = frame_offsets[f + 1] - frame_offsets[f];
 
-    SubDesc d;
-    d.info = 0;
-    d.flags = SELA_HIP_FLAG_BAD_FRAME;
     bool ok = fbytes >= 4 && (fbytes & 3) == 0 && reinterpret_cast<const uint32_t*>(fb)[0] == SELA_SYNC_WORD;
     uint64_t p = 4;
     uint32_t channel = 0, type = 0, parent = 0, ck = 0, cw = 0, order = 0, rk = 0, rw = 0, n = 0;
@@ -137,49 +232,82 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
     }
     ok = ok && channel < channels && order <= (uint32_t)kMaxOrder && n == (uint32_t)kBlock && ck < 32 && rk < 32 && type <= 1
         && (type == 0 || parent < channels);
-    if (!ok) {
-        desc[g] = d;
-        return;
+    if (!ok) { // parse nothing: an empty stream of zeros keeps the lane in step with the wave
+        p = 4, cw = 0, rw = 0, order = 0, ck = 0, rk = 0;
     }
     uint32_t flags = 0;
+    const bool store = ok && in_range;
 
     // coefficient stream: starts 3 bytes into the aligned word at p + 4 (behind word count + order);
     // its last word shares an aligned word with the residue k, hence cw + 1 aligned words.
     {
-        BitReader br;
-        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(fb + p + 4);
-        br.init(w0, w0 + cw + 1);
-        br.refill();
-        br.skip(24);
+        StreamReader r;
+        reader_open(r, reinterpret_cast<const uint32_t*>(fb + p + 4), ok ? cw + 1 : 0, 24, tile, lane);
         const uint32_t kmask = ck ? (0xFFFFFFFFu >> (32 - ck)) : 0u;
         int32_t* qo = q_out + (size_t)g * kQStride;
-        for (uint32_t i = 0; i < order; i++)
-            qo[i] = br.codeword(ck, kmask);
-        if (br.starved > 2) // up to two look-ahead words past the end are normal
-            flags |= SELA_HIP_FLAG_RICE_OVERRUN;
-    }
-    // residue stream (aligned)
-    {
-        BitReader br;
-        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(fb + p + 12 + 4 * (uint64_t)cw);
-        br.init(w0, w0 + rw);
-        const uint32_t kmask = rk ? (0xFFFFFFFFu >> (32 - rk)) : 0u;
-        int4* ro = reinterpret_cast<int4*>(residues + (size_t)g * kBlock);
-#pragma unroll 1
-        for (uint32_t i = 0; i < (uint32_t)kBlock / 4; i++) {
-            int4 v;
-            v.x = br.codeword(rk, kmask);
-            v.y = br.codeword(rk, kmask);
-            v.z = br.codeword(rk, kmask);
-            v.w = br.codeword(rk, kmask);
-            ro[i] = v;
+        uint32_t max_order = order;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)max_order, m, 64);
+            max_order = o > max_order ? o : max_order;
         }
-        if (br.starved > 2)
+        for (uint32_t i = 0; i < max_order; i += 4) {
+            uint32_t live_mask = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                live_mask |= (i + j < order ? 1u : 0u) << j;
+            int32_t v[4];
+            reader_codewords4(r, tile, lane, ck, kmask, live_mask, v);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (((live_mask >> j) & 1u) && store)
+                    qo[i + j] = v[j];
+        }
+        if (r.bp > 24 + 32 * cw)
             flags |= SELA_HIP_FLAG_RICE_OVERRUN;
     }
-    d.info = channel | (type << 8) | (parent << 16) | (order << 24);
-    d.flags = flags;
-    desc[g] = d;
+    // residue stream (aligned).  Values are staged in LDS, 32 per lane, and written out as full
+    // 128-byte lines (8 lanes per subframe row) instead of 64 scattered stores per value.
+    {
+        StreamReader r;
+        reader_open(r, reinterpret_cast<const uint32_t*>(fb + p + 12 + 4 * (uint64_t)cw), rw, 0, tile, lane);
+        const uint32_t kmask = rk ? (0xFFFFFFFFu >> (32 - rk)) : 0u;
+        const unsigned long long store_mask = __ballot(store);
+        const uint32_t live_mask = ok ? 0xFu : 0u;
+#pragma unroll 1
+        for (uint32_t blk = 0; blk < (uint32_t)kBlock / kStageVals; blk++) {
+#pragma unroll
+            for (int j = 0; j < kStageVals; j += 4) {
+                int32_t v[4];
+                reader_codewords4(r, tile, lane, rk, kmask, live_mask, v);
+                stage[lane * kStageStride + j] = v[0];
+                stage[lane * kStageStride + j + 1] = v[1];
+                stage[lane * kStageStride + j + 2] = v[2];
+                stage[lane * kStageStride + j + 3] = v[3];
+            }
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 8; i++) { // 8 rows x 8 lanes x 16 bytes per wave-store
+                const int row = 8 * i + (lane >> 3);
+                const int c4 = (lane & 7) * 4;
+                const int32_t* src = stage + row * kStageStride + c4;
+                int4 v;
+                v.x = src[0], v.y = src[1], v.z = src[2], v.w = src[3];
+                const uint32_t g_row = blockIdx.x * 64 + (uint32_t)row;
+                if ((store_mask >> row) & 1ull)
+                    *reinterpret_cast<int4*>(residues + (size_t)g_row * kBlock + blk * kStageVals + c4) = v;
+            }
+            wave_sync();
+        }
+        if (r.bp > 32 * rw)
+            flags |= SELA_HIP_FLAG_RICE_OVERRUN;
+    }
+    if (in_range) {
+        SubDesc d;
+        d.info = ok ? channel | (type << 8) | (parent << 16) | (order << 24) : 0u;
+        d.flags = ok ? flags : (uint32_t)SELA_HIP_FLAG_BAD_FRAME;
+        desc[g] = d;
+    }
 }
 
 // ---- synthesis filter ----------------------------------------------------------------------------------
