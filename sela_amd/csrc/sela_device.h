@@ -83,6 +83,15 @@ __device__ __forceinline__ uint64_t wave_shl1(uint64_t fill, uint64_t x)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Every lane receives the value of lane I of its own row of 16 lanes (one v_mov_b64_dpp row_newbcast).
+template <int I>
+__device__ __forceinline__ double row_broadcast(double v)
+{
+    const long long x = __builtin_bit_cast(long long, v);
+    const long long y = __builtin_amdgcn_mov_dpp(x, 0x150 + I /* row_newbcast:I */, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, y);
+}
+
 __device__ __forceinline__ double read_first_lane(double v)
 {
     const uint64_t x = __builtin_bit_cast(uint64_t, v);

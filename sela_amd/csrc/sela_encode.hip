@@ -86,25 +86,71 @@ __device__ __forceinline__ uint32_t put_codeword(uint32_t* buf, uint32_t pos, ui
 }
 
 // rice::RiceEncoder::calculateOptimumRiceParam (src/rice/rice_encoder.cpp:20-33) for the values
-// u[0..V) of every lane (invalid slots hold 0 and are not counted in n).  Exact 64-bit sums;
-// first minimum wins.
+// u[0..V) of every lane (invalid slots hold 0 and are not counted in n): the FIRST k in [0, 20) that
+// minimises  bits(k) = sum(u >> k) + n * (1 + k).
+//
+// The reference evaluates all 20 candidates; the same answer needs only a few of them because
+// bits() is convex in k:  T(k) = sum(u >> k) drops by d(k) = sum(ceil((u >> k) / 2)) from k to k+1 and
+// ceil(floor(v/2)/2) <= ceil(v/2) makes d(k) non-increasing, so bits(k+1) - bits(k) = n - d(k) is
+// non-decreasing.  Hence the first minimum is the smallest k with d(k) <= n (k = 19 if there is none),
+// found by walking from a guess near log2(mean u).  Exact 64-bit sums throughout.
+template <int V>
+__device__ __forceinline__ uint64_t rice_shifted_sum(const uint32_t (&u)[V], uint32_t k)
+{
+    uint64_t part = 0;
+#pragma unroll
+    for (int t = 0; t < V; t++)
+        part += u[t] >> k;
+    return wave_sum(part);
+}
+
 template <int V>
 __device__ __forceinline__ void rice_plan(const uint32_t (&u)[V], uint32_t n, uint32_t& best_k, uint64_t& best_bits)
 {
-    best_k = 0;
-    best_bits = 0;
-#pragma unroll 1
-    for (uint32_t k = 0; k < SELA_MAX_RICE_PARAM; k++) {
-        uint64_t part = 0;
-#pragma unroll
-        for (int t = 0; t < V; t++)
-            part += u[t] >> k;
-        const uint64_t bits = wave_sum(part) + (uint64_t)n * (1 + k);
-        if (k == 0 || bits < best_bits) {
-            best_bits = bits;
-            best_k = k;
+    constexpr uint32_t kLast = SELA_MAX_RICE_PARAM - 1;
+    const uint64_t t0 = rice_shifted_sum<V>(u, 0);
+    const uint64_t mean = n ? t0 / n : 0;
+    uint32_t k = mean ? 63u - (uint32_t)__clzll(mean) : 0u; // floor(log2(mean))
+    k = k > kLast - 1 ? kLast - 1 : k;
+    uint64_t ta = k ? rice_shifted_sum<V>(u, k) : t0; // T(k)
+    uint64_t tb = rice_shifted_sum<V>(u, k + 1);      // T(k + 1)
+    if (ta - tb <= n) { // bits(k+1) >= bits(k): the first minimum is at or below k
+        while (k > 0) {
+            const uint64_t tc = k == 1 ? t0 : rice_shifted_sum<V>(u, k - 1);
+            if (tc - ta > n)
+                break;
+            k--;
+            tb = ta;
+            ta = tc;
+        }
+    } else { // still descending: move up
+        for (;;) {
+            k++;
+            ta = tb;
+            if (k == kLast)
+                break;
+            tb = rice_shifted_sum<V>(u, k + 1);
+            if (ta - tb <= n)
+                break;
         }
     }
+    best_k = k;
+    best_bits = ta + (uint64_t)n * (1 + k);
+}
+
+// Steps I .. 15 of a 16-step autocorrelation trip (see k_encode_blocks).  C holds c[j0 + (lane & 15)];
+// pe/po point at E[m0 - L] / O[m0 - L] with m0 = j0 / 2.
+template <int I>
+__device__ __forceinline__ void autocorr_steps(double C, const double* pe, const double* po, double& A, double& B,
+    double& acc_e, double& acc_o)
+{
+    const double cj = row_broadcast<I>(C);
+    acc_e += cj * A; // lag 2L   : c[j] * c[j - 2L]
+    acc_o += cj * B; // lag 2L+1 : c[j] * c[j - 2L - 1]
+    B = A;
+    A = (I & 1) ? pe[I / 2 + 1] : po[I / 2]; // c[j + 1 - 2L]
+    if constexpr (I < 15)
+        autocorr_steps<I + 1>(C, pe, po, A, B, acc_e, acc_o);
 }
 
 // kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts
@@ -182,13 +228,34 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     SELA_STAMP(1);
     // ---- mean (src/lpc/residue_generator.cpp:27-30): one strictly sequential sum -----------------
     // Every lane walks the same chain from broadcast LDS reads, so the result is wave-uniform.
+    // (a pure dependency chain: run it at raised wave priority so that its adds issue the moment
+    // they are ready instead of queueing behind the co-resident wave's throughput-bound phases)
+    __builtin_amdgcn_s_setprio(3);
     double sum = 0.0;
-#pragma unroll 8
-    for (int m = 0; m < kBlock / 2; m++) {
-        sum += E[m];
-        sum += O[m];
+    {
+        constexpr int kB = 8; // batch: the reads of batch b+1 are in flight while batch b is summed
+        double ce[kB], co[kB];
+#pragma unroll
+        for (int i = 0; i < kB; i++)
+            ce[i] = E[i], co[i] = O[i];
+#pragma unroll 1
+        for (int m = 0; m < kBlock / 2; m += kB) {
+            double ne[kB], no[kB];
+#pragma unroll
+            for (int i = 0; i < kB; i++) // (reads 8 elements past the end on the last trip: still inside the LDS plan)
+                ne[i] = E[m + kB + i], no[i] = O[m + kB + i];
+#pragma unroll
+            for (int i = 0; i < kB; i++) {
+                sum += ce[i];
+                sum += co[i];
+            }
+#pragma unroll
+            for (int i = 0; i < kB; i++)
+                ce[i] = ne[i], co[i] = no[i];
+        }
     }
     const double mean = sum / (double)kBlock;
+    __builtin_amdgcn_s_setprio(0);
 
     SELA_STAMP(2);
     // c[j] = x[j] - mean, in place (same value at every use)
@@ -202,7 +269,8 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     // Lane L owns lags 2L and 2L+1 (lanes 0..50 matter).  At step j it needs
     //     A = c[j - 2L]      (lag 2L)       B = c[j - 2L - 1]   (lag 2L+1)
     // and the wave-uniform c[j], which is lane 0's A.  Going to j+1: B' = A, A' = c[j+1-2L], whose
-    // parity is that of j+1 for every lane -> one conflict-free ds_read_b64 per step.  Each
+    // parity is that of j+1 for every lane -> one conflict-free ds_read_b64 per step.  (c[j] itself
+    // comes from a register that holds 16 consecutive c values, see below.)  Each
     // accumulator sees its products in ascending j exactly like the reference loop; the extra
     // leading terms c[j]*0 (j < lag) leave an accumulator at +0.0.
     double acc_e = 0.0, acc_o = 0.0;
@@ -211,20 +279,13 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
         const double* po = O - lane;
         double A = pe[0]; // c[0 - 2L]
         double B = 0.0;   // c[-2L - 1]
-#pragma unroll 4
-        for (int m = 0; m < kBlock / 2; m++) {
-            // j = 2m (even)
-            double cj = read_first_lane(A);
-            acc_e += cj * A;
-            acc_o += cj * B;
-            B = A;
-            A = po[m]; // c[2m + 1 - 2L]
-            // j = 2m + 1 (odd)
-            cj = read_first_lane(A);
-            acc_e += cj * A;
-            acc_o += cj * B;
-            B = A;
-            A = pe[m + 1]; // c[2m + 2 - 2L]
+        // sixteen steps per trip: the sixteen wave-uniform multipliers c[j0 .. j0+15] are fetched once,
+        // replicated in every row of 16 lanes, and handed out by DPP row broadcast (v_mov_b64_dpp)
+        const double* bc = ((lane & 1) ? O : E) + ((lane & 15) >> 1);
+#pragma unroll 1
+        for (int m0 = 0; m0 < kBlock / 2; m0 += 8) {
+            const double C = bc[m0]; // lane 16r + i holds c[2*m0 + i]
+            autocorr_steps<0>(C, pe + m0, po + m0, A, B, acc_e, acc_o);
         }
     }
     wave_sync(); // c[] is dead from here on
@@ -244,6 +305,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     // Column j of gen[0]/gen[1] lives in lane j (j < 64) and lane j - 64 of a second register.
     // Stage i reads gen1[j+1] (old) -> a one-lane shift; all columns update from old values.
     double k_lo = 0.0, k_hi = 0.0; // k[lane], k[lane + 64]
+    __builtin_amdgcn_s_setprio(2); // latency-bound (100 dependent stages, one division each)
     {
         double g0a = sm->ac[lane + 1], g1a = g0a;
         double g0b = lane < 36 ? sm->ac[lane + 65] : 0.0, g1b = g0b;
@@ -319,6 +381,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     SELA_STAMP(6);
     // ---- step-up to the Q35 predictor (src/lpc/linear_predictor.cpp:30-61) ---------------------------
     step_up(sm->k, sm->t, sm->a, order, lane, flags);
+    __builtin_amdgcn_s_setprio(0);
     if (kTrace) {
         sela_hip_trace* tr = trace + block_id;
         for (int i = lane; i <= order; i += 64)
