@@ -232,27 +232,10 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     // they are ready instead of queueing behind the co-resident wave's throughput-bound phases)
     __builtin_amdgcn_s_setprio(3);
     double sum = 0.0;
-    {
-        constexpr int kB = 8; // batch: the reads of batch b+1 are in flight while batch b is summed
-        double ce[kB], co[kB];
-#pragma unroll
-        for (int i = 0; i < kB; i++)
-            ce[i] = E[i], co[i] = O[i];
-#pragma unroll 1
-        for (int m = 0; m < kBlock / 2; m += kB) {
-            double ne[kB], no[kB];
-#pragma unroll
-            for (int i = 0; i < kB; i++) // (reads 8 elements past the end on the last trip: still inside the LDS plan)
-                ne[i] = E[m + kB + i], no[i] = O[m + kB + i];
-#pragma unroll
-            for (int i = 0; i < kB; i++) {
-                sum += ce[i];
-                sum += co[i];
-            }
-#pragma unroll
-            for (int i = 0; i < kB; i++)
-                ce[i] = ne[i], co[i] = no[i];
-        }
+#pragma unroll 8
+    for (int m = 0; m < kBlock / 2; m++) {
+        sum += E[m];
+        sum += O[m];
     }
     const double mean = sum / (double)kBlock;
     __builtin_amdgcn_s_setprio(0);
