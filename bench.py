@@ -72,6 +72,23 @@ def cpu_baseline(pcm, repeats_target_s=12.0):
     }
 
 
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN/traffic.json,
+    written by tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes of this same command,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no summary is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    for name, d in data.items():
+        if kernel in name and "hbm_bytes_per_launch_fetch_x2" in d:
+            return d["hbm_bytes_per_launch_fetch_x2"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,12 +121,16 @@ def main():
     pcm = torch.from_numpy(pcm_host).cuda()
     enc = codec.Encoder(n_frames, CHANNELS)
     dec = codec.Decoder(n_frames, CHANNELS)
-    sizes = torch.zeros(world, dtype=torch.int64, device="cuda")
+    all_sizes = torch.zeros(world * n_frames, dtype=torch.int64, device="cuda")
 
     def step():
         out = enc.encode(pcm)
-        if dist is not None:  # the path's only exchange: compressed sizes -> file offsets of every rank
-            dist.all_gather_into_tensor(sizes, out.offsets[-1:].contiguous())
+        if dist is not None:
+            # the path's only exchange: per-frame compressed sizes of every rank, so that
+            # each rank knows where its frames land in the job's output stream (sela_amd/sharding.py);
+            # 8 bytes x frames, latency bound -- RCCL over xGMI
+            dist.all_gather_into_tensor(all_sizes, out.offsets[1:] - out.offsets[:-1])
+            torch.cumsum(all_sizes, 0)
         back = dec.decode(out.frames, out.offsets, n_frames)
         return out, back
 
@@ -153,6 +174,7 @@ def main():
     pcm_bytes = pcm_host.nbytes
     algo_bytes = pcm_bytes + payload_bytes  # PCM16 read + .sela frame bytes written
     achieved = algo_bytes / (enc_blocks_ms * 1e-3) / 1e9
+    traffic = measured_traffic("k_encode_blocks")
 
     if rank == 0:
         samples = n_frames * 2048
@@ -185,7 +207,7 @@ def main():
                           "decode_synthesize": float(k_dec[:, 1].mean())},
             "roofline": {
                 "kernel": "k_encode_blocks", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "note": "the path is FP64-issue/latency bound, not HBM bound (DESIGN.md): 7 B per stereo sample",
             },

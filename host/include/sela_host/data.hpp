@@ -1,0 +1,88 @@
+// data.hpp -- value types that cross the frame-codec boundary of the C++ host.
+//
+// Same namespaces, class names and public members as the reference's src/include/data/*.hpp
+// (wav_frame.hpp:8-16, sela_frame.hpp:7-18, sela_sub_frame.hpp:7-45, rice_encoded_data.hpp:8-21,
+// sela_header.hpp:7-14, exception.hpp:7-14), so code written against the reference compiles against
+// this host.  Everything is a plain value type; on the fast path (sela::Encoder / sela::Decoder) these
+// objects are only materialised for callers that ask for them -- the bytes travel as flat buffers.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace data {
+
+// Thrown (by value, not derived from std::exception -- like the reference) by the file parsers and by
+// the codec classes when the GPU path reports an error.
+class Exception {
+public:
+    const std::string exceptionMessage;
+    explicit Exception(std::string message) noexcept : exceptionMessage(std::move(message)) {}
+};
+
+// One block of de-interleaved PCM: samples[channel][i].
+class WavFrame {
+public:
+    uint8_t bitsPerSample;
+    std::vector<std::vector<int32_t>> samples;
+    WavFrame(uint8_t bps, std::vector<std::vector<int32_t>> s) : bitsPerSample(bps), samples(std::move(s)) {}
+};
+
+// A Golomb-Rice coded integer sequence: parameter, value count, LSB-first packed words.
+class RiceEncodedData {
+public:
+    uint32_t optimumRiceParam;
+    uint32_t dataCount;
+    std::vector<uint32_t> encodedData;
+    RiceEncodedData(uint32_t param, uint32_t count, std::vector<uint32_t> words)
+        : optimumRiceParam(param), dataCount(count), encodedData(std::move(words))
+    {
+    }
+};
+
+// One channel of a frame as stored on disk (field widths are the on-disk widths).
+class SelaSubFrame {
+public:
+    uint8_t channel;
+    uint8_t subFrameType;        // 0 independent, 1 difference against parentChannelNumber
+    uint8_t parentChannelNumber;
+    uint8_t reflectionCoefficientRiceParam;
+    uint16_t reflectionCoefficientRequiredInts;
+    uint8_t optimumLpcOrder;
+    std::vector<uint32_t> encodedReflectionCoefficients;
+    uint8_t residueRiceParam;
+    uint16_t residueRequiredInts;
+    uint16_t samplesPerChannel;
+    std::vector<uint32_t> encodedResidues;
+
+    SelaSubFrame(uint8_t ch, uint8_t type, uint8_t parent, const RiceEncodedData& refl, const RiceEncodedData& resid)
+        : channel(ch), subFrameType(type), parentChannelNumber(parent),
+          reflectionCoefficientRiceParam((uint8_t)refl.optimumRiceParam),
+          reflectionCoefficientRequiredInts((uint16_t)refl.encodedData.size()), optimumLpcOrder((uint8_t)refl.dataCount),
+          encodedReflectionCoefficients(refl.encodedData), residueRiceParam((uint8_t)resid.optimumRiceParam),
+          residueRequiredInts((uint16_t)resid.encodedData.size()), samplesPerChannel((uint16_t)resid.dataCount),
+          encodedResidues(resid.encodedData)
+    {
+    }
+};
+
+class SelaFrame {
+public:
+    int32_t syncWord = (int32_t)0xAA55FF00;
+    std::vector<SelaSubFrame> subFrames;
+    uint8_t bitsPerSample; // not written to the stream
+    explicit SelaFrame(uint8_t bps) : bitsPerSample(bps) {}
+};
+
+class SelaHeader {
+public:
+    uint8_t magicNumber[4] = { 'S', 'e', 'L', 'a' };
+    uint32_t sampleRate = 0;
+    uint16_t bitsPerSample = 0;
+    uint8_t channels = 0;
+    uint32_t numFrames = 0;
+};
+
+} // namespace data

@@ -1,0 +1,53 @@
+// files.hpp -- file::WavFile and file::SelaFile (reference: src/include/file/wav_file.hpp:10-19,
+// src/include/file/sela_file.hpp:10-18), re-designed around flat buffers:
+//
+//   * WavFile keeps the data chunk as the interleaved little-endian int16 array it already is -- that
+//     array IS the input format of sela_hip_encode, so encoding is zero-copy on the host.  The
+//     reference's per-frame de-interleaved `wavFrames` are still available (demuxSamples()).
+//   * SelaFile keeps the frame byte stream exactly as it goes to disk (one write()) plus the frame
+//     offsets; `selaFrames` objects are materialised for callers that want them.
+#pragma once
+
+#include <fstream>
+#include <string>
+
+#include "sela_host/data.hpp"
+
+namespace file {
+
+class WavFile {
+public:
+    size_t samplesPerChannelPerFrame = 2048;
+    uint32_t sampleRate = 0;
+    uint16_t bitsPerSample = 16;
+    uint16_t numChannels = 0;
+    std::vector<int16_t> pcm;               // interleaved, whole data chunk
+    std::vector<data::WavFrame> wavFrames;  // filled by demuxSamples()
+
+    WavFile() {}
+    WavFile(uint32_t rate, uint16_t bps, uint16_t channels, std::vector<data::WavFrame>&& frames);
+    WavFile(uint32_t rate, uint16_t channels, std::vector<int16_t>&& interleaved);
+
+    void readFromFile(std::ifstream& in);   // throws data::Exception with the reference's messages
+    void writeToFile(std::ofstream& out);   // canonical 44-byte header + data
+    void demuxSamples();                    // pcm -> wavFrames (whole frames only, tail dropped)
+    size_t frameCount() const { return numChannels ? pcm.size() / numChannels / samplesPerChannelPerFrame : 0; }
+};
+
+class SelaFile {
+public:
+    data::SelaHeader selaHeader;
+    std::vector<data::SelaFrame> selaFrames; // filled by readFromFile() and materializeFrames()
+    std::vector<uint8_t> frameBytes;          // the stream behind the 15-byte header
+    std::vector<uint64_t> frameOffsets;       // [numFrames + 1] byte offsets into frameBytes
+
+    SelaFile() {}
+    SelaFile(uint32_t rate, uint16_t bps, uint8_t channels, std::vector<data::SelaFrame>&& frames);
+    SelaFile(uint32_t rate, uint16_t bps, uint8_t channels, std::vector<uint8_t>&& bytes, std::vector<uint64_t>&& offsets);
+
+    void readFromFile(std::ifstream& in);
+    void writeToFile(std::ofstream& out);
+    void materializeFrames(); // frameBytes -> selaFrames
+};
+
+} // namespace file

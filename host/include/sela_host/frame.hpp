@@ -1,0 +1,36 @@
+// frame.hpp -- frame::FrameEncoder / frame::FrameDecoder with the reference's signatures
+// (src/include/frame.hpp:8-24), running on the MI355X through libsela_hip.so (batch of one frame).
+//
+// Also the flat <-> object conversions between the .sela frame byte stream (what the GPU path reads
+// and writes) and data::SelaFrame objects.
+#pragma once
+
+#include <cstddef>
+
+#include "sela_host/data.hpp"
+
+namespace frame {
+
+class FrameEncoder {
+    const data::WavFrame& wavFrame;
+
+public:
+    explicit FrameEncoder(const data::WavFrame& frame) : wavFrame(frame) {}
+    data::SelaFrame process(); // throws data::Exception if the GPU path fails
+};
+
+class FrameDecoder {
+    const data::SelaFrame& selaFrame;
+
+public:
+    explicit FrameDecoder(const data::SelaFrame& frame) : selaFrame(frame) {}
+    data::WavFrame process();
+};
+
+// On-disk bytes of one frame (layout of the reference's src/file/sela_file.cpp:115-135) -> object.
+// Returns the number of bytes consumed; throws data::Exception on a truncated or malformed frame.
+size_t parseFrame(const uint8_t* bytes, size_t available, uint8_t channels, uint8_t bitsPerSample, data::SelaFrame& out);
+// Object -> on-disk bytes, appended to `out`.
+void appendFrame(const data::SelaFrame& frame, std::vector<uint8_t>& out);
+
+} // namespace frame

@@ -1,0 +1,163 @@
+// selftest.cpp -- CPU-only checks of the host's container code (no GPU needed).
+// Exit code 0 = all passed.  Driven by tests/test_host_cpp.py.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "sela_host/files.hpp"
+#include "sela_host/frame.hpp"
+
+namespace {
+
+int failures = 0;
+#define CHECK(cond)                                                        \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            std::fprintf(stderr, "FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); \
+            failures++;                                                    \
+        }                                                                  \
+    } while (0)
+
+std::string expectError(const std::string& path, bool asWav)
+{
+    try {
+        std::ifstream in(path, std::ios::binary);
+        if (asWav) {
+            file::WavFile w;
+            w.readFromFile(in);
+        } else {
+            file::SelaFile s;
+            s.readFromFile(in);
+        }
+    } catch (const data::Exception& e) {
+        return e.exceptionMessage;
+    }
+    return "";
+}
+
+void writeBytes(const std::string& path, const std::string& bytes)
+{
+    std::ofstream out(path, std::ios::binary);
+    out.write(bytes.data(), (std::streamsize)bytes.size());
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+
+    // ---- WAV round trip, tail handling, de-interleave ------------------------------------------------
+    {
+        std::vector<int16_t> pcm(2 * (2048 * 2 + 100));
+        for (size_t i = 0; i < pcm.size(); i++)
+            pcm[i] = (int16_t)((i * 7919u) ^ (i >> 3));
+        file::WavFile w(44100, 2, std::vector<int16_t>(pcm));
+        {
+            std::ofstream out(dir + "/t.wav", std::ios::binary);
+            w.writeToFile(out);
+        }
+        std::ifstream in(dir + "/t.wav", std::ios::binary);
+        file::WavFile r;
+        r.readFromFile(in);
+        CHECK(r.numChannels == 2 && r.sampleRate == 44100 && r.bitsPerSample == 16);
+        CHECK(r.pcm == pcm);
+        CHECK(r.frameCount() == 2); // 100 tail samples per channel are dropped
+        r.demuxSamples();
+        CHECK(r.wavFrames.size() == 2 && r.wavFrames[1].samples[1][5] == pcm[(2048 + 5) * 2 + 1]);
+    }
+    // ---- WAV error paths (messages as the reference's src/file/wav_file.cpp) ---------------------------
+    {
+        writeBytes(dir + "/small.wav", "RIFF");
+        CHECK(expectError(dir + "/small.wav", true) == "File is too small, probably not a wav file.");
+        std::string bad(64, '\0');
+        std::memcpy(&bad[0], "RIFX", 4);
+        writeBytes(dir + "/bad.wav", bad);
+        CHECK(expectError(dir + "/bad.wav", true) == "chunkId is not RIFF, probably not a wav file.");
+        std::string w24(64, '\0');
+        std::memcpy(&w24[0], "RIFF", 4);
+        w24[4] = 56;
+        std::memcpy(&w24[8], "WAVEfmt ", 8);
+        w24[16] = 16;
+        w24[20] = 1;
+        w24[22] = 2;
+        w24[34] = 24; // 24 bits per sample
+        writeBytes(dir + "/w24.wav", w24);
+        CHECK(expectError(dir + "/w24.wav", true) == "Only 16bits per sample wav is supported.");
+    }
+    // ---- .sela container: objects -> bytes -> objects ---------------------------------------------------
+    {
+        std::vector<data::SelaFrame> frames;
+        for (int f = 0; f < 3; f++) {
+            data::SelaFrame fr(16);
+            for (int c = 0; c < 2; c++) {
+                std::vector<uint32_t> cw = { 0x4914dd7fu + (uint32_t)f, 0x4a519ce4u, 0x6318c108u };
+                std::vector<uint32_t> rw(10 + 5 * f + c, 0xA5A50000u + (uint32_t)c);
+                fr.subFrames.emplace_back((uint8_t)c, (uint8_t)c, (uint8_t)0, data::RiceEncodedData(4, 17, cw), data::RiceEncodedData(7, 2048, rw));
+            }
+            frames.push_back(fr);
+        }
+        file::SelaFile s(48000, 16, 2, std::move(frames));
+        CHECK(s.frameOffsets.size() == 4 && s.frameOffsets[1] == 4 + 2 * 12 + 4 * (3 + 10 + 3 + 11));
+        {
+            std::ofstream out(dir + "/t.sela", std::ios::binary);
+            s.writeToFile(out);
+        }
+        std::ifstream in(dir + "/t.sela", std::ios::binary);
+        file::SelaFile r;
+        r.readFromFile(in);
+        CHECK(r.selaHeader.sampleRate == 48000 && r.selaHeader.channels == 2 && r.selaHeader.numFrames == 3);
+        CHECK(r.frameBytes == s.frameBytes && r.frameOffsets == s.frameOffsets);
+        CHECK(r.selaFrames.size() == 3 && r.selaFrames[2].subFrames[1].encodedResidues.size() == 21);
+        CHECK(r.selaFrames[1].subFrames[1].subFrameType == 1 && r.selaFrames[1].subFrames[0].optimumLpcOrder == 17);
+        CHECK(r.selaFrames[0].subFrames[0].encodedReflectionCoefficients[0] == 0x4914dd7fu);
+        // a broken sync word silently ends the file (src/file/sela_file.cpp:54-56)
+        std::ifstream again(dir + "/t.sela", std::ios::binary);
+        std::string raw((std::istreambuf_iterator<char>(again)), std::istreambuf_iterator<char>());
+        raw[15 + (size_t)s.frameOffsets[1]] ^= 0x01;
+        writeBytes(dir + "/cut.sela", raw);
+        std::ifstream cut(dir + "/cut.sela", std::ios::binary);
+        file::SelaFile c;
+        c.readFromFile(cut);
+        CHECK(c.selaFrames.size() == 1 && c.selaHeader.numFrames == 3);
+        writeBytes(dir + "/magic.sela", "NoPe00000000000000");
+        CHECK(expectError(dir + "/magic.sela", false) == "Magic number is incorrect, probably not a sela file.");
+    }
+    // ---- GPU mode: the reference's own frame tests (test/frametests.cpp:8-70) through the host classes --
+    if (argc > 2 && std::string(argv[2]) == "gpu") {
+        try {
+            std::vector<int32_t> sine(2048);
+            for (int i = 0; i < 2048; i++)
+                sine[i] = (int32_t)(32767 * std::sin((double)i * (3.141592653589793238462643383279502884 / 180)));
+            data::WavFrame input(16, { sine, sine });
+            data::SelaFrame coded = frame::FrameEncoder(input).process();
+            CHECK(coded.subFrames.size() == 2);
+            // channel 0 independent (order 17, 552 residue words), channel 1 a silent difference
+            CHECK(coded.subFrames[0].subFrameType == 0 && coded.subFrames[0].optimumLpcOrder == 17);
+            CHECK(coded.subFrames[0].reflectionCoefficientRiceParam == 4 && coded.subFrames[0].residueRiceParam == 7);
+            CHECK(coded.subFrames[0].encodedResidues.size() == 552 && coded.subFrames[0].encodedReflectionCoefficients.size() == 3);
+            CHECK(coded.subFrames[0].encodedReflectionCoefficients[0] == 0x4914dd7fu);
+            CHECK(coded.subFrames[1].subFrameType == 1 && coded.subFrames[1].parentChannelNumber == 0);
+            CHECK(coded.subFrames[1].optimumLpcOrder == 1 && coded.subFrames[1].encodedResidues.size() == 64);
+            data::WavFrame output = frame::FrameDecoder(coded).process();
+            CHECK(output.samples.size() == 2 && output.samples[0] == sine && output.samples[1] == sine);
+            // mono + a sample outside 16 bits is rejected loudly
+            std::vector<int32_t> wide(2048, 40000);
+            bool threw = false;
+            try {
+                frame::FrameEncoder(data::WavFrame(16, { wide })).process();
+            } catch (const data::Exception&) {
+                threw = true;
+            }
+            CHECK(threw);
+        } catch (const data::Exception& e) {
+            std::fprintf(stderr, "FAIL exception: %s\n", e.exceptionMessage.c_str());
+            failures++;
+        }
+    }
+    std::printf(failures ? "selftest: %d failure(s)\n" : "selftest: ok\n", failures);
+    return failures ? 1 : 0;
+}
