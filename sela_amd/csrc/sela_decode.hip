@@ -322,9 +322,8 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
 // one-position move between lanes is a DPP wave shift.  The recurrence itself (z_0 -> s_i) runs on
 // the scalar unit: s_i stays in an SGPR and feeds the multiply-adds as a scalar operand.
 //
-// 64x32-bit products in two instructions: a = ah*2^32 + al with al = (int32)a, so
-//     a*s mod 2^64 = al*s (v_mad_i64_i32, exact) + ((ah*s mod 2^32) << 32)
-// and a position carries the pair (acc1, acc2) with z = acc1 + (acc2 << 32).
+// 64x32-bit products: a = ah*2^32 + al with al = (int32)a, so
+//     z + a*s mod 2^64 = (z + al*s)  [v_mad_i64_i32, exact]  +  ((ah*s mod 2^32) << 32)  [v_mul_lo_u32 + v_add_u32]
 template <int P>
 __device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int lane)
 {
@@ -337,11 +336,10 @@ __device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int 
         al[h] = (int32_t)(uint32_t)(uint64_t)av;
         ah[h] = (uint32_t)((uint64_t)(av - (int64_t)al[h]) >> 32);
     }
-    uint64_t acc1[P];
-    uint32_t acc2[P];
+    uint64_t z[P];
 #pragma unroll
     for (int h = 0; h < P; h++)
-        acc1[h] = 0, acc2[h] = 0;
+        z[h] = 0;
     const uint64_t half = (uint64_t)1 << (SELA_Q_SHIFT - 1);
 #pragma unroll 1
     for (int base = 0; base < kBlock; base += 64) {
@@ -350,23 +348,18 @@ __device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int 
 #pragma unroll
         for (int m = 0; m < 64; m++) {
             // scalar side: P_i sits in lane 0, position 0
-            const uint32_t p_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)acc1[0]);
-            const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(acc1[0] >> 32))
-                + (uint32_t)__builtin_amdgcn_readfirstlane((int)acc2[0]);
-            const uint64_t pv = ((uint64_t)p_hi << 32) | p_lo;
+            const uint64_t pv = read_first_lane(z[0]);
             const int32_t pred = (int32_t)((int64_t)(half - pv) >> SELA_Q_SHIFT);
             const int32_t r_i = __builtin_amdgcn_readlane(r_chunk, m);
             const int32_t s_i = (int32_t)((uint32_t)r_i - (uint32_t)pred);
             asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(s_chunk) : "s"(s_i), "n"(m));
             // vector side: move every partial sum down one position and add this sample's products
-            const uint64_t in1 = wave_shl1_zero(acc1[0]);
-            const uint32_t in2 = wave_shl1_zero(acc2[0]);
+            const uint64_t in = wave_shl1_zero(z[0]);
 #pragma unroll
             for (int h = 0; h < P; h++) {
-                const uint64_t up1 = h + 1 < P ? acc1[h + 1 < P ? h + 1 : h] : in1;
-                const uint32_t up2 = h + 1 < P ? acc2[h + 1 < P ? h + 1 : h] : in2;
-                acc1[h] = (uint64_t)((int64_t)up1 + (int64_t)al[h] * (int64_t)s_i);
-                acc2[h] = (uint32_t)((uint64_t)up2 + (uint64_t)ah[h] * (uint32_t)s_i);
+                const uint64_t up = h + 1 < P ? z[h + 1 < P ? h + 1 : h] : in;
+                const uint64_t lo = (uint64_t)((int64_t)up + (int64_t)al[h] * (int64_t)s_i);
+                z[h] = lo + ((uint64_t)(ah[h] * (uint32_t)s_i) << 32);
             }
         }
         rs[base + lane] = s_chunk;
