@@ -17,9 +17,10 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
     hipEvent_t* ev, uint64_t* d_phase_cycles);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles);
+    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles,
+    hipStream_t side, hipEvent_t fork, hipEvent_t* parsed);
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
-size_t decode_lds_bytes(uint32_t channels, int n_waves);
+size_t decode_lds_bytes(uint32_t channels, int n_waves, uint32_t v_count);
 int decode_waves(uint32_t channels);
 } // namespace sela
 
@@ -94,6 +95,52 @@ struct KernelTiming {
     }
 };
 thread_local KernelTiming g_timing;
+// Side stream + events of the decode pipeline (parse chunk j+1 overlaps synthesis of chunk j), per
+// calling thread and device.
+struct DecodePipeline {
+    int device = -1;
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr;
+    hipEvent_t parsed[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    bool ready()
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess)
+            return false;
+        if (dev == device && side)
+            return true;
+        release();
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) {
+            side = nullptr;
+            return false;
+        }
+        bool ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : parsed)
+            ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            release();
+            return false;
+        }
+        device = dev;
+        return true;
+    }
+    void release()
+    {
+        if (side)
+            (void)hipStreamDestroy(side);
+        if (fork)
+            (void)hipEventDestroy(fork);
+        for (auto& e : parsed) {
+            if (e)
+                (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        side = nullptr;
+        fork = nullptr;
+        device = -1;
+    }
+};
+thread_local DecodePipeline g_pipeline;
 thread_local uint64_t* g_phase_cycles = nullptr; // debug: per-block phase cycle counts (sela_hip_debug_phase_buffer)
 
 uint32_t flags_to_error(uint32_t flags)
@@ -131,7 +178,11 @@ int sela_hip_init(int device)
     return SELA_HIP_OK;
 }
 
-void sela_hip_shutdown(void) { g_ctx.release(); }
+void sela_hip_shutdown(void)
+{
+    g_ctx.release();
+    g_pipeline.release();
+}
 
 void sela_hip_debug_phase_buffer(uint64_t* d_cycles) { g_phase_cycles = d_cycles; }
 
@@ -183,7 +234,7 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
 {
     if (channels == 0 || channels > 255)
         return fail(SELA_HIP_EINVAL, "channels must be in 1..255");
-    if (sela::decode_lds_bytes(channels, sela::decode_waves(channels)) > 160 * 1024)
+    if (sela::decode_lds_bytes(channels, sela::decode_waves(channels), SELA_HIP_SAMPLES_PER_FRAME) > 160 * 1024)
         return fail(SELA_HIP_EINVAL, "too many channels for the on-chip decoder (LDS budget)");
     if (!d_status || (n_frames && (!d_frames || !d_frame_offsets || !d_pcm_out || !d_workspace)))
         return fail(SELA_HIP_EINVAL, "null device pointer");
@@ -193,8 +244,9 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
         return fail(SELA_HIP_ECAPACITY, "workspace smaller than sela_hip_decode_workspace_bytes()");
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 2 : 0;
+    const bool piped = n_frames && !ev && !g_phase_cycles && g_pipeline.ready();
     hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, d_workspace,
-        static_cast<hipStream_t>(stream), ev, g_phase_cycles);
+        static_cast<hipStream_t>(stream), ev, g_phase_cycles, piped ? g_pipeline.side : nullptr, g_pipeline.fork, g_pipeline.parsed);
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
     return SELA_HIP_OK;

@@ -27,6 +27,7 @@ namespace sela {
 
 constexpr int kDecMaxWaves = 8;
 constexpr int kQStride = 128; // int32 slots per subframe for the quantised coefficients
+constexpr int kDecodeChunks = 4; // sample-axis pipeline depth of one decode call (2048 / 4 = 512 values per chunk)
 
 // per-subframe record written by k_parse_subframes
 struct SubDesc {
@@ -187,9 +188,14 @@ __device__ __forceinline__ void reader_open(StreamReader& r, const uint32_t* bas
     retile(r, tile, lane);
 }
 
+// Values [v_begin, v_begin + v_count) of every residue stream (v_count a multiple of kStageVals); the
+// call with v_begin == 0 also parses the coefficient streams and writes the descriptors.  The bit
+// position each stream stopped at is kept in bit_pos[] for the next call, which lets the host pipeline
+// parse(chunk j+1) against synthesize(chunk j).
 __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, SubDesc* __restrict__ desc,
-    int32_t* __restrict__ q_out, int32_t* __restrict__ residues)
+    int32_t* __restrict__ q_out, int32_t* __restrict__ residues, uint32_t* __restrict__ bit_pos, uint32_t v_begin,
+    uint32_t v_count)
 {
     __shared__ uint32_t tile[64 * kTileStride + 8];
     __shared__ int32_t stage[64 * kStageStride];
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
 
     // coefficient stream: starts 3 bytes into the aligned word at p + 4 (behind word count + order);
     // its last word shares an aligned word with the residue k, hence cw + 1 aligned words.
-    {
+    if (v_begin == 0) {
         StreamReader r;
         reader_open(r, reinterpret_cast<const uint32_t*>(fb + p + 4), ok ? cw + 1 : 0, 24, tile, lane);
         const uint32_t kmask = ck ? (0xFFFFFFFFu >> (32 - ck)) : 0u;
@@ -270,12 +276,13 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
     // 128-byte lines (8 lanes per subframe row) instead of 64 scattered stores per value.
     {
         StreamReader r;
-        reader_open(r, reinterpret_cast<const uint32_t*>(fb + p + 12 + 4 * (uint64_t)cw), rw, 0, tile, lane);
+        const uint32_t start_bit = v_begin == 0 ? 0u : bit_pos[g];
+        reader_open(r, reinterpret_cast<const uint32_t*>(fb + p + 12 + 4 * (uint64_t)cw), rw, ok ? start_bit : 0u, tile, lane);
         const uint32_t kmask = rk ? (0xFFFFFFFFu >> (32 - rk)) : 0u;
         const unsigned long long store_mask = __ballot(store);
         const uint32_t live_mask = ok ? 0xFu : 0u;
 #pragma unroll 1
-        for (uint32_t blk = 0; blk < (uint32_t)kBlock / kStageVals; blk++) {
+        for (uint32_t blk = v_begin / kStageVals; blk < (v_begin + v_count) / kStageVals; blk++) {
 #pragma unroll
             for (int j = 0; j < kStageVals; j += 4) {
                 int32_t v[4];
@@ -299,14 +306,20 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
             }
             wave_sync();
         }
-        if (r.bp > 32 * rw)
+        if (v_begin + v_count == (uint32_t)kBlock && r.bp > 32 * rw)
             flags |= SELA_HIP_FLAG_RICE_OVERRUN;
+        if (in_range)
+            bit_pos[g] = r.bp;
     }
     if (in_range) {
-        SubDesc d;
-        d.info = ok ? channel | (type << 8) | (parent << 16) | (order << 24) : 0u;
-        d.flags = ok ? flags : (uint32_t)SELA_HIP_FLAG_BAD_FRAME;
-        desc[g] = d;
+        if (v_begin == 0) {
+            SubDesc d;
+            d.info = ok ? channel | (type << 8) | (parent << 16) | (order << 24) : 0u;
+            d.flags = ok ? flags : (uint32_t)SELA_HIP_FLAG_BAD_FRAME;
+            desc[g] = d;
+        } else if (flags) {
+            desc[g].flags |= flags;
+        }
     }
 }
 
@@ -324,8 +337,10 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
 //
 // 64x32-bit products: a = ah*2^32 + al with al = (int32)a, so
 //     z + a*s mod 2^64 = (z + al*s)  [v_mad_i64_i32, exact]  +  ((ah*s mod 2^32) << 32)  [v_mul_lo_u32 + v_add_u32]
+// `rs` holds n_samples residues (a multiple of 64) of one chunk; zs is the subframe's partial-sum
+// state in the workspace (position-major), carried from chunk to chunk.
 template <int P>
-__device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int lane)
+__device__ inline void synthesize(int32_t* rs, int n_samples, const int64_t* a, int order, uint64_t* zs, bool first, int lane)
 {
     int32_t al[P];
     uint32_t ah[P];
@@ -339,10 +354,10 @@ __device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int 
     uint64_t z[P];
 #pragma unroll
     for (int h = 0; h < P; h++)
-        z[h] = 0;
+        z[h] = first ? 0 : zs[P * lane + h];
     const uint64_t half = (uint64_t)1 << (SELA_Q_SHIFT - 1);
 #pragma unroll 1
-    for (int base = 0; base < kBlock; base += 64) {
+    for (int base = 0; base < n_samples; base += 64) {
         const int32_t r_chunk = rs[base + lane];
         int32_t s_chunk = 0;
 #pragma unroll
@@ -364,8 +379,17 @@ __device__ inline void synthesize(int32_t* rs, const int64_t* a, int order, int 
         }
         rs[base + lane] = s_chunk;
     }
+#pragma unroll
+    for (int h = 0; h < P; h++)
+        zs[P * lane + h] = z[h];
     wave_sync();
 }
+
+// per-subframe state carried between the chunks of one decode call (workspace)
+struct SynthState {
+    int64_t a[104];   // Q35 predictor
+    uint64_t z[128];  // partial sums by tap position
+};
 
 struct SynthWaveLds {
     double k[104];
@@ -376,8 +400,9 @@ struct SynthWaveLds {
 // kProf: also write per-phase cycle counts (debug hook sela_hip_debug_phase_buffer; 16 uint64 per subframe).
 template <bool kProf>
 __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const SubDesc* __restrict__ desc,
-    const int32_t* __restrict__ q_in, const int32_t* __restrict__ residues, uint32_t n_frames, uint32_t channels,
-    int16_t* __restrict__ pcm_out, uint32_t* __restrict__ status, uint64_t* __restrict__ phase_cycles)
+    const int32_t* __restrict__ q_in, const int32_t* __restrict__ residues, SynthState* __restrict__ state, uint32_t n_frames,
+    uint32_t channels, uint32_t v_begin, uint32_t v_count, int16_t* __restrict__ pcm_out, uint32_t* __restrict__ status,
+    uint64_t* __restrict__ phase_cycles)
 {
     long long stamp[6];
     for (int i = 0; i < 6; i++)
@@ -386,12 +411,13 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
     if (kProf)
         stamp[0] = clock64();
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    // [channels][2048] int32 samples, then one SynthWaveLds per wave, then per-channel type/parent
+    // [channels][v_count] int32 samples, then one SynthWaveLds per wave, then per-channel type/parent
     int32_t* const samples = reinterpret_cast<int32_t*>(dyn);
     const int n_waves = blockDim.x / 64;
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    SynthWaveLds* const wl = reinterpret_cast<SynthWaveLds*>(dyn + (size_t)channels * kBlock * 4) + wave;
-    uint32_t* const sub_info = reinterpret_cast<uint32_t*>(dyn + (size_t)channels * kBlock * 4 + (size_t)n_waves * sizeof(SynthWaveLds));
+    SynthWaveLds* const wl = reinterpret_cast<SynthWaveLds*>(dyn + (size_t)channels * v_count * 4) + wave;
+    uint32_t* const sub_info = reinterpret_cast<uint32_t*>(dyn + (size_t)channels * v_count * 4 + (size_t)n_waves * sizeof(SynthWaveLds));
+    const bool first = v_begin == 0;
 
     const uint32_t f = blockIdx.x;
     if (f >= n_frames)
@@ -408,26 +434,36 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
         if (d.flags & SELA_HIP_FLAG_BAD_FRAME)
             continue;
         const uint32_t channel = d.info & 0xFF, type = (d.info >> 8) & 0xFF, parent = (d.info >> 16) & 0xFF, order = d.info >> 24;
-        int32_t* dst = samples + (size_t)channel * kBlock;
-        // residues -> LDS (coalesced 16-byte loads)
-        const int4* rsrc = reinterpret_cast<const int4*>(residues + (size_t)g * kBlock);
+        int32_t* dst = samples + (size_t)channel * v_count;
+        // this chunk's residues -> LDS (coalesced 16-byte loads)
+        const int4* rsrc = reinterpret_cast<const int4*>(residues + (size_t)g * kBlock + v_begin);
         int4* rdst = reinterpret_cast<int4*>(dst);
-#pragma unroll
-        for (int t = 0; t < kBlock / 4 / 64; t++)
-            rdst[lane + 64 * t] = rsrc[lane + 64 * t];
-        // dequantise (src/lpc/linear_predictor.cpp:16-28)
-        for (uint32_t i = lane; i < order; i += 64)
-            wl->k[i] = order <= 1 ? 0.0 : dequant((int)i, q_in[(size_t)g * kQStride + i], flags);
-        wave_sync();
-        if (kProf)
-            stamp[1] = clock64(), prof_sub = c;
-        step_up(wl->k, wl->t, wl->a, (int)order, lane, flags);
+        for (uint32_t t4 = lane; t4 < v_count / 4; t4 += 64)
+            rdst[t4] = rsrc[t4];
+        SynthState* st = state + g;
+        if (first) {
+            // dequantise (src/lpc/linear_predictor.cpp:16-28) + step-up, kept for the later chunks
+            for (uint32_t i = lane; i < order; i += 64)
+                wl->k[i] = order <= 1 ? 0.0 : dequant((int)i, q_in[(size_t)g * kQStride + i], flags);
+            wave_sync();
+            if (kProf)
+                stamp[1] = clock64(), prof_sub = c;
+            step_up(wl->k, wl->t, wl->a, (int)order, lane, flags);
+            for (uint32_t i = lane; i <= order; i += 64)
+                st->a[i] = wl->a[i];
+        } else {
+            for (uint32_t i = lane; i <= order; i += 64)
+                wl->a[i] = st->a[i];
+            wave_sync();
+            if (kProf)
+                stamp[1] = clock64(), prof_sub = c;
+        }
         if (kProf)
             stamp[2] = clock64();
         if (order <= 64)
-            synthesize<1>(dst, wl->a, (int)order, lane);
+            synthesize<1>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
         else
-            synthesize<2>(dst, wl->a, (int)order, lane);
+            synthesize<2>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
         if (kProf)
             stamp[3] = clock64();
         if (lane == 0)
@@ -440,16 +476,16 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
     // ---- second pass of frame::FrameDecoder + interleave to int16 ------------------------------------
     // dependent channels become parent - difference (parents are independent subframes); a channel
     // that no valid subframe delivered decodes to silence and raises BAD_FRAME.
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kBlock; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < v_count; i += blockDim.x) {
         for (uint32_t c = 0; c < channels; c++) {
             const uint32_t info = sub_info[c];
-            int32_t v = info == 0xFFFFFFFFu ? 0 : samples[(size_t)c * kBlock + i];
+            int32_t v = info == 0xFFFFFFFFu ? 0 : samples[(size_t)c * v_count + i];
             if (info != 0xFFFFFFFFu && (info & 0xFF) == 1) {
                 const uint32_t par = info >> 8;
-                const int32_t pv = sub_info[par] == 0xFFFFFFFFu ? 0 : samples[(size_t)par * kBlock + i];
+                const int32_t pv = sub_info[par] == 0xFFFFFFFFu ? 0 : samples[(size_t)par * v_count + i];
                 v = (int32_t)((uint32_t)pv - (uint32_t)v);
             }
-            pcm_out[((size_t)f * kBlock + i) * channels + c] = (int16_t)(uint16_t)v;
+            pcm_out[((size_t)f * kBlock + v_begin + i) * channels + c] = (int16_t)(uint16_t)v;
         }
     }
     if (threadIdx.x == 0) {
@@ -465,7 +501,7 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
         flags |= (uint32_t)__shfl_xor((int)flags, m, 64);
     if (lane == 0 && flags) {
         atomicOr(&status[0], flags);
-        if (wave == 0 && (flags & SELA_HIP_FLAG_BAD_FRAME))
+        if (wave == 0 && first && (flags & SELA_HIP_FLAG_BAD_FRAME))
             atomicAdd(&status[1], 1u);
     }
     if (kProf && lane == 0 && prof_sub != 0xFFFFFFFFu) { // (one subframe per wave is reported)
@@ -475,9 +511,9 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
     }
 }
 
-size_t decode_lds_bytes(uint32_t channels, int n_waves)
+size_t decode_lds_bytes(uint32_t channels, int n_waves, uint32_t v_count)
 {
-    return (size_t)channels * kBlock * 4 + (size_t)n_waves * sizeof(SynthWaveLds) + (size_t)channels * 4 + 16;
+    return (size_t)channels * v_count * 4 + (size_t)n_waves * sizeof(SynthWaveLds) + (size_t)channels * 4 + 16;
 }
 
 int decode_waves(uint32_t channels)
@@ -485,34 +521,43 @@ int decode_waves(uint32_t channels)
     return channels < (uint32_t)kDecMaxWaves ? (int)channels : kDecMaxWaves;
 }
 
+static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels)
 {
     const size_t subs = (size_t)n_frames * channels;
-    size_t bytes = 0;
-    bytes += (subs * sizeof(SubDesc) + 255) & ~(size_t)255;
-    bytes += (subs * kQStride * 4 + 255) & ~(size_t)255;
-    bytes += (subs * kBlock * 4 + 255) & ~(size_t)255;
-    return bytes + 256;
+    return round256(subs * sizeof(SubDesc)) + round256(subs * kQStride * 4) + round256(subs * kBlock * 4) + round256(subs * 4)
+        + round256(subs * sizeof(SynthState)) + 256;
 }
 
+// Decode = parse + synthesise, pipelined along the sample axis: the parse of values chunk j+1 (a
+// latency-bound kernel that occupies ~1 wave per 64 subframes) runs on a side stream while chunk j is
+// synthesised on the caller's stream.  `side`/`parsed` are owned by the caller (sela_capi.hip); with
+// side == nullptr the call degenerates to one chunk on the caller's stream.
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev /* 3 events or nullptr */,
-    uint64_t* d_phase_cycles)
+    uint64_t* d_phase_cycles, hipStream_t side, hipEvent_t fork, hipEvent_t* parsed /* kDecodeChunks events */)
 {
     hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
     if (err != hipSuccess || n_frames == 0)
         return err;
     const size_t subs = (size_t)n_frames * channels;
-    unsigned char* ws = static_cast<unsigned char*>(d_workspace);
-    ws = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    unsigned char* ws = reinterpret_cast<unsigned char*>(((uintptr_t)d_workspace + 255) & ~(uintptr_t)255);
     SubDesc* desc = reinterpret_cast<SubDesc*>(ws);
-    ws += (subs * sizeof(SubDesc) + 255) & ~(size_t)255;
+    ws += round256(subs * sizeof(SubDesc));
     int32_t* q = reinterpret_cast<int32_t*>(ws);
-    ws += (subs * kQStride * 4 + 255) & ~(size_t)255;
+    ws += round256(subs * kQStride * 4);
     int32_t* residues = reinterpret_cast<int32_t*>(ws);
+    ws += round256(subs * kBlock * 4);
+    uint32_t* bit_pos = reinterpret_cast<uint32_t*>(ws);
+    ws += round256(subs * 4);
+    SynthState* state = reinterpret_cast<SynthState*>(ws);
 
+    const bool pipelined = side != nullptr && ev == nullptr && d_phase_cycles == nullptr;
+    const uint32_t chunks = pipelined ? (uint32_t)kDecodeChunks : 1u;
+    const uint32_t v_count = (uint32_t)kBlock / chunks;
     const int n_waves = decode_waves(channels);
-    const size_t lds = decode_lds_bytes(channels, n_waves);
+    const size_t lds = decode_lds_bytes(channels, n_waves, v_count);
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_synthesize_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -520,20 +565,34 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_synthesize_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess)
         return err;
-    if (ev)
-        (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL(k_parse_subframes, dim3((unsigned)((subs + 63) / 64)), dim3(64), 0, stream, d_frames, d_frame_offsets, n_frames,
-        channels, desc, q, residues);
-    if (ev)
-        (void)hipEventRecord(ev[1], stream);
-    if (d_phase_cycles)
-        hipLaunchKernelGGL(k_synthesize_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, n_frames, channels,
-            d_pcm_out, d_status, d_phase_cycles);
-    else
-        hipLaunchKernelGGL(k_synthesize_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, n_frames, channels,
-            d_pcm_out, d_status, d_phase_cycles);
-    if (ev)
-        (void)hipEventRecord(ev[2], stream);
+    const dim3 parse_grid((unsigned)((subs + 63) / 64));
+    hipStream_t parse_stream = stream;
+    if (pipelined) {
+        if ((err = hipEventRecord(fork, stream)) != hipSuccess || (err = hipStreamWaitEvent(side, fork, 0)) != hipSuccess)
+            return err;
+        parse_stream = side;
+    }
+    for (uint32_t j = 0; j < chunks; j++) {
+        const uint32_t v_begin = j * v_count;
+        if (ev)
+            (void)hipEventRecord(ev[0], stream);
+        hipLaunchKernelGGL(k_parse_subframes, parse_grid, dim3(64), 0, parse_stream, d_frames, d_frame_offsets, n_frames, channels, desc, q,
+            residues, bit_pos, v_begin, v_count);
+        if (pipelined) {
+            if ((err = hipEventRecord(parsed[j], side)) != hipSuccess || (err = hipStreamWaitEvent(stream, parsed[j], 0)) != hipSuccess)
+                return err;
+        }
+        if (ev)
+            (void)hipEventRecord(ev[1], stream);
+        if (d_phase_cycles)
+            hipLaunchKernelGGL(k_synthesize_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, state, n_frames,
+                channels, v_begin, v_count, d_pcm_out, d_status, d_phase_cycles);
+        else
+            hipLaunchKernelGGL(k_synthesize_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, state, n_frames,
+                channels, v_begin, v_count, d_pcm_out, d_status, d_phase_cycles);
+        if (ev)
+            (void)hipEventRecord(ev[2], stream);
+    }
     return hipGetLastError();
 }
 
