@@ -560,11 +560,13 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
     const size_t lds = decode_lds_bytes(channels, n_waves, v_count);
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_synthesize_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err == hipSuccess)
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_synthesize_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err != hipSuccess)
-        return err;
+    if (lds > 64 * 1024) { // above the default dynamic-LDS limit (many channels, unpipelined call)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_synthesize_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_synthesize_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess)
+            return err;
+    }
     const dim3 parse_grid((unsigned)((subs + 63) / 64));
     hipStream_t parse_stream = stream;
     if (pipelined) {
