@@ -225,3 +225,48 @@ def test_reference_library_agrees_when_present(gpu):
     assert np.array_equal(frames, ref_frames) and np.array_equal(offsets, ref_offsets)
     ref_back, _ = ref.decode_frames(ref_frames, ref_offsets, 2, threads=8)
     assert np.array_equal(_decode(gpu, frames, offsets, 2), ref_back)
+
+
+def test_decoder_survives_corrupt_streams(gpu):
+    """Bit flips anywhere in the frame stream must end in an error code or garbage PCM, never a hang,
+    a crash or an out-of-bounds access (the reference has no bounds checks here)."""
+    from sela_amd import capi, codec
+
+    pcm = synth_frames(24, 2, 33)
+    frames, offsets = codec.encode_host(pcm)
+    rng = np.random.default_rng(9)
+    for trial in range(12):
+        bad = frames.copy()
+        for _ in range(1 + trial * 3):
+            pos = int(rng.integers(0, len(bad)))
+            bad[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        try:
+            out = codec.decode_host(bad, offsets, 2)
+            assert out.shape == pcm.shape
+        except capi.SelaHipError as e:
+            assert e.code == -5
+    # all-ones payload: maximal unary runs everywhere
+    bad = frames.copy()
+    bad[int(offsets[3]) + 40: int(offsets[4])] = 0xFF
+    try:
+        codec.decode_host(bad, offsets, 2)
+    except capi.SelaHipError as e:
+        assert e.code == -5
+    # after all that the decoder still works
+    assert np.array_equal(codec.decode_host(frames, offsets, 2), pcm)
+
+
+def test_long_unary_runs_round_trip(gpu):
+    """Sparse full-scale impulses: residues of +-32767 next to zeros give codewords of thousands of
+    bits (encoder put_codeword loop, parser slow path)."""
+    o = oracle()
+    rng = np.random.default_rng(4)
+    pcm = np.zeros((8, 2048, 2), np.int16)
+    for f in range(8):
+        idx = rng.integers(0, 2048, 3 + f)
+        pcm[f, idx, 0] = rng.choice([-32768, 32767], len(idx))
+        pcm[f, idx[:2], 1] = 32767
+    frames, offsets, _, _ = _encode(gpu, pcm)
+    ref_frames, ref_offsets, _ = o.encode_frames(pcm, threads=4)
+    assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames)
+    assert np.array_equal(_decode(gpu, frames, offsets, 2), pcm)
