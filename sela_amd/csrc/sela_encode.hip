@@ -27,19 +27,20 @@ namespace sela {
 //                        E[m] = c[2m], O[m] = c[2m+1], each with kPadC zeros in front (lags reach
 //                        back before the block start; x + (+-0) is exact) and 2 behind.
 // Phase B (after the autocorrelation c[] is dead): the same bytes hold
-//                        [0, 8704)      biased samples s' = s + 2^17 with 128 words of bias in front
-//                                       (FIR warm-up: "no sample" == 0), later the transposed residues
-//                        [8704, ...)    first the small analysis arrays (ac, k, t, a, q), later the
+//                        [0, 8992)      biased samples s' = s + 2^17 with 128 words of bias in front
+//                                       (FIR warm-up: "no sample" == 0), index i stored at i + i/32
+//                        [8992, ...)    first the small analysis arrays (ac, k, t, a, q), later the
 //                                       packed residue words
 constexpr int kPadC = 64;
 constexpr int kParityLen = kPadC + kBlock / 2 + 2;   // 1090 doubles
-constexpr int kBigBytes = 17664;                      // >= 2 * 1090 * 8 = 17440
 constexpr int kPadS = 128;
-constexpr int kSBufWords = kPadS + kBlock;            // 2176 words = 8704 bytes
-constexpr int kSmallBase = kSBufWords * 4;            // 8704
+constexpr int kSBufWords = (kPadS + kBlock) / 32 * 33; // biased samples, one pad word per 32: 2244 words
+constexpr int kSmallBase = 8992;                      // >= kSBufWords * 4 = 8976, 16-byte aligned
+constexpr int kBigBytes = kSmallBase + 8832;          // >= 2 * 1090 * 8 = 17440 and room for the residue words
 constexpr uint32_t kBias = 1u << 17;                  // |ch0 - ch1| <= 65535 < 2^17
 static_assert(kSmallBase + kResWordsCap * 4 <= kBigBytes, "packed residue words must fit behind the sample buffer");
-static_assert((kBlock + kBlock / 32) * 4 <= kSmallBase, "transposed residues must fit in the sample buffer");
+static_assert(kSBufWords * 4 <= kSmallBase && kSmallBase % 16 == 0, "sample buffer must end below the analysis arrays");
+static_assert(kBigBytes >= 2 * kParityLen * 8, "the FP64 parity arrays must fit");
 
 struct SmallArrays { // lives at kSmallBase during analysis; dead before the residue words are packed
     double ac[104];
@@ -151,6 +152,31 @@ __device__ __forceinline__ void autocorr_steps(double C, const double* pe, const
     A = (I & 1) ? pe[I / 2 + 1] : po[I / 2]; // c[j + 1 - 2L]
     if constexpr (I < 15)
         autocorr_steps<I + 1>(C, pe, po, A, B, acc_e, acc_o);
+}
+
+// Taps j0 + JJ + 1 .. j0 + 32 of the residue FIR (see k_encode_blocks), stopping at `order`.  JJ is a
+// template parameter so that the 32-register sample window is addressed statically: tap j uses
+// win[(t - j) mod 32] = s'[32 lane + t - j] and loads the one new element s'[32 lane - j].
+template <int JJ>
+__device__ __forceinline__ void fir_taps(int j0, int order, int lane, const uint32_t* sT, const int64_t* a,
+    uint32_t (&win)[kPerLane], uint64_t (&acc)[kPerLane], uint64_t (&hi)[kPerLane], uint64_t& sum_a)
+{
+    const int j = j0 + JJ + 1;
+    if (j > order)
+        return;
+    const uint64_t aj = read_first_lane((uint64_t)a[j]);
+    const uint32_t a_lo = (uint32_t)aj, a_hi = (uint32_t)(aj >> 32);
+    sum_a += aj;
+    const int e = kPadS + 32 * lane - j;
+    win[(32 - JJ - 1) & 31] = sT[e + (e >> 5)];
+#pragma unroll
+    for (int t = 0; t < kPerLane; t++) {
+        const uint32_t sp = win[(t - JJ - 1) & 31]; // s'[32 lane + t - j]
+        acc[t] += (uint64_t)a_lo * sp;
+        hi[t] += (uint64_t)a_hi * sp;
+    }
+    if constexpr (JJ < 31)
+        fir_taps<JJ + 1>(j0, order, lane, sT, a, win, acc, hi, sum_a);
 }
 
 // kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts
@@ -380,43 +406,49 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     // per sample in any order.  To keep the multiplier operand unsigned the samples are biased,
     // s' = s + 2^17 >= 0 (pad = 2^17 == "sample 0"), and 2^17 * sum(a) is removed at the end:
     //   a * s' mod 2^64 = lo32(a) * s'  +  (hi32(a) * s' mod 2^32) << 32      (two v_mad_u64_u32).
-    uint32_t* const sbuf = reinterpret_cast<uint32_t*>(big);
+    //
+    // Lane l owns the 32 CONSECUTIVE samples 32l .. 32l+31 (the layout the Rice packer wants) and
+    // slides a 32-register window over its history: tap j needs s'[32l + t - j] for t = 0..31, i.e.
+    // the window of tap j-1 moved down by one, so every tap costs ONE new LDS word per lane (index
+    // i stored at i + i/32: the lanes' 32-word strides fall on different banks) and 64 multiply-adds.
+    // The tap loop is unrolled by 32 so that the window registers are addressed statically.
+    uint32_t* const sT = reinterpret_cast<uint32_t*>(big);
     for (int m = lane; m < kPadS; m += 64)
-        sbuf[m] = kBias;
+        sT[m + (m >> 5)] = kBias;
 #pragma unroll
-    for (int t = 0; t < kPerLane; t++)
-        sbuf[kPadS + lane + 64 * t] = (uint32_t)(s[t] + (int32_t)kBias);
+    for (int t = 0; t < kPerLane; t++) {
+        const int i = kPadS + lane + 64 * t;
+        sT[i + (i >> 5)] = (uint32_t)(s[t] + (int32_t)kBias);
+    }
     wave_sync();
 
-    int32_t r[kPerLane];
+    uint32_t ru[kPerLane]; // zig-zagged residues of samples 32 lane + t
+    bool wide = false;
     {
+        uint32_t win[kPerLane], own[kPerLane];
+        const uint32_t* mine_s = sT + (kPadS + 32 * lane) + ((kPadS + 32 * lane) >> 5); // &s'[32 l], 32 words without a pad inside
+#pragma unroll
+        for (int t = 0; t < kPerLane; t++)
+            own[t] = win[t] = mine_s[t];
         uint64_t acc[kPerLane], hi[kPerLane];
 #pragma unroll
         for (int t = 0; t < kPerLane; t++)
             acc[t] = 0, hi[t] = 0;
         uint64_t sum_a = 0;
-        const uint32_t* base = sbuf + kPadS + lane;
 #pragma unroll 1
-        for (int j = 1; j <= order; j++) {
-            const uint64_t aj = read_first_lane((uint64_t)sm->a[j]);
-            const uint32_t a_lo = (uint32_t)aj, a_hi = (uint32_t)(aj >> 32);
-            sum_a += aj;
-            const uint32_t* p = base - j;
-#pragma unroll
-            for (int t = 0; t < kPerLane; t++) {
-                const uint32_t sp = p[64 * t];
-                acc[t] += (uint64_t)a_lo * sp;
-                hi[t] += (uint64_t)a_hi * sp;
-            }
-        }
+        for (int j0 = 0; j0 < order; j0 += 32)
+            fir_taps<0>(j0, order, lane, sT, sm->a, win, acc, hi, sum_a);
         const uint64_t corr = ((uint64_t)1 << (SELA_Q_SHIFT - 1)) - (sum_a << 17);
 #pragma unroll
         for (int t = 0; t < kPerLane; t++) {
             const uint64_t total = acc[t] + (hi[t] << 32) + corr;
-            r[t] = (int32_t)((uint32_t)s[t] - (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT));
+            const int32_t st = (int32_t)(own[t] - kBias);
+            const int32_t rt = (int32_t)((uint32_t)st - (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT));
+            ru[t] = zigzag32(rt);
+            wide |= (rt >= (1 << 30)) || (rt < -(1 << 30)); // zig-zag would not fit 32 bits
         }
     }
-    wave_sync(); // sbuf is dead
+    wave_sync(); // sT is dead
 
     SELA_STAMP(8);
     // ---- Rice parameters -----------------------------------------------------------------------------
@@ -429,13 +461,6 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     rice_plan<2>(cu, (uint32_t)order, coef_k, coef_bits);
     const uint32_t coef_words = words_for_bits(coef_bits);
 
-    uint32_t ru[kPerLane];
-    bool wide = false;
-#pragma unroll
-    for (int t = 0; t < kPerLane; t++) {
-        ru[t] = zigzag32(r[t]);
-        wide |= (r[t] >= (1 << 30)) || (r[t] < -(1 << 30)); // zig-zag would not fit 32 bits
-    }
     if (__any(wide))
         flags |= SELA_HIP_FLAG_RICE_RANGE;
     uint32_t res_k;
@@ -464,32 +489,21 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
 
     SELA_STAMP(10);
     // ---- pack the residue stream ----------------------------------------------------------------------
-    // Transpose through LDS so that lane l owns the 32 consecutive residues 32l .. 32l+31 (index
-    // i stored at i + i/32: both sides conflict-free), scan the per-lane bit counts, then every lane
-    // appends its codewords.  The analysis arrays die here: out_words overlays them.
-    uint32_t* const rT = reinterpret_cast<uint32_t*>(big);
+    // Lane l already owns the 32 consecutive residues 32l .. 32l+31: scan the per-lane bit counts, then
+    // every lane appends its codewords.  The analysis arrays die here: out_words overlays them.
     uint32_t* const out_words = reinterpret_cast<uint32_t*>(big + kSmallBase);
-#pragma unroll
-    for (int t = 0; t < kPerLane; t++) {
-        const int i = lane + 64 * t;
-        rT[i + (i >> 5)] = ru[t];
-    }
-    wave_sync();
     for (uint32_t w = lane; w < res_words; w += 64)
         out_words[w] = 0;
-    uint32_t lu[kPerLane];
     uint32_t lane_bits = 0;
 #pragma unroll
-    for (int t = 0; t < kPerLane; t++) {
-        lu[t] = rT[33 * lane + t];
-        lane_bits += (lu[t] >> res_k) + 1 + res_k;
-    }
+    for (int t = 0; t < kPerLane; t++)
+        lane_bits += (ru[t] >> res_k) + 1 + res_k;
     wave_sync();
     if (res_words) {
         uint32_t pos = wave_exclusive_scan(lane_bits, lane);
 #pragma unroll 4
         for (int t = 0; t < kPerLane; t++)
-            pos = put_codeword(out_words, pos, lu[t], res_k);
+            pos = put_codeword(out_words, pos, ru[t], res_k);
     }
     wave_sync();
 
