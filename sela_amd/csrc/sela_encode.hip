@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     // they are ready instead of queueing behind the co-resident wave's throughput-bound phases)
     __builtin_amdgcn_s_setprio(3);
     double sum = 0.0;
-#pragma unroll 8
+#pragma unroll 16
     for (int m = 0; m < kBlock / 2; m++) {
         sum += E[m];
         sum += O[m];
