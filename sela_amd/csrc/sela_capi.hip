@@ -68,6 +68,19 @@ struct DeviceBuffer {
 
 struct HostContext {
     DeviceBuffer pcm, frames, offsets, status, workspace;
+    int device = -1;
+    // the buffers belong to the device that was current when they were allocated
+    bool bind_current_device()
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess)
+            return false;
+        if (dev != device) {
+            release();
+            device = dev;
+        }
+        return true;
+    }
     void release()
     {
         pcm.release();
@@ -262,6 +275,8 @@ int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, ui
     int rc = sela_hip_init(-1);
     if (rc != SELA_HIP_OK)
         return rc;
+    if (!g_ctx.bind_current_device())
+        return fail(SELA_HIP_ENODEV, "hipGetDevice failed");
     const size_t pcm_bytes = (size_t)n_frames * sela::kBlock * channels * sizeof(int16_t);
     const size_t bound = sela_hip_encode_bound_bytes(n_frames, channels);
     const size_t dev_cap = ((frames_cap < bound ? frames_cap : bound) + 3) & ~(size_t)3;
@@ -307,6 +322,8 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
     for (uint32_t f = 0; f < n_frames; f++)
         if (frame_offsets[f + 1] < frame_offsets[f] || (frame_offsets[f] & 3))
             return fail(SELA_HIP_EFORMAT, "frame offsets must be ascending multiples of 4");
+    if (!g_ctx.bind_current_device())
+        return fail(SELA_HIP_ENODEV, "hipGetDevice failed");
     const size_t total = (size_t)frame_offsets[n_frames];
     const size_t pcm_bytes = (size_t)n_frames * sela::kBlock * channels * sizeof(int16_t);
     hipError_t e;
