@@ -46,11 +46,6 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // ---- cross-lane moves (DPP on the GFX9 family: the shift crosses all four rows) ----------------
-// lane l <- lane l-1 ; lane 0 receives `fill`.
-__device__ __forceinline__ int wave_shr1(int fill, int v)
-{
-    return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-}
 // lane l <- lane l+1 ; lane 63 receives `fill`.
 __device__ __forceinline__ int wave_shl1(int fill, int v)
 {
@@ -76,12 +71,6 @@ __device__ __forceinline__ double wave_shl1(double fill, double v)
     const uint32_t hi = (uint32_t)wave_shl1((int)(uint32_t)(f >> 32), (int)(uint32_t)(x >> 32));
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
-__device__ __forceinline__ uint64_t wave_shl1(uint64_t fill, uint64_t x)
-{
-    const uint32_t lo = (uint32_t)wave_shl1((int)(uint32_t)fill, (int)(uint32_t)x);
-    const uint32_t hi = (uint32_t)wave_shl1((int)(uint32_t)(fill >> 32), (int)(uint32_t)(x >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
 
 // Every lane receives the value of lane I of its own row of 16 lanes (one v_mov_b64_dpp row_newbcast).
 template <int I>
@@ -99,13 +88,6 @@ __device__ __forceinline__ double read_first_lane(double v)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
-__device__ __forceinline__ double read_lane(double v, int lane)
-{
-    const uint64_t x = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
-    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
 __device__ __forceinline__ uint64_t read_first_lane(uint64_t x)
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
@@ -121,22 +103,6 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v)
         const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64);
         const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
         v += ((uint64_t)hi << 32) | lo;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v += (uint32_t)__shfl_xor((int)v, m, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max(uint32_t v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
-        v = o > v ? o : v;
     }
     return v;
 }
@@ -160,11 +126,6 @@ __device__ __forceinline__ uint32_t zigzag32(int32_t x)
 {
     const uint32_t t = (uint32_t)x << 1;
     return x < 0 ? (0u - t - 1u) : t;
-}
-__device__ __forceinline__ int32_t unzigzag(uint64_t u)
-{
-    // src/rice/rice_decoder.cpp:49-50
-    return (int32_t)((u & 1) ? -(int64_t)((u + 1) >> 1) : (int64_t)(u >> 1));
 }
 // requiredInts = ceil((float)requiredBits / 32), src/rice/rice_encoder.cpp:37,63
 __device__ __forceinline__ uint32_t words_for_bits(uint64_t bits)

@@ -278,3 +278,23 @@ def test_long_unary_runs_round_trip(gpu):
     # reproducing exactly that.
     ref_back, _ = o.decode_frames(ref_frames, ref_offsets, 2, threads=4)
     assert np.array_equal(_decode(gpu, frames, offsets, 2), ref_back)
+
+
+def test_decode_only_10k_frames(gpu):
+    """BASELINE.json configs[4] at full size (10k pre-encoded stereo frames): size-independent checks --
+    lossless round trip of the whole batch, frame sizes consistent with the stream, and a random sample
+    of 96 frames bit-exact against the oracle in both directions."""
+    o = oracle()
+    n = 10000
+    pcm = synth_frames(n, 2, 2)
+    frames, offsets, _, out = _encode(gpu, pcm)
+    assert offsets[0] == 0 and np.all(np.diff(offsets.astype(np.int64)) > 28) and offsets[-1] == len(frames)
+    assert np.all(frames[offsets[:-1].astype(np.int64)] == 0x00) and np.all(frames[offsets[:-1].astype(np.int64) + 3] == 0xAA)
+    back = _decode(gpu, frames, offsets, 2)
+    assert np.array_equal(back, pcm)
+    pick = np.random.default_rng(0).choice(n, 96, replace=False)
+    ref_frames, ref_offsets, _ = o.encode_frames(pcm[pick], threads=8)
+    for i, f in enumerate(pick):
+        a = frames[int(offsets[f]): int(offsets[f + 1])]
+        b = ref_frames[int(ref_offsets[i]): int(ref_offsets[i + 1])]
+        assert np.array_equal(a, b), int(f)
