@@ -5,6 +5,7 @@ FP64 intermediates of the analysis (compared as bit patterns, tolerance zero).
 """
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -281,9 +282,10 @@ def test_long_unary_runs_round_trip(gpu):
 
 
 def test_decode_only_10k_frames(gpu):
-    """BASELINE.json configs[4] at full size (10k pre-encoded stereo frames): size-independent checks --
-    lossless round trip of the whole batch, frame sizes consistent with the stream, and a random sample
-    of 96 frames bit-exact against the oracle in both directions."""
+    """BASELINE.json configs[4] at full size (10k pre-encoded stereo frames): frame sizes consistent with
+    the stream, the decode of the whole batch bit-exact against the oracle's decode, and a random sample
+    of 96 frames bit-exact against the oracle's encode.  (Not "== pcm": the reference is off by one LSB
+    per sample in frames 635 and 946 of this track -- half-up/half-down rounding, SURVEY.md App. E.)"""
     o = oracle()
     n = 10000
     pcm = synth_frames(n, 2, 2)
@@ -291,7 +293,9 @@ def test_decode_only_10k_frames(gpu):
     assert offsets[0] == 0 and np.all(np.diff(offsets.astype(np.int64)) > 28) and offsets[-1] == len(frames)
     assert np.all(frames[offsets[:-1].astype(np.int64)] == 0x00) and np.all(frames[offsets[:-1].astype(np.int64) + 3] == 0xAA)
     back = _decode(gpu, frames, offsets, 2)
-    assert np.array_equal(back, pcm)
+    ref_back, _ = o.decode_frames(frames, offsets, 2, threads=os.cpu_count() or 1)
+    assert np.array_equal(back, ref_back)
+    assert (back != pcm).reshape(n, -1).any(axis=1).sum() <= 4
     pick = np.random.default_rng(0).choice(n, 96, replace=False)
     ref_frames, ref_offsets, _ = o.encode_frames(pcm[pick], threads=8)
     for i, f in enumerate(pick):
