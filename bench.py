@@ -30,6 +30,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_UNFUSED_PEAK_TOPS = 39.3  # vector FP64: 78.6 TFLOP/s counts an FMA as 2; mul and add issue separately here
+# unfused FP64 operations the reference's analysis needs per 2048-sample block:
+# 101 lags x (2048 - lag) x (mul + add) for the autocorrelation + 4950 Schur column updates x 4
+FP64_OPS_PER_BLOCK = 2 * sum(2048 - i for i in range(101)) + 4 * 4950
 TRACK_SECONDS, SAMPLE_RATE, CHANNELS = 180, 44100, 2
 
 
@@ -216,6 +220,10 @@ def main():
                           "encode_assemble": float(k_enc[:, 2].mean()), "decode_parse": float(k_dec[:, 0].mean()),
                           "decode_synthesize": float(k_dec[:, 1].mean())},
             "roundtrip_lossy_frames": lossy_frames,
+            "fp64_valu": {  # the resource that actually binds k_encode_blocks
+                "achieved": FP64_OPS_PER_BLOCK * n_frames * 3 / (enc_blocks_ms * 1e-3) / 1e12, "peak": FP64_UNFUSED_PEAK_TOPS,
+                "unit": "T unfused FP64 op/s", "frac": FP64_OPS_PER_BLOCK * n_frames * 3 / (enc_blocks_ms * 1e-3) / 1e12 / FP64_UNFUSED_PEAK_TOPS,
+            },
             "roofline": {
                 "kernel": "k_encode_blocks", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
