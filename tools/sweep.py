@@ -37,3 +37,26 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def host_api(n=3875):
+    """PCIe-inclusive rate of the host-pointer API (pageable numpy buffers): H2D + kernels + D2H."""
+    import numpy as np
+
+    pcm = synth_frames(n, 2, 0)
+    frames, offs = codec.encode_host(pcm)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        codec.encode_host(pcm)
+    te = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        codec.decode_host(frames, offs, 2)
+    td = (time.perf_counter() - t0) / reps
+    print(f"host-pointer API, {n} frames: encode {te * 1e3:.2f} ms ({n * 2048 / te / 1e9:.2f} Gs/s), "
+          f"decode {td * 1e3:.2f} ms ({n * 2048 / td / 1e9:.2f} Gs/s)")
+
+
+if __name__ == "__main__" and os.environ.get("SELA_SWEEP_HOST", "1") == "1":
+    host_api()
