@@ -1,5 +1,6 @@
 // selftest.cpp -- CPU-only checks of the host's container code (no GPU needed).
 // Exit code 0 = all passed.  Driven by tests/test_host_cpp.py.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -7,6 +8,7 @@
 #include <iostream>
 #include <string>
 
+#include "sela_hip.h"
 #include "sela_host/files.hpp"
 #include "sela_host/frame.hpp"
 
@@ -156,6 +158,41 @@ int main(int argc, char** argv)
         } catch (const data::Exception& e) {
             std::fprintf(stderr, "FAIL exception: %s\n", e.exceptionMessage.c_str());
             failures++;
+        }
+        // host-pointer API timing on a 3-minute stereo track of pseudo-random-walk PCM (informational)
+        {
+            const uint32_t frames = 3875, ch = 2;
+            std::vector<int16_t> pcm((size_t)frames * 2048 * ch);
+            uint32_t x = 12345u;
+            int v[2] = { 0, 0 };
+            for (size_t i = 0; i < pcm.size(); i++) {
+                x = x * 1664525u + 1013904223u;
+                int& s = v[i & 1];
+                s += (int)((x >> 20) & 1023) - 512;
+                s = s > 30000 ? 30000 : (s < -30000 ? -30000 : s);
+                pcm[i] = (int16_t)s;
+            }
+            std::vector<uint8_t> bytes(sela_hip_encode_bound_bytes(frames, ch));
+            std::vector<uint64_t> offs(frames + 1);
+            std::vector<int16_t> back(pcm.size());
+            double enc_ms = 0, dec_ms = 0;
+            for (int rep = 0; rep < 4; rep++) {
+                auto t0 = std::chrono::steady_clock::now();
+                CHECK(sela_hip_encode(pcm.data(), frames, ch, 2048, bytes.data(), bytes.size(), offs.data()) == SELA_HIP_OK);
+                auto t1 = std::chrono::steady_clock::now();
+                CHECK(sela_hip_decode(bytes.data(), offs.data(), frames, ch, back.data()) == SELA_HIP_OK);
+                auto t2 = std::chrono::steady_clock::now();
+                if (rep) {
+                    enc_ms += std::chrono::duration<double, std::milli>(t1 - t0).count() / 3;
+                    dec_ms += std::chrono::duration<double, std::milli>(t2 - t1).count() / 3;
+                }
+            }
+            size_t diff = 0;
+            for (size_t i = 0; i < pcm.size(); i++)
+                diff += pcm[i] != back[i];
+            CHECK(diff < pcm.size() / 100);
+            std::printf("host-pointer API, 3875 stereo frames: encode %.2f ms, decode %.2f ms (PCIe inclusive), %zu bytes\n", enc_ms, dec_ms,
+                (size_t)offs[frames]);
         }
     }
     std::printf(failures ? "selftest: %d failure(s)\n" : "selftest: ok\n", failures);
