@@ -339,8 +339,15 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
 //     z + a*s mod 2^64 = (z + al*s)  [v_mad_i64_i32, exact]  +  ((ah*s mod 2^32) << 32)  [v_mul_lo_u32 + v_add_u32]
 // `rs` holds n_samples residues (a multiple of 64) of one chunk; zs is the subframe's partial-sum
 // state in the workspace (position-major), carried from chunk to chunk.
-template <int P>
-__device__ inline void synthesize(int32_t* rs, int n_samples, const int64_t* a, int order, uint64_t* zs, bool first, int lane)
+//
+// kFold: the residue is folded into the partial sum before the recurrence needs it,
+//     Z = P + r * 2^35  (one v_lshl_add per 64 samples)   ==>   s = -((2^34 - Z) >> 35),
+// which drops the per-sample v_readlane of r.  The shift keeps 29 bits, so this equals the reference's
+// 32-bit  r - (int32)((2^34 - P) >> 35)  exactly when |s| < 2^28; every 64 samples are checked against
+// 2^27 and the function returns false (state untouched) if any is larger -- the caller then re-runs the
+// chunk with kFold = false.  16-bit audio never gets there; crafted streams do (tests).
+template <int P, bool kFold>
+__device__ inline bool synthesize(int32_t* rs, int n_samples, const int64_t* a, int order, uint64_t* zs, bool first, int lane)
 {
     int32_t al[P];
     uint32_t ah[P];
@@ -356,17 +363,30 @@ __device__ inline void synthesize(int32_t* rs, int n_samples, const int64_t* a, 
     for (int h = 0; h < P; h++)
         z[h] = first ? 0 : zs[P * lane + h];
     const uint64_t half = (uint64_t)1 << (SELA_Q_SHIFT - 1);
+    bool in_range = true;
 #pragma unroll 1
     for (int base = 0; base < n_samples; base += 64) {
         const int32_t r_chunk = rs[base + lane];
+        if (kFold) { // position p of this block completes at sample base + p: give it its residue now
+            if (P == 1) {
+                z[0] += (uint64_t)((uint32_t)r_chunk << 3) << 32;
+            } else if (lane < 32) {
+#pragma unroll
+                for (int h = 0; h < P; h++)
+                    z[h] += (uint64_t)((uint32_t)rs[base + P * lane + h] << 3) << 32;
+            }
+        }
         int32_t s_chunk = 0;
 #pragma unroll
         for (int m = 0; m < 64; m++) {
             // scalar side: P_i sits in lane 0, position 0
             const uint64_t pv = read_first_lane(z[0]);
             const int32_t pred = (int32_t)((int64_t)(half - pv) >> SELA_Q_SHIFT);
-            const int32_t r_i = __builtin_amdgcn_readlane(r_chunk, m);
-            const int32_t s_i = (int32_t)((uint32_t)r_i - (uint32_t)pred);
+            int32_t s_i;
+            if (kFold)
+                s_i = (int32_t)(0u - (uint32_t)pred);
+            else
+                s_i = (int32_t)((uint32_t)__builtin_amdgcn_readlane(r_chunk, m) - (uint32_t)pred);
             asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(s_chunk) : "s"(s_i), "n"(m));
             // vector side: move every partial sum down one position and add this sample's products
             const uint64_t in = wave_shl1_zero(z[0]);
@@ -377,12 +397,17 @@ __device__ inline void synthesize(int32_t* rs, int n_samples, const int64_t* a, 
                 z[h] = lo + ((uint64_t)(ah[h] * (uint32_t)s_i) << 32);
             }
         }
+        if (kFold)
+            in_range &= (uint32_t)(s_chunk + (1 << 27)) < (1u << 28);
         rs[base + lane] = s_chunk;
     }
+    if (kFold && __any(!in_range))
+        return false;
 #pragma unroll
     for (int h = 0; h < P; h++)
         zs[P * lane + h] = z[h];
     wave_sync();
+    return true;
 }
 
 // per-subframe state carried between the chunks of one decode call (workspace)
@@ -460,10 +485,18 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
         }
         if (kProf)
             stamp[2] = clock64();
-        if (order <= 64)
-            synthesize<1>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
-        else
-            synthesize<2>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
+        const bool exact_needed = order <= 64 ? !synthesize<1, true>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane)
+                                              : !synthesize<2, true>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
+        if (exact_needed) { // a sample left the 28-bit range of the folded form: redo this chunk the long way
+            wave_sync();
+            for (uint32_t t4 = lane; t4 < v_count / 4; t4 += 64)
+                rdst[t4] = rsrc[t4];
+            wave_sync();
+            if (order <= 64)
+                synthesize<1, false>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
+            else
+                synthesize<2, false>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
+        }
         if (kProf)
             stamp[3] = clock64();
         if (lane == 0)

@@ -115,9 +115,13 @@ class Oracle:
     def rice_encode(self, values):
         v = np.ascontiguousarray(values, dtype=np.int32)
         cap = 64 + 2 * len(v) * 4
-        words = np.zeros(cap, np.uint32)
-        k = C.c_uint32(0)
-        nw = self._renc(v, len(v), C.byref(k), words, cap, *self._fl())
+        while True:
+            words = np.zeros(cap, np.uint32)
+            k = C.c_uint32(0)
+            nw = self._renc(v, len(v), C.byref(k), words, cap, *self._fl())
+            if nw >= 0 or cap > (1 << 24):
+                break
+            cap *= 8  # very long unary runs
         assert nw >= 0
         return k.value, words[:nw].copy()
 

@@ -302,3 +302,52 @@ def test_decode_only_10k_frames(gpu):
         a = frames[int(offsets[f]): int(offsets[f + 1])]
         b = ref_frames[int(ref_offsets[i]): int(ref_offsets[i + 1])]
         assert np.array_equal(a, b), int(f)
+
+
+def _build_frame(subframes):
+    """Hand-assemble on-disk frame bytes from (channel, type, parent, q[], residues[]) tuples, Rice-coding
+    with the oracle (layout of src/file/sela_file.cpp:115-135)."""
+    import struct
+
+    o = oracle()
+    out = struct.pack("<I", 0xAA55FF00)
+    for channel, typ, parent, q, res in subframes:
+        ck, cw = o.rice_encode(np.asarray(q, np.int32))
+        rk, rw = o.rice_encode(np.asarray(res, np.int32))
+        out += struct.pack("<BBBBHB", channel, typ, parent, ck, len(cw), len(q)) + cw.astype("<u4").tobytes()
+        out += struct.pack("<BHH", rk, len(rw), len(res)) + rw.astype("<u4").tobytes()
+    return out
+
+
+def test_decoder_on_streams_no_encoder_would_write(gpu, kats):
+    """Hand-built frames: residues far outside 16 bits (forces the synthesis filter off its folded fast
+    path onto the exact 32-bit one, and the parser onto very long unary runs), order 0 and order 100,
+    a difference channel -- all against the oracle's decoder."""
+    o = oracle()
+    rng = np.random.default_rng(12)
+    q_sine = kats["blk/sine_deg/q"]                      # a real order-17 predictor
+    q_noise = kats["blk/white_fullscale/q"]              # order 93
+    big = rng.integers(-2000, 2000, 2048).astype(np.int32)
+    big[rng.choice(2048, 48, replace=False)] = rng.integers(1 << 27, 1 << 28, 48) * rng.choice([-1, 1], 48)
+    mixed = rng.integers(-300, 300, 2048).astype(np.int32)
+    mixed[1000] = 1 << 28                                 # one huge sample in the middle of a chunk
+    frames = [
+        _build_frame([(0, 0, 0, [0], big)]),                                   # order 1: samples == residues
+        _build_frame([(0, 0, 0, q_sine, mixed)]),
+        _build_frame([(0, 0, 0, q_noise, mixed[::-1].copy())]),
+        _build_frame([(0, 0, 0, q_sine, rng.integers(-50, 50, 2048))]),         # ordinary
+        _build_frame([(0, 0, 0, np.zeros(100, np.int32), rng.integers(-9, 9, 2048))]),  # order 100, all-zero q
+        _build_frame([(0, 0, 0, [], rng.integers(-9, 9, 2048))]),                # order 0
+    ]
+    stream = np.frombuffer(b"".join(frames), np.uint8).copy()
+    offsets = np.cumsum([0] + [len(f) for f in frames]).astype(np.uint64)
+    got = _decode(gpu, stream, offsets, 1)
+    for i, f in enumerate(frames):
+        want, used = o.frame_decode(f, 1)
+        assert used == len(f)
+        assert np.array_equal(got[i], want), i
+    # stereo with a difference channel whose parent has huge samples
+    st = _build_frame([(0, 0, 0, q_sine, mixed), (1, 1, 0, q_noise, rng.integers(-40, 40, 2048))])
+    got = _decode(gpu, np.frombuffer(st, np.uint8).copy(), np.array([0, len(st)], np.uint64), 2)
+    want, _ = o.frame_decode(st, 2)
+    assert np.array_equal(got[0], want)
