@@ -1,4 +1,4 @@
-// main.cpp -- command line front end of the MI355X SELA host:
+// sela_cli.cpp -- command line front end of the MI355X SELA host:
 //   sela_mi355x -e in.wav out.sela     encode
 //   sela_mi355x -d in.sela out.wav     decode
 // Same verbs as the reference CLI (src/main.cpp:16-27); playback (-p) is not part of this build.
