@@ -194,12 +194,14 @@ __device__ __forceinline__ void reader_open(StreamReader& r, const uint32_t* bas
 // parse(chunk j+1) against synthesize(chunk j).
 __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, SubDesc* __restrict__ desc,
-    int32_t* __restrict__ q_out, int32_t* __restrict__ residues, uint32_t* __restrict__ bit_pos, uint32_t v_begin,
-    uint32_t v_count)
+    int32_t* __restrict__ q_out, int32_t* __restrict__ residues, uint32_t* __restrict__ bit_pos, uint32_t* __restrict__ status,
+    uint32_t v_begin, uint32_t v_count)
 {
     __shared__ uint32_t tile[64 * kTileStride + 8];
     __shared__ int32_t stage[64 * kStageStride];
     const int lane = threadIdx.x;
+    if (v_begin == 0 && blockIdx.x == 0 && lane < 4)
+        status[lane] = 0; // ordered before every k_synthesize_frames of this call (stream / event order)
     const uint32_t n_subs = n_frames * channels;
     const uint32_t g_raw = blockIdx.x * 64 + lane; // subframe index = frame * channels + position
     const bool in_range = g_raw < n_subs;
@@ -571,9 +573,9 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev /* 3 events or nullptr */,
     uint64_t* d_phase_cycles, hipStream_t side, hipEvent_t fork, hipEvent_t* parsed /* kDecodeChunks events */)
 {
-    hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
-    if (err != hipSuccess || n_frames == 0)
-        return err;
+    hipError_t err = hipSuccess;
+    if (n_frames == 0)
+        return hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
     const size_t subs = (size_t)n_frames * channels;
     unsigned char* ws = reinterpret_cast<unsigned char*>(((uintptr_t)d_workspace + 255) & ~(uintptr_t)255);
     SubDesc* desc = reinterpret_cast<SubDesc*>(ws);
@@ -612,7 +614,7 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
         if (ev)
             (void)hipEventRecord(ev[0], stream);
         hipLaunchKernelGGL(k_parse_subframes, parse_grid, dim3(64), 0, parse_stream, d_frames, d_frame_offsets, n_frames, channels, desc, q,
-            residues, bit_pos, v_begin, v_count);
+            residues, bit_pos, d_status, v_begin, v_count);
         if (pipelined) {
             if ((err = hipEventRecord(parsed[j], side)) != hipSuccess || (err = hipStreamWaitEvent(stream, parsed[j], 0)) != hipSuccess)
                 return err;

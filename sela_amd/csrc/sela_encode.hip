@@ -575,6 +575,9 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
 {
     __shared__ uint64_t part[kPlanThreads];
     const uint32_t tid = threadIdx.x;
+    if (tid < 4)
+        status[tid] = 0; // this single workgroup is the only writer of the encode status words
+    __syncthreads();
     const uint32_t per = (n_frames + kPlanThreads - 1) / kPlanThreads;
     const uint32_t begin = tid * per, end = min(begin + per, n_frames);
     uint64_t bytes = 0;
@@ -691,11 +694,9 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     ws += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
     uint8_t* choice = ws;
 
-    hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
-    if (err != hipSuccess)
-        return err;
     if (n_frames == 0) {
-        return hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), stream);
+        hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
+        return err != hipSuccess ? err : hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), stream);
     }
     const uint32_t groups = (n_frames + 7) / 8;
     const dim3 grid(groups * 8 * n_sig), wg(64);
