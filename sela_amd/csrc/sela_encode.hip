@@ -33,6 +33,7 @@ namespace sela {
 //                                       packed residue words
 constexpr int kPadC = 64;
 constexpr int kParityLen = kPadC + kBlock / 2 + 2;   // 1090 doubles
+constexpr int kCRowLen = kBlock + 16;                 // scratch row of centred samples + prefetch pad (64-byte multiple)
 constexpr int kPadS = 128;
 constexpr int kSBufWords = (kPadS + kBlock) / 32 * 33; // biased samples, one pad word per 32: 2244 words
 constexpr int kSmallBase = 8992;                      // >= kSBufWords * 4 = 8976, 16-byte aligned
@@ -139,19 +140,86 @@ __device__ __forceinline__ void rice_plan(const uint32_t (&u)[V], uint32_t n, ui
     best_bits = ta + (uint64_t)n * (1 + k);
 }
 
-// Steps I .. 15 of a 16-step autocorrelation trip (see k_encode_blocks).  C holds c[j0 + (lane & 15)];
-// pe/po point at E[m0 - L] / O[m0 - L] with m0 = j0 / 2.
-template <int I>
-__device__ __forceinline__ void autocorr_steps(double C, const double* pe, const double* po, double& A, double& B,
-    double& acc_e, double& acc_o)
+// ---- autocorrelation operand fetch (see k_encode_blocks) -------------------------------------------
+// One fetch = the operands of a 16-step trip: the sixteen wave-uniform multipliers c[j] as 32 SGPRs
+// (two s_load_dwordx16 from the block's scratch row, so that v_mul_f64 takes them as scalar operands)
+// and this lane's sixteen new window values c[j + 1 - 2L] (eight ds_read2_b64, alternating between
+// the odd and even parity arrays).  Issue and wait are separate asm statements and a fetch is in
+// flight for a whole trip: the scalar cache answers in ~500 cycles, and LDS and scalar loads share
+// one counter (lgkmcnt), so a wait for either is a wait for both -- hence ONE wait per trip, and the
+// compiler must never see a pending load of its own in this loop (it would add more).
+typedef int sgpr16 __attribute__((ext_vector_type(16)));
+typedef double f64x8 __attribute__((ext_vector_type(8)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+struct AcFetch {
+    sgpr16 c_lo, c_hi;          // c[j .. j+7], c[j+8 .. j+15]
+    f64x2 o0, o1, o2, o3;       // O[q .. q+7]      (new values of the even steps)
+    f64x2 e0, e1, e2, e3;       // E[q+1 .. q+8]    (new values of the odd steps)
+};
+
+// Issue the scalar half: S0, S1 = byte offsets into the scratch row.  The accumulators are named so
+// that the statement keeps its place among the steps.
+#define SELA_AC_ISSUE_S(F, c_ptr, S0, S1, acc_e, acc_o)                                   \
+    asm volatile("s_load_dwordx16 %0, %4, " #S0 "\n\ts_load_dwordx16 %1, %4, " #S1          \
+                 : "=&s"(F.c_lo), "=&s"(F.c_hi), "+v"(acc_e), "+v"(acc_o) : "s"(c_ptr) : "memory")
+
+// Issue the vector half: O[q..q+7] and E[q+1..q+8] relative to addr_o / addr_e (offsets in doubles).
+#define SELA_AC_ISSUE_V(F, addr_e, addr_o, Q0, Q1, Q2, Q3, Q4, Q5, Q6, Q7, Q8, acc_e, acc_o) \
+    asm volatile("ds_read2_b64 %0, %11 offset0:" #Q0 " offset1:" #Q1 "\n\t"                   \
+                 "ds_read2_b64 %4, %10 offset0:" #Q1 " offset1:" #Q2 "\n\t"                   \
+                 "ds_read2_b64 %1, %11 offset0:" #Q2 " offset1:" #Q3 "\n\t"                   \
+                 "ds_read2_b64 %5, %10 offset0:" #Q3 " offset1:" #Q4 "\n\t"                   \
+                 "ds_read2_b64 %2, %11 offset0:" #Q4 " offset1:" #Q5 "\n\t"                   \
+                 "ds_read2_b64 %6, %10 offset0:" #Q5 " offset1:" #Q6 "\n\t"                   \
+                 "ds_read2_b64 %3, %11 offset0:" #Q6 " offset1:" #Q7 "\n\t"                   \
+                 "ds_read2_b64 %7, %10 offset0:" #Q7 " offset1:" #Q8                           \
+                 : "=&v"(F.o0), "=&v"(F.o1), "=&v"(F.o2), "=&v"(F.o3), "=&v"(F.e0), "=&v"(F.e1), \
+                 "=&v"(F.e2), "=&v"(F.e3), "+v"(acc_e), "+v"(acc_o)                           \
+                 : "v"(addr_e), "v"(addr_o)                                                   \
+                 : "memory")
+
+// Lands the fetch: the fetched registers become defined here, behind the steps issued so far.
+__device__ __forceinline__ void ac_wait(AcFetch& f, double& acc_e, double& acc_o)
 {
-    const double cj = row_broadcast<I>(C);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+s"(f.c_lo), "+s"(f.c_hi), "+v"(f.o0), "+v"(f.o1), "+v"(f.o2), "+v"(f.o3), "+v"(f.e0), "+v"(f.e1),
+                 "+v"(f.e2), "+v"(f.e3), "+v"(acc_e), "+v"(acc_o));
+}
+
+__device__ __forceinline__ void ac_step(double cj, double nw, double& A, double& B, double& acc_e, double& acc_o)
+{
     acc_e += cj * A; // lag 2L   : c[j] * c[j - 2L]
     acc_o += cj * B; // lag 2L+1 : c[j] * c[j - 2L - 1]
     B = A;
-    A = (I & 1) ? pe[I / 2 + 1] : po[I / 2]; // c[j + 1 - 2L]
-    if constexpr (I < 15)
-        autocorr_steps<I + 1>(C, pe, po, A, B, acc_e, acc_o);
+    A = nw;          // c[j + 1 - 2L]
+}
+
+// steps 0 and 1 of a trip: the last to read the previous fetch's registers (through A and B)
+__device__ __forceinline__ void ac_steps_head(const AcFetch& f, double& A, double& B, double& acc_e, double& acc_o)
+{
+    const f64x8 c = __builtin_bit_cast(f64x8, f.c_lo);
+    ac_step(c[0], f.o0[0], A, B, acc_e, acc_o);
+    ac_step(c[1], f.e0[0], A, B, acc_e, acc_o);
+}
+
+__device__ __forceinline__ void ac_steps_tail(const AcFetch& f, double& A, double& B, double& acc_e, double& acc_o)
+{
+    const f64x8 c = __builtin_bit_cast(f64x8, f.c_lo), d = __builtin_bit_cast(f64x8, f.c_hi);
+    ac_step(c[2], f.o0[1], A, B, acc_e, acc_o);
+    ac_step(c[3], f.e0[1], A, B, acc_e, acc_o);
+    ac_step(c[4], f.o1[0], A, B, acc_e, acc_o);
+    ac_step(c[5], f.e1[0], A, B, acc_e, acc_o);
+    ac_step(c[6], f.o1[1], A, B, acc_e, acc_o);
+    ac_step(c[7], f.e1[1], A, B, acc_e, acc_o);
+    ac_step(d[0], f.o2[0], A, B, acc_e, acc_o);
+    ac_step(d[1], f.e2[0], A, B, acc_e, acc_o);
+    ac_step(d[2], f.o2[1], A, B, acc_e, acc_o);
+    ac_step(d[3], f.e2[1], A, B, acc_e, acc_o);
+    ac_step(d[4], f.o3[0], A, B, acc_e, acc_o);
+    ac_step(d[5], f.e3[0], A, B, acc_e, acc_o);
+    ac_step(d[6], f.o3[1], A, B, acc_e, acc_o);
+    ac_step(d[7], f.e3[1], A, B, acc_e, acc_o);
 }
 
 // Taps j0 + JJ + 1 .. j0 + 32 of the residue FIR (see k_encode_blocks), stopping at `order`.  JJ is a
@@ -190,7 +258,7 @@ __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const uint
 template <int kMode>
 __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
-    sela_hip_trace* __restrict__ trace, uint64_t* __restrict__ phase_cycles)
+    double* __restrict__ c_rows, sela_hip_trace* __restrict__ trace, uint64_t* __restrict__ phase_cycles)
 {
     constexpr bool kTrace = kMode == 1;
     long long stamp[14];
@@ -268,9 +336,17 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
 
     SELA_STAMP(2);
     // c[j] = x[j] - mean, in place (same value at every use)
+    // A second copy goes to this block's scratch row in natural order: the scalar unit reads the
+    // wave-uniform multiplier c[j] from there (agent-scope stores: they must be in L2 before the
+    // scalar cache, which sits beside the vector L1, fetches them).
+    double* const c_row = reinterpret_cast<double*>(read_first_lane((uint64_t)(c_rows + (size_t)block_id * kCRowLen)));
 #pragma unroll
-    for (int t = 0; t < kPerLane; t++)
-        mine[half + 32 * t] = mine[half + 32 * t] - mean;
+    for (int t = 0; t < kPerLane; t++) {
+        const double c = mine[half + 32 * t] - mean;
+        mine[half + 32 * t] = c;
+        __hip_atomic_store((__attribute__((address_space(1))) double*)c_row + lane + 64 * t, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv" ::: "memory");
     wave_sync();
 
     SELA_STAMP(3);
@@ -284,18 +360,37 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     // leading terms c[j]*0 (j < lag) leave an accumulator at +0.0.
     double acc_e = 0.0, acc_o = 0.0;
     {
-        const double* pe = E - lane; // E[m - L]
-        const double* po = O - lane;
-        double A = pe[0]; // c[0 - 2L]
-        double B = 0.0;   // c[-2L - 1]
-        // sixteen steps per trip: the sixteen wave-uniform multipliers c[j0 .. j0+15] are fetched once,
-        // replicated in every row of 16 lanes, and handed out by DPP row broadcast (v_mov_b64_dpp)
-        const double* bc = ((lane & 1) ? O : E) + ((lane & 15) >> 1);
+        double A = E[-lane]; // c[0 - 2L]
+        double B = 0.0;      // c[-2L - 1]
+        // LDS byte addresses of E[m0 - L] and O[m0 - L]; scratch pointer at c[2 m0]
+        uint32_t addr_e = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)(E - lane);
+        uint32_t addr_o = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)(O - lane);
+        const double* c_ptr = c_row;
+        AcFetch f0, f1;
+        asm volatile("" : "+v"(A)); // land A here: a compiler-placed wait inside the loop would drain the prefetch
+        SELA_AC_ISSUE_S(f0, c_ptr, 0, 64, acc_e, acc_o);
+        SELA_AC_ISSUE_V(f0, addr_e, addr_o, 0, 1, 2, 3, 4, 5, 6, 7, 8, acc_e, acc_o);
+        // two 16-step trips per iteration.  A fetch's scalar half is issued a whole trip ahead, its
+        // vector half after the first two steps of the running trip, once the registers it overwrites
+        // are dead.  (The last fetch lands in the scratch row's pad and in LDS behind the parity
+        // arrays; it is never used.)
 #pragma unroll 1
-        for (int m0 = 0; m0 < kBlock / 2; m0 += 8) {
-            const double C = bc[m0]; // lane 16r + i holds c[2*m0 + i]
-            autocorr_steps<0>(C, pe + m0, po + m0, A, B, acc_e, acc_o);
+        for (int m0 = 0; m0 < kBlock / 2; m0 += 16) {
+            ac_wait(f0, acc_e, acc_o);
+            SELA_AC_ISSUE_S(f1, c_ptr, 128, 192, acc_e, acc_o);
+            ac_steps_head(f0, A, B, acc_e, acc_o);
+            SELA_AC_ISSUE_V(f1, addr_e, addr_o, 8, 9, 10, 11, 12, 13, 14, 15, 16, acc_e, acc_o);
+            ac_steps_tail(f0, A, B, acc_e, acc_o);
+            ac_wait(f1, acc_e, acc_o);
+            SELA_AC_ISSUE_S(f0, c_ptr, 256, 320, acc_e, acc_o);
+            ac_steps_head(f1, A, B, acc_e, acc_o);
+            SELA_AC_ISSUE_V(f0, addr_e, addr_o, 16, 17, 18, 19, 20, 21, 22, 23, 24, acc_e, acc_o);
+            ac_steps_tail(f1, A, B, acc_e, acc_o);
+            c_ptr += 32;
+            addr_e += 128;
+            addr_o += 128;
         }
+        ac_wait(f0, acc_e, acc_o); // drain the fetch past the end
     }
     wave_sync(); // c[] is dead from here on
 
@@ -677,6 +772,7 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
     bytes += (blocks * sizeof(BlockMeta) + 255) & ~(size_t)255;
     bytes += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
     bytes += ((size_t)n_frames + 255) & ~(size_t)255; // choice
+    bytes += blocks * kCRowLen * sizeof(double);      // centred-sample rows for the scalar unit
     return bytes + 256;
 }
 
@@ -693,6 +789,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     uint32_t* slots = reinterpret_cast<uint32_t*>(ws);
     ws += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
     uint8_t* choice = ws;
+    ws += ((size_t)n_frames + 255) & ~(size_t)255;
+    double* c_rows = reinterpret_cast<double*>(ws);
 
     if (n_frames == 0) {
         hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
@@ -703,11 +801,11 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
-        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, c_rows, d_trace, d_phase_cycles);
     else if (d_trace)
-        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, c_rows, d_trace, d_phase_cycles);
     else
-        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, c_rows, d_trace, d_phase_cycles);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap,
