@@ -420,7 +420,6 @@ struct SynthState {
 
 struct SynthWaveLds {
     double k[104];
-    double t[104];
     int64_t a[104];
 };
 
@@ -475,7 +474,7 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
             wave_sync();
             if (kProf)
                 stamp[1] = clock64(), prof_sub = c;
-            step_up(wl->k, wl->t, wl->a, (int)order, lane, flags);
+            step_up(wl->k, wl->a, (int)order, lane, flags);
             for (uint32_t i = lane; i <= order; i += 64)
                 st->a[i] = wl->a[i];
         } else {

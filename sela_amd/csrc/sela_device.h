@@ -157,33 +157,60 @@ __device__ __forceinline__ int64_t q35_trunc(double v, uint32_t& flags)
 
 // ---- step-up recursion, shared by encoder and decoder -------------------------------------------
 // Reflection coefficients kd[0..order) (LDS) -> Q35 predictor a[0..order] (LDS, int64).
-// src/lpc/linear_predictor.cpp:30-61.  Stage i updates every m < i from the OLD values,
-//   t[m] <- t[m] + kd[i] * t[i-1-m]
-// which is the reference's pairwise update (and its odd-i middle element) written per element;
-// the reads of a stage all precede its writes, so the lanes are independent.  One wave.
-__device__ inline void step_up(const double* kd, double* t, int64_t* a, int order, int lane, uint32_t& flags)
+// src/lpc/linear_predictor.cpp:30-61.  Stage i turns every t[m], m < i, into t[m] + k_i * t[i-1-m]
+// (the reference's pairwise update and its odd-i middle element, written per element from the OLD
+// values) and appends t[i] = k_i.  The whole recursion stays in registers: lane m (+64 in a second
+// register) holds t[m] and, beside it, the mirrored element u[m] = t[i-1-m] it is about to meet.
+// The mirror of the NEW array is u'[m] = t'[i-m] = u[m-1] + k_i * t[m-1], i.e. the same
+// multiply-add with the roles swapped, moved up one lane, and u'[0] = k_i.  Elements beyond the
+// current length are kept at +0.0 (0 + k*0 = +0 under round-to-nearest), so no lane is masked.
+__device__ __forceinline__ double read_lane(double v, int src_lane /* wave-uniform */)
 {
-    for (int i = 0; i < order; i++) {
-        const double ki = kd[i];
-        const int m0 = lane, m1 = lane + 64;
-        double n0 = 0.0, n1 = 0.0;
-        if (m0 < i)
-            n0 = t[m0] + ki * t[i - 1 - m0];
-        if (m1 < i)
-            n1 = t[m1] + ki * t[i - 1 - m1];
-        wave_sync();
-        if (m0 < i)
-            t[m0] = n0;
-        if (m1 < i)
-            t[m1] = n1;
-        if (lane == 0)
-            t[i] = ki;
-        wave_sync();
+    const uint64_t x = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), src_lane);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// lane l <- lane l-1 ; lane 0 receives 0
+__device__ __forceinline__ double wave_shr1_zero(double v)
+{
+    const uint64_t x = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+__device__ inline void step_up(const double* kd, int64_t* a, int order, int lane, uint32_t& flags)
+{
+    const double k_lo = lane < order ? kd[lane] : 0.0;
+    const double k_hi = lane + 64 < order ? kd[lane + 64] : 0.0;
+    double t_lo = 0.0, u_lo = 0.0, t_hi = 0.0, u_hi = 0.0;
+    const int n_lo = order < 64 ? order : 64;
+    for (int i = 0; i < n_lo; i++) { // everything still fits the first register
+        const double ki = read_lane(k_lo, i);
+        const double tn = t_lo + ki * u_lo;
+        const double un = u_lo + ki * t_lo;
+        t_lo = lane == i ? ki : tn;
+        const double us = wave_shr1_zero(un);
+        u_lo = lane == 0 ? ki : us;
+    }
+    for (int i = 64; i < order; i++) {
+        const double ki = read_lane(k_hi, i - 64);
+        const double tn_lo = t_lo + ki * u_lo, un_lo = u_lo + ki * t_lo;
+        const double tn_hi = t_hi + ki * u_hi, un_hi = u_hi + ki * t_hi;
+        t_lo = tn_lo;
+        t_hi = lane + 64 == i ? ki : tn_hi;
+        const double carry = read_lane(un_lo, 63);
+        const double us_lo = wave_shr1_zero(un_lo), us_hi = wave_shr1_zero(un_hi);
+        u_lo = lane == 0 ? ki : us_lo;
+        u_hi = lane == 0 ? carry : us_hi;
     }
     if (lane == 0)
         a[0] = 0;
-    for (int m = lane; m < order; m += 64)
-        a[m + 1] = q35_trunc(-t[m], flags);
+    if (lane < order)
+        a[lane + 1] = q35_trunc(-t_lo, flags);
+    if (lane + 64 < order)
+        a[lane + 65] = q35_trunc(-t_hi, flags);
     wave_sync();
 }
 

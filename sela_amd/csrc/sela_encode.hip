@@ -46,7 +46,6 @@ static_assert(kBigBytes >= 2 * kParityLen * 8, "the FP64 parity arrays must fit"
 struct SmallArrays { // lives at kSmallBase during analysis; dead before the residue words are packed
     double ac[104];
     double k[104];   // reflection coefficients, later the dequantised ones
-    double t[104];   // step-up scratch
     int64_t a[104];  // Q35 predictor
     int32_t q[128];
 };
@@ -484,7 +483,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
 
     SELA_STAMP(6);
     // ---- step-up to the Q35 predictor (src/lpc/linear_predictor.cpp:30-61) ---------------------------
-    step_up(sm->k, sm->t, sm->a, order, lane, flags);
+    step_up(sm->k, sm->a, order, lane, flags);
     __builtin_amdgcn_s_setprio(0);
     if (kTrace) {
         sela_hip_trace* tr = trace + block_id;
