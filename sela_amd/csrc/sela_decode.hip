@@ -337,53 +337,66 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
 // one-position move between lanes is a DPP wave shift.  The recurrence itself (z_0 -> s_i) runs on
 // the scalar unit: s_i stays in an SGPR and feeds the multiply-adds as a scalar operand.
 //
-// 64x32-bit products: a = ah*2^32 + al with al = (int32)a, so
-//     z + a*s mod 2^64 = (z + al*s)  [v_mad_i64_i32, exact]  +  ((ah*s mod 2^32) << 32)  [v_mul_lo_u32 + v_add_u32]
+// What is accumulated is N = 2^34 - sum(a_j s_(i-j)): the coefficients are negated once and every
+// position receives the rounding constant 2^34 when it enters its last 64 samples, so the prediction
+// (int32)((2^34 - P) >> 35) is the arithmetic shift (int32)N_hi >> 3 of the HIGH word alone (the
+// reference's cast keeps exactly those 29 bits) -- one v_readfirstlane and two SALU ops per sample.
+//
+// 64x32-bit products: a' = ah*2^32 + al with al = (int32)a', so
+//     z + a'*s mod 2^64 = (z + al*s)  [v_mad_i64_i32, exact]  +  ((ah*s mod 2^32) << 32)
 // `rs` holds n_samples residues (a multiple of 64) of one chunk; zs is the subframe's partial-sum
 // state in the workspace (position-major), carried from chunk to chunk.
 //
 // kFold: the residue is folded into the partial sum before the recurrence needs it,
-//     Z = P + r * 2^35  (one v_lshl_add per 64 samples)   ==>   s = -((2^34 - Z) >> 35),
-// which drops the per-sample v_readlane of r.  The shift keeps 29 bits, so this equals the reference's
-// 32-bit  r - (int32)((2^34 - P) >> 35)  exactly when |s| < 2^28; every 64 samples are checked against
-// 2^27 and the function returns false (state untouched) if any is larger -- the caller then re-runs the
-// chunk with kFold = false.  16-bit audio never gets there; crafted streams do (tests).
+//     N' = N - r * 2^35  (one add on the high word per 64 samples)   ==>   s = -(N' >> 35),
+// which drops the per-sample v_readlane of r, and the high product is one v_mad_i32_i24.  Both need
+// small operands: the shift keeps 29 bits and the multiplier 24, so this equals the reference's 32-bit
+// r - (int32)((2^34 - P) >> 35) exactly while |s| < 2^23 and |a| < 2^55; the coefficients are checked
+// up front and every 64 samples against 2^23, and the function returns false (state untouched) on a
+// violation -- the caller then re-runs the chunk with kFold = false (v_readlane of r, v_mul_lo_u32 +
+// v_add_u32).  16-bit audio never gets there; crafted streams do (tests).
 template <int P, bool kFold>
 __device__ inline bool synthesize(int32_t* rs, int n_samples, const int64_t* a, int order, uint64_t* zs, bool first, int lane)
 {
+    // The partial sums carry N = 2^34 - sum(a_j s_(i-j)) [- r_i 2^35 when folded], i.e. the NEGATED
+    // coefficients are accumulated, so that the prediction is one arithmetic shift of the high word:
+    // pred = N >> 35 = (int32)N_hi >> 3 -- the low word never leaves the vector unit.
     int32_t al[P];
-    uint32_t ah[P];
+    int32_t ah[P];
+    bool mad24_ok = true;
 #pragma unroll
     for (int h = 0; h < P; h++) {
         const int idx = P * lane + h + 1;
-        const int64_t av = idx <= order ? a[idx] : 0;
-        al[h] = (int32_t)(uint32_t)(uint64_t)av;
-        ah[h] = (uint32_t)((uint64_t)(av - (int64_t)al[h]) >> 32);
+        const uint64_t nv = 0 - (uint64_t)(idx <= order ? a[idx] : 0);
+        al[h] = (int32_t)(uint32_t)nv;
+        ah[h] = (int32_t)(uint32_t)((nv - (uint64_t)(int64_t)al[h]) >> 32); // nv = ah 2^32 + al, al signed
+        mad24_ok &= ah[h] >= -(1 << 23) && ah[h] < (1 << 23);
     }
+    if (kFold && __any(!mad24_ok))
+        return false; // |a| >= 2^55: the 24-bit multiply of the folded form does not apply
     uint64_t z[P];
 #pragma unroll
     for (int h = 0; h < P; h++)
         z[h] = first ? 0 : zs[P * lane + h];
-    const uint64_t half = (uint64_t)1 << (SELA_Q_SHIFT - 1);
     bool in_range = true;
 #pragma unroll 1
     for (int base = 0; base < n_samples; base += 64) {
         const int32_t r_chunk = rs[base + lane];
-        if (kFold) { // position p of this block completes at sample base + p: give it its residue now
-            if (P == 1) {
-                z[0] += (uint64_t)((uint32_t)r_chunk << 3) << 32;
-            } else if (lane < 32) {
+        // position p of this block completes at sample base + p: give it the rounding constant 2^34
+        // (and, folded, its residue) now -- one add on the high word
+        if (P == 1) {
+            z[0] += (uint64_t)(4u - (kFold ? (uint32_t)r_chunk << 3 : 0u)) << 32;
+        } else if (lane < 32) {
 #pragma unroll
-                for (int h = 0; h < P; h++)
-                    z[h] += (uint64_t)((uint32_t)rs[base + P * lane + h] << 3) << 32;
-            }
+            for (int h = 0; h < P; h++)
+                z[h] += (uint64_t)(4u - (kFold ? (uint32_t)rs[base + P * lane + h] << 3 : 0u)) << 32;
         }
         int32_t s_chunk = 0;
 #pragma unroll
         for (int m = 0; m < 64; m++) {
-            // scalar side: P_i sits in lane 0, position 0
-            const uint64_t pv = read_first_lane(z[0]);
-            const int32_t pred = (int32_t)((int64_t)(half - pv) >> SELA_Q_SHIFT);
+            // scalar side: N_i sits in lane 0, position 0
+            const int32_t n_hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(z[0] >> 32));
+            const int32_t pred = n_hi >> 3;
             int32_t s_i;
             if (kFold)
                 s_i = (int32_t)(0u - (uint32_t)pred);
@@ -396,11 +409,16 @@ __device__ inline bool synthesize(int32_t* rs, int n_samples, const int64_t* a, 
             for (int h = 0; h < P; h++) {
                 const uint64_t up = h + 1 < P ? z[h + 1 < P ? h + 1 : h] : in;
                 const uint64_t lo = (uint64_t)((int64_t)up + (int64_t)al[h] * (int64_t)s_i);
-                z[h] = lo + ((uint64_t)(ah[h] * (uint32_t)s_i) << 32);
+                uint32_t hi;
+                if (kFold) // high part of the product: both factors fit 24 bits in the folded form (checked)
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hi) : "v"(ah[h]), "s"(s_i), "v"((uint32_t)(lo >> 32)));
+                else
+                    hi = (uint32_t)(lo >> 32) + (uint32_t)ah[h] * (uint32_t)s_i;
+                z[h] = ((uint64_t)hi << 32) | (uint32_t)lo;
             }
         }
         if (kFold)
-            in_range &= (uint32_t)(s_chunk + (1 << 27)) < (1u << 28);
+            in_range &= (uint32_t)(s_chunk + (1 << 23)) < (1u << 24);
         rs[base + lane] = s_chunk;
     }
     if (kFold && __any(!in_range))
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
             stamp[2] = clock64();
         const bool exact_needed = order <= 64 ? !synthesize<1, true>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane)
                                               : !synthesize<2, true>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
-        if (exact_needed) { // a sample left the 28-bit range of the folded form: redo this chunk the long way
+        if (exact_needed) { // a sample or coefficient left the range of the folded form: redo this chunk the long way
             wave_sync();
             for (uint32_t t4 = lane; t4 < v_count / 4; t4 += 64)
                 rdst[t4] = rsrc[t4];
