@@ -33,6 +33,8 @@ constexpr int kDecodeChunks = 4; // sample-axis pipeline depth of one decode cal
 struct SubDesc {
     uint32_t info;  // channel | type << 8 | parent << 16 | order << 24
     uint32_t flags; // SELA_HIP_FLAG_* bits; BAD_FRAME means "do not synthesise"
+    uint32_t res_k; // Rice parameter of the residue stream (to unpack kPacked residue words)
+    uint32_t pad;
 };
 
 // ---- lane-per-stream Rice parser --------------------------------------------------------------------
@@ -43,7 +45,18 @@ struct SubDesc {
 //
 // Codewords are decoded four at a time from a 128-bit register window read at the lane's bit
 // position (one LDS round trip per four values).  A group falls back to the bit-by-window slow path
-// when any lane meets a codeword longer than 31 bits (long unary run).
+// when any lane meets a codeword longer than 30 bits (long unary run).
+//
+// The tile holds the stream INVERTED (zero padding beyond a stream's end becomes ones): the unary run
+// length is then one v_ffbl_b32, with no v_not_b32 on the per-value path.
+//
+// This kernel is the serial part of decoding -- 64 streams per wave, one wave per SIMD, every
+// instruction of the per-value path costs its full issue latency -- so the residue path does the
+// bare minimum per codeword: find its length, cut out the remainder bits, move the window.  It emits
+// PACKED words, (ones + 1) << 24 | inverted remainder bits, and leaves bit reversal, un-zig-zag and
+// friends to unpack_residue(), which runs in k_synthesize_frames across all lanes of 64x more waves.
+// Blocks of 32 values in which some group took the slow path are stored as final values instead;
+// one bit per block in res_raw[] says which (src/rice/rice_decoder.cpp:27-51 either way).
 constexpr int kTileWords = 96;
 constexpr int kTileStride = kTileWords + 1; // odd stride: lanes reading the same column hit different banks
 constexpr int kTileMargin = 12;             // re-tile when a lane is within this many words of its row end
@@ -87,10 +100,10 @@ __device__ inline void retile(StreamReader& r, uint32_t* tile, int lane)
                 v.z = src[idx + 2];
         }
         uint32_t* dst = tile + row * kTileStride + c4;
-        dst[0] = v.x;
-        dst[1] = v.y;
-        dst[2] = v.z;
-        dst[3] = v.w;
+        dst[0] = ~v.x;
+        dst[1] = ~v.y;
+        dst[2] = ~v.z;
+        dst[3] = ~v.w;
     }
     r.tile_first = new_first;
     wave_sync();
@@ -108,7 +121,7 @@ __device__ __forceinline__ uint64_t reader_window(const StreamReader& r, const u
     const uint32_t* w = tile + lane * kTileStride + (col < (uint32_t)kTileWords - 2 ? col : (uint32_t)kTileWords - 3);
     const uint32_t sh = bp & 31;
     const uint64_t lo = ((uint64_t)w[1] << 32) | w[0];
-    return sh ? (lo >> sh) | ((uint64_t)w[2] << (64 - sh)) : lo;
+    return ~(sh ? (lo >> sh) | ((uint64_t)w[2] << (64 - sh)) : lo); // the tile is inverted
 }
 
 __device__ __forceinline__ int32_t rice_value(uint32_t ones, uint32_t field, uint32_t k)
@@ -152,8 +165,8 @@ __device__ __forceinline__ void reader_codewords4(StreamReader& r, uint32_t* til
     const uint32_t* w = tile + lane * kTileStride + col;
     const uint32_t sh = r.bp & 31;
     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
-    uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
-    uint32_t x2 = __builtin_amdgcn_alignbit(w3, w2, sh), x3 = __builtin_amdgcn_alignbit(w4, w3, sh);
+    uint32_t x0 = ~__builtin_amdgcn_alignbit(w1, w0, sh), x1 = ~__builtin_amdgcn_alignbit(w2, w1, sh); // the tile is inverted
+    uint32_t x2 = ~__builtin_amdgcn_alignbit(w3, w2, sh), x3 = ~__builtin_amdgcn_alignbit(w4, w3, sh);
     uint32_t used = 0;
     bool slow = false;
 #pragma unroll
@@ -180,6 +193,56 @@ __device__ __forceinline__ void reader_codewords4(StreamReader& r, uint32_t* til
     }
 }
 
+// ---- residue fast path: four PACKED codewords per lane, every lane live --------------------------------
+// packed word = (ones + 1) << 24 | the k remainder bits as they sit in the INVERTED stream (LSB first).
+constexpr uint32_t kPackShift = 24;
+constexpr uint32_t kPackMaxK = 24;   // remainder bits must fit below the run length
+constexpr uint32_t kPackMaxLen = 30; // longest codeword the register window handles (ones + 1 + k)
+
+__device__ __forceinline__ int32_t unpack_residue(uint32_t p, uint32_t k, uint32_t kmask)
+{
+    return rice_value((p >> kPackShift) - 1u, ~p & kmask, k);
+}
+
+// Returns true if the group was decoded (out = packed words, position advanced); false if some lane met
+// a codeword the window cannot hold -- nothing is consumed then and the caller redoes the group slowly.
+__device__ __forceinline__ bool reader_packed4(StreamReader& r, uint32_t* tile, int lane, uint32_t k, uint32_t kmask, bool k_fits,
+    uint32_t (&out)[4])
+{
+    if (__any(reader_near_end(r)))
+        retile(r, tile, lane);
+    const uint32_t col = (r.bp >> 5) - r.tile_first;
+    const uint32_t* w = tile + lane * kTileStride + col;
+    const uint32_t sh = r.bp & 31;
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+    uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh); // inverted bits
+    uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, sh), n3 = __builtin_amdgcn_alignbit(w4, w3, sh);
+    uint32_t used = 0;
+    bool fast = k_fits;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        // ones + 1 = index of the first set bit of (inverted window << 1); the sentinel caps it at 31
+        const uint32_t t1 = (uint32_t)__builtin_ctz((n0 << 1) | 0x80000000u);
+        const uint32_t len = t1 + k;
+        fast &= len <= kPackMaxLen;
+        const uint32_t field = __builtin_amdgcn_alignbit(n1, n0, t1) & kmask;
+        out[j] = (t1 << kPackShift) | field;
+        if (j < 3) { // (shift amounts are taken mod 32: a too-long codeword garbles a group that is redone anyway)
+            n0 = __builtin_amdgcn_alignbit(n1, n0, len);
+            n1 = __builtin_amdgcn_alignbit(n2, n1, len);
+            if (j < 2)
+                n2 = __builtin_amdgcn_alignbit(n3, n2, len);
+            if (j < 1)
+                n3 >>= len & 31;
+        }
+        used += len;
+    }
+    if (__any(!fast))
+        return false;
+    r.bp += used;
+    return true;
+}
+
 __device__ __forceinline__ void reader_open(StreamReader& r, const uint32_t* base, uint32_t n_words, uint32_t start_bit, uint32_t* tile, int lane)
 {
     r.base = base;
@@ -194,8 +257,8 @@ __device__ __forceinline__ void reader_open(StreamReader& r, const uint32_t* bas
 // parse(chunk j+1) against synthesize(chunk j).
 __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, SubDesc* __restrict__ desc,
-    int32_t* __restrict__ q_out, int32_t* __restrict__ residues, uint32_t* __restrict__ bit_pos, uint32_t* __restrict__ status,
-    uint32_t v_begin, uint32_t v_count)
+    int32_t* __restrict__ q_out, int32_t* __restrict__ residues, uint32_t* __restrict__ bit_pos, uint64_t* __restrict__ res_raw,
+    uint32_t* __restrict__ status, uint32_t v_begin, uint32_t v_count)
 {
     __shared__ uint32_t tile[64 * kTileStride + 8];
     __shared__ int32_t stage[64 * kStageStride];
@@ -274,34 +337,52 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
         if (r.bp > 24 + 32 * cw)
             flags |= SELA_HIP_FLAG_RICE_OVERRUN;
     }
-    // residue stream (aligned).  Values are staged in LDS, 32 per lane, and written out as full
+    // residue stream (aligned).  Words are staged in LDS, 32 per lane, and written out as full
     // 128-byte lines (8 lanes per subframe row) instead of 64 scattered stores per value.
     {
         StreamReader r;
         const uint32_t start_bit = v_begin == 0 ? 0u : bit_pos[g];
         reader_open(r, reinterpret_cast<const uint32_t*>(fb + p + 12 + 4 * (uint64_t)cw), rw, ok ? start_bit : 0u, tile, lane);
         const uint32_t kmask = rk ? (0xFFFFFFFFu >> (32 - rk)) : 0u;
+        const bool k_fits = rk <= kPackMaxK;
         const unsigned long long store_mask = __ballot(store);
-        const uint32_t live_mask = ok ? 0xFu : 0u;
+        uint64_t raw_blocks = 0; // wave-uniform: blocks of 32 values stored as final values
 #pragma unroll 1
         for (uint32_t blk = v_begin / kStageVals; blk < (v_begin + v_count) / kStageVals; blk++) {
+            uint32_t slow_groups = 0; // wave-uniform
 #pragma unroll
             for (int j = 0; j < kStageVals; j += 4) {
-                int32_t v[4];
-                reader_codewords4(r, tile, lane, rk, kmask, live_mask, v);
-                stage[lane * kStageStride + j] = v[0];
-                stage[lane * kStageStride + j + 1] = v[1];
-                stage[lane * kStageStride + j + 2] = v[2];
-                stage[lane * kStageStride + j + 3] = v[3];
+                uint32_t pk[4];
+                if (!reader_packed4(r, tile, lane, rk, kmask, k_fits, pk)) {
+                    slow_groups |= 1u << (j / 4);
+#pragma unroll 1
+                    for (int jj = 0; jj < 4; jj++) // lanes of rejected subframes walk an empty stream
+                        pk[jj] = (uint32_t)reader_codeword_slow(r, tile, lane, rk, kmask, true);
+                }
+                stage[lane * kStageStride + j] = (int32_t)pk[0];
+                stage[lane * kStageStride + j + 1] = (int32_t)pk[1];
+                stage[lane * kStageStride + j + 2] = (int32_t)pk[2];
+                stage[lane * kStageStride + j + 3] = (int32_t)pk[3];
             }
+            if (slow_groups)
+                raw_blocks |= 1ull << blk;
             wave_sync();
 #pragma unroll
-            for (int i = 0; i < 8; i++) { // 8 rows x 8 lanes x 16 bytes per wave-store
+            for (int i = 0; i < 8; i++) { // 8 rows x 8 lanes x 16 bytes per wave-store; a lane's 4 words are one group
                 const int row = 8 * i + (lane >> 3);
                 const int c4 = (lane & 7) * 4;
                 const int32_t* src = stage + row * kStageStride + c4;
                 int4 v;
                 v.x = src[0], v.y = src[1], v.z = src[2], v.w = src[3];
+                if (slow_groups) { // raw block (wave-uniform, rare): finish its packed groups here
+                    const uint32_t row_k = (uint32_t)__shfl((int)rk, row, 64), row_mask = (uint32_t)__shfl((int)kmask, row, 64);
+                    if (!((slow_groups >> (lane & 7)) & 1u)) {
+                        v.x = unpack_residue((uint32_t)v.x, row_k, row_mask);
+                        v.y = unpack_residue((uint32_t)v.y, row_k, row_mask);
+                        v.z = unpack_residue((uint32_t)v.z, row_k, row_mask);
+                        v.w = unpack_residue((uint32_t)v.w, row_k, row_mask);
+                    }
+                }
                 const uint32_t g_row = blockIdx.x * 64 + (uint32_t)row;
                 if ((store_mask >> row) & 1ull)
                     *reinterpret_cast<int4*>(residues + (size_t)g_row * kBlock + blk * kStageVals + c4) = v;
@@ -310,14 +391,18 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
         }
         if (v_begin + v_count == (uint32_t)kBlock && r.bp > 32 * rw)
             flags |= SELA_HIP_FLAG_RICE_OVERRUN;
-        if (in_range)
+        if (in_range) {
             bit_pos[g] = r.bp;
+            res_raw[g] = v_begin == 0 ? raw_blocks : res_raw[g] | raw_blocks;
+        }
     }
     if (in_range) {
         if (v_begin == 0) {
             SubDesc d;
             d.info = ok ? channel | (type << 8) | (parent << 16) | (order << 24) : 0u;
             d.flags = ok ? flags : (uint32_t)SELA_HIP_FLAG_BAD_FRAME;
+            d.res_k = rk;
+            d.pad = 0;
             desc[g] = d;
         } else if (flags) {
             desc[g].flags |= flags;
@@ -327,126 +412,198 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
 
 // ---- synthesis filter ----------------------------------------------------------------------------------
 // lpc::SampleGenerator::generateSamples (src/lpc/sample_generator.cpp:11-30), in place over the
-// residues in LDS.  Transposed direct form: once sample s_i is known every tap position p adds
-// a[p+1]*s_i to the partial sum that completes p+1 steps later and the partial sums move down one
-// position:
-//     z_p <- z_{p+1} + a[p+1] * s_i ,        P_{i+1} = z_0 ,
-//     s_{i+1} = r_{i+1} - (int32)((2^34 - P_{i+1}) >> 35)
-// which reproduces both reference loops (during warm-up the higher positions simply have not
-// received anything yet).  Lane L owns positions P*L .. P*L+P-1 (P = 1 for order <= 64, else 2); the
-// one-position move between lanes is a DPP wave shift.  The recurrence itself (z_0 -> s_i) runs on
-// the scalar unit: s_i stays in an SGPR and feeds the multiply-adds as a scalar operand.
+// residues in LDS.  Transposed direct form without data movement: every sample that is still to come
+// owns a partial sum, and the sum of sample j lives in lane j mod 64 for its whole life (a ring over
+// the lanes; orders above 60 use two registers per lane = a ring of 128).  Once sample s_i is known,
+// the lane that owns sample i + d adds a[d] * s_i; its coefficient a[(lane - i) mod ring] comes out of
+// a doubled table in LDS at a compile-time offset (the 64 steps of a block are unrolled), so nothing is
+// shifted between lanes.  The recurrence itself (sum -> s_i) runs on the scalar unit: v_readlane of the
+// finished sum, two SALU ops, and s_i feeds the multiply-adds as a scalar operand.
 //
-// What is accumulated is N = 2^34 - sum(a_j s_(i-j)): the coefficients are negated once and every
-// position receives the rounding constant 2^34 when it enters its last 64 samples, so the prediction
-// (int32)((2^34 - P) >> 35) is the arithmetic shift (int32)N_hi >> 3 of the HIGH word alone (the
-// reference's cast keeps exactly those 29 bits) -- one v_readfirstlane and two SALU ops per sample.
+// What is accumulated is N = 2^34 - sum(a_j s_(i-j)): the coefficients are negated once and every sum
+// starts at the rounding constant 2^34, so the prediction (int32)((2^34 - P) >> 35) is the arithmetic
+// shift (int32)N_hi >> 3 of the HIGH word alone (the reference's cast keeps exactly those 29 bits).
+//
+// A finished sum is not touched again until its lane is recycled: the coefficients of lags
+// ring - G + 1 .. ring - 1 are zero (order <= ring - G), so lanes are recycled in aligned groups of G
+// (three DPP moves under a row/bank mask: keep the finished high words, restart the sums), and the
+// 64 samples of a block are derived from the kept words in one vector step.  Per sample that is
+// 3 + 3/G VALU instructions (5 + 3/G on the ring of 128) and one (two) ds_read_b64.
 //
 // 64x32-bit products: a' = ah*2^32 + al with al = (int32)a', so
 //     z + a'*s mod 2^64 = (z + al*s)  [v_mad_i64_i32, exact]  +  ((ah*s mod 2^32) << 32)
-// `rs` holds n_samples residues (a multiple of 64) of one chunk; zs is the subframe's partial-sum
-// state in the workspace (position-major), carried from chunk to chunk.
+// `rs` holds n_samples residues (a multiple of the ring) of one chunk; zs is the subframe's partial-sum
+// state in the workspace (register-major), carried from chunk to chunk.
 //
-// kFold: the residue is folded into the partial sum before the recurrence needs it,
-//     N' = N - r * 2^35  (one add on the high word per 64 samples)   ==>   s = -(N' >> 35),
+// kFold: the residue is folded into its sum at the start of its block of 64,
+//     N' = N - r * 2^35  (one subtract on the high word per 64 samples)   ==>   s = -(N' >> 35),
 // which drops the per-sample v_readlane of r, and the high product is one v_mad_i32_i24.  Both need
 // small operands: the shift keeps 29 bits and the multiplier 24, so this equals the reference's 32-bit
 // r - (int32)((2^34 - P) >> 35) exactly while |s| < 2^23 and |a| < 2^55; the coefficients are checked
-// up front and every 64 samples against 2^23, and the function returns false (state untouched) on a
-// violation -- the caller then re-runs the chunk with kFold = false (v_readlane of r, v_mul_lo_u32 +
-// v_add_u32).  16-bit audio never gets there; crafted streams do (tests).
-template <int P, bool kFold>
-__device__ inline bool synthesize(int32_t* rs, int n_samples, const int64_t* a, int order, uint64_t* zs, bool first, int lane)
+// when the table is built and every 64 samples against 2^23, and the function returns false (state
+// untouched) on a violation -- the caller then re-runs the chunk with kFold = false (v_readlane of r,
+// v_mul_lo_u32 + v_add_u32).  16-bit audio never gets there; crafted streams do (tests).
+template <bool kFold>
+__device__ __forceinline__ void synth_mac(uint32_t& zl, uint32_t& zh, uint64_t coef, int32_t s_i)
 {
-    // The partial sums carry N = 2^34 - sum(a_j s_(i-j)) [- r_i 2^35 when folded], i.e. the NEGATED
-    // coefficients are accumulated, so that the prediction is one arithmetic shift of the high word:
-    // pred = N >> 35 = (int32)N_hi >> 3 -- the low word never leaves the vector unit.
-    int32_t al[P];
-    int32_t ah[P];
-    bool mad24_ok = true;
-#pragma unroll
-    for (int h = 0; h < P; h++) {
-        const int idx = P * lane + h + 1;
-        const uint64_t nv = 0 - (uint64_t)(idx <= order ? a[idx] : 0);
-        al[h] = (int32_t)(uint32_t)nv;
-        ah[h] = (int32_t)(uint32_t)((nv - (uint64_t)(int64_t)al[h]) >> 32); // nv = ah 2^32 + al, al signed
-        mad24_ok &= ah[h] >= -(1 << 23) && ah[h] < (1 << 23);
+    const int32_t al = (int32_t)(uint32_t)coef, ah = (int32_t)(uint32_t)(coef >> 32);
+    const uint64_t z = ((uint64_t)zh << 32) | zl;
+    const uint64_t lo = (uint64_t)((int64_t)z + (int64_t)al * (int64_t)s_i);
+    if (kFold) // both factors fit 24 bits in the folded form (checked)
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(zh) : "v"(ah), "s"(s_i), "v"((uint32_t)(lo >> 32)));
+    else
+        zh = (uint32_t)(lo >> 32) + (uint32_t)ah * (uint32_t)s_i;
+    zl = (uint32_t)lo;
+}
+
+// Coefficient prefetch depth (steps).  The table reads have compile-time addresses, so left alone the
+// scheduler hoists all 64 (128) of a block to its top and spills; instead each step consumes the
+// value fetched kAhead steps earlier, issues the fetch for step M + kAhead and ends in a scheduling
+// barrier.
+constexpr int kAhead = 4;
+// volatile: keeps the two reads of a ring-of-128 step as ds_read_b64 (2 LDS cycles each); merged into
+// one ds_read2_b64 they would take 8 (MI355X_MICROARCH.md, LDS table) and the kernel turns LDS-bound
+typedef const volatile __attribute__((address_space(3))) uint64_t* LdsTable;
+
+// Steps M .. 63 of one block of 64 samples.  (cl, ch): the register whose sums finish in this block;
+// (ol, oh): the other register of the ring of 128 (R == 2).  tab_lane = table + lane.
+template <int R, bool kFold, int G, int M>
+__device__ __forceinline__ void synth_steps(uint32_t& cl, uint32_t& ch, uint32_t& ol, uint32_t& oh, uint32_t& kept,
+    LdsTable tab_lane, int32_t r_block, uint32_t four, uint32_t zero, uint64_t (&pf_c)[kAhead], uint64_t (&pf_o)[kAhead])
+{
+    // scalar side: the sum of this sample sits in lane M
+    const int32_t pred = __builtin_amdgcn_readlane((int)ch, M) >> 3;
+    int32_t s_i;
+    if (kFold)
+        s_i = (int32_t)(0u - (uint32_t)pred);
+    else
+        s_i = (int32_t)((uint32_t)__builtin_amdgcn_readlane(r_block, M) - (uint32_t)pred);
+    // vector side: lane L adds a'[(L - M) mod ring] * s_i  (a'[0] = 0: the finished sum stays)
+    synth_mac<kFold>(cl, ch, pf_c[M % kAhead], s_i);
+    if (R == 2)
+        synth_mac<kFold>(ol, oh, pf_o[M % kAhead], s_i);
+    if constexpr (M + kAhead < 64) {
+        pf_c[M % kAhead] = tab_lane[64 * R - (M + kAhead)];
+        if (R == 2)
+            pf_o[M % kAhead] = tab_lane[64 - (M + kAhead)];
     }
-    if (kFold && __any(!mad24_ok))
-        return false; // |a| >= 2^55: the 24-bit multiply of the folded form does not apply
-    uint64_t z[P];
+    if constexpr ((M + 1) % G == 0) { // recycle lanes M + 1 - G .. M
+        constexpr int first_lane = M + 1 - G;
+        constexpr int row_mask = 1 << (first_lane / 16);
+        constexpr int bank_mask = G == 16 ? 0xf : 1 << ((first_lane % 16) / 4);
+        kept = (uint32_t)__builtin_amdgcn_update_dpp((int)kept, (int)ch, 0xE4 /* quad_perm:[0,1,2,3] */, row_mask, bank_mask, false);
+        ch = (uint32_t)__builtin_amdgcn_update_dpp((int)ch, (int)four, 0xE4, row_mask, bank_mask, false);
+        cl = (uint32_t)__builtin_amdgcn_update_dpp((int)cl, (int)zero, 0xE4, row_mask, bank_mask, false);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (M < 63)
+        synth_steps<R, kFold, G, M + 1>(cl, ch, ol, oh, kept, tab_lane, r_block, four, zero, pf_c, pf_o);
+}
+
+// One block of 64 samples at rs[0..63]; returns false if a sample left the range of the folded form.
+template <int R, bool kFold, int G>
+__device__ __forceinline__ bool synth_block(int32_t* rs, uint32_t& cl, uint32_t& ch, uint32_t& ol, uint32_t& oh,
+    LdsTable tab_lane, int lane, uint32_t four, uint32_t zero)
+{
+    uint64_t pf_c[kAhead], pf_o[kAhead];
 #pragma unroll
-    for (int h = 0; h < P; h++)
-        z[h] = first ? 0 : zs[P * lane + h];
+    for (int m = 0; m < kAhead; m++) {
+        pf_c[m] = tab_lane[64 * R - m];
+        pf_o[m] = R == 2 ? tab_lane[64 - m] : 0;
+    }
+    const int32_t r_block = rs[lane];
+    if (kFold)
+        ch -= (uint32_t)r_block << 3; // sample lane of this block: N -= r * 2^35
+    uint32_t kept = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    synth_steps<R, kFold, G, 0>(cl, ch, ol, oh, kept, tab_lane, r_block, four, zero, pf_c, pf_o);
+    const int32_t s = (int32_t)((kFold ? 0u : (uint32_t)r_block) - (uint32_t)((int32_t)kept >> 3));
+    rs[lane] = s;
+    return !kFold || (uint32_t)(s + (1 << 23)) < (1u << 24);
+}
+
+// R = ring / 64 (1: order <= 64 - G, 2: order <= 128 - G); G = recycling group (4 or 16).
+template <int R, bool kFold, int G>
+__device__ inline bool synthesize(int32_t* rs, int n_samples, const uint64_t* tab, uint64_t* zs, bool first, int lane)
+{
+    static_assert(G == 4 || G == 16, "groups are DPP banks or rows");
+    uint32_t zl[2], zh[2];
+#pragma unroll
+    for (int h = 0; h < R; h++) {
+        const uint64_t z = first ? (uint64_t)4 << 32 : zs[64 * h + lane]; // every sum starts at 2^34
+        zl[h] = (uint32_t)z;
+        zh[h] = (uint32_t)(z >> 32);
+    }
+    uint32_t four = 4, zero = 0;
+    asm volatile("" : "+v"(four), "+v"(zero)); // DPP sources must be VGPRs
+    const LdsTable tab_lane = (LdsTable)(tab + lane); // the table is in LDS: ds_read with immediate offsets
     bool in_range = true;
 #pragma unroll 1
-    for (int base = 0; base < n_samples; base += 64) {
-        const int32_t r_chunk = rs[base + lane];
-        // position p of this block completes at sample base + p: give it the rounding constant 2^34
-        // (and, folded, its residue) now -- one add on the high word
-        if (P == 1) {
-            z[0] += (uint64_t)(4u - (kFold ? (uint32_t)r_chunk << 3 : 0u)) << 32;
-        } else if (lane < 32) {
-#pragma unroll
-            for (int h = 0; h < P; h++)
-                z[h] += (uint64_t)(4u - (kFold ? (uint32_t)rs[base + P * lane + h] << 3 : 0u)) << 32;
-        }
-        int32_t s_chunk = 0;
-#pragma unroll
-        for (int m = 0; m < 64; m++) {
-            // scalar side: N_i sits in lane 0, position 0
-            const int32_t n_hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(z[0] >> 32));
-            const int32_t pred = n_hi >> 3;
-            int32_t s_i;
-            if (kFold)
-                s_i = (int32_t)(0u - (uint32_t)pred);
-            else
-                s_i = (int32_t)((uint32_t)__builtin_amdgcn_readlane(r_chunk, m) - (uint32_t)pred);
-            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(s_chunk) : "s"(s_i), "n"(m));
-            // vector side: move every partial sum down one position and add this sample's products
-            const uint64_t in = wave_shl1_zero(z[0]);
-#pragma unroll
-            for (int h = 0; h < P; h++) {
-                const uint64_t up = h + 1 < P ? z[h + 1 < P ? h + 1 : h] : in;
-                const uint64_t lo = (uint64_t)((int64_t)up + (int64_t)al[h] * (int64_t)s_i);
-                uint32_t hi;
-                if (kFold) // high part of the product: both factors fit 24 bits in the folded form (checked)
-                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hi) : "v"(ah[h]), "s"(s_i), "v"((uint32_t)(lo >> 32)));
-                else
-                    hi = (uint32_t)(lo >> 32) + (uint32_t)ah[h] * (uint32_t)s_i;
-                z[h] = ((uint64_t)hi << 32) | (uint32_t)lo;
-            }
-        }
-        if (kFold)
-            in_range &= (uint32_t)(s_chunk + (1 << 23)) < (1u << 24);
-        rs[base + lane] = s_chunk;
+    for (int base = 0; base < n_samples; base += 64 * R) {
+        in_range &= synth_block<R, kFold, G>(rs + base, zl[0], zh[0], zl[R - 1], zh[R - 1], tab_lane, lane, four, zero);
+        if (R == 2)
+            in_range &= synth_block<R, kFold, G>(rs + base + 64, zl[1], zh[1], zl[0], zh[0], tab_lane, lane, four, zero);
     }
     if (kFold && __any(!in_range))
         return false;
 #pragma unroll
-    for (int h = 0; h < P; h++)
-        zs[P * lane + h] = z[h];
+    for (int h = 0; h < R; h++)
+        zs[64 * h + lane] = ((uint64_t)zh[h] << 32) | zl[h];
     wave_sync();
     return true;
+}
+
+// Negated coefficients a'[d] = -a[d] (0 for d = 0 and beyond `order`), packed {al, ah}, ring-periodic
+// and doubled, written over the wave's k[] / a[] arrays.  Returns whether every ah fits 24 bits.
+__device__ inline bool build_synth_table(const int64_t* a, uint64_t* tab, int order, int lane)
+{
+    uint64_t c[2];
+    bool fits = true;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int d = lane + 64 * h;
+        const uint64_t nv = 0 - (uint64_t)(d >= 1 && d <= order ? a[d] : 0);
+        const int32_t al = (int32_t)(uint32_t)nv;
+        const int32_t ah = (int32_t)(uint32_t)((nv - (uint64_t)(int64_t)al) >> 32); // nv = ah 2^32 + al, al signed
+        fits &= ah >= -(1 << 23) && ah < (1 << 23);
+        c[h] = ((uint64_t)(uint32_t)ah << 32) | (uint32_t)al;
+    }
+    wave_sync(); // a[] has been read by every lane
+    if (order <= 60) { // ring of 64
+        tab[lane] = c[0];
+        tab[lane + 64] = c[0];
+    } else {           // ring of 128
+        tab[lane] = c[0];
+        tab[lane + 64] = c[1];
+        tab[lane + 128] = c[0];
+        tab[lane + 192] = c[1];
+    }
+    wave_sync();
+    return !__any(!fits);
 }
 
 // per-subframe state carried between the chunks of one decode call (workspace)
 struct SynthState {
     int64_t a[104];   // Q35 predictor
-    uint64_t z[128];  // partial sums by tap position
+    uint64_t z[128];  // partial sums: register h of lane l at [64 h + l]
 };
 
 struct SynthWaveLds {
-    double k[104];
-    int64_t a[104];
+    union {
+        struct {
+            double k[104];
+            int64_t a[104];
+        };
+        uint64_t tab[256]; // synthesis coefficient table (build_synth_table), replaces k[] and a[]
+    };
 };
 
 // kProf: also write per-phase cycle counts (debug hook sela_hip_debug_phase_buffer; 16 uint64 per subframe).
 template <bool kProf>
 __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const SubDesc* __restrict__ desc,
-    const int32_t* __restrict__ q_in, const int32_t* __restrict__ residues, SynthState* __restrict__ state, uint32_t n_frames,
-    uint32_t channels, uint32_t v_begin, uint32_t v_count, int16_t* __restrict__ pcm_out, uint32_t* __restrict__ status,
-    uint64_t* __restrict__ phase_cycles)
+    const int32_t* __restrict__ q_in, const int32_t* __restrict__ residues, const uint64_t* __restrict__ res_raw,
+    SynthState* __restrict__ state, uint32_t n_frames, uint32_t channels, uint32_t v_begin, uint32_t v_count,
+    int16_t* __restrict__ pcm_out, uint32_t* __restrict__ status, uint64_t* __restrict__ phase_cycles)
 {
     long long stamp[6];
     for (int i = 0; i < 6; i++)
@@ -479,11 +636,25 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
             continue;
         const uint32_t channel = d.info & 0xFF, type = (d.info >> 8) & 0xFF, parent = (d.info >> 16) & 0xFF, order = d.info >> 24;
         int32_t* dst = samples + (size_t)channel * v_count;
-        // this chunk's residues -> LDS (coalesced 16-byte loads)
+        // this chunk's residues -> LDS (coalesced 16-byte loads), finishing the parser's packed words
+        // (every block of 32 values whose bit in res_raw is clear) on the way
         const int4* rsrc = reinterpret_cast<const int4*>(residues + (size_t)g * kBlock + v_begin);
         int4* rdst = reinterpret_cast<int4*>(dst);
-        for (uint32_t t4 = lane; t4 < v_count / 4; t4 += 64)
-            rdst[t4] = rsrc[t4];
+        const uint64_t raw_blocks = res_raw[g];
+        const uint32_t res_k = d.res_k, res_kmask = res_k ? (0xFFFFFFFFu >> (32 - res_k)) : 0u;
+        auto load_residues = [&]() {
+            for (uint32_t t4 = lane; t4 < v_count / 4; t4 += 64) {
+                int4 v = rsrc[t4];
+                if (!((raw_blocks >> ((v_begin + 4 * t4) / kStageVals)) & 1ull)) {
+                    v.x = unpack_residue((uint32_t)v.x, res_k, res_kmask);
+                    v.y = unpack_residue((uint32_t)v.y, res_k, res_kmask);
+                    v.z = unpack_residue((uint32_t)v.z, res_k, res_kmask);
+                    v.w = unpack_residue((uint32_t)v.w, res_k, res_kmask);
+                }
+                rdst[t4] = v;
+            }
+        };
+        load_residues();
         SynthState* st = state + g;
         if (first) {
             // dequantise (src/lpc/linear_predictor.cpp:16-28) + step-up, kept for the later chunks
@@ -504,17 +675,23 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
         }
         if (kProf)
             stamp[2] = clock64();
-        const bool exact_needed = order <= 64 ? !synthesize<1, true>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane)
-                                              : !synthesize<2, true>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
-        if (exact_needed) { // a sample or coefficient left the range of the folded form: redo this chunk the long way
+        const bool fits24 = build_synth_table(wl->a, wl->tab, (int)order, lane);
+        // ring / recycling group by order: <= 48: 64 / 16, <= 60: 64 / 4, else 128 / 16
+        bool done = false;
+        if (fits24)
+            done = order <= 48 ? synthesize<1, true, 16>(dst, (int)v_count, wl->tab, st->z, first, lane)
+                 : order <= 60 ? synthesize<1, true, 4>(dst, (int)v_count, wl->tab, st->z, first, lane)
+                               : synthesize<2, true, 16>(dst, (int)v_count, wl->tab, st->z, first, lane);
+        if (!done) { // a sample or coefficient left the range of the folded form: redo this chunk the long way
             wave_sync();
-            for (uint32_t t4 = lane; t4 < v_count / 4; t4 += 64)
-                rdst[t4] = rsrc[t4];
+            load_residues();
             wave_sync();
-            if (order <= 64)
-                synthesize<1, false>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
+            if (order <= 48)
+                synthesize<1, false, 16>(dst, (int)v_count, wl->tab, st->z, first, lane);
+            else if (order <= 60)
+                synthesize<1, false, 4>(dst, (int)v_count, wl->tab, st->z, first, lane);
             else
-                synthesize<2, false>(dst, (int)v_count, wl->a, (int)order, st->z, first, lane);
+                synthesize<2, false, 16>(dst, (int)v_count, wl->tab, st->z, first, lane);
         }
         if (kProf)
             stamp[3] = clock64();
@@ -579,7 +756,7 @@ size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels)
 {
     const size_t subs = (size_t)n_frames * channels;
     return round256(subs * sizeof(SubDesc)) + round256(subs * kQStride * 4) + round256(subs * kBlock * 4) + round256(subs * 4)
-        + round256(subs * sizeof(SynthState)) + 256;
+        + round256(subs * 8) + round256(subs * sizeof(SynthState)) + 256;
 }
 
 // Decode = parse + synthesise, pipelined along the sample axis: the parse of values chunk j+1 (a
@@ -603,6 +780,8 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
     ws += round256(subs * kBlock * 4);
     uint32_t* bit_pos = reinterpret_cast<uint32_t*>(ws);
     ws += round256(subs * 4);
+    uint64_t* res_raw = reinterpret_cast<uint64_t*>(ws);
+    ws += round256(subs * 8);
     SynthState* state = reinterpret_cast<SynthState*>(ws);
 
     const bool pipelined = side != nullptr && ev == nullptr && d_phase_cycles == nullptr;
@@ -631,7 +810,7 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
         if (ev)
             (void)hipEventRecord(ev[0], stream);
         hipLaunchKernelGGL(k_parse_subframes, parse_grid, dim3(64), 0, parse_stream, d_frames, d_frame_offsets, n_frames, channels, desc, q,
-            residues, bit_pos, d_status, v_begin, v_count);
+            residues, bit_pos, res_raw, d_status, v_begin, v_count);
         if (pipelined) {
             if ((err = hipEventRecord(parsed[j], side)) != hipSuccess || (err = hipStreamWaitEvent(stream, parsed[j], 0)) != hipSuccess)
                 return err;
@@ -639,10 +818,10 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
         if (ev)
             (void)hipEventRecord(ev[1], stream);
         if (d_phase_cycles)
-            hipLaunchKernelGGL(k_synthesize_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, state, n_frames,
+            hipLaunchKernelGGL(k_synthesize_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, res_raw, state, n_frames,
                 channels, v_begin, v_count, d_pcm_out, d_status, d_phase_cycles);
         else
-            hipLaunchKernelGGL(k_synthesize_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, state, n_frames,
+            hipLaunchKernelGGL(k_synthesize_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, desc, q, residues, res_raw, state, n_frames,
                 channels, v_begin, v_count, d_pcm_out, d_status, d_phase_cycles);
         if (ev)
             (void)hipEventRecord(ev[2], stream);
