@@ -57,56 +57,66 @@ struct SubDesc {
 // friends to unpack_residue(), which runs in k_synthesize_frames across all lanes of 64x more waves.
 // Blocks of 32 values in which some group took the slow path are stored as final values instead;
 // one bit per block in res_raw[] says which (src/rice/rice_decoder.cpp:27-51 either way).
-constexpr int kTileWords = 96;
+constexpr int kTileWords = 256;             // one wave-wide 16-byte load fills one row
 constexpr int kTileStride = kTileWords + 1; // odd stride: lanes reading the same column hit different banks
 constexpr int kTileMargin = 12;             // re-tile when a lane is within this many words of its row end
 constexpr int kStageVals = 32;              // decoded values staged per lane before a coalesced store
 constexpr int kStageStride = kStageVals + 1;
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct StreamReader {
-    const uint32_t* base; // first aligned word of the stream (global)
+    const uint8_t* wg_frames; // this workgroup's part of the frame bytes and its size (wave-uniform)
+    uint32_t wg_bytes;
+    uint32_t base;        // byte offset of the stream's first aligned word in it
     uint32_t n_words;     // words in the stream; reads beyond are zero
     uint32_t tile_first;  // stream index of tile column 0
     uint32_t bp;          // bit position of the next unread bit
+    long long t_retile;   // cycles spent refilling the tile, and how often (phase profile)
+    uint32_t n_retile;
 };
 
-// Refill every lane's row so that it starts at the word holding the lane's next unread bit.
+// Refill every lane's row so that it starts at the word holding the lane's next unread bit.  One
+// bounds-checked buffer_load_dwordx4 per row (64 lanes x 16 bytes = the row): no branches, so all 64
+// loads are in flight together; the row's start and length travel through SGPRs (v_readlane).
 __device__ inline void retile(StreamReader& r, uint32_t* tile, int lane)
 {
+    const long long t_in = clock64();
     const uint32_t new_first = r.bp >> 5;
-    const uint64_t my_base = reinterpret_cast<uint64_t>(r.base);
+    const uint32_t row_start = r.base + 4 * new_first;                          // byte offset of column 0
+    const uint32_t row_words = new_first < r.n_words ? r.n_words - new_first : 0; // stream words from there on
+    const uint32_t c4 = 4 * (uint32_t)lane;
+    // bounds-checked raw-dword resource; rebuilt from scalars here because a resource that travelled
+    // through this function's arguments is no longer known to be wave-uniform
+    const __amdgpu_buffer_rsrc_t frames = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(read_first_lane(reinterpret_cast<uint64_t>(r.wg_frames))), 0,
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)r.wg_bytes), 0x00020000);
     wave_sync(); // earlier reads of the tile are done
-#pragma unroll 4
-    for (int i = 0; i < kTileWords / 4; i++) { // one wave-load = 16 bytes per lane; 64 rows x 24 loads in all
-        // 24 lanes cover one row of 96 words; rows are dealt out 64 lanes at a time
-        const int slot = i * 64 + lane; // 0 .. 64 * 24 - 1
-        const int row = slot / (kTileWords / 4);
-        const uint32_t c4 = (uint32_t)(slot % (kTileWords / 4)) * 4;
-        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)my_base, row, 64);
-        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(my_base >> 32), row, 64);
-        const uint32_t first = (uint32_t)__shfl((int)new_first, row, 64);
-        const uint32_t nw = (uint32_t)__shfl((int)r.n_words, row, 64);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(((uint64_t)hi << 32) | lo);
-        const uint32_t idx = first + c4;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (idx + 4 <= nw) {
-            v = *reinterpret_cast<const uint4*>(src + idx); // dword-aligned 16-byte load
-        } else { // row reaches the end of its stream: never touch memory past it
-            if (idx < nw)
-                v.x = src[idx];
-            if (idx + 1 < nw)
-                v.y = src[idx + 1];
-            if (idx + 2 < nw)
-                v.z = src[idx + 2];
+    constexpr int kBatch = 16; // rows in flight together
+#pragma unroll 1
+    for (int row0 = 0; row0 < 64; row0 += kBatch) {
+        u32x4 v[kBatch];
+        uint32_t words[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) { // all loads first ...
+            const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)row_start, row0 + i);
+            words[i] = (uint32_t)__builtin_amdgcn_readlane((int)row_words, row0 + i);
+            v[i] = __builtin_amdgcn_raw_buffer_load_b128(frames, 16 * (uint32_t)lane, start, 0); // 0 past the buffer end
         }
-        uint32_t* dst = tile + row * kTileStride + c4;
-        dst[0] = ~v.x;
-        dst[1] = ~v.y;
-        dst[2] = ~v.z;
-        dst[3] = ~v.w;
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler would otherwise pair each load with its use and serialise them)
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) { // ... then into the tile: stream words inverted, zero padding behind the stream
+            uint32_t* dst = tile + (row0 + i) * kTileStride + c4;
+            dst[0] = c4 + 0 < words[i] ? ~v[i].x : 0xFFFFFFFFu;
+            dst[1] = c4 + 1 < words[i] ? ~v[i].y : 0xFFFFFFFFu;
+            dst[2] = c4 + 2 < words[i] ? ~v[i].z : 0xFFFFFFFFu;
+            dst[3] = c4 + 3 < words[i] ? ~v[i].w : 0xFFFFFFFFu;
+        }
     }
     r.tile_first = new_first;
     wave_sync();
+    r.t_retile += clock64() - t_in;
+    r.n_retile++;
 }
 
 __device__ __forceinline__ bool reader_near_end(const StreamReader& r)
@@ -243,11 +253,16 @@ __device__ __forceinline__ bool reader_packed4(StreamReader& r, uint32_t* tile, 
     return true;
 }
 
-__device__ __forceinline__ void reader_open(StreamReader& r, const uint32_t* base, uint32_t n_words, uint32_t start_bit, uint32_t* tile, int lane)
+__device__ __forceinline__ void reader_open(StreamReader& r, const uint8_t* wg_frames, uint32_t wg_bytes, uint32_t base, uint32_t n_words,
+    uint32_t start_bit, uint32_t* tile, int lane)
 {
+    r.wg_frames = wg_frames;
+    r.wg_bytes = wg_bytes;
     r.base = base;
     r.n_words = n_words;
     r.bp = start_bit;
+    r.t_retile = 0;
+    r.n_retile = 0;
     retile(r, tile, lane);
 }
 
@@ -258,8 +273,9 @@ __device__ __forceinline__ void reader_open(StreamReader& r, const uint32_t* bas
 __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, SubDesc* __restrict__ desc,
     int32_t* __restrict__ q_out, int32_t* __restrict__ residues, uint32_t* __restrict__ bit_pos, uint64_t* __restrict__ res_raw,
-    uint32_t* __restrict__ status, uint32_t v_begin, uint32_t v_count)
+    uint32_t* __restrict__ status, uint32_t v_begin, uint32_t v_count, uint64_t* __restrict__ phase_cycles)
 {
+    const long long t_start = clock64();
     __shared__ uint32_t tile[64 * kTileStride + 8];
     __shared__ int32_t stage[64 * kStageStride];
     const int lane = threadIdx.x;
@@ -272,6 +288,11 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
     const uint32_t f = g / channels, c = g % channels;
     const uint8_t* fb = frames + frame_offsets[f];
     const uint64_t fbytes = frame_offsets[f + 1] - frame_offsets[f];
+    // The streams are read through a bounds-checked buffer resource that starts at this workgroup's
+    // first frame (64 subframes span far less than 4 GB) and ends with the frame bytes.
+    const uint64_t wg_base = frame_offsets[(blockIdx.x * 64) / channels];
+    const uint64_t wg_bytes = frame_offsets[n_frames] - wg_base;
+    const uint32_t wg_size = wg_bytes < 0xFFFFFFFFull ? (uint32_t)wg_bytes : 0xFFFFFFFFu;
 
     bool ok = fbytes >= 4 && (fbytes & 3) == 0 && reinterpret_cast<const uint32_t*>(fb)[0] == SELA_SYNC_WORD;
     uint64_t p = 4;
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
     // its last word shares an aligned word with the residue k, hence cw + 1 aligned words.
     if (v_begin == 0) {
         StreamReader r;
-        reader_open(r, reinterpret_cast<const uint32_t*>(fb + p + 4), ok ? cw + 1 : 0, 24, tile, lane);
+        reader_open(r, frames + wg_base, wg_size, (uint32_t)(frame_offsets[f] - wg_base + p + 4), ok ? cw + 1 : 0, 24, tile, lane);
         const uint32_t kmask = ck ? (0xFFFFFFFFu >> (32 - ck)) : 0u;
         int32_t* qo = q_out + (size_t)g * kQStride;
         uint32_t max_order = order;
@@ -342,11 +363,13 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
     {
         StreamReader r;
         const uint32_t start_bit = v_begin == 0 ? 0u : bit_pos[g];
-        reader_open(r, reinterpret_cast<const uint32_t*>(fb + p + 12 + 4 * (uint64_t)cw), rw, ok ? start_bit : 0u, tile, lane);
+        reader_open(r, frames + wg_base, wg_size, (uint32_t)(frame_offsets[f] - wg_base + p + 12 + 4 * (uint64_t)cw), rw, ok ? start_bit : 0u, tile, lane);
         const uint32_t kmask = rk ? (0xFFFFFFFFu >> (32 - rk)) : 0u;
         const bool k_fits = rk <= kPackMaxK;
         const unsigned long long store_mask = __ballot(store);
         uint64_t raw_blocks = 0; // wave-uniform: blocks of 32 values stored as final values
+        const long long t_residues = clock64();
+        long long t_store = 0;
 #pragma unroll 1
         for (uint32_t blk = v_begin / kStageVals; blk < (v_begin + v_count) / kStageVals; blk++) {
             uint32_t slow_groups = 0; // wave-uniform
@@ -366,6 +389,7 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
             }
             if (slow_groups)
                 raw_blocks |= 1ull << blk;
+            const long long t_s0 = clock64();
             wave_sync();
 #pragma unroll
             for (int i = 0; i < 8; i++) { // 8 rows x 8 lanes x 16 bytes per wave-store; a lane's 4 words are one group
@@ -384,10 +408,20 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
                     }
                 }
                 const uint32_t g_row = blockIdx.x * 64 + (uint32_t)row;
-                if ((store_mask >> row) & 1ull)
+                if (store_mask == ~0ull || ((store_mask >> row) & 1ull)) // (the uniform test keeps the 8 stores branch-free)
                     *reinterpret_cast<int4*>(residues + (size_t)g_row * kBlock + blk * kStageVals + c4) = v;
             }
             wave_sync();
+            t_store += clock64() - t_s0;
+        }
+        if (phase_cycles && lane == 0) { // slots 8.. of this wave's first subframe (tools/phase_profile.py)
+            uint64_t* pc = phase_cycles + (size_t)blockIdx.x * 64 * 16 + 8;
+            const long long t_end = clock64();
+            pc[0] = (uint64_t)(t_residues - t_start);                       // headers + coefficient streams + open
+            pc[1] = (uint64_t)(t_end - t_residues - t_store - r.t_retile);  // codeword groups
+            pc[2] = (uint64_t)r.t_retile;                                   // tile refills ...
+            pc[3] = r.n_retile;                                             // ... and their number
+            pc[4] = (uint64_t)t_store;                                      // staged stores
         }
         if (v_begin + v_count == (uint32_t)kBlock && r.bp > 32 * rw)
             flags |= SELA_HIP_FLAG_RICE_OVERRUN;
@@ -810,7 +844,7 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
         if (ev)
             (void)hipEventRecord(ev[0], stream);
         hipLaunchKernelGGL(k_parse_subframes, parse_grid, dim3(64), 0, parse_stream, d_frames, d_frame_offsets, n_frames, channels, desc, q,
-            residues, bit_pos, res_raw, d_status, v_begin, v_count);
+            residues, bit_pos, res_raw, d_status, v_begin, v_count, d_phase_cycles);
         if (pipelined) {
             if ((err = hipEventRecord(parsed[j], side)) != hipSuccess || (err = hipStreamWaitEvent(stream, parsed[j], 0)) != hipSuccess)
                 return err;

@@ -45,6 +45,12 @@ def main():
     print(f"decoder, mean cycles per subframe over {len(d)} subframes (total {d.sum(1).mean():.0f}):")
     for name, v in zip(DEC, d.mean(0)):
         print(f"  {name:28s} {v:10.0f}  {100 * v / d.sum(1).mean():5.1f}%")
+    ps = dd[::64, 8:13]  # one record per parser wave (64 subframes), whole block of 2048 values
+    tot = ps[:, [0, 1, 2, 4]].sum(1).mean()
+    print(f"parser, mean cycles per wave (64 streams x 2048 values) over {len(ps)} waves (total {tot:.0f}):")
+    for name, col in (("headers + coefficient streams", 0), ("codeword groups", 1), ("tile refills", 2), ("staged stores", 4)):
+        print(f"  {name:28s} {ps[:, col].mean():10.0f}  {100 * ps[:, col].mean() / tot:5.1f}%")
+    print(f"  tile refills per wave        {ps[:, 3].mean():10.1f}")
 
 
 if __name__ == "__main__":
