@@ -139,6 +139,55 @@ __device__ __forceinline__ void rice_plan(const uint32_t (&u)[V], uint32_t n, ui
     best_bits = ta + (uint64_t)n * (1 + k);
 }
 
+// x = s / 32767 (src/lpc/residue_generator.cpp:12-18) without the ~30-instruction IEEE division:
+// q0 = s * RN(1/32767), one residual fma, one correction fma.  The result equals the correctly rounded
+// quotient for EVERY |s| <= 70000 (exhaustive check: tests/test_host_logic.py::test_scale_division_is_exact);
+// 16-bit channels and their difference stay within 65535.
+__device__ __forceinline__ double scale_sample(int32_t s)
+{
+    constexpr double r = 1.0 / SELA_SAMPLE_SCALE;
+    const double x = (double)s;
+    const double q0 = x * r;
+    const double e = __builtin_fma(-SELA_SAMPLE_SCALE, q0, x);
+    return __builtin_fma(e, r, q0);
+}
+
+// ---- mean chain operand fetch (see k_encode_blocks): E[m..m+7] and O[m..m+7] by broadcast reads ------
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+struct MeanFetch {
+    f64x2 e0, e1, e2, e3, o0, o1, o2, o3;
+};
+#define SELA_MEAN_STR2(x) #x
+#define SELA_MEAN_STR(x) SELA_MEAN_STR2(x)
+#define SELA_MEAN_ISSUE(F, addr, OFF, sum)                                                    \
+    asm volatile("ds_read_b128 %0, %9 offset:" #OFF "+0\n\t"                                    \
+                 "ds_read_b128 %4, %9 offset:" #OFF "+8720\n\t"                                 \
+                 "ds_read_b128 %1, %9 offset:" #OFF "+16\n\t"                                   \
+                 "ds_read_b128 %5, %9 offset:" #OFF "+8736\n\t"                                 \
+                 "ds_read_b128 %2, %9 offset:" #OFF "+32\n\t"                                   \
+                 "ds_read_b128 %6, %9 offset:" #OFF "+8752\n\t"                                 \
+                 "ds_read_b128 %3, %9 offset:" #OFF "+48\n\t"                                   \
+                 "ds_read_b128 %7, %9 offset:" #OFF "+8768"                                      \
+                 : "=&v"(F.e0), "=&v"(F.e1), "=&v"(F.e2), "=&v"(F.e3), "=&v"(F.o0), "=&v"(F.o1), "=&v"(F.o2), \
+                 "=&v"(F.o3), "+v"(sum)                                                         \
+                 : "v"(addr)                                                                    \
+                 : "memory")
+static_assert(kParityLen * 8 == 8720, "SELA_MEAN_ISSUE hard-codes the E -> O distance");
+
+__device__ __forceinline__ void mean_wait(MeanFetch& f, double& sum)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.e0), "+v"(f.e1), "+v"(f.e2), "+v"(f.e3), "+v"(f.o0), "+v"(f.o1), "+v"(f.o2), "+v"(f.o3), "+v"(sum));
+}
+
+__device__ __forceinline__ void mean_steps(const MeanFetch& f, double& sum)
+{
+    sum += f.e0[0]; sum += f.o0[0]; sum += f.e0[1]; sum += f.o0[1];
+    sum += f.e1[0]; sum += f.o1[0]; sum += f.e1[1]; sum += f.o1[1];
+    sum += f.e2[0]; sum += f.o2[0]; sum += f.e2[1]; sum += f.o2[1];
+    sum += f.e3[0]; sum += f.o3[0]; sum += f.e3[1]; sum += f.o3[1];
+}
+
 // ---- autocorrelation operand fetch (see k_encode_blocks) -------------------------------------------
 // One fetch = the operands of a 16-step trip: the sixteen wave-uniform multipliers c[j] as 32 SGPRs
 // (two s_load_dwordx16 from the block's scratch row, so that v_mul_f64 takes them as scalar operands)
@@ -149,7 +198,6 @@ __device__ __forceinline__ void rice_plan(const uint32_t (&u)[V], uint32_t n, ui
 // compiler must never see a pending load of its own in this loop (it would add more).
 typedef int sgpr16 __attribute__((ext_vector_type(16)));
 typedef double f64x8 __attribute__((ext_vector_type(8)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 struct AcFetch {
     sgpr16 c_lo, c_hi;          // c[j .. j+7], c[j+8 .. j+15]
@@ -315,7 +363,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     }
 #pragma unroll
     for (int t = 0; t < kPerLane; t++)
-        mine[half + 32 * t] = (double)s[t] / SELA_SAMPLE_SCALE;
+        mine[half + 32 * t] = scale_sample(s[t]);
     wave_sync();
 
     SELA_STAMP(1);
@@ -323,12 +371,25 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     // Every lane walks the same chain from broadcast LDS reads, so the result is wave-uniform.
     // (a pure dependency chain: run it at raised wave priority so that its adds issue the moment
     // they are ready instead of queueing behind the co-resident wave's throughput-bound phases)
+    // The operands are fetched one half-trip (16 values) ahead by hand, like the autocorrelation's:
+    // left to the compiler each batch of reads is issued only after the previous batch's last add.
     __builtin_amdgcn_s_setprio(3);
     double sum = 0.0;
-#pragma unroll 16
-    for (int m = 0; m < kBlock / 2; m++) {
-        sum += E[m];
-        sum += O[m];
+    {
+        uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)E;
+        MeanFetch f0, f1;
+        SELA_MEAN_ISSUE(f0, addr, 0, sum);
+#pragma unroll 1
+        for (int m0 = 0; m0 < kBlock / 2; m0 += 16) {
+            mean_wait(f0, sum);
+            SELA_MEAN_ISSUE(f1, addr, 64, sum);
+            mean_steps(f0, sum);
+            mean_wait(f1, sum);
+            SELA_MEAN_ISSUE(f0, addr, 128, sum); // (the last one reads 8 values past both arrays: in bounds, unused)
+            mean_steps(f1, sum);
+            addr += 128;
+        }
+        mean_wait(f0, sum);
     }
     const double mean = sum / (double)kBlock;
     __builtin_amdgcn_s_setprio(0);

@@ -1,4 +1,6 @@
 """CPU-only checks of host-side logic and of the mathematical claims the kernels rely on."""
+import os
+
 import numpy as np
 
 from oracle_lib import oracle
@@ -90,3 +92,15 @@ def test_frame_stream_layout_constants():
         p += 5 + 4 * rw
         total_words += cw + rw
     assert p == len(b) == 4 + 2 * 12 + 4 * total_words and len(b) % 4 == 0
+
+
+def test_scale_division_is_exact(tmp_path):
+    """sela_encode.hip:scale_sample replaces x = s / 32767 (src/lpc/residue_generator.cpp:12-18) by a
+    multiply and two fmas; tests/c/scale_division.c proves bit-equality with the IEEE quotient for
+    every |s| <= 70000 (16-bit samples and stereo differences stay within 65535)."""
+    import subprocess
+
+    exe = tmp_path / "scale_division"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c", "scale_division.c")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), src, "-lm"])
+    assert subprocess.check_output([str(exe)]).decode().strip() == "0"
