@@ -27,7 +27,12 @@ namespace sela {
 
 constexpr int kDecMaxWaves = 8;
 constexpr int kQStride = 128; // int32 slots per subframe for the quantised coefficients
-constexpr int kDecodeChunks = 4; // sample-axis pipeline depth of one decode call (2048 / 4 = 512 values per chunk)
+constexpr int kDecodeChunks = 4; // sample-axis pipeline depth of one decode call
+// Values per chunk (multiples of 128).  Only the first parse is exposed -- and it also walks the headers
+// and the coefficient streams -- so the first chunk is the short one.
+constexpr uint32_t kChunkValues[kDecodeChunks] = { 256, 512, 640, 640 };
+constexpr uint32_t kChunkMax = 640;
+static_assert(kChunkValues[0] + kChunkValues[1] + kChunkValues[2] + kChunkValues[3] == (uint32_t)kBlock, "chunks cover the block");
 
 // per-subframe record written by k_parse_subframes
 struct SubDesc {
@@ -820,9 +825,8 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
 
     const bool pipelined = side != nullptr && ev == nullptr && d_phase_cycles == nullptr;
     const uint32_t chunks = pipelined ? (uint32_t)kDecodeChunks : 1u;
-    const uint32_t v_count = (uint32_t)kBlock / chunks;
     const int n_waves = decode_waves(channels);
-    const size_t lds = decode_lds_bytes(channels, n_waves, v_count);
+    size_t lds = decode_lds_bytes(channels, n_waves, pipelined ? kChunkMax : (uint32_t)kBlock);
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
     if (lds > 64 * 1024) { // above the default dynamic-LDS limit (many channels, unpipelined call)
@@ -839,8 +843,10 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
             return err;
         parse_stream = side;
     }
-    for (uint32_t j = 0; j < chunks; j++) {
-        const uint32_t v_begin = j * v_count;
+    uint32_t v_begin = 0;
+    for (uint32_t j = 0; j < chunks; j++, v_begin += (pipelined ? kChunkValues[j - 1] : (uint32_t)kBlock)) {
+        const uint32_t v_count = pipelined ? kChunkValues[j] : (uint32_t)kBlock;
+        lds = decode_lds_bytes(channels, n_waves, v_count);
         if (ev)
             (void)hipEventRecord(ev[0], stream);
         hipLaunchKernelGGL(k_parse_subframes, parse_grid, dim3(64), 0, parse_stream, d_frames, d_frame_offsets, n_frames, channels, desc, q,
