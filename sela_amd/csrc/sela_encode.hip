@@ -33,7 +33,14 @@ namespace sela {
 //                                       packed residue words
 constexpr int kPadC = 64;
 constexpr int kParityLen = kPadC + kBlock / 2 + 2;   // 1090 doubles
-constexpr int kCRowLen = kBlock + 16;                 // scratch row of centred samples + prefetch pad (64-byte multiple)
+// Scalar-operand scratch: each running block borrows a ring of 2 x 256 centred samples (+ a copy of the
+// first values of half A behind half B, so that a fetch may run across the wrap) from a pool that is
+// private to its XCD -- 512 rings per XCD, handed out through a bitmap -- so the ring stays in that
+// XCD's L2 and the scratch never reaches HBM.
+constexpr int kRingHalf = 256;
+constexpr int kRingLen = 2 * kRingHalf + 64;          // doubles (4608 bytes, a multiple of 64)
+constexpr int kRingsPerXcd = 512;                      // >= blocks resident on one XCD (9 per CU x 32 CUs)
+constexpr int kXcds = 8;
 constexpr int kPadS = 128;
 constexpr int kSBufWords = (kPadS + kBlock) / 32 * 33; // biased samples, one pad word per 32: 2244 words
 constexpr int kSmallBase = 8992;                      // >= kSBufWords * 4 = 8976, 16-byte aligned
@@ -305,7 +312,8 @@ __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const uint
 template <int kMode>
 __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
-    double* __restrict__ c_rows, sela_hip_trace* __restrict__ trace, uint64_t* __restrict__ phase_cycles)
+    double* __restrict__ rings, uint32_t* __restrict__ ring_bitmap, sela_hip_trace* __restrict__ trace,
+    uint64_t* __restrict__ phase_cycles)
 {
     constexpr bool kTrace = kMode == 1;
     long long stamp[14];
@@ -396,61 +404,113 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
 
     SELA_STAMP(2);
     // c[j] = x[j] - mean, in place (same value at every use)
-    // A second copy goes to this block's scratch row in natural order: the scalar unit reads the
-    // wave-uniform multiplier c[j] from there (agent-scope stores: they must be in L2 before the
-    // scalar cache, which sits beside the vector L1, fetches them).
-    double* const c_row = reinterpret_cast<double*>(read_first_lane((uint64_t)(c_rows + (size_t)block_id * kCRowLen)));
 #pragma unroll
-    for (int t = 0; t < kPerLane; t++) {
-        const double c = mine[half + 32 * t] - mean;
-        mine[half + 32 * t] = c;
-        __hip_atomic_store((__attribute__((address_space(1))) double*)c_row + lane + 64 * t, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv" ::: "memory");
+    for (int t = 0; t < kPerLane; t++)
+        mine[half + 32 * t] = mine[half + 32 * t] - mean;
     wave_sync();
 
     SELA_STAMP(3);
     // ---- autocorrelation (src/lpc/residue_generator.cpp:33-38) -------------------------------------
     // Lane L owns lags 2L and 2L+1 (lanes 0..50 matter).  At step j it needs
     //     A = c[j - 2L]      (lag 2L)       B = c[j - 2L - 1]   (lag 2L+1)
-    // and the wave-uniform c[j], which is lane 0's A.  Going to j+1: B' = A, A' = c[j+1-2L], whose
-    // parity is that of j+1 for every lane -> one conflict-free ds_read_b64 per step.  (c[j] itself
-    // comes from a register that holds 16 consecutive c values, see below.)  Each
+    // and the wave-uniform c[j].  Going to j+1: B' = A, A' = c[j+1-2L], whose parity is that of j+1
+    // for every lane -> one conflict-free LDS read per step.  c[j] reaches the multiplies as a SCALAR
+    // operand: the wave copies its centred samples, 256 at a time, into a ring in global memory that
+    // it alone uses (L2-resident, see kRingLen) and reads them back with s_load_dwordx16.  Each
     // accumulator sees its products in ascending j exactly like the reference loop; the extra
     // leading terms c[j]*0 (j < lag) leave an accumulator at +0.0.
     double acc_e = 0.0, acc_o = 0.0;
     {
+        // borrow a ring from this XCD's pool (only workgroups on the same XCD, i.e. behind the same L2,
+        // ever touch a pool: no cross-L2 coherence is needed for the rings or for the bitmap)
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= kXcds - 1;
+        uint32_t* const pool = ring_bitmap + xcc * (kRingsPerXcd / 32);
+        uint32_t slot = 0;
+        if (lane == 0) {
+            // workgroups that run together have nearby indices within their XCD: each starts at its own
+            // bit (index mod 512), so that in the common case one atomic takes a ring without a retry
+            const uint32_t idx = blockIdx.x >> 3;
+            uint32_t w = idx & (kRingsPerXcd / 32 - 1), pos = (idx / (kRingsPerXcd / 32)) & 31;
+            for (;;) {
+                const uint32_t bit = 1u << pos;
+                const uint32_t old = atomicOr(pool + w, bit);
+                if (!(old & bit)) {
+                    slot = w * 32 + pos;
+                    break;
+                }
+                const uint32_t free_bits = ~(old | bit);
+                if (free_bits) { // next free bit at or after pos, cyclically
+                    const uint32_t rot = (free_bits >> pos) | (free_bits << ((32 - pos) & 31));
+                    pos = (pos + (uint32_t)__builtin_ctz(rot)) & 31;
+                } else {
+                    w = (w + 1) & (kRingsPerXcd / 32 - 1);
+                }
+            }
+        }
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        double* const ring = reinterpret_cast<double*>(
+            read_first_lane((uint64_t)(rings + ((size_t)xcc * kRingsPerXcd + slot) * kRingLen)));
+        __attribute__((address_space(1))) double* const ring_g = (__attribute__((address_space(1))) double*)ring;
+        // samples [256 k, 256 k + 256) -> half k & 1 (natural order; lane's element i = lane + 64 t)
+        auto store_chunk = [&](int k) {
+#pragma unroll
+            for (int t = 0; t < kRingHalf / 64; t++) {
+                const double c = mine[half + 32 * (t + (kRingHalf / 64) * k)];
+                ring_g[(k & 1) * kRingHalf + lane + 64 * t] = c;
+                if (t == 0 && !(k & 1))
+                    ring_g[2 * kRingHalf + lane] = c; // what a fetch running off the end of half B must find
+            }
+        };
+        store_chunk(0);
+        store_chunk(1);
+        // the stores are in L2 once vmcnt drains (the scalar loads are glc: they bypass the scalar
+        // cache, which may hold older contents of the ring)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv" ::: "memory");
+
         double A = E[-lane]; // c[0 - 2L]
         double B = 0.0;      // c[-2L - 1]
-        // LDS byte addresses of E[m0 - L] and O[m0 - L]; scratch pointer at c[2 m0]
+        // LDS byte addresses of E[m0 - L] and O[m0 - L]; ring pointer at c[2 m0]
         uint32_t addr_e = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)(E - lane);
         uint32_t addr_o = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)(O - lane);
-        const double* c_ptr = c_row;
+        const double* c_ptr = ring;
         AcFetch f0, f1;
         asm volatile("" : "+v"(A)); // land A here: a compiler-placed wait inside the loop would drain the prefetch
         SELA_AC_ISSUE_S(f0, c_ptr, 0, 64, acc_e, acc_o);
         SELA_AC_ISSUE_V(f0, addr_e, addr_o, 0, 1, 2, 3, 4, 5, 6, 7, 8, acc_e, acc_o);
-        // two 16-step trips per iteration.  A fetch's scalar half is issued a whole trip ahead, its
-        // vector half after the first two steps of the running trip, once the registers it overwrites
-        // are dead.  (The last fetch lands in the scratch row's pad and in LDS behind the parity
-        // arrays; it is never used.)
+        // Two 16-step trips per iteration, eight iterations per chunk of 256.  A fetch's scalar half is
+        // issued a whole trip ahead, its vector half after the first two steps of the running trip,
+        // once the registers it overwrites are dead.  (The last fetch of the block lands behind the
+        // ring's half B and in LDS behind the parity arrays; it is never used.)
 #pragma unroll 1
-        for (int m0 = 0; m0 < kBlock / 2; m0 += 16) {
-            ac_wait(f0, acc_e, acc_o);
-            SELA_AC_ISSUE_S(f1, c_ptr, 128, 192, acc_e, acc_o);
-            ac_steps_head(f0, A, B, acc_e, acc_o);
-            SELA_AC_ISSUE_V(f1, addr_e, addr_o, 8, 9, 10, 11, 12, 13, 14, 15, 16, acc_e, acc_o);
-            ac_steps_tail(f0, A, B, acc_e, acc_o);
-            ac_wait(f1, acc_e, acc_o);
-            SELA_AC_ISSUE_S(f0, c_ptr, 256, 320, acc_e, acc_o);
-            ac_steps_head(f1, A, B, acc_e, acc_o);
-            SELA_AC_ISSUE_V(f0, addr_e, addr_o, 16, 17, 18, 19, 20, 21, 22, 23, 24, acc_e, acc_o);
-            ac_steps_tail(f1, A, B, acc_e, acc_o);
-            c_ptr += 32;
-            addr_e += 128;
-            addr_o += 128;
+        for (int k = 0; k < kBlock / kRingHalf; k++) {
+            if (k >= 1 && k + 1 < kBlock / kRingHalf)
+                store_chunk(k + 1); // over chunk k - 1, which is consumed
+#pragma unroll 1
+            for (int it = 0; it < kRingHalf / 32; it++) {
+                if (it == kRingHalf / 32 - 1) // this iteration's prefetch crosses into chunk k + 1
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv" ::: "memory");
+                ac_wait(f0, acc_e, acc_o);
+                SELA_AC_ISSUE_S(f1, c_ptr, 128, 192, acc_e, acc_o);
+                ac_steps_head(f0, A, B, acc_e, acc_o);
+                SELA_AC_ISSUE_V(f1, addr_e, addr_o, 8, 9, 10, 11, 12, 13, 14, 15, 16, acc_e, acc_o);
+                ac_steps_tail(f0, A, B, acc_e, acc_o);
+                ac_wait(f1, acc_e, acc_o);
+                SELA_AC_ISSUE_S(f0, c_ptr, 256, 320, acc_e, acc_o);
+                ac_steps_head(f1, A, B, acc_e, acc_o);
+                SELA_AC_ISSUE_V(f0, addr_e, addr_o, 16, 17, 18, 19, 20, 21, 22, 23, 24, acc_e, acc_o);
+                ac_steps_tail(f1, A, B, acc_e, acc_o);
+                c_ptr += 32;
+                addr_e += 128;
+                addr_o += 128;
+            }
+            if (k & 1)
+                c_ptr = ring; // half B is followed by half A (the fetch in flight came from the copy behind B)
         }
         ac_wait(f0, acc_e, acc_o); // drain the fetch past the end
+        if (lane == 0)
+            atomicAnd(pool + (slot >> 5), ~(1u << (slot & 31))); // hand the ring back
     }
     wave_sync(); // c[] is dead from here on
 
@@ -832,7 +892,8 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
     bytes += (blocks * sizeof(BlockMeta) + 255) & ~(size_t)255;
     bytes += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
     bytes += ((size_t)n_frames + 255) & ~(size_t)255; // choice
-    bytes += blocks * kCRowLen * sizeof(double);      // centred-sample rows for the scalar unit
+    bytes += (size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 256; // scalar-operand rings (L2-resident) ...
+    bytes += (size_t)kXcds * kRingsPerXcd / 8 + 256;                          // ... and their allocation bitmap
     return bytes + 256;
 }
 
@@ -850,7 +911,9 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     ws += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
     uint8_t* choice = ws;
     ws += ((size_t)n_frames + 255) & ~(size_t)255;
-    double* c_rows = reinterpret_cast<double*>(ws);
+    double* rings = reinterpret_cast<double*>(ws);
+    ws += ((size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 255) & ~(size_t)255;
+    uint32_t* ring_bitmap = reinterpret_cast<uint32_t*>(ws);
 
     if (n_frames == 0) {
         hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
@@ -858,14 +921,17 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     }
     const uint32_t groups = (n_frames + 7) / 8;
     const dim3 grid(groups * 8 * n_sig), wg(64);
+    hipError_t err0 = hipMemsetAsync(ring_bitmap, 0, (size_t)kXcds * kRingsPerXcd / 8, stream); // every ring free
+    if (err0 != hipSuccess)
+        return err0;
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
-        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, c_rows, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_bitmap, d_trace, d_phase_cycles);
     else if (d_trace)
-        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, c_rows, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_bitmap, d_trace, d_phase_cycles);
     else
-        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, c_rows, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_bitmap, d_trace, d_phase_cycles);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap,
