@@ -37,7 +37,7 @@ constexpr int kParityLen = kPadC + kBlock / 2 + 2;   // 1090 doubles
 // first values of half A behind half B, so that a fetch may run across the wrap) from a pool that is
 // private to its XCD -- 512 rings per XCD, handed out through a bitmap -- so the ring stays in that
 // XCD's L2 and the scratch never reaches HBM.
-constexpr int kRingHalf = 256;
+constexpr int kRingHalf = 128;
 constexpr int kRingLen = 2 * kRingHalf + 64;          // doubles (4608 bytes, a multiple of 64)
 constexpr int kRingsPerXcd = 512;                      // >= blocks resident on one XCD (9 per CU x 32 CUs)
 constexpr int kXcds = 8;
