@@ -761,6 +761,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
 // choice[f] = 1 when the second channel of an exactly-stereo frame is stored as the difference
 // signal (src/frame/frame_encoder.cpp:64-72).
 constexpr int kPlanThreads = 1024;
+constexpr int kPlanLdsFrames = 12288; // frame sizes staged in LDS up to this batch size (48 KB)
 
 __device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t channels, uint32_t n_sig, uint32_t& choice,
     uint32_t& flags)
@@ -789,19 +790,37 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
     uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status)
 {
     __shared__ uint64_t part[kPlanThreads];
+    __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of every frame when the batch fits
     const uint32_t tid = threadIdx.x;
     if (tid < 4)
         status[tid] = 0; // this single workgroup is the only writer of the encode status words
     __syncthreads();
     const uint32_t per = (n_frames + kPlanThreads - 1) / kPlanThreads;
     const uint32_t begin = tid * per, end = min(begin + per, n_frames);
+    const bool staged = n_frames <= (uint32_t)kPlanLdsFrames;
     uint64_t bytes = 0;
     uint32_t flags = 0;
-    for (uint32_t f = begin; f < end; f++) {
-        uint32_t choice;
-        const uint32_t words = frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, flags);
-        choice_out[f] = (uint8_t)choice;
-        bytes += sela_frame_bytes(channels, words);
+    if (staged) {
+        // frame f by thread f mod 1024: the metadata loads of one pass are independent and coalesced,
+        // and the passes do not depend on each other (a thread that walks `per` consecutive frames waits
+        // for memory `per` times)
+#pragma unroll 4
+        for (uint32_t f = tid; f < n_frames; f += kPlanThreads) {
+            uint32_t choice;
+            const uint32_t words = frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, flags);
+            choice_out[f] = (uint8_t)choice;
+            frame_size[f] = (uint32_t)sela_frame_bytes(channels, words);
+        }
+        __syncthreads();
+        for (uint32_t f = begin; f < end; f++)
+            bytes += frame_size[f];
+    } else {
+        for (uint32_t f = begin; f < end; f++) {
+            uint32_t choice;
+            const uint32_t words = frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, flags);
+            choice_out[f] = (uint8_t)choice;
+            bytes += sela_frame_bytes(channels, words);
+        }
     }
     part[tid] = bytes;
     __syncthreads();
@@ -814,11 +833,16 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
     uint64_t off = part[tid] - bytes;
     uint32_t overflow = 0;
     for (uint32_t f = begin; f < end; f++) {
-        uint32_t choice;
-        uint32_t dummy = 0;
-        const uint32_t words = frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, dummy);
+        uint64_t size;
+        if (staged) {
+            size = frame_size[f];
+        } else {
+            uint32_t choice;
+            uint32_t dummy = 0;
+            size = sela_frame_bytes(channels, frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, dummy));
+        }
         frame_offsets[f] = off;
-        off += sela_frame_bytes(channels, words);
+        off += size;
         if (off > frames_cap)
             overflow++;
     }

@@ -304,16 +304,33 @@ def test_decode_only_10k_frames(gpu):
         assert np.array_equal(a, b), int(f)
 
 
-def _build_frame(subframes):
+def _rice_words(values, k):
+    """Rice-code `values` with a GIVEN parameter k (src/rice/rice_encoder.cpp:35-71 without the parameter
+    search): zig-zag, u >> k ones, a zero, k remainder bits MSB first; stream bit t = bit t % 32 of word t / 32."""
+    bits = []
+    for v in values:
+        v = int(v)
+        u = -2 * v - 1 if v < 0 else 2 * v
+        bits += [1] * (u >> k) + [0] + [(u >> (k - 1 - i)) & 1 for i in range(k)]
+    bits += [0] * (-len(bits) % 32)
+    b = np.array(bits, np.uint64).reshape(-1, 32)
+    return (b << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+
+
+def _build_frame(subframes, res_k=None):
     """Hand-assemble on-disk frame bytes from (channel, type, parent, q[], residues[]) tuples, Rice-coding
-    with the oracle (layout of src/file/sela_file.cpp:115-135)."""
+    with the oracle -- or, for the residues, with the parameter `res_k` no encoder would pick
+    (layout of src/file/sela_file.cpp:115-135)."""
     import struct
 
     o = oracle()
     out = struct.pack("<I", 0xAA55FF00)
     for channel, typ, parent, q, res in subframes:
         ck, cw = o.rice_encode(np.asarray(q, np.int32))
-        rk, rw = o.rice_encode(np.asarray(res, np.int32))
+        if res_k is None:
+            rk, rw = o.rice_encode(np.asarray(res, np.int32))
+        else:
+            rk, rw = res_k, _rice_words(res, res_k)
         out += struct.pack("<BBBBHB", channel, typ, parent, ck, len(cw), len(q)) + cw.astype("<u4").tobytes()
         out += struct.pack("<BHH", rk, len(rw), len(res)) + rw.astype("<u4").tobytes()
     return out
@@ -338,6 +355,12 @@ def test_decoder_on_streams_no_encoder_would_write(gpu, kats):
         _build_frame([(0, 0, 0, q_sine, rng.integers(-50, 50, 2048))]),         # ordinary
         _build_frame([(0, 0, 0, np.zeros(100, np.int32), rng.integers(-9, 9, 2048))]),  # order 100, all-zero q
         _build_frame([(0, 0, 0, [], rng.integers(-9, 9, 2048))]),                # order 0
+        _build_frame([(0, 0, 0, q_noise[:55], mixed)]),                          # order 55: ring of 64, groups of 4, exact path
+        _build_frame([(0, 0, 0, q_noise[:55], rng.integers(-50, 50, 2048))]),     # ... and its folded path
+        _build_frame([(0, 0, 0, q_noise[:40], mixed[::-1].copy())]),             # order 40: groups of 16, exact path
+        _build_frame([(0, 0, 0, q_sine, rng.integers(-50, 50, 2048))], res_k=27), # k too wide for packed words: slow parser path throughout
+        _build_frame([(0, 0, 0, q_sine, rng.integers(-5000, 5000, 2048))], res_k=3),   # fast and slow groups mixed within blocks
+        _build_frame([(0, 0, 0, q_noise, rng.integers(-300, 300, 2048))], res_k=0),    # unary only
     ]
     stream = np.frombuffer(b"".join(frames), np.uint8).copy()
     offsets = np.cumsum([0] + [len(f) for f in frames]).astype(np.uint64)
