@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "sela_device.h"
 
@@ -66,8 +67,20 @@ struct DeviceBuffer {
     }
 };
 
+// Host-pointer calls run as a chunked pipeline: while chunk i is in the kernels,
+// chunk i+1 is copied in and chunk i-1 is copied out, on three streams.  Two sets of device buffers
+// alternate; the workspace is shared because the kernels of consecutive chunks run in stream order.
+// Frames per chunk; batches below two chunks go in one piece.  Encoding 1024 frames takes 0.22 ms, about
+// as long as copying them in and out; decoding is latency-bound below a few thousand frames (one lane
+// per stream), so its chunks are larger.
+constexpr uint32_t kHostChunkFramesEncode = 1024;
+constexpr uint32_t kHostChunkFramesDecode = 4096;
+
 struct HostContext {
-    DeviceBuffer pcm, frames, offsets, status, workspace;
+    DeviceBuffer pcm[2], frames[2], offsets[2], status[2], workspace;
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    hipEvent_t copied_in[2] = { nullptr, nullptr }, ran[2] = { nullptr, nullptr };
+    std::vector<uint64_t> rebased[2]; // decode: a chunk's frame offsets relative to its first byte
     int device = -1;
     // the buffers belong to the device that was current when they were allocated
     bool bind_current_device()
@@ -81,13 +94,36 @@ struct HostContext {
         }
         return true;
     }
+    hipError_t streams()
+    {
+        hipError_t e = hipSuccess;
+        for (hipStream_t* s : { &s_in, &s_run, &s_out })
+            if (!*s && (e = hipStreamCreateWithFlags(s, hipStreamNonBlocking)) != hipSuccess)
+                return e;
+        for (hipEvent_t* ev : { &copied_in[0], &copied_in[1], &ran[0], &ran[1] })
+            if (!*ev && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
+                return e;
+        return e;
+    }
     void release()
     {
-        pcm.release();
-        frames.release();
-        offsets.release();
-        status.release();
+        for (int b = 0; b < 2; b++) {
+            pcm[b].release();
+            frames[b].release();
+            offsets[b].release();
+            status[b].release();
+        }
         workspace.release();
+        for (hipStream_t* s : { &s_in, &s_run, &s_out }) {
+            if (*s)
+                (void)hipStreamDestroy(*s);
+            *s = nullptr;
+        }
+        for (hipEvent_t* ev : { &copied_in[0], &copied_in[1], &ran[0], &ran[1] }) {
+            if (*ev)
+                (void)hipEventDestroy(*ev);
+            *ev = nullptr;
+        }
     }
 };
 thread_local HostContext g_ctx;
@@ -277,36 +313,94 @@ int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, ui
         return rc;
     if (!g_ctx.bind_current_device())
         return fail(SELA_HIP_ENODEV, "hipGetDevice failed");
-    const size_t pcm_bytes = (size_t)n_frames * sela::kBlock * channels * sizeof(int16_t);
-    const size_t bound = sela_hip_encode_bound_bytes(n_frames, channels);
-    const size_t dev_cap = ((frames_cap < bound ? frames_cap : bound) + 3) & ~(size_t)3;
-    hipError_t e;
-    if ((e = g_ctx.pcm.reserve(pcm_bytes + 4)) != hipSuccess || (e = g_ctx.frames.reserve(dev_cap + 4)) != hipSuccess
-        || (e = g_ctx.offsets.reserve(((size_t)n_frames + 1) * 8)) != hipSuccess || (e = g_ctx.status.reserve(16)) != hipSuccess
-        || (e = g_ctx.workspace.reserve(sela::encode_workspace_bytes(n_frames, channels))) != hipSuccess)
+    frame_offsets_out[0] = 0;
+    if (n_frames == 0)
+        return SELA_HIP_OK;
+    const uint32_t chunk = n_frames >= 2 * kHostChunkFramesEncode ? kHostChunkFramesEncode : n_frames;
+    const uint32_t n_chunks = (n_frames + chunk - 1) / chunk;
+    const int n_sets = n_chunks > 1 ? 2 : 1;
+    const size_t frame_pcm = (size_t)sela::kBlock * channels * sizeof(int16_t);
+    const size_t chunk_bound = sela_hip_encode_bound_bytes(chunk, channels);
+    hipError_t e = g_ctx.streams();
+    if (e != hipSuccess)
+        return fail_hip(e, "hipStreamCreate");
+    for (int b = 0; b < n_sets; b++)
+        if ((e = g_ctx.pcm[b].reserve(chunk * frame_pcm + 4)) != hipSuccess || (e = g_ctx.frames[b].reserve(chunk_bound + 4)) != hipSuccess
+            || (e = g_ctx.offsets[b].reserve(((size_t)chunk + 1) * 8)) != hipSuccess || (e = g_ctx.status[b].reserve(16)) != hipSuccess)
+            return fail_hip(e, "hipMalloc");
+    if ((e = g_ctx.workspace.reserve(sela::encode_workspace_bytes(chunk, channels))) != hipSuccess)
         return fail_hip(e, "hipMalloc");
-    if (pcm_bytes && (e = hipMemcpyAsync(g_ctx.pcm.ptr, pcm, pcm_bytes, hipMemcpyHostToDevice, nullptr)) != hipSuccess)
-        return fail_hip(e, "H2D pcm");
-    rc = sela_hip_encode_device(static_cast<const int16_t*>(g_ctx.pcm.ptr), n_frames, channels, static_cast<uint8_t*>(g_ctx.frames.ptr),
-        frames_cap < bound ? (frames_cap & ~(size_t)3) : bound, static_cast<uint64_t*>(g_ctx.offsets.ptr),
-        static_cast<uint32_t*>(g_ctx.status.ptr), g_ctx.workspace.ptr, g_ctx.workspace.cap, nullptr, nullptr);
-    if (rc != SELA_HIP_OK)
-        return rc;
-    uint32_t status[4];
-    if ((e = hipMemcpy(status, g_ctx.status.ptr, sizeof status, hipMemcpyDeviceToHost)) != hipSuccess)
-        return fail_hip(e, "D2H status");
-    if ((e = hipMemcpy(frame_offsets_out, g_ctx.offsets.ptr, ((size_t)n_frames + 1) * 8, hipMemcpyDeviceToHost)) != hipSuccess)
-        return fail_hip(e, "D2H offsets");
-    if (flags_to_error(status[0])) {
-        char msg[160];
-        std::snprintf(msg, sizeof msg, "a block left the range the .sela format can carry (flags 0x%x)", status[0]);
-        return fail(SELA_HIP_ERANGE, msg);
+
+    auto frames_of = [&](uint32_t i) { return i + 1 < n_chunks ? chunk : n_frames - i * chunk; };
+    auto copy_in = [&](uint32_t i) -> hipError_t {
+        const int b = (int)(i & 1);
+        hipError_t err;
+        if (i >= 2 && (err = hipStreamWaitEvent(g_ctx.s_in, g_ctx.ran[b], 0)) != hipSuccess) // chunk i-2 has read this buffer
+            return err;
+        if ((err = hipMemcpyAsync(g_ctx.pcm[b].ptr, pcm + (size_t)i * chunk * sela::kBlock * channels, frames_of(i) * frame_pcm,
+                 hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess)
+            return err;
+        return hipEventRecord(g_ctx.copied_in[b], g_ctx.s_in);
+    };
+    size_t base = 0; // bytes of the chunks already copied out
+    std::vector<uint64_t> chunk_offsets((size_t)chunk + 1);
+    auto copy_out = [&](uint32_t i) -> int {
+        const int b = (int)(i & 1);
+        const uint32_t nf = frames_of(i);
+        hipError_t err;
+        uint32_t status[4];
+        if ((err = hipEventSynchronize(g_ctx.ran[b])) != hipSuccess
+            || (err = hipMemcpyAsync(status, g_ctx.status[b].ptr, sizeof status, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
+            || (err = hipMemcpyAsync(chunk_offsets.data(), g_ctx.offsets[b].ptr, ((size_t)nf + 1) * 8, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
+            || (err = hipStreamSynchronize(g_ctx.s_out)) != hipSuccess)
+            return fail_hip(err, "D2H status/offsets");
+        if (flags_to_error(status[0])) {
+            char msg[160];
+            std::snprintf(msg, sizeof msg, "a block left the range the .sela format can carry (flags 0x%x)", status[0]);
+            return fail(SELA_HIP_ERANGE, msg);
+        }
+        const size_t total = (size_t)chunk_offsets[nf];
+        if (status[1] || base + total > frames_cap)
+            return fail(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes)");
+        for (uint32_t f = 0; f <= nf; f++)
+            frame_offsets_out[(size_t)i * chunk + f] = base + chunk_offsets[f];
+        if (total && ((err = hipMemcpyAsync(frames_out + base, g_ctx.frames[b].ptr, total, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
+                         || (err = hipStreamSynchronize(g_ctx.s_out)) != hipSuccess))
+            return fail_hip(err, "D2H frames");
+        base += total;
+        return SELA_HIP_OK;
+    };
+
+    rc = SELA_HIP_OK;
+    if ((e = copy_in(0)) != hipSuccess)
+        rc = fail_hip(e, "H2D pcm");
+    for (uint32_t i = 0; rc == SELA_HIP_OK && i <= n_chunks; i++) {
+        if (i < n_chunks) {
+            const int b = (int)(i & 1);
+            if ((e = hipStreamWaitEvent(g_ctx.s_run, g_ctx.copied_in[b], 0)) != hipSuccess) {
+                rc = fail_hip(e, "hipStreamWaitEvent");
+                break;
+            }
+            rc = sela_hip_encode_device(static_cast<const int16_t*>(g_ctx.pcm[b].ptr), frames_of(i), channels,
+                static_cast<uint8_t*>(g_ctx.frames[b].ptr), chunk_bound, static_cast<uint64_t*>(g_ctx.offsets[b].ptr),
+                static_cast<uint32_t*>(g_ctx.status[b].ptr), g_ctx.workspace.ptr, g_ctx.workspace.cap, nullptr, g_ctx.s_run);
+            if (rc != SELA_HIP_OK)
+                break;
+            if ((e = hipEventRecord(g_ctx.ran[b], g_ctx.s_run)) != hipSuccess || (i + 1 < n_chunks && (e = copy_in(i + 1)) != hipSuccess)) {
+                rc = fail_hip(e, "H2D pcm");
+                break;
+            }
+        }
+        if (i >= 1)
+            rc = copy_out(i - 1);
     }
-    if (status[1])
-        return fail(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes)");
-    const size_t total = (size_t)frame_offsets_out[n_frames];
-    if (total && (e = hipMemcpy(frames_out, g_ctx.frames.ptr, total, hipMemcpyDeviceToHost)) != hipSuccess)
-        return fail_hip(e, "D2H frames");
+    if (rc != SELA_HIP_OK) { // leave nothing in flight behind an error
+        const std::string msg = sela_hip_last_error();
+        (void)hipStreamSynchronize(g_ctx.s_in);
+        (void)hipStreamSynchronize(g_ctx.s_run);
+        (void)hipStreamSynchronize(g_ctx.s_out);
+        return fail(rc, msg.c_str());
+    }
     return SELA_HIP_OK;
 }
 
@@ -324,29 +418,91 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
             return fail(SELA_HIP_EFORMAT, "frame offsets must be ascending multiples of 4");
     if (!g_ctx.bind_current_device())
         return fail(SELA_HIP_ENODEV, "hipGetDevice failed");
-    const size_t total = (size_t)frame_offsets[n_frames];
-    const size_t pcm_bytes = (size_t)n_frames * sela::kBlock * channels * sizeof(int16_t);
-    hipError_t e;
-    if ((e = g_ctx.pcm.reserve(pcm_bytes + 4)) != hipSuccess || (e = g_ctx.frames.reserve(total + 8)) != hipSuccess
-        || (e = g_ctx.offsets.reserve(((size_t)n_frames + 1) * 8)) != hipSuccess || (e = g_ctx.status.reserve(16)) != hipSuccess
-        || (e = g_ctx.workspace.reserve(sela::decode_workspace_bytes(n_frames, channels))) != hipSuccess)
+    const uint32_t chunk = n_frames >= 2 * kHostChunkFramesDecode ? kHostChunkFramesDecode : n_frames;
+    const uint32_t n_chunks = (n_frames + chunk - 1) / chunk;
+    const int n_sets = n_chunks > 1 ? 2 : 1;
+    const size_t frame_pcm = (size_t)sela::kBlock * channels * sizeof(int16_t);
+    auto frames_of = [&](uint32_t i) { return i + 1 < n_chunks ? chunk : n_frames - i * chunk; };
+    size_t max_bytes = 0;
+    for (uint32_t i = 0; i < n_chunks; i++) {
+        const size_t bytes = (size_t)(frame_offsets[(size_t)i * chunk + frames_of(i)] - frame_offsets[(size_t)i * chunk]);
+        max_bytes = bytes > max_bytes ? bytes : max_bytes;
+    }
+    hipError_t e = g_ctx.streams();
+    if (e != hipSuccess)
+        return fail_hip(e, "hipStreamCreate");
+    for (int b = 0; b < n_sets; b++)
+        if ((e = g_ctx.pcm[b].reserve(chunk * frame_pcm + 4)) != hipSuccess || (e = g_ctx.frames[b].reserve(max_bytes + 8)) != hipSuccess
+            || (e = g_ctx.offsets[b].reserve(((size_t)chunk + 1) * 8)) != hipSuccess || (e = g_ctx.status[b].reserve(16)) != hipSuccess)
+            return fail_hip(e, "hipMalloc");
+    if ((e = g_ctx.workspace.reserve(sela::decode_workspace_bytes(chunk, channels))) != hipSuccess)
         return fail_hip(e, "hipMalloc");
-    if ((e = hipMemcpyAsync(g_ctx.frames.ptr, frames, total, hipMemcpyHostToDevice, nullptr)) != hipSuccess
-        || (e = hipMemcpyAsync(g_ctx.offsets.ptr, frame_offsets, ((size_t)n_frames + 1) * 8, hipMemcpyHostToDevice, nullptr)) != hipSuccess)
-        return fail_hip(e, "H2D frames");
-    rc = sela_hip_decode_device(static_cast<const uint8_t*>(g_ctx.frames.ptr), static_cast<const uint64_t*>(g_ctx.offsets.ptr), n_frames,
-        channels, static_cast<int16_t*>(g_ctx.pcm.ptr), static_cast<uint32_t*>(g_ctx.status.ptr), g_ctx.workspace.ptr, g_ctx.workspace.cap,
-        nullptr);
-    if (rc != SELA_HIP_OK)
-        return rc;
-    uint32_t status[4];
-    if ((e = hipMemcpy(status, g_ctx.status.ptr, sizeof status, hipMemcpyDeviceToHost)) != hipSuccess)
-        return fail_hip(e, "D2H status");
-    if ((e = hipMemcpy(pcm_out, g_ctx.pcm.ptr, pcm_bytes, hipMemcpyDeviceToHost)) != hipSuccess)
-        return fail_hip(e, "D2H pcm");
-    if (status[0] & SELA_HIP_FLAG_BAD_FRAME)
+
+    auto copy_in = [&](uint32_t i) -> hipError_t {
+        const int b = (int)(i & 1);
+        const uint32_t nf = frames_of(i);
+        const uint64_t* off = frame_offsets + (size_t)i * chunk;
+        hipError_t err;
+        if (i >= 2 && (err = hipStreamWaitEvent(g_ctx.s_in, g_ctx.ran[b], 0)) != hipSuccess) // chunk i-2 has read these buffers
+            return err;
+        std::vector<uint64_t>& rel = g_ctx.rebased[b];
+        rel.resize((size_t)nf + 1);
+        for (uint32_t f = 0; f <= nf; f++)
+            rel[f] = off[f] - off[0];
+        if ((err = hipMemcpyAsync(g_ctx.frames[b].ptr, frames + off[0], (size_t)rel[nf], hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
+            || (err = hipMemcpyAsync(g_ctx.offsets[b].ptr, rel.data(), ((size_t)nf + 1) * 8, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess)
+            return err;
+        return hipEventRecord(g_ctx.copied_in[b], g_ctx.s_in);
+    };
+    uint32_t seen_flags = 0;
+    auto copy_out = [&](uint32_t i) -> int {
+        const int b = (int)(i & 1);
+        hipError_t err;
+        uint32_t status[4];
+        if ((err = hipEventSynchronize(g_ctx.ran[b])) != hipSuccess
+            || (err = hipMemcpyAsync(status, g_ctx.status[b].ptr, sizeof status, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
+            || (err = hipMemcpyAsync(pcm_out + (size_t)i * chunk * sela::kBlock * channels, g_ctx.pcm[b].ptr, frames_of(i) * frame_pcm,
+                    hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
+            || (err = hipStreamSynchronize(g_ctx.s_out)) != hipSuccess)
+            return fail_hip(err, "D2H pcm");
+        seen_flags |= status[0];
+        return SELA_HIP_OK;
+    };
+
+    rc = SELA_HIP_OK;
+    if ((e = copy_in(0)) != hipSuccess)
+        rc = fail_hip(e, "H2D frames");
+    for (uint32_t i = 0; rc == SELA_HIP_OK && i <= n_chunks; i++) {
+        if (i < n_chunks) {
+            const int b = (int)(i & 1);
+            if ((e = hipStreamWaitEvent(g_ctx.s_run, g_ctx.copied_in[b], 0)) != hipSuccess) {
+                rc = fail_hip(e, "hipStreamWaitEvent");
+                break;
+            }
+            rc = sela_hip_decode_device(static_cast<const uint8_t*>(g_ctx.frames[b].ptr), static_cast<const uint64_t*>(g_ctx.offsets[b].ptr),
+                frames_of(i), channels, static_cast<int16_t*>(g_ctx.pcm[b].ptr), static_cast<uint32_t*>(g_ctx.status[b].ptr),
+                g_ctx.workspace.ptr, g_ctx.workspace.cap, g_ctx.s_run);
+            if (rc != SELA_HIP_OK)
+                break;
+            if ((e = hipEventRecord(g_ctx.ran[b], g_ctx.s_run)) != hipSuccess || (i + 1 < n_chunks && (e = copy_in(i + 1)) != hipSuccess)) {
+                rc = fail_hip(e, "H2D frames");
+                break;
+            }
+        }
+        if (i >= 1)
+            rc = copy_out(i - 1);
+    }
+    if (rc != SELA_HIP_OK) { // leave nothing in flight behind an error
+        const std::string msg = sela_hip_last_error();
+        (void)hipStreamSynchronize(g_ctx.s_in);
+        (void)hipStreamSynchronize(g_ctx.s_run);
+        (void)hipStreamSynchronize(g_ctx.s_out);
+        return fail(rc, msg.c_str());
+    }
+    // every frame is decoded (bad ones to silence) before the verdict, as in the one-piece call
+    if (seen_flags & SELA_HIP_FLAG_BAD_FRAME)
         return fail(SELA_HIP_EFORMAT, "malformed frame stream (bad sync word or subframe header)");
-    if (status[0] & SELA_HIP_FLAG_RICE_OVERRUN)
+    if (seen_flags & SELA_HIP_FLAG_RICE_OVERRUN)
         return fail(SELA_HIP_EFORMAT, "a Rice stream ended before all its values were read");
     return SELA_HIP_OK;
 }

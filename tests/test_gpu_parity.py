@@ -207,6 +207,32 @@ def test_host_pointer_api(gpu):
     assert len(f0) == 0 and o0.tolist() == [0]
 
 
+def test_host_pointer_api_chunked_pipeline(gpu):
+    """Batches of two chunks and more go through the three-stream copy-in / kernels / copy-out pipeline
+    (sela_capi.hip: 1024 frames per chunk encoding, 4096 decoding): same bytes as the device-pointer call
+    on the whole batch, including a short last chunk, and a corrupt frame in a later chunk is still reported."""
+    from sela_amd import capi, codec
+
+    n = 2 * 1024 + 300
+    pcm = synth_frames(n, 2, 31)
+    frames, offsets = codec.encode_host(pcm)
+    dev_frames, dev_offsets, _, _ = _encode(gpu, pcm)
+    assert np.array_equal(offsets, dev_offsets) and np.array_equal(frames, dev_frames)
+    assert np.array_equal(codec.index_frames(frames, n, 2), offsets)
+    assert np.array_equal(codec.decode_host(frames, offsets, 2), _decode(gpu, frames, offsets, 2))
+    # mono, nine encode chunks / three decode chunks, the last of a single frame
+    n1 = 2 * 4096 + 1
+    pcm1 = np.tile(synth_frames(683, 1, 32), (13, 1, 1))[:n1]
+    f1, o1 = codec.encode_host(pcm1)
+    d1, do1, _, _ = _encode(gpu, pcm1)
+    assert np.array_equal(o1, do1) and np.array_equal(f1, d1)
+    assert np.array_equal(codec.decode_host(f1, o1, 1), _decode(gpu, f1, o1, 1))
+    bad = f1.copy()
+    bad[int(o1[5000])] ^= 0xFF  # sync word of a frame in the second decode chunk
+    with pytest.raises(capi.SelaHipError):
+        codec.decode_host(bad, o1, 1)
+
+
 def test_decoder_rejects_corrupt_frames(gpu):
     from sela_amd import capi, codec
 
