@@ -744,6 +744,37 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
     // ---- second pass of frame::FrameDecoder + interleave to int16 ------------------------------------
     // dependent channels become parent - difference (parents are independent subframes); a channel
     // that no valid subframe delivered decodes to silence and raises BAD_FRAME.
+    if (channels == 2) {
+        // stereo: four samples of both channels per thread, one 16-byte store (wave-uniform case analysis)
+        const uint32_t i0 = sub_info[0], i1 = sub_info[1];
+        const bool have0 = i0 != 0xFFFFFFFFu, have1 = i1 != 0xFFFFFFFFu;
+        const bool dep0 = have0 && (i0 & 0xFF) == 1, dep1 = have1 && (i1 & 0xFF) == 1;
+        const uint32_t par0 = i0 >> 8, par1 = i1 >> 8; // parent channel of a dependent subframe (0 or 1, checked by the parser)
+        const int4* s0 = reinterpret_cast<const int4*>(samples);
+        const int4* s1 = reinterpret_cast<const int4*>(samples + v_count);
+        uint4* out = reinterpret_cast<uint4*>(pcm_out + ((size_t)f * kBlock + v_begin) * 2);
+        for (uint32_t i4 = threadIdx.x; i4 < v_count / 4; i4 += blockDim.x) {
+            const int4 zero = make_int4(0, 0, 0, 0);
+            const int4 r0 = have0 ? s0[i4] : zero, r1 = have1 ? s1[i4] : zero; // raw subframe outputs
+            int4 a = r0, b = r1;
+            if (dep0) { // parent - difference; the parent's own (independent) samples
+                const int4 pv = par0 == 0 ? r0 : r1;
+                a = make_int4((int)((uint32_t)pv.x - (uint32_t)r0.x), (int)((uint32_t)pv.y - (uint32_t)r0.y),
+                    (int)((uint32_t)pv.z - (uint32_t)r0.z), (int)((uint32_t)pv.w - (uint32_t)r0.w));
+            }
+            if (dep1) {
+                const int4 pv = par1 == 0 ? r0 : r1;
+                b = make_int4((int)((uint32_t)pv.x - (uint32_t)r1.x), (int)((uint32_t)pv.y - (uint32_t)r1.y),
+                    (int)((uint32_t)pv.z - (uint32_t)r1.z), (int)((uint32_t)pv.w - (uint32_t)r1.w));
+            }
+            uint4 w;
+            w.x = ((uint32_t)a.x & 0xFFFFu) | ((uint32_t)b.x << 16);
+            w.y = ((uint32_t)a.y & 0xFFFFu) | ((uint32_t)b.y << 16);
+            w.z = ((uint32_t)a.z & 0xFFFFu) | ((uint32_t)b.z << 16);
+            w.w = ((uint32_t)a.w & 0xFFFFu) | ((uint32_t)b.w << 16);
+            out[i4] = w;
+        }
+    } else
     for (uint32_t i = threadIdx.x; i < v_count; i += blockDim.x) {
         for (uint32_t c = 0; c < channels; c++) {
             const uint32_t info = sub_info[c];
