@@ -17,6 +17,8 @@
 // Arithmetic contract: this file must be compiled with -ffp-contract=off.  Every
 // FP64 accumulator is updated in the reference's order: the lanes of a wave carry *independent*
 // accumulators (autocorrelation lags, Schur columns, step-up elements), never a split of one sum.
+#include <atomic>
+
 #include "sela_device.h"
 
 namespace sela {
@@ -33,10 +35,13 @@ namespace sela {
 //                                       packed residue words
 constexpr int kPadC = 64;
 constexpr int kParityLen = kPadC + kBlock / 2 + 2;   // 1090 doubles
-// Scalar-operand scratch: each running block borrows a ring of 2 x 256 centred samples (+ a copy of the
+// Scalar-operand scratch: each running block borrows a ring of 2 x 128 centred samples (+ a copy of the
 // first values of half A behind half B, so that a fetch may run across the wrap) from a pool that is
-// private to its XCD -- 512 rings per XCD, handed out through a bitmap -- so the ring stays in that
-// XCD's L2 and the scratch never reaches HBM.
+// private to its XCD -- 512 rings per XCD -- so the ring stays in that XCD's L2 and the scratch never
+// reaches HBM.  A ring is taken by swapping the launch's ticket (a number no earlier launch on this
+// workspace used) into its owner word: whoever gets back anything else owns it; it is handed back by
+// writing 0.  Stale or uninitialised owner words therefore read as "free" and nothing has to be
+// cleared between launches.
 constexpr int kRingHalf = 128;
 constexpr int kRingLen = 2 * kRingHalf + 64;          // doubles (4608 bytes, a multiple of 64)
 constexpr int kRingsPerXcd = 512;                      // >= blocks resident on one XCD (9 per CU x 32 CUs)
@@ -312,7 +317,7 @@ __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const uint
 template <int kMode>
 __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
-    double* __restrict__ rings, uint32_t* __restrict__ ring_bitmap, sela_hip_trace* __restrict__ trace,
+    double* __restrict__ rings, uint32_t* __restrict__ ring_owner, uint32_t ticket, sela_hip_trace* __restrict__ trace,
     uint64_t* __restrict__ phase_cycles)
 {
     constexpr bool kTrace = kMode == 1;
@@ -422,32 +427,18 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     double acc_e = 0.0, acc_o = 0.0;
     {
         // borrow a ring from this XCD's pool (only workgroups on the same XCD, i.e. behind the same L2,
-        // ever touch a pool: no cross-L2 coherence is needed for the rings or for the bitmap)
+        // ever touch a pool: no cross-L2 coherence is needed for the rings or for their owner words)
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= kXcds - 1;
-        uint32_t* const pool = ring_bitmap + xcc * (kRingsPerXcd / 32);
+        uint32_t* const pool = ring_owner + xcc * kRingsPerXcd;
         uint32_t slot = 0;
         if (lane == 0) {
             // workgroups that run together have nearby indices within their XCD: each starts at its own
-            // bit (index mod 512), so that in the common case one atomic takes a ring without a retry
-            const uint32_t idx = blockIdx.x >> 3;
-            uint32_t w = idx & (kRingsPerXcd / 32 - 1), pos = (idx / (kRingsPerXcd / 32)) & 31;
-            for (;;) {
-                const uint32_t bit = 1u << pos;
-                const uint32_t old = atomicOr(pool + w, bit);
-                if (!(old & bit)) {
-                    slot = w * 32 + pos;
-                    break;
-                }
-                const uint32_t free_bits = ~(old | bit);
-                if (free_bits) { // next free bit at or after pos, cyclically
-                    const uint32_t rot = (free_bits >> pos) | (free_bits << ((32 - pos) & 31));
-                    pos = (pos + (uint32_t)__builtin_ctz(rot)) & 31;
-                } else {
-                    w = (w + 1) & (kRingsPerXcd / 32 - 1);
-                }
-            }
+            // ring (index mod 512), so that in the common case one atomic takes a ring without a retry
+            slot = (blockIdx.x >> 3) & (kRingsPerXcd - 1);
+            while (atomicExch(pool + slot, ticket) == ticket)
+                slot = (slot + 1) & (kRingsPerXcd - 1);
         }
         slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
         double* const ring = reinterpret_cast<double*>(
@@ -510,7 +501,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
         }
         ac_wait(f0, acc_e, acc_o); // drain the fetch past the end
         if (lane == 0)
-            atomicAnd(pool + (slot >> 5), ~(1u << (slot & 31))); // hand the ring back
+            atomicExch(pool + slot, 0u); // hand the ring back (0 is never a ticket)
     }
     wave_sync(); // c[] is dead from here on
 
@@ -917,7 +908,7 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
     bytes += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
     bytes += ((size_t)n_frames + 255) & ~(size_t)255; // choice
     bytes += (size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 256; // scalar-operand rings (L2-resident) ...
-    bytes += (size_t)kXcds * kRingsPerXcd / 8 + 256;                          // ... and their allocation bitmap
+    bytes += (size_t)kXcds * kRingsPerXcd * 4 + 256;                          // ... and their owner words
     return bytes + 256;
 }
 
@@ -937,7 +928,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     ws += ((size_t)n_frames + 255) & ~(size_t)255;
     double* rings = reinterpret_cast<double*>(ws);
     ws += ((size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 255) & ~(size_t)255;
-    uint32_t* ring_bitmap = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* ring_owner = reinterpret_cast<uint32_t*>(ws);
 
     if (n_frames == 0) {
         hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
@@ -945,17 +936,19 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     }
     const uint32_t groups = (n_frames + 7) / 8;
     const dim3 grid(groups * 8 * n_sig), wg(64);
-    hipError_t err0 = hipMemsetAsync(ring_bitmap, 0, (size_t)kXcds * kRingsPerXcd / 8, stream); // every ring free
-    if (err0 != hipSuccess)
-        return err0;
+    // ring ticket: unique per launch in this process, never 0 (see kRingLen)
+    static std::atomic<uint32_t> next_ticket{ 0x5E1A0001u };
+    uint32_t ticket = next_ticket.fetch_add(1, std::memory_order_relaxed);
+    if (ticket == 0)
+        ticket = next_ticket.fetch_add(1, std::memory_order_relaxed);
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
-        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_bitmap, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles);
     else if (d_trace)
-        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_bitmap, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles);
     else
-        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_bitmap, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap,
