@@ -106,6 +106,29 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v)
     }
     return v;
 }
+// Sum of one 32-bit value per lane (the total must fit 32 bits) by DPP adds -- row_shr 1/2/4/8 (a prefix
+// sum within each row of 16), then row_bcast 15/31 under row masks: six full-rate instructions instead of six
+// ds_bpermute round trips; the total lands in lane 63.
+__device__ __forceinline__ uint32_t wave_sum_small(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    // lane 15 of every row now holds its row's total
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Exact wave sum of per-lane values below 2^40 (sums of 32 Rice quotients are below 2^37): two 20-bit
+// limbs, each summed without overflow.
+__device__ __forceinline__ uint64_t wave_sum_40(uint64_t v)
+{
+    const uint32_t lo = wave_sum_small((uint32_t)v & 0xFFFFFu);
+    const uint32_t hi = wave_sum_small((uint32_t)(v >> 20));
+    return ((uint64_t)hi << 20) + lo;
+}
+
 // Exclusive prefix sum over the 64 lanes.
 __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, int lane)
 {

@@ -114,7 +114,7 @@ __device__ __forceinline__ uint64_t rice_shifted_sum(const uint32_t (&u)[V], uin
 #pragma unroll
     for (int t = 0; t < V; t++)
         part += u[t] >> k;
-    return wave_sum(part);
+    return wave_sum_40(part); // V <= 32 values below 2^32 each
 }
 
 template <int V>
