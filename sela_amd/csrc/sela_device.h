@@ -95,17 +95,7 @@ __device__ __forceinline__ uint64_t read_first_lane(uint64_t x)
     return ((uint64_t)hi << 32) | lo;
 }
 
-// ---- wave reductions / scans (butterfly over ds_bpermute; exact integer arithmetic) ----------------
-__device__ __forceinline__ uint64_t wave_sum(uint64_t v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64);
-        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
-        v += ((uint64_t)hi << 32) | lo;
-    }
-    return v;
-}
+// ---- wave reductions / scans (exact integer arithmetic) ----------------------------------------------
 // Sum of one 32-bit value per lane (the total must fit 32 bits) by DPP adds -- row_shr 1/2/4/8 (a prefix
 // sum within each row of 16), then row_bcast 15/31 under row masks: six full-rate instructions instead of six
 // ds_bpermute round trips; the total lands in lane 63.
@@ -129,16 +119,18 @@ __device__ __forceinline__ uint64_t wave_sum_40(uint64_t v)
     return ((uint64_t)hi << 20) + lo;
 }
 
-// Exclusive prefix sum over the 64 lanes.
+// Exclusive prefix sum over the 64 lanes (totals must fit 32 bits): the same DPP ladder -- prefix sums
+// within each row of 16, then the totals of the rows before are broadcast in.
 __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, int lane)
 {
+    (void)lane;
     uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-        if (lane >= d)
-            incl += o;
-    }
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
     return incl - v;
 }
 
