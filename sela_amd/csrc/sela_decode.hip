@@ -796,8 +796,7 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_synthesize_frames(const S
                 flags |= SELA_HIP_FLAG_BAD_FRAME; // a parent that is itself dependent is outside what the reference defines
         }
     }
-    for (int m = 32; m >= 1; m >>= 1)
-        flags |= (uint32_t)__shfl_xor((int)flags, m, 64);
+    flags = wave_or(flags);
     if (lane == 0 && flags) {
         atomicOr(&status[0], flags);
         if (wave == 0 && first && (flags & SELA_HIP_FLAG_BAD_FRAME))

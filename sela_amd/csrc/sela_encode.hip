@@ -530,14 +530,28 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
         err += g * ki;
         if (lane == 0)
             k_lo = ki;
+        // stage i only needs columns j < 100 - i: the second register (columns 64..99) is dead from
+        // stage 37 on, and with it the value shifted into lane 63
+        constexpr int kTwoRegs = kMaxOrder - 64 + 1; // 37
 #pragma unroll 1
-        for (int i = 1; i < kMaxOrder; i++) {
+        for (int i = 1; i < kTwoRegs; i++) {
             const double sa = wave_shl1(read_first_lane(g1b), g1a); // gen1[j+1], j = lane
             const double sb = wave_shl1_zero(g1b);                  // gen1[j+1], j = lane + 64
             g1a = sa + ki * g0a;
             g0a = sa * ki + g0a;
             g1b = sb + ki * g0b;
             g0b = sb * ki + g0b;
+            g = read_first_lane(g1a);
+            ki = -g / err;
+            err += g * ki;
+            if (lane == i)
+                k_lo = ki;
+        }
+#pragma unroll 1
+        for (int i = kTwoRegs; i < kMaxOrder; i++) {
+            const double sa = wave_shl1_zero(g1a);
+            g1a = sa + ki * g0a;
+            g0a = sa * ki + g0a;
             g = read_first_lane(g1a);
             ki = -g / err;
             err += g * ki;
@@ -720,10 +734,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
         slot[lane] = cw_buf[lane];
     for (uint32_t w = lane; w < res_words; w += 64)
         slot[kCoefWordsCap + w] = out_words[w];
-    uint32_t all_flags = flags; // OR over the wave
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        all_flags |= (uint32_t)__shfl_xor((int)all_flags, m, 64);
+    const uint32_t all_flags = wave_or(flags);
     if (lane == 0) {
         BlockMeta bm;
         bm.order = (uint8_t)order;
