@@ -132,16 +132,27 @@ def main():
     enc = codec.Encoder(n_frames, CHANNELS)
     dec = codec.Decoder(n_frames, CHANNELS)
     all_sizes = torch.zeros(world * n_frames, dtype=torch.int64, device="cuda")
+    my_sizes = torch.zeros(n_frames, dtype=torch.int64, device="cuda")
+    layout = torch.zeros(world * n_frames, dtype=torch.int64, device="cuda")
+    exchange = torch.cuda.Stream() if dist is not None else None
 
     def step():
         out = enc.encode(pcm)
         if dist is not None:
             # the path's only exchange: per-frame compressed sizes of every rank, so that
             # each rank knows where its frames land in the job's output stream (sela_amd/sharding.py);
-            # 8 bytes x frames, latency bound -- RCCL over xGMI
-            dist.all_gather_into_tensor(all_sizes, out.offsets[1:] - out.offsets[:-1])
-            torch.cumsum(all_sizes, 0)
+            # 8 bytes x frames, latency bound -- RCCL over xGMI.  Decoding the local frames does not need
+            # the layout, so the exchange runs beside it on its own stream and is joined at the end of
+            # the step (it is still inside the timed region).
+            main = torch.cuda.current_stream()
+            torch.sub(out.offsets[1:], out.offsets[:-1], out=my_sizes)
+            exchange.wait_stream(main)
+            with torch.cuda.stream(exchange):
+                dist.all_gather_into_tensor(all_sizes, my_sizes)
+                torch.cumsum(all_sizes, 0, out=layout)
         back = dec.decode(out.frames, out.offsets, n_frames)
+        if dist is not None:
+            torch.cuda.current_stream().wait_stream(exchange)
         return out, back
 
     def barrier():

@@ -81,7 +81,8 @@ int sela_hip_device_count(void);
 /* ---- sizing ------------------------------------------------------------------------------------ */
 /* Number of signals analysed per frame: channels, +1 for exactly-stereo input. */
 uint32_t sela_hip_signals_per_frame(uint32_t channels);
-/* Bytes of device workspace the *_device calls need for a batch of n_frames. */
+/* Bytes of device workspace the *_device calls need for a batch of n_frames.  The workspace needs no
+ * initialisation and may be reused by later calls; one call at a time may use it. */
 size_t sela_hip_encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 size_t sela_hip_decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 /* Upper bound of the frame byte stream produced by encoding n_frames (what `frames_cap` must be
@@ -103,15 +104,20 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
 /*
  * Decode n_frames frames.  d_frames / d_frame_offsets as produced above (or by parsing a .sela
  * file).  d_pcm_out: int16 [n_frames][2048][channels].  d_status: uint32[4], [0] = OR of flag
- * bits, [1] = number of malformed frames.  Launches 2 kernels on `stream`; d_workspace holds the parsed
- * residues between them (sela_hip_decode_workspace_bytes()).
+ * bits, [1] = number of malformed frames.  d_workspace holds the parsed residues and the filter state
+ * between the kernels (sela_hip_decode_workspace_bytes()).  The call is cut into four chunks along the
+ * sample axis: the parse kernel of chunk j+1 runs on a library-owned side stream beside the synthesis
+ * kernel of chunk j on `stream`; all of it is ordered after earlier work on `stream`, and later work on
+ * `stream` is ordered after all of it.
  */
 int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames,
     uint32_t channels, int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, size_t workspace_bytes,
     void* stream);
 
 /* ---- host-pointer API (synchronous) -------------------------------------------------------------- */
-/* frames_out must hold sela_hip_encode_bound_bytes() or the call may return SELA_HIP_ECAPACITY. */
+/* frames_out must hold sela_hip_encode_bound_bytes() or the call may return SELA_HIP_ECAPACITY.
+ * Large batches run as a chunked pipeline on three library-owned streams (copy in / kernels / copy out
+ * overlapped); results are identical to one call on the whole batch. */
 int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel,
     uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out /* [n_frames+1] */);
 int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels,
