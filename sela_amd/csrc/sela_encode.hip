@@ -29,7 +29,7 @@ namespace sela {
 //                        E[m] = c[2m], O[m] = c[2m+1], each with kPadC zeros in front (lags reach
 //                        back before the block start; x + (+-0) is exact) and 2 behind.
 // Phase B (after the autocorrelation c[] is dead): the same bytes hold
-//                        [0, 8992)      biased samples s' = s + 2^17 with 128 words of bias in front
+//                        [0, 8992)      samples s with 128 zero words ("no sample") in front
 //                                       (FIR warm-up: "no sample" == 0), index i stored at i + i/32
 //                        [8992, ...)    first the small analysis arrays (ac, k, t, a, q), later the
 //                                       packed residue words
@@ -47,10 +47,9 @@ constexpr int kRingLen = 2 * kRingHalf + 64;          // doubles (4608 bytes, a 
 constexpr int kRingsPerXcd = 512;                      // >= blocks resident on one XCD (9 per CU x 32 CUs)
 constexpr int kXcds = 8;
 constexpr int kPadS = 128;
-constexpr int kSBufWords = (kPadS + kBlock) / 32 * 33; // biased samples, one pad word per 32: 2244 words
+constexpr int kSBufWords = (kPadS + kBlock) / 32 * 33; // samples, one pad word per 32: 2244 words
 constexpr int kSmallBase = 8992;                      // >= kSBufWords * 4 = 8976, 16-byte aligned
 constexpr int kBigBytes = kSmallBase + 8832;          // >= 2 * 1090 * 8 = 17440 and room for the residue words
-constexpr uint32_t kBias = 1u << 17;                  // |ch0 - ch1| <= 65535 < 2^17
 static_assert(kSmallBase + kResWordsCap * 4 <= kBigBytes, "packed residue words must fit behind the sample buffer");
 static_assert(kSBufWords * 4 <= kSmallBase && kSmallBase % 16 == 0, "sample buffer must end below the analysis arrays");
 static_assert(kBigBytes >= 2 * kParityLen * 8, "the FP64 parity arrays must fit");
@@ -283,27 +282,32 @@ __device__ __forceinline__ void ac_steps_tail(const AcFetch& f, double& A, doubl
 
 // Taps j0 + JJ + 1 .. j0 + 32 of the residue FIR (see k_encode_blocks), stopping at `order`.  JJ is a
 // template parameter so that the 32-register sample window is addressed statically: tap j uses
-// win[(t - j) mod 32] = s'[32 lane + t - j] and loads the one new element s'[32 lane - j].
+// win[(t - j) mod 32] = s[32 lane + t - j] and loads the one new element s[32 lane - j].
+// a = a_hi 2^32 + a_lo with a_lo = (int32)a:  a s mod 2^64 = a_lo s [v_mad_i64_i32] + (a_hi s mod 2^32) << 32;
+// a_hi is zero -- and its 32 multiply-adds are skipped, a wave-uniform branch -- whenever the Q35
+// coefficient fits 32 signed bits, i.e. |coefficient| < 1/16: 85 % of the taps on the bench track.
 template <int JJ>
-__device__ __forceinline__ void fir_taps(int j0, int order, int lane, const uint32_t* sT, const int64_t* a,
-    uint32_t (&win)[kPerLane], uint64_t (&acc)[kPerLane], uint64_t (&hi)[kPerLane], uint64_t& sum_a)
+__device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int32_t* sT, const int64_t* a,
+    int32_t (&win)[kPerLane], int64_t (&acc)[kPerLane], int64_t (&hi)[kPerLane])
 {
     const int j = j0 + JJ + 1;
     if (j > order)
         return;
     const uint64_t aj = read_first_lane((uint64_t)a[j]);
-    const uint32_t a_lo = (uint32_t)aj, a_hi = (uint32_t)(aj >> 32);
-    sum_a += aj;
+    const int32_t a_lo = (int32_t)(uint32_t)aj;
+    const int32_t a_hi = (int32_t)(uint32_t)((aj - (uint64_t)(int64_t)a_lo) >> 32);
     const int e = kPadS + 32 * lane - j;
     win[(32 - JJ - 1) & 31] = sT[e + (e >> 5)];
 #pragma unroll
-    for (int t = 0; t < kPerLane; t++) {
-        const uint32_t sp = win[(t - JJ - 1) & 31]; // s'[32 lane + t - j]
-        acc[t] += (uint64_t)a_lo * sp;
-        hi[t] += (uint64_t)a_hi * sp;
+    for (int t = 0; t < kPerLane; t++)
+        acc[t] += (int64_t)a_lo * (int64_t)win[(t - JJ - 1) & 31]; // s[32 lane + t - j]
+    if (a_hi != 0) {
+#pragma unroll
+        for (int t = 0; t < kPerLane; t++)
+            hi[t] += (int64_t)a_hi * (int64_t)win[(t - JJ - 1) & 31]; // (only the low 32 bits are used)
     }
     if constexpr (JJ < 31)
-        fir_taps<JJ + 1>(j0, order, lane, sT, a, win, acc, hi, sum_a);
+        fir_taps<JJ + 1>(j0, order, lane, sT, a, win, acc, hi);
 }
 
 // kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts
@@ -622,48 +626,44 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     SELA_STAMP(7);
     // ---- residues (src/lpc/residue_generator.cpp:98-119) -----------------------------------------------
     // r[i] = s[i] - (int32)((2^34 + sum_{j=1..order} a[j] s[i-j]) >> 35), samples before the block
-    // count as absent.  Integer wrap-around arithmetic is associative, so the taps are accumulated
-    // per sample in any order.  To keep the multiplier operand unsigned the samples are biased,
-    // s' = s + 2^17 >= 0 (pad = 2^17 == "sample 0"), and 2^17 * sum(a) is removed at the end:
-    //   a * s' mod 2^64 = lo32(a) * s'  +  (hi32(a) * s' mod 2^32) << 32      (two v_mad_u64_u32).
+    // count as absent (0).  Integer wrap-around arithmetic is associative, so the taps are accumulated
+    // per sample in any order.
     //
     // Lane l owns the 32 CONSECUTIVE samples 32l .. 32l+31 (the layout the Rice packer wants) and
-    // slides a 32-register window over its history: tap j needs s'[32l + t - j] for t = 0..31, i.e.
+    // slides a 32-register window over its history: tap j needs s[32l + t - j] for t = 0..31, i.e.
     // the window of tap j-1 moved down by one, so every tap costs ONE new LDS word per lane (index
-    // i stored at i + i/32: the lanes' 32-word strides fall on different banks) and 64 multiply-adds.
-    // The tap loop is unrolled by 32 so that the window registers are addressed statically.
-    uint32_t* const sT = reinterpret_cast<uint32_t*>(big);
+    // i stored at i + i/32: the lanes' 32-word strides fall on different banks) and 32 multiply-adds
+    // (64 for the few large coefficients, see fir_taps).  The tap loop is unrolled by 32 so that the
+    // window registers are addressed statically.
+    int32_t* const sT = reinterpret_cast<int32_t*>(big);
     for (int m = lane; m < kPadS; m += 64)
-        sT[m + (m >> 5)] = kBias;
+        sT[m + (m >> 5)] = 0;
 #pragma unroll
     for (int t = 0; t < kPerLane; t++) {
         const int i = kPadS + lane + 64 * t;
-        sT[i + (i >> 5)] = (uint32_t)(s[t] + (int32_t)kBias);
+        sT[i + (i >> 5)] = s[t];
     }
     wave_sync();
 
     uint32_t ru[kPerLane]; // zig-zagged residues of samples 32 lane + t
     bool wide = false;
     {
-        uint32_t win[kPerLane], own[kPerLane];
-        const uint32_t* mine_s = sT + (kPadS + 32 * lane) + ((kPadS + 32 * lane) >> 5); // &s'[32 l], 32 words without a pad inside
+        int32_t win[kPerLane], own[kPerLane];
+        const int32_t* mine_s = sT + (kPadS + 32 * lane) + ((kPadS + 32 * lane) >> 5); // &s[32 l], 32 words without a pad inside
 #pragma unroll
         for (int t = 0; t < kPerLane; t++)
             own[t] = win[t] = mine_s[t];
-        uint64_t acc[kPerLane], hi[kPerLane];
+        int64_t acc[kPerLane], hi[kPerLane];
 #pragma unroll
         for (int t = 0; t < kPerLane; t++)
-            acc[t] = 0, hi[t] = 0;
-        uint64_t sum_a = 0;
+            acc[t] = (int64_t)1 << (SELA_Q_SHIFT - 1), hi[t] = 0;
 #pragma unroll 1
         for (int j0 = 0; j0 < order; j0 += 32)
-            fir_taps<0>(j0, order, lane, sT, sm->a, win, acc, hi, sum_a);
-        const uint64_t corr = ((uint64_t)1 << (SELA_Q_SHIFT - 1)) - (sum_a << 17);
+            fir_taps<0>(j0, order, lane, sT, sm->a, win, acc, hi);
 #pragma unroll
         for (int t = 0; t < kPerLane; t++) {
-            const uint64_t total = acc[t] + (hi[t] << 32) + corr;
-            const int32_t st = (int32_t)(own[t] - kBias);
-            const int32_t rt = (int32_t)((uint32_t)st - (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT));
+            const uint64_t total = (uint64_t)acc[t] + ((uint64_t)hi[t] << 32);
+            const int32_t rt = (int32_t)((uint32_t)own[t] - (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT));
             ru[t] = zigzag32(rt);
             wide |= (rt >= (1 << 30)) || (rt < -(1 << 30)); // zig-zag would not fit 32 bits
         }
