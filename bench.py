@@ -82,6 +82,15 @@ def cpu_baseline(pcm, repeats_target_s=12.0, gpu_frames=None, gpu_offsets=None, 
     }
 
 
+def _flush_c_stdio():
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def measured_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN/traffic.json,
     written by tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes of this same command,
@@ -119,10 +128,13 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SELA_BENCH_FORCE_EXCHANGE") == "1":  # (the override runs the N>1 code path on one GPU)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     lib = capi.lib()  # raises if the HIP library is missing: there is no CPU fallback
@@ -131,25 +143,22 @@ def main():
     pcm = torch.from_numpy(pcm_host).cuda()
     enc = codec.Encoder(n_frames, CHANNELS)
     dec = codec.Decoder(n_frames, CHANNELS)
-    all_sizes = torch.zeros(world * n_frames, dtype=torch.int64, device="cuda")
-    my_sizes = torch.zeros(n_frames, dtype=torch.int64, device="cuda")
-    layout = torch.zeros(world * n_frames, dtype=torch.int64, device="cuda")
+    all_ends = torch.zeros(world * n_frames, dtype=torch.int64, device="cuda")
     exchange = torch.cuda.Stream() if dist is not None else None
 
     def step():
         out = enc.encode(pcm)
         if dist is not None:
-            # the path's only exchange: per-frame compressed sizes of every rank, so that
-            # each rank knows where its frames land in the job's output stream (sela_amd/sharding.py);
-            # 8 bytes x frames, latency bound -- RCCL over xGMI.  Decoding the local frames does not need
-            # the layout, so the exchange runs beside it on its own stream and is joined at the end of
-            # the step (it is still inside the timed region).
-            main = torch.cuda.current_stream()
-            torch.sub(out.offsets[1:], out.offsets[:-1], out=my_sizes)
-            exchange.wait_stream(main)
+            # the path's only exchange: every rank learns where every frame of the job
+            # lands in the output stream.  The encoder has already scanned its own frame sizes, so what is
+            # gathered are each rank's local frame END offsets (8 bytes x frames per rank, latency bound --
+            # RCCL over xGMI); a frame's global position is its local offset plus the totals of the ranks
+            # before it, which is O(ranks) arithmetic on the gathered array (sela_amd/sharding.py does the
+            # same with sizes).  Decoding the local frames does not need the layout, so the collective
+            # runs beside it on its own stream and is joined at the end of the step, inside the timed region.
+            exchange.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(exchange):
-                dist.all_gather_into_tensor(all_sizes, my_sizes)
-                torch.cumsum(all_sizes, 0, out=layout)
+                dist.all_gather_into_tensor(all_ends, out.offsets[1:])
         back = dec.decode(out.frames, out.offsets, n_frames)
         if dist is not None:
             torch.cuda.current_stream().wait_stream(exchange)
@@ -246,10 +255,12 @@ def main():
             g_frames, g_offsets = out.to_host()
             result["cpu_baseline"] = cpu_baseline(pcm_host, gpu_frames=g_frames, gpu_offsets=g_offsets, gpu_decoded=back.cpu().numpy())
             assert result["cpu_baseline"]["bit_exact_vs_gpu"], "GPU output differs from the CPU reference"
-        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()  # RCCL prints its version banner through C stdio; keep the JSON line the LAST line of stdout
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
