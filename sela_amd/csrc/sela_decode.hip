@@ -335,11 +335,13 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
     uint32_t flags = 0;
     const bool store = ok && in_range;
 
-    // coefficient stream: starts 3 bytes into the aligned word at p + 4 (behind word count + order);
-    // its last word shares an aligned word with the residue k, hence cw + 1 aligned words.
+    // coefficient stream: starts 3 bytes into the aligned word at p + 4 (behind word count + order); cw
+    // words later come the 5 bytes of the residue header and then, aligned again, the residue words at
+    // aligned word cw + 2.  The first chunk opens ONE tile row over both streams (one refill less).
+    StreamReader r;
+    uint32_t res_origin = 0; // bit position of the residue stream within the row the reader was opened on
     if (v_begin == 0) {
-        StreamReader r;
-        reader_open(r, frames + wg_base, wg_size, (uint32_t)(frame_offsets[f] - wg_base + p + 4), ok ? cw + 1 : 0, 24, tile, lane);
+        reader_open(r, frames + wg_base, wg_size, (uint32_t)(frame_offsets[f] - wg_base + p + 4), ok ? cw + 2 + rw : 0, 24, tile, lane);
         const uint32_t kmask = ck ? (0xFFFFFFFFu >> (32 - ck)) : 0u;
         int32_t* qo = q_out + (size_t)g * kQStride;
         uint32_t max_order = order;
@@ -362,13 +364,15 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
         }
         if (r.bp > 24 + 32 * cw)
             flags |= SELA_HIP_FLAG_RICE_OVERRUN;
+        res_origin = ok ? 32 * (cw + 2) : 0u;
+        r.bp = res_origin;
+    } else {
+        reader_open(r, frames + wg_base, wg_size, (uint32_t)(frame_offsets[f] - wg_base + p + 12 + 4 * (uint64_t)cw), rw, ok ? bit_pos[g] : 0u,
+            tile, lane);
     }
     // residue stream (aligned).  Words are staged in LDS, 32 per lane, and written out as full
     // 128-byte lines (8 lanes per subframe row) instead of 64 scattered stores per value.
     {
-        StreamReader r;
-        const uint32_t start_bit = v_begin == 0 ? 0u : bit_pos[g];
-        reader_open(r, frames + wg_base, wg_size, (uint32_t)(frame_offsets[f] - wg_base + p + 12 + 4 * (uint64_t)cw), rw, ok ? start_bit : 0u, tile, lane);
         const uint32_t kmask = rk ? (0xFFFFFFFFu >> (32 - rk)) : 0u;
         const bool k_fits = rk <= kPackMaxK;
         const unsigned long long store_mask = __ballot(store);
@@ -428,10 +432,10 @@ __global__ __launch_bounds__(64) void k_parse_subframes(const uint8_t* __restric
             pc[3] = r.n_retile;                                             // ... and their number
             pc[4] = (uint64_t)t_store;                                      // staged stores
         }
-        if (v_begin + v_count == (uint32_t)kBlock && r.bp > 32 * rw)
+        if (v_begin + v_count == (uint32_t)kBlock && r.bp > res_origin + 32 * rw)
             flags |= SELA_HIP_FLAG_RICE_OVERRUN;
         if (in_range) {
-            bit_pos[g] = r.bp;
+            bit_pos[g] = r.bp - res_origin;
             res_raw[g] = v_begin == 0 ? raw_blocks : res_raw[g] | raw_blocks;
         }
     }
