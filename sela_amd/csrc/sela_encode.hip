@@ -23,18 +23,24 @@
 
 namespace sela {
 
-// ---- LDS plan of k_encode_blocks (one 64-lane workgroup) -----------------------------------------
-// Phase A (analysis):  centred samples c[] as FP64, split by index parity so that the per-lane
-//                      operand of the lag-pair autocorrelation is a conflict-free ds_read_b64:
-//                        E[m] = c[2m], O[m] = c[2m+1], each with kPadC zeros in front (lags reach
-//                        back before the block start; x + (+-0) is exact) and 2 behind.
+// ---- LDS plan of k_encode_blocks (one 64-lane workgroup): 12.1 KB, twelve blocks per CU --------------
+// Phase A (analysis):  samples as FP64 (x, later the centred c), split by index parity so that the
+//                      per-lane operand of the lag-pair autocorrelation is a conflict-free LDS read:
+//                        E[m] = c[2m], O[m] = c[2m+1].  Only HALF a block is resident at a time: each
+//                      parity array holds entries [lo - 64, lo + 576) for lo = 0, then lo = 512 (the 64
+//                      in front are the lags' reach back -- zeros before the block starts, x + (+-0)
+//                      is exact -- the 64 behind are what is fetched ahead); the second half is
+//                      recomputed from the samples in registers when the first is consumed.
 // Phase B (after the autocorrelation c[] is dead): the same bytes hold
 //                        [0, 8992)      samples s with 128 zero words ("no sample") in front
-//                                       (FIR warm-up: "no sample" == 0), index i stored at i + i/32
-//                        [8992, ...)    first the small analysis arrays (ac, k, t, a, q), later the
-//                                       packed residue words
+//                                       (FIR warm-up: "no sample" == 0), index i stored at i + i/32;
+//                                       later the packed residue words
+//                        [8992, 12000)  the small analysis arrays (ac, k, a, q)
 constexpr int kPadC = 64;
-constexpr int kParityLen = kPadC + kBlock / 2 + 2;   // 1090 doubles
+constexpr int kHalfEntries = kBlock / 4;                 // 512 entries (1024 samples) of each parity per half
+constexpr int kParityLen = kPadC + kHalfEntries + 64;    // 640 doubles
+constexpr int kLastT0 = (kHalfEntries + 64) / 32 - 1;    // 17: first half holds samples lane + 64 t, t <= 17
+constexpr int kFirstT1 = (kHalfEntries - kPadC) / 32;    // 14: second half holds t >= 14
 // Scalar-operand scratch: each running block borrows a ring of 2 x 128 centred samples (+ a copy of the
 // first values of half A behind half B, so that a fetch may run across the wrap) from a pool that is
 // private to its XCD -- 512 rings per XCD -- so the ring stays in that XCD's L2 and the scratch never
@@ -49,8 +55,8 @@ constexpr int kXcds = 8;
 constexpr int kPadS = 128;
 constexpr int kSBufWords = (kPadS + kBlock) / 32 * 33; // samples, one pad word per 32: 2244 words
 constexpr int kSmallBase = 8992;                      // >= kSBufWords * 4 = 8976, 16-byte aligned
-constexpr int kBigBytes = kSmallBase + 8832;          // >= 2 * 1090 * 8 = 17440 and room for the residue words
-static_assert(kSmallBase + kResWordsCap * 4 <= kBigBytes, "packed residue words must fit behind the sample buffer");
+constexpr int kBigBytes = kSmallBase + 3008;          // 12000
+static_assert(kResWordsCap * 4 <= kSmallBase, "packed residue words must fit the dead sample buffer");
 static_assert(kSBufWords * 4 <= kSmallBase && kSmallBase % 16 == 0, "sample buffer must end below the analysis arrays");
 static_assert(kBigBytes >= 2 * kParityLen * 8, "the FP64 parity arrays must fit");
 
@@ -75,6 +81,8 @@ __device__ __forceinline__ void or_bits(uint32_t* buf, uint32_t pos, uint32_t v,
 // Append one Golomb-Rice codeword (src/rice/rice_encoder.cpp:41-53): u >> k ones, a zero, then the
 // low k bits MSB first.  Stream bit t lives at bit t%32 of word t/32, so the MSB-first remainder is
 // the bit-reversed remainder in stream order.
+__device__ __attribute__((noinline)) uint32_t put_long_codeword(uint32_t* buf, uint32_t pos, uint32_t u, uint32_t k);
+
 __device__ __forceinline__ uint32_t put_codeword(uint32_t* buf, uint32_t pos, uint32_t u, uint32_t k)
 {
     uint32_t ones = u >> k;
@@ -95,6 +103,11 @@ __device__ __forceinline__ uint32_t put_codeword(uint32_t* buf, uint32_t pos, ui
         pos += k;
     }
     return pos;
+}
+
+__device__ __attribute__((noinline)) uint32_t put_long_codeword(uint32_t* buf, uint32_t pos, uint32_t u, uint32_t k)
+{
+    return put_codeword(buf, pos, u, k);
 }
 
 // rice::RiceEncoder::calculateOptimumRiceParam (src/rice/rice_encoder.cpp:20-33) for the values
@@ -172,18 +185,18 @@ struct MeanFetch {
 #define SELA_MEAN_STR(x) SELA_MEAN_STR2(x)
 #define SELA_MEAN_ISSUE(F, addr, OFF, sum)                                                    \
     asm volatile("ds_read_b128 %0, %9 offset:" #OFF "+0\n\t"                                    \
-                 "ds_read_b128 %4, %9 offset:" #OFF "+8720\n\t"                                 \
+                 "ds_read_b128 %4, %9 offset:" #OFF "+5120\n\t"                                 \
                  "ds_read_b128 %1, %9 offset:" #OFF "+16\n\t"                                   \
-                 "ds_read_b128 %5, %9 offset:" #OFF "+8736\n\t"                                 \
+                 "ds_read_b128 %5, %9 offset:" #OFF "+5136\n\t"                                 \
                  "ds_read_b128 %2, %9 offset:" #OFF "+32\n\t"                                   \
-                 "ds_read_b128 %6, %9 offset:" #OFF "+8752\n\t"                                 \
+                 "ds_read_b128 %6, %9 offset:" #OFF "+5152\n\t"                                 \
                  "ds_read_b128 %3, %9 offset:" #OFF "+48\n\t"                                   \
-                 "ds_read_b128 %7, %9 offset:" #OFF "+8768"                                      \
+                 "ds_read_b128 %7, %9 offset:" #OFF "+5168"                                      \
                  : "=&v"(F.e0), "=&v"(F.e1), "=&v"(F.e2), "=&v"(F.e3), "=&v"(F.o0), "=&v"(F.o1), "=&v"(F.o2), \
                  "=&v"(F.o3), "+v"(sum)                                                         \
                  : "v"(addr)                                                                    \
                  : "memory")
-static_assert(kParityLen * 8 == 8720, "SELA_MEAN_ISSUE hard-codes the E -> O distance");
+static_assert(kParityLen * 8 == 5120, "SELA_MEAN_ISSUE hard-codes the E -> O distance");
 
 __device__ __forceinline__ void mean_wait(MeanFetch& f, double& sum)
 {
@@ -288,7 +301,7 @@ __device__ __forceinline__ void ac_steps_tail(const AcFetch& f, double& A, doubl
 // coefficient fits 32 signed bits, i.e. |coefficient| < 1/16: 85 % of the taps on the bench track.
 template <int JJ>
 __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int32_t* sT, const int64_t* a,
-    int32_t (&win)[kPerLane], int64_t (&acc)[kPerLane], int64_t (&hi)[kPerLane])
+    int32_t (&win)[kPerLane], int64_t (&acc)[kPerLane], uint32_t (&hi)[kPerLane])
 {
     const int j = j0 + JJ + 1;
     if (j > order)
@@ -301,10 +314,16 @@ __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int3
 #pragma unroll
     for (int t = 0; t < kPerLane; t++)
         acc[t] += (int64_t)a_lo * (int64_t)win[(t - JJ - 1) & 31]; // s[32 lane + t - j]
-    if (a_hi != 0) {
+    if (a_hi != 0) { // only the low 32 bits of a_hi s matter; both factors fit 24 bits unless |a| >= 2^55
+        if (((a_hi << 8) >> 8) == a_hi) {
 #pragma unroll
-        for (int t = 0; t < kPerLane; t++)
-            hi[t] += (int64_t)a_hi * (int64_t)win[(t - JJ - 1) & 31]; // (only the low 32 bits are used)
+            for (int t = 0; t < kPerLane; t++)
+                asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(hi[t]) : "s"(a_hi), "v"(win[(t - JJ - 1) & 31]));
+        } else {
+#pragma unroll 1
+            for (int t = 0; t < kPerLane; t++) // (degenerate predictor: not worth 32 more unrolled instructions per tap)
+                hi[t] += (uint32_t)a_hi * (uint32_t)win[(t - JJ - 1) & 31];
+        }
     }
     if constexpr (JJ < 31)
         fir_taps<JJ + 1>(j0, order, lane, sT, a, win, acc, hi);
@@ -319,7 +338,7 @@ __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int3
     } while (0)
 
 template <int kMode>
-__global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
     double* __restrict__ rings, uint32_t* __restrict__ ring_owner, uint32_t ticket, sela_hip_trace* __restrict__ trace,
     uint64_t* __restrict__ phase_cycles)
@@ -343,8 +362,10 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     const uint32_t block_id = frame * n_sig + sig;
     uint32_t flags = 0;
 
-    double* const E = reinterpret_cast<double*>(big) + kPadC;             // E[-64 .. 1025]
-    double* const O = reinterpret_cast<double*>(big) + kParityLen + kPadC; // O[-64 .. 1025]
+    double* const E = reinterpret_cast<double*>(big) + kPadC;              // first half: E[-64 .. 575]
+    double* const O = reinterpret_cast<double*>(big) + kParityLen + kPadC; // first half: O[-64 .. 575]
+    double* const E1 = E - kHalfEntries;                                   // second half: E1[448 .. 1087]
+    double* const O1 = O - kHalfEntries;
     SmallArrays* const sm = reinterpret_cast<SmallArrays*>(big + kSmallBase);
 
     // ---- load this signal: s[t] = sample lane + 64 t  (coalesced) ---------------------------------
@@ -368,18 +389,15 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
 
     // ---- quantizeSamples (src/lpc/residue_generator.cpp:12-18): x = s / 32767 ----------------------
     // sample i = lane + 64 t has parity lane & 1 and half-index (lane >> 1) + 32 t.
-    double* const mine = (lane & 1) ? O : E;
+    double* const mine = (lane & 1) ? O : E;    // first half
+    double* const mine1 = (lane & 1) ? O1 : E1; // second half
     const int half = lane >> 1;
     for (int m = lane; m < kPadC; m += 64) { // zero pads in front of both parity arrays
         E[m - kPadC] = 0.0;
         O[m - kPadC] = 0.0;
     }
-    if (lane < 2) {
-        E[kBlock / 2 + lane] = 0.0;
-        O[kBlock / 2 + lane] = 0.0;
-    }
 #pragma unroll
-    for (int t = 0; t < kPerLane; t++)
+    for (int t = 0; t <= kLastT0; t++)
         mine[half + 32 * t] = scale_sample(s[t]);
     wave_sync();
 
@@ -392,17 +410,25 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     // left to the compiler each batch of reads is issued only after the previous batch's last add.
     __builtin_amdgcn_s_setprio(3);
     double sum = 0.0;
-    {
-        uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)E;
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        if (h == 1) { // the chain has consumed entries 0 .. 511: bring in the second half
+            wave_sync();
+#pragma unroll
+            for (int t = kFirstT1; t < kPerLane; t++)
+                mine1[half + 32 * t] = scale_sample(s[t]);
+            wave_sync();
+        }
+        uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)E; // entry lo of either half
         MeanFetch f0, f1;
         SELA_MEAN_ISSUE(f0, addr, 0, sum);
 #pragma unroll 1
-        for (int m0 = 0; m0 < kBlock / 2; m0 += 16) {
+        for (int m0 = 0; m0 < kHalfEntries; m0 += 16) {
             mean_wait(f0, sum);
             SELA_MEAN_ISSUE(f1, addr, 64, sum);
             mean_steps(f0, sum);
             mean_wait(f1, sum);
-            SELA_MEAN_ISSUE(f0, addr, 128, sum); // (the last one reads 8 values past both arrays: in bounds, unused)
+            SELA_MEAN_ISSUE(f0, addr, 128, sum); // (the last one reads 8 values past the half: in bounds, unused)
             mean_steps(f1, sum);
             addr += 128;
         }
@@ -412,10 +438,15 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     __builtin_amdgcn_s_setprio(0);
 
     SELA_STAMP(2);
-    // c[j] = x[j] - mean, in place (same value at every use)
+    // c[j] = x[j] - mean (same value at every use): the first half again
+    wave_sync();
+    for (int m = lane; m < kPadC; m += 64) { // (the second half of x overwrote the zero pads)
+        E[m - kPadC] = 0.0;
+        O[m - kPadC] = 0.0;
+    }
 #pragma unroll
-    for (int t = 0; t < kPerLane; t++)
-        mine[half + 32 * t] = mine[half + 32 * t] - mean;
+    for (int t = 0; t <= kLastT0; t++)
+        mine[half + 32 * t] = scale_sample(s[t]) - mean;
     wave_sync();
 
     SELA_STAMP(3);
@@ -449,17 +480,17 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
             read_first_lane((uint64_t)(rings + ((size_t)xcc * kRingsPerXcd + slot) * kRingLen)));
         __attribute__((address_space(1))) double* const ring_g = (__attribute__((address_space(1))) double*)ring;
         // samples [256 k, 256 k + 256) -> half k & 1 (natural order; lane's element i = lane + 64 t)
-        auto store_chunk = [&](int k) {
+        auto store_chunk = [&](int k, const double* resident) { // resident = mine or mine1, whichever holds chunk k
 #pragma unroll
             for (int t = 0; t < kRingHalf / 64; t++) {
-                const double c = mine[half + 32 * (t + (kRingHalf / 64) * k)];
+                const double c = resident[half + 32 * (t + (kRingHalf / 64) * k)];
                 ring_g[(k & 1) * kRingHalf + lane + 64 * t] = c;
                 if (t == 0 && !(k & 1))
                     ring_g[2 * kRingHalf + lane] = c; // what a fetch running off the end of half B must find
             }
         };
-        store_chunk(0);
-        store_chunk(1);
+        store_chunk(0, mine);
+        store_chunk(1, mine);
         // the stores are in L2 once vmcnt drains (the scalar loads are glc: they bypass the scalar
         // cache, which may hold older contents of the ring)
         asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv" ::: "memory");
@@ -478,10 +509,22 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
         // issued a whole trip ahead, its vector half after the first two steps of the running trip,
         // once the registers it overwrites are dead.  (The last fetch of the block lands behind the
         // ring's half B and in LDS behind the parity arrays; it is never used.)
+        constexpr int kSwitch = kBlock / 2 / kRingHalf; // chunk at which the second half of c[] takes over (8)
 #pragma unroll 1
         for (int k = 0; k < kBlock / kRingHalf; k++) {
+            if (k == kSwitch) {
+                // steps 0 .. 1023 are done, the window fetch in flight was issued from the first half
+                // (LDS serves a wave's reads and writes in order): recompute c[896 ..] over it
+                wave_sync();
+#pragma unroll
+                for (int t = kFirstT1; t < kPerLane; t++)
+                    mine1[half + 32 * t] = scale_sample(s[t]) - mean;
+                wave_sync();
+                addr_e -= kHalfEntries * 8;
+                addr_o -= kHalfEntries * 8;
+            }
             if (k >= 1 && k + 1 < kBlock / kRingHalf)
-                store_chunk(k + 1); // over chunk k - 1, which is consumed
+                store_chunk(k + 1, k >= kSwitch ? mine1 : mine); // over chunk k - 1, which is consumed
 #pragma unroll 1
             for (int it = 0; it < kRingHalf / 32; it++) {
                 if (it == kRingHalf / 32 - 1) // this iteration's prefetch crosses into chunk k + 1
@@ -648,12 +691,13 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     uint32_t ru[kPerLane]; // zig-zagged residues of samples 32 lane + t
     bool wide = false;
     {
-        int32_t win[kPerLane], own[kPerLane];
+        int32_t win[kPerLane];
         const int32_t* mine_s = sT + (kPadS + 32 * lane) + ((kPadS + 32 * lane) >> 5); // &s[32 l], 32 words without a pad inside
 #pragma unroll
         for (int t = 0; t < kPerLane; t++)
-            own[t] = win[t] = mine_s[t];
-        int64_t acc[kPerLane], hi[kPerLane];
+            win[t] = mine_s[t];
+        int64_t acc[kPerLane];
+        uint32_t hi[kPerLane];
 #pragma unroll
         for (int t = 0; t < kPerLane; t++)
             acc[t] = (int64_t)1 << (SELA_Q_SHIFT - 1), hi[t] = 0;
@@ -663,7 +707,7 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
 #pragma unroll
         for (int t = 0; t < kPerLane; t++) {
             const uint64_t total = (uint64_t)acc[t] + ((uint64_t)hi[t] << 32);
-            const int32_t rt = (int32_t)((uint32_t)own[t] - (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT));
+            const int32_t rt = (int32_t)((uint32_t)mine_s[t] - (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT));
             ru[t] = zigzag32(rt);
             wide |= (rt >= (1 << 30)) || (rt < -(1 << 30)); // zig-zag would not fit 32 bits
         }
@@ -710,8 +754,8 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
     SELA_STAMP(10);
     // ---- pack the residue stream ----------------------------------------------------------------------
     // Lane l already owns the 32 consecutive residues 32l .. 32l+31: scan the per-lane bit counts, then
-    // every lane appends its codewords.  The analysis arrays die here: out_words overlays them.
-    uint32_t* const out_words = reinterpret_cast<uint32_t*>(big + kSmallBase);
+    // every lane appends its codewords.  The sample buffer is dead: out_words overlays it.
+    uint32_t* const out_words = reinterpret_cast<uint32_t*>(big); // over the dead sample buffer
     for (uint32_t w = lane; w < res_words; w += 64)
         out_words[w] = 0;
     uint32_t lane_bits = 0;
@@ -720,10 +764,20 @@ __global__ __launch_bounds__(64) void k_encode_blocks(const int16_t* __restrict_
         lane_bits += (ru[t] >> res_k) + 1 + res_k;
     wave_sync();
     if (res_words) {
+        // fully unrolled: the residues are addressed statically and stay in registers; codewords longer
+        // than a word go through an out-of-line helper
         uint32_t pos = wave_exclusive_scan(lane_bits, lane);
-#pragma unroll 4
-        for (int t = 0; t < kPerLane; t++)
-            pos = put_codeword(out_words, pos, ru[t], res_k);
+#pragma unroll
+        for (int t = 0; t < kPerLane; t++) {
+            const uint32_t u = ru[t], ones = u >> res_k, len = ones + 1 + res_k;
+            if (len <= 32) {
+                const uint32_t rem = res_k ? __brev(u << (32 - res_k)) : 0u; // low k bits of u, reversed
+                or_bits(out_words, pos, ((1u << ones) - 1u) | (rem << (ones + 1)), len);
+                pos += len;
+            } else {
+                pos = put_long_codeword(out_words, pos, u, res_k);
+            }
+        }
     }
     wave_sync();
 
