@@ -48,8 +48,8 @@ constexpr int kFirstT1 = (kHalfEntries - kPadC) / 32;    // 14: second half hold
 // workspace used) into its owner word: whoever gets back anything else owns it; it is handed back by
 // writing 0.  Stale or uninitialised owner words therefore read as "free" and nothing has to be
 // cleared between launches.
-constexpr int kRingHalf = 128;
-constexpr int kRingLen = 2 * kRingHalf + 64;          // doubles (4608 bytes, a multiple of 64)
+constexpr int kRingHalf = 64;
+constexpr int kRingLen = 2 * kRingHalf + 64;          // doubles (a multiple of 8, i.e. of 64 bytes)
 constexpr int kRingsPerXcd = 512;                      // >= blocks resident on one XCD (9 per CU x 32 CUs)
 constexpr int kXcds = 8;
 constexpr int kPadS = 128;
@@ -485,8 +485,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for (int t = 0; t < kRingHalf / 64; t++) {
                 const double c = resident[half + 32 * (t + (kRingHalf / 64) * k)];
                 ring_g[(k & 1) * kRingHalf + lane + 64 * t] = c;
-                if (t == 0 && !(k & 1))
-                    ring_g[2 * kRingHalf + lane] = c; // what a fetch running off the end of half B must find
+                if (t == 0 && !(k & 1) && lane < 16)
+                    ring_g[2 * kRingHalf + lane] = c; // the 16 values a fetch running off the end of half B must find
             }
         };
         store_chunk(0, mine);
