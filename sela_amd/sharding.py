@@ -85,3 +85,53 @@ def encode_sharded(pcm_local, n_frames_total: int, rank: int, world: int, encode
     out = encoder.encode(pcm_local)
     layout = gather_frame_sizes(out.offsets, n_frames_total, rank, world, group)
     return out, layout
+
+
+# ---- many tracks in one job (BASELINE.json configs[3]: 100 tracks over 8 GPUs) ----------------------------
+# The job's frames are the tracks' frames back to back; ranks still own contiguous ranges of that one
+# index space, so a rank's range may start or end in the middle of a track.  Each track becomes its own
+# .sela file: 15-byte header (src/file/sela_file.cpp:108-114) + that track's frames.
+SELA_HEADER_BYTES = 15
+
+
+@dataclass
+class TrackPiece:
+    """The part of one track that one rank holds."""
+    track: int
+    first_frame: int       # within the track
+    n_frames: int
+    job_frame: int         # index of first_frame in the job's flattened frame space
+    file_offset: int       # where the piece's bytes go in the track's .sela file (behind its header)
+    n_bytes: int
+
+
+def track_starts(track_frames: List[int]) -> np.ndarray:
+    """Job-level index of every track's first frame (+ the total at the end)."""
+    out = np.zeros(len(track_frames) + 1, np.int64)
+    np.cumsum(np.asarray(track_frames, np.int64), out=out[1:])
+    return out
+
+
+def rank_track_pieces(layout: FileLayout, track_frames: List[int], rank: int) -> List[TrackPiece]:
+    """Split the frame range of `rank` at track boundaries and place every piece in its track's file."""
+    starts = track_starts(track_frames)
+    assert int(starts[-1]) == len(layout.frame_sizes)
+    begin, end = layout.rank_ranges[rank]
+    pieces = []
+    t = int(np.searchsorted(starts, begin, side="right")) - 1
+    while begin < end:
+        while int(starts[t + 1]) <= begin:  # skip empty tracks
+            t += 1
+        stop = min(end, int(starts[t + 1]))
+        pieces.append(TrackPiece(
+            track=t, first_frame=begin - int(starts[t]), n_frames=stop - begin, job_frame=begin,
+            file_offset=SELA_HEADER_BYTES + int(layout.frame_offsets[begin] - layout.frame_offsets[int(starts[t])]),
+            n_bytes=int(layout.frame_offsets[stop] - layout.frame_offsets[begin])))
+        begin = stop
+    return pieces
+
+
+def sela_header(sample_rate: int, bits_per_sample: int, channels: int, n_frames: int) -> bytes:
+    import struct
+
+    return b"SeLa" + struct.pack("<IHBI", sample_rate, bits_per_sample, channels, n_frames)

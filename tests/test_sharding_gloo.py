@@ -89,3 +89,59 @@ def test_single_rank_layout():
 
     lay = sharding.gather_frame_sizes(np.array([0, 10, 30, 34], np.uint64), 3, 0, 1)
     assert lay.frame_sizes.tolist() == [10, 20, 4] and lay.rank_byte_range(0) == (0, 34)
+
+
+# ---- many tracks, one job (configs[3]) --------------------------------------------------------------------
+TRACKS = [(5, 44100), (0, 48000), (3, 48000), (7, 96000), (1, 44100)]  # (frames, sample rate): unequal, one empty
+
+
+def _multi_track_worker(rank, world, port, channels, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import oracle
+    from sela_amd import sharding
+    from sela_amd.synth import synth_frames
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames = [n for n, _ in TRACKS]
+        job = np.concatenate([synth_frames(n, channels, 40 + i) for i, n in enumerate(frames)])
+        b, e = sharding.my_range(len(job), rank, world)
+        blob, offs, _ = oracle().encode_frames(job[b:e], threads=1)
+        layout = sharding.gather_frame_sizes(torch.from_numpy(offs.astype(np.int64)), len(job), rank, world)
+        # the rank that owns nothing of a track never touches its file; rank 0 creates all files with headers
+        if rank == 0:
+            starts = sharding.track_starts(frames)
+            for i, (n, rate) in enumerate(TRACKS):
+                size = sharding.SELA_HEADER_BYTES + int(layout.frame_offsets[starts[i + 1]] - layout.frame_offsets[starts[i]])
+                with open(os.path.join(tmpdir, f"track{i}.sela"), "wb") as f:
+                    f.write(sharding.sela_header(rate, 16, channels, n))
+                    f.truncate(size)
+        dist.barrier()
+        local_base = int(layout.frame_offsets[b])
+        for piece in sharding.rank_track_pieces(layout, frames, rank):
+            lo = int(layout.frame_offsets[piece.job_frame]) - local_base
+            with open(os.path.join(tmpdir, f"track{piece.track}.sela"), "r+b") as f:
+                f.seek(piece.file_offset)
+                f.write(blob[lo: lo + piece.n_bytes].tobytes())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_many_tracks_sharded_across_ranks(tmp_path, world):
+    """Ranks own contiguous ranges of the flattened (track, frame) space, cut anywhere; every track's .sela
+    file (header + frames, src/file/sela_file.cpp:105-137) must equal what one process writes."""
+    from oracle_lib import oracle
+    from sela_amd import sharding
+    from sela_amd.synth import synth_frames
+
+    channels = 2
+    mp.spawn(_multi_track_worker, args=(world, _free_port(), channels, str(tmp_path)), nprocs=world, join=True)
+    for i, (n, rate) in enumerate(TRACKS):
+        blob, _, _ = oracle().encode_frames(synth_frames(n, channels, 40 + i), threads=1)
+        want = sharding.sela_header(rate, 16, channels, n) + blob.tobytes()
+        assert (tmp_path / f"track{i}.sela").read_bytes() == want, i
