@@ -144,7 +144,7 @@ def test_block_kats_as_frames(gpu, kats):
     assert np.array_equal(back, mono)
 
 
-@pytest.mark.parametrize("channels,track,n_frames", [(1, 11, 70), (2, 12, 150), (3, 13, 40), (6, 14, 20)])
+@pytest.mark.parametrize("channels,track,n_frames", [(1, 11, 70), (2, 12, 150), (3, 13, 40), (6, 14, 20), (9, 15, 5), (17, 16, 2)])
 def test_random_batches_match_oracle(gpu, channels, track, n_frames):
     o = oracle()
     pcm = synth_frames(n_frames, channels, track)
