@@ -41,7 +41,7 @@ constexpr int kHalfEntries = kBlock / 4;                 // 512 entries (1024 sa
 constexpr int kParityLen = kPadC + kHalfEntries + 64;    // 640 doubles
 constexpr int kLastT0 = (kHalfEntries + 64) / 32 - 1;    // 17: first half holds samples lane + 64 t, t <= 17
 constexpr int kFirstT1 = (kHalfEntries - kPadC) / 32;    // 14: second half holds t >= 14
-// Scalar-operand scratch: each running block borrows a ring of 2 x 128 centred samples (+ a copy of the
+// Scalar-operand scratch: each running block borrows a ring of 2 x 64 centred samples (+ a copy of the
 // first values of half A behind half B, so that a fetch may run across the wrap) from a pool that is
 // private to its XCD -- 512 rings per XCD -- so the ring stays in that XCD's L2 and the scratch never
 // reaches HBM.  A ring is taken by swapping the launch's ticket (a number no earlier launch on this
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     //     A = c[j - 2L]      (lag 2L)       B = c[j - 2L - 1]   (lag 2L+1)
     // and the wave-uniform c[j].  Going to j+1: B' = A, A' = c[j+1-2L], whose parity is that of j+1
     // for every lane -> one conflict-free LDS read per step.  c[j] reaches the multiplies as a SCALAR
-    // operand: the wave copies its centred samples, 256 at a time, into a ring in global memory that
+    // operand: the wave copies its centred samples, one ring half (kRingHalf) at a time, into a ring in global memory that
     // it alone uses (L2-resident, see kRingLen) and reads them back with s_load_dwordx16.  Each
     // accumulator sees its products in ascending j exactly like the reference loop; the extra
     // leading terms c[j]*0 (j < lag) leave an accumulator at +0.0.
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         double* const ring = reinterpret_cast<double*>(
             read_first_lane((uint64_t)(rings + ((size_t)xcc * kRingsPerXcd + slot) * kRingLen)));
         __attribute__((address_space(1))) double* const ring_g = (__attribute__((address_space(1))) double*)ring;
-        // samples [256 k, 256 k + 256) -> half k & 1 (natural order; lane's element i = lane + 64 t)
+        // samples [kRingHalf k, kRingHalf (k + 1)) -> half k & 1 (natural order; lane's element i = lane + 64 t)
         auto store_chunk = [&](int k, const double* resident) { // resident = mine or mine1, whichever holds chunk k
 #pragma unroll
             for (int t = 0; t < kRingHalf / 64; t++) {
@@ -505,11 +505,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         asm volatile("" : "+v"(A)); // land A here: a compiler-placed wait inside the loop would drain the prefetch
         SELA_AC_ISSUE_S(f0, c_ptr, 0, 64, acc_e, acc_o);
         SELA_AC_ISSUE_V(f0, addr_e, addr_o, 0, 1, 2, 3, 4, 5, 6, 7, 8, acc_e, acc_o);
-        // Two 16-step trips per iteration, eight iterations per chunk of 256.  A fetch's scalar half is
+        // Two 16-step trips per iteration, kRingHalf / 32 iterations per chunk.  A fetch's scalar half is
         // issued a whole trip ahead, its vector half after the first two steps of the running trip,
         // once the registers it overwrites are dead.  (The last fetch of the block lands behind the
         // ring's half B and in LDS behind the parity arrays; it is never used.)
-        constexpr int kSwitch = kBlock / 2 / kRingHalf; // chunk at which the second half of c[] takes over (8)
+        constexpr int kSwitch = kBlock / 2 / kRingHalf; // chunk at which the second half of c[] takes over
 #pragma unroll 1
         for (int k = 0; k < kBlock / kRingHalf; k++) {
             if (k == kSwitch) {
