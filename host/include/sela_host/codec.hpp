@@ -7,6 +7,7 @@
 #pragma once
 
 #include <fstream>
+#include <vector>
 
 #include "sela_host/files.hpp"
 
@@ -33,5 +34,11 @@ public:
     explicit Decoder(std::ifstream& in) : ifStream(in) {}
     file::WavFile process();
 };
+
+// Many files, one GPU batch per channel count (BASELINE.json configs[3]: an album is a few thousand
+// frames per track -- batching the tracks fills the device where one track would leave it in its
+// launch tail).  Results are what Encoder / Decoder give file by file.
+std::vector<file::SelaFile> encodeBatch(const std::vector<file::WavFile>& wavs);
+std::vector<file::WavFile> decodeBatch(const std::vector<file::SelaFile>& selas);
 
 } // namespace sela

@@ -83,3 +83,35 @@ def test_cli_files_match_reference_bytes(tmp_path, channels, seconds):
     assert raw[:4] == b"RIFF" and raw[36:40] == b"data"
     got = np.frombuffer(raw[44:], dtype="<i2").reshape(-1, channels)
     assert np.array_equal(got, pcm[: frames * 2048])  # the tail is dropped
+
+
+@pytest.mark.gpu
+def test_cli_batch_of_files_equals_file_by_file(tmp_path):
+    """`-E` / `-D` push many files through ONE GPU batch per channel count (BASELINE.json configs[3]);
+    every output must be the byte-identical file the single-file verbs write."""
+    _build()
+    cli = os.path.join(HOST, "sela_mi355x")
+    specs = [("a", 2, 44100, 5 * 2048 + 777), ("b", 2, 48000, 3 * 2048), ("c", 1, 96000, 2 * 2048 + 5), ("d", 2, 44100, 100), ("e", 1, 44100, 4 * 2048)]
+    wavs = []
+    for name, ch, rate, n in specs:
+        p = tmp_path / f"{name}.wav"
+        _write_wav(p, synth_pcm(n, ch, 60 + len(wavs)), rate)
+        wavs.append(p)
+    single, batch, back1, backn = (tmp_path / d for d in ("single", "batch", "back1", "backn"))
+    for d in (single, batch, back1, backn):
+        d.mkdir()
+    for w in wavs:
+        r = subprocess.run([cli, "-e", str(w), str(single / (w.stem + ".sela"))], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run([cli, "-E", str(batch)] + [str(w) for w in wavs], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for w in wavs:
+        assert (batch / (w.stem + ".sela")).read_bytes() == (single / (w.stem + ".sela")).read_bytes(), w.stem
+    selas = [batch / (w.stem + ".sela") for w in wavs]
+    for s in selas:
+        r = subprocess.run([cli, "-d", str(s), str(back1 / (s.stem + ".wav"))], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run([cli, "-D", str(backn)] + [str(s) for s in selas], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for s in selas:
+        assert (backn / (s.stem + ".wav")).read_bytes() == (back1 / (s.stem + ".wav")).read_bytes(), s.stem
