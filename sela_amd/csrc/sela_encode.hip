@@ -314,19 +314,31 @@ __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int3
 #pragma unroll
     for (int t = 0; t < kPerLane; t++)
         acc[t] += (int64_t)a_lo * (int64_t)win[(t - JJ - 1) & 31]; // s[32 lane + t - j]
-    if (a_hi != 0) { // only the low 32 bits of a_hi s matter; both factors fit 24 bits unless |a| >= 2^55
-        if (((a_hi << 8) >> 8) == a_hi) {
+    if (a_hi != 0) { // only the low 32 bits of a_hi s matter; both factors fit 24 bits (the caller checked |a| < 2^55)
 #pragma unroll
-            for (int t = 0; t < kPerLane; t++)
-                asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(hi[t]) : "s"(a_hi), "v"(win[(t - JJ - 1) & 31]));
-        } else {
-#pragma unroll 1
-            for (int t = 0; t < kPerLane; t++) // (degenerate predictor: not worth 32 more unrolled instructions per tap)
-                hi[t] += (uint32_t)a_hi * (uint32_t)win[(t - JJ - 1) & 31];
-        }
+        for (int t = 0; t < kPerLane; t++)
+            asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(hi[t]) : "s"(a_hi), "v"(win[(t - JJ - 1) & 31]));
     }
     if constexpr (JJ < 31)
         fir_taps<JJ + 1>(j0, order, lane, sT, a, win, acc, hi);
+}
+
+// The predictions for a predictor with coefficients beyond 2^55: one multiply-add per (sample, tap) in
+// full 64-bit wrap-around arithmetic, samples straight from LDS; (int32)((2^34 + sum) >> 35) of sample
+// 32 lane + t goes to pred_out[t * 64 + lane] (global scratch: the block's own output slot, unused so
+// far).  Slow, out of line, and never needed by real audio.
+__device__ __attribute__((noinline)) void fir_plain(int order, int lane, const int32_t* sT, const int64_t* a, uint32_t* pred_out)
+{
+#pragma unroll 1
+    for (int t = 0; t < kPerLane; t++) {
+        uint64_t sum = (uint64_t)1 << (SELA_Q_SHIFT - 1);
+#pragma unroll 1
+        for (int j = 1; j <= order; j++) {
+            const int e = kPadS + 32 * lane + t - j;
+            sum += (uint64_t)a[j] * (uint64_t)(int64_t)sT[e + (e >> 5)];
+        }
+        pred_out[t * 64 + lane] = (uint32_t)(int32_t)((int64_t)sum >> SELA_Q_SHIFT);
+    }
 }
 
 // kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts
@@ -701,13 +713,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
         for (int t = 0; t < kPerLane; t++)
             acc[t] = (int64_t)1 << (SELA_Q_SHIFT - 1), hi[t] = 0;
+        // the 24-bit multiply of the high parts needs |a[j]| < 2^55 -- true of any predictor worth the
+        // name; a block that violates it takes a plain loop instead of the unrolled window
+        bool fits = true;
+        for (int j = 1 + lane; j <= order; j += 64) {
+            const int64_t aj = sm->a[j];
+            fits &= aj >= -((int64_t)1 << 55) && aj < ((int64_t)1 << 55);
+        }
+        // (the trace build, which only tests run, always takes the plain loop so that it is exercised too)
+        const bool plain = kTrace || __any(!fits);
+        uint32_t* const plain_pred = slots + (size_t)block_id * kSlotWords; // 2048 words of the block's own slot
+        if (plain) {
+            fir_plain(order, lane, sT, sm->a, plain_pred);
+        } else {
 #pragma unroll 1
-        for (int j0 = 0; j0 < order; j0 += 32)
-            fir_taps<0>(j0, order, lane, sT, sm->a, win, acc, hi);
+            for (int j0 = 0; j0 < order; j0 += 32)
+                fir_taps<0>(j0, order, lane, sT, sm->a, win, acc, hi);
+        }
 #pragma unroll
         for (int t = 0; t < kPerLane; t++) {
             const uint64_t total = (uint64_t)acc[t] + ((uint64_t)hi[t] << 32);
-            const int32_t rt = (int32_t)((uint32_t)mine_s[t] - (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT));
+            const uint32_t pred = plain ? plain_pred[t * 64 + lane] : (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT);
+            const int32_t rt = (int32_t)((uint32_t)mine_s[t] - pred);
             ru[t] = zigzag32(rt);
             wide |= (rt >= (1 << 30)) || (rt < -(1 << 30)); // zig-zag would not fit 32 bits
         }

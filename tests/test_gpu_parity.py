@@ -77,6 +77,8 @@ def test_analysis_stages_bit_exact(gpu, kats):
     pcm_sets = [mono, synth_frames(24, 2, 3), synth_frames(5, 3, 4)]
     for pcm in pcm_sets:
         frames, offsets, enc, out = _encode(gpu, pcm, with_trace=True)
+        ref_frames, ref_offsets, _ = o.encode_frames(pcm, threads=4)  # (the trace build runs the plain FIR loop)
+        assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames)
         traces = enc.traces(pcm.shape[0])
         ch = pcm.shape[2]
         n_sig = 3 if ch == 2 else ch
