@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_QUARTER_RATE_GIPS = 256 * 4 * 2.4 / 4  # wave-instructions/ns the 1024 SIMDs can retire at 4 cycles each, 2.4 GHz peak clock
 FP64_UNFUSED_PEAK_TOPS = 39.3  # vector FP64: 78.6 TFLOP/s counts an FMA as 2; mul and add issue separately here
 # unfused FP64 operations the reference's analysis needs per 2048-sample block:
 # 101 lags x (2048 - lag) x (mul + add) for the autocorrelation + 4950 Schur column updates x 4
@@ -89,6 +90,25 @@ def _flush_c_stdio():
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
+
+
+def measured_valu_instructions(kernel: str):
+    """Vector instructions per launch of `kernel` (SQ_INSTS_VALU, whole GPU) from the newest committed counter
+    summary (profiles/rNN/valu_counters.txt, written by tools/valu_counters.sh).  None if there is none."""
+    import ast
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "valu_counters.txt")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        for line in f:
+            if kernel in line and "SQ_INSTS_VALU" in line:
+                try:
+                    return float(ast.literal_eval(line[line.index("{"):].strip())["SQ_INSTS_VALU"])
+                except (ValueError, SyntaxError, KeyError):
+                    return None
+    return None
 
 
 def measured_traffic(kernel: str):
@@ -209,6 +229,7 @@ def main():
     algo_bytes = pcm_bytes + payload_bytes  # PCM16 read + .sela frame bytes written
     achieved = algo_bytes / (enc_blocks_ms * 1e-3) / 1e9
     traffic = measured_traffic("k_encode_blocks")
+    valu_instr = measured_valu_instructions("k_encode_blocks")
 
     if rank == 0:
         samples = n_frames * 2048
@@ -243,6 +264,14 @@ def main():
             "fp64_valu": {  # the resource that actually binds k_encode_blocks
                 "achieved": FP64_OPS_PER_BLOCK * n_frames * 3 / (enc_blocks_ms * 1e-3) / 1e12, "peak": FP64_UNFUSED_PEAK_TOPS,
                 "unit": "T unfused FP64 op/s", "frac": FP64_OPS_PER_BLOCK * n_frames * 3 / (enc_blocks_ms * 1e-3) / 1e12 / FP64_UNFUSED_PEAK_TOPS,
+            },
+            # what binds the kernel in practice: issue slots of the vector ALU.  Quarter-rate instructions
+            # (FP64, 64-bit integer multiply-add: most of this kernel) take 4 cycles of a SIMD each.
+            "valu_issue": None if valu_instr is None else {
+                "achieved": valu_instr / (enc_blocks_ms * 1e-3) / 1e9, "peak": VALU_QUARTER_RATE_GIPS, "unit": "G wave-instructions/s",
+                "frac": valu_instr / (enc_blocks_ms * 1e-3) / 1e9 / VALU_QUARTER_RATE_GIPS,
+                "instructions_per_launch": valu_instr,
+                "note": "SQ_INSTS_VALU from profiles/ (committed counter pass) / live kernel time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles",
             },
             "roofline": {
                 "kernel": "k_encode_blocks", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
