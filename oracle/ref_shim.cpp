@@ -16,9 +16,14 @@
 #include <thread>
 #include <vector>
 
+#include <fstream>
+
+#include "data/exception.hpp"
 #include "frame.hpp"
 #include "lpc.hpp"
 #include "rice.hpp"
+#include "sela/decoder.hpp"
+#include "sela/encoder.hpp"
 
 namespace {
 
@@ -242,6 +247,37 @@ double ref_decode_frames_mt(const uint8_t* in, const uint64_t* offsets, uint32_t
             f++;
         }
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// The reference's own file-to-file verbs (src/main.cpp:29-41): sela::Encoder + SelaFile::writeToFile
+// (src/sela/encoder.cpp:94-100, src/file/sela_file.cpp:105-137) and sela::Decoder + WavFile::writeToFile
+// (src/sela/decoder.cpp, src/file/wav_file.cpp:222-267).  Return 0, or 1 when the reference throws.
+int ref_encode_file(const char* wav_path, const char* sela_path)
+{
+    try {
+        std::ifstream in(wav_path, std::ios::binary);
+        std::ofstream out(sela_path, std::ios::binary);
+        sela::Encoder encoder(in);
+        file::SelaFile sela_file = encoder.process();
+        sela_file.writeToFile(out);
+    } catch (data::Exception&) {
+        return 1;
+    }
+    return 0;
+}
+
+int ref_decode_file(const char* sela_path, const char* wav_path)
+{
+    try {
+        std::ifstream in(sela_path, std::ios::binary);
+        std::ofstream out(wav_path, std::ios::binary);
+        sela::Decoder decoder(in);
+        file::WavFile wav_file = decoder.process();
+        wav_file.writeToFile(out);
+    } catch (data::Exception&) {
+        return 1;
+    }
+    return 0;
 }
 
 uint32_t ref_hardware_concurrency(void) { return std::thread::hardware_concurrency(); }

@@ -77,6 +77,72 @@ def synth_pcm(n_samples: int, channels: int = 2, track: int = 0, noise_shift: in
     return out
 
 
+# ---- the same generator on torch tensors (any device) --------------------------------------------------
+# Album-sized workloads (BASELINE.json configs[3]: 1.1 G stereo samples) take minutes in numpy on one core;
+# on torch the same integer arithmetic runs on all host cores or on the GPU.  int64 two's-complement
+# wrap-around stands in for numpy's uint64 (logical shifts are masked arithmetic shifts); the result is
+# bit-identical to synth_pcm (tests/test_host_logic.py::test_torch_synth_matches_numpy).
+def _i64(c: int) -> int:
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def _lsr(x, s: int):
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _mix64_t(x):
+    x = x ^ _lsr(x, 30)
+    x = x * _i64(0xBF58476D1CE4E5B9)
+    x = x ^ _lsr(x, 27)
+    x = x * _i64(0x94D049BB133111EB)
+    return x ^ _lsr(x, 31)
+
+
+def _noise_t(n, seed: int, stream: int):
+    h = _mix64_t(((n << 4) | stream) + _i64((seed * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)))
+    return (h & 1023) + (_lsr(h, 10) & 1023) + (_lsr(h, 20) & 1023) + (_lsr(h, 30) & 1023) - 2046
+
+
+def synth_pcm_torch(n_samples: int, channels: int = 2, track: int = 0, start: int = 0, device="cpu"):
+    """Samples [start, start + n_samples) of synth_pcm(..., channels, track) as an int16 torch tensor
+    [n_samples, channels] on `device`."""
+    import torch
+
+    tab = torch.from_numpy(_sin_table()).to(device)
+    n = torch.arange(start, start + n_samples, dtype=torch.int64, device=device)
+    out = torch.empty((n_samples, channels), dtype=torch.int16, device=device)
+    seed = 0x5E1A0000 + track
+    common = _noise_t(n, seed, 0)
+    w = (n >> 13) % 5
+    for c in range(channels):
+        f1 = 37 + 2 * track % 17
+        f2 = 211 + 82 * c + 3 * (track % 5)
+        phi = 977 * c + 131 * track
+        p1 = (n * f1 + (((n >> 9) * (n >> 9)) >> 7)) & 4095
+        p2 = (n * f2 + phi + (n >> 6)) & 4095
+        tone = ((19660 - 2000 * c) * tab[p1] + (6553 + 1500 * c) * tab[p2]) >> 15
+        noise = (common * w + _noise_t(n, seed, c + 1) * (4 - w)) >> 2
+        out[:, c] = torch.clamp(tone + noise, -32768, 32767).to(torch.int16)
+    return out
+
+
+def synth_frames_torch(n_frames: int, channels: int = 2, track: int = 0, first_frame: int = 0, device="cpu"):
+    """Frames [first_frame, first_frame + n_frames) of a track: int16 tensor [n_frames, BLOCK, channels]."""
+    return synth_pcm_torch(n_frames * BLOCK, channels, track, first_frame * BLOCK, device).reshape(n_frames, BLOCK, channels)
+
+
+# ---- BASELINE.json configs[3]: the 100-track album (SURVEY.md 8(d) item 4) ---------------------------------
+ALBUM_TRACKS = 100
+ALBUM_RATES = (44100, 48000, 96000)
+ALBUM_SECONDS = 180
+
+
+def album_tracks(n_tracks: int = ALBUM_TRACKS, seconds: float = ALBUM_SECONDS):
+    """[(track id, sample rate, whole frames)]: rates round-robin over 44.1 / 48 / 96 kHz, 16-bit stereo.
+    The full album is 34 / 33 / 33 tracks of 3875 / 4218 / 8437 frames = 549,365 frames."""
+    return [(t, ALBUM_RATES[t % 3], frames_for_seconds(seconds, ALBUM_RATES[t % 3])) for t in range(n_tracks)]
+
+
 def synth_frames(n_frames: int, channels: int = 2, track: int = 0) -> np.ndarray:
     """int16 PCM of shape [n_frames, BLOCK, channels]."""
     return synth_pcm(n_frames * BLOCK, channels, track).reshape(n_frames, BLOCK, channels)

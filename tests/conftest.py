@@ -26,3 +26,22 @@ def digests():
 
     with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
         return json.load(f)
+
+
+def _load_json(name):
+    import json
+
+    with open(os.path.join(ROOT, "tests", "golden", name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def file_digests():
+    """Whole-file SHA-256s written by the reference's own sela::Encoder/Decoder + file classes."""
+    return _load_json("file_digests.json")
+
+
+@pytest.fixture(scope="session")
+def album_digests():
+    """BASELINE.json configs[3]: per-track .sela file / decoded PCM SHA-256s from the reference."""
+    return _load_json("album_digests.json")

@@ -6,13 +6,16 @@ which compiles the unmodified reference from /root/reference).  The fixtures are
 inputs and the reference's outputs.  Commit the resulting .npz / .json files; the GPU box
 and CI only ever read them.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [kats] [configs] [files] [album]     (default: all four sections)
 """
+import ctypes as C
 import hashlib
 import json
 import math
 import os
+import struct
 import sys
+import tempfile
 
 import numpy as np
 
@@ -21,7 +24,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle_lib import reference  # noqa: E402
-from sela_amd.synth import synth_frames  # noqa: E402
+from sela_amd.synth import album_tracks, synth_frames, synth_frames_torch, synth_pcm  # noqa: E402
 
 
 def edge_blocks():
@@ -46,9 +49,89 @@ def edge_blocks():
     return blocks
 
 
+def write_wav(path, pcm, rate):
+    """Canonical 44-byte-header WAV (what the reference's own writer emits, src/file/wav_file.cpp:222-242)."""
+    data = np.ascontiguousarray(pcm, dtype="<i2").tobytes()
+    ch = pcm.shape[1]
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IhHIIHH", 16, 1, ch, rate, rate * ch * 2, ch * 2, 16))
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
+
+
+def sha_file(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    return h.hexdigest(), os.path.getsize(path)
+
+
+def file_digests(ref):
+    """FILE-level pins: the reference's own sela::Encoder + SelaFile::writeToFile and sela::Decoder +
+    WavFile::writeToFile (ref_encode_file / ref_decode_file in oracle/ref_shim.cpp) on real WAV files --
+    whole .sela and decoded .wav files, headers and dropped tails included."""
+    lib = ref.lib
+    for fn in (lib.ref_encode_file, lib.ref_decode_file):
+        fn.argtypes = [C.c_char_p, C.c_char_p]
+        fn.restype = C.c_int
+    out = {}
+    cases = [("config0_mono_10s", 441000, 1, 44100, 0), ("config1_stereo_3min", 7938000, 2, 44100, 0),
+             ("stereo_48k_tail", 5 * 2048 + 777, 2, 48000, 17), ("three_channel_96k", 3 * 2048 + 5, 3, 96000, 5),
+             ("shorter_than_a_frame", 100, 2, 44100, 9)]
+    with tempfile.TemporaryDirectory() as tmp:
+        for label, n, ch, rate, track in cases:
+            wav, sela, back = (os.path.join(tmp, label + e) for e in (".wav", ".sela", ".back.wav"))
+            write_wav(wav, synth_pcm(n, ch, track), rate)
+            assert lib.ref_encode_file(wav.encode(), sela.encode()) == 0
+            assert lib.ref_decode_file(sela.encode(), back.encode()) == 0
+            (wsha, wsize), (ssha, ssize), (bsha, bsize) = sha_file(wav), sha_file(sela), sha_file(back)
+            out[label] = {"samples_per_channel": n, "channels": ch, "sample_rate": rate, "track": track,
+                          "wav_sha256": wsha, "wav_bytes": wsize, "sela_sha256": ssha, "sela_bytes": ssize,
+                          "decoded_wav_sha256": bsha, "decoded_wav_bytes": bsize}
+            print(label, out[label])
+    return out
+
+
+def album_digests(ref, threads=8):
+    """BASELINE.json configs[3]: the 100-track album (sela_amd.synth.album_tracks), every track encoded and
+    decoded by the reference; per track the SHA-256 of the whole .sela FILE (15-byte header + frames) and
+    of the decoded PCM, plus one digest over all of them."""
+    tracks = []
+    total = hashlib.sha256()
+    for track, rate, frames in album_tracks():
+        pcm = synth_frames_torch(frames, 2, track).numpy()
+        blob, offs, _ = ref.encode_frames(pcm, threads=threads)
+        dec, _ = ref.decode_frames(blob, offs, 2, threads=threads)
+        header = b"SeLa" + struct.pack("<IHBI", rate, 16, 2, frames)
+        sela_sha = hashlib.sha256(header + blob.tobytes()).hexdigest()
+        dec_sha = hashlib.sha256(dec.tobytes()).hexdigest()
+        total.update(bytes.fromhex(sela_sha))
+        tracks.append({"track": track, "sample_rate": rate, "n_frames": frames, "sela_bytes": 15 + int(len(blob)),
+                       "sela_sha256": sela_sha, "decoded_sha256": dec_sha,
+                       "lossy_frames": int((dec != pcm).reshape(frames, -1).any(axis=1).sum())})
+        print(tracks[-1], flush=True)
+    return {"n_tracks": len(tracks), "n_frames": sum(t["n_frames"] for t in tracks), "channels": 2,
+            "sha256_of_track_sela_sha256s": total.hexdigest(), "tracks": tracks}
+
+
 def main():
     ref = reference()
     assert ref is not None, "build oracle/_ref first: make -C oracle ref"
+    sections = set(sys.argv[1:]) or {"kats", "configs", "files", "album"}
+    if "files" in sections:
+        with open(os.path.join(HERE, "file_digests.json"), "w") as f:
+            json.dump(file_digests(ref), f, indent=1, sort_keys=True)
+    if "album" in sections:
+        with open(os.path.join(HERE, "album_digests.json"), "w") as f:
+            json.dump(album_digests(ref), f, indent=1, sort_keys=True)
+    if "kats" in sections:
+        kats(ref)
+    if "configs" in sections:
+        config_digests(ref)
+
+
+def kats(ref):
     out = {}
 
     # ---- per-stage KATs on single blocks --------------------------------------------------
@@ -113,6 +196,8 @@ def main():
 
     np.savez_compressed(os.path.join(HERE, "kats.npz"), **out)
 
+
+def config_digests(ref):
     # ---- whole-config digests (BASELINE.json configs; inputs are regenerated from synth) -------
     digests = {}
     for label, nf, ch, track in [("config0_mono_10s", 215, 1, 0), ("config1_stereo_3min", 3875, 2, 0),

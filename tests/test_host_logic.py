@@ -104,3 +104,18 @@ def test_scale_division_is_exact(tmp_path):
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c", "scale_division.c")
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), src, "-lm"])
     assert subprocess.check_output([str(exe)]).decode().strip() == "0"
+
+
+def test_torch_synth_matches_numpy():
+    """The torch generator (album-sized workloads, any device) is bit-identical to the numpy one, at any offset."""
+    import numpy as np
+
+    from sela_amd.synth import album_tracks, synth_pcm, synth_pcm_torch
+
+    for track, ch in [(5, 2), (0, 1), (99, 3)]:
+        a = synth_pcm(70000, ch, track)
+        assert np.array_equal(a, synth_pcm_torch(70000, ch, track).numpy())
+        assert np.array_equal(a[12345:20000], synth_pcm_torch(7655, ch, track, start=12345).numpy())
+    tracks = album_tracks()
+    assert len(tracks) == 100 and sum(f for _, _, f in tracks) == 549365
+    assert [tracks[i][2] for i in range(3)] == [3875, 4218, 8437]

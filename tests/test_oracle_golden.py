@@ -11,8 +11,10 @@ import os
 import numpy as np
 import pytest
 
+import struct
+
 from oracle_lib import oracle
-from sela_amd.synth import synth_frames
+from sela_amd.synth import synth_frames, synth_frames_torch, synth_pcm
 
 
 def test_block_kats(kats):
@@ -114,3 +116,49 @@ def test_thread_count_does_not_change_output():
     for t in (2, 5, 13, 32):
         blob, offs, _ = o.encode_frames(pcm, threads=t)
         assert np.array_equal(blob, base[0]) and np.array_equal(offs, base[1])
+
+
+def wav_header(rate, channels, data_bytes):
+    """The canonical 44-byte header the reference writes (src/file/wav_file.cpp:222-242)."""
+    return (b"RIFF" + struct.pack("<I", 36 + data_bytes) + b"WAVE" + b"fmt " + struct.pack("<IhHIIHH", 16, 1, channels, rate,
+            rate * channels * 2, channels * 2, 16) + b"data" + struct.pack("<I", data_bytes))
+
+
+def sela_header(rate, channels, n_frames):
+    """15 bytes, src/file/sela_file.cpp:108-114."""
+    return b"SeLa" + struct.pack("<IHBI", rate, 16, channels, n_frames)
+
+
+@pytest.mark.parametrize("label", ["config0_mono_10s", "stereo_48k_tail", "three_channel_96k", "shorter_than_a_frame"])
+def test_file_digests(file_digests, label):
+    """FILE level: header + frame stream of the restatement == the .sela file the reference's own
+    sela::Encoder + SelaFile::writeToFile wrote, and canonical header + decoded PCM == the .wav its
+    sela::Decoder + WavFile::writeToFile wrote (tail dropped: src/file/wav_file.cpp:184,203)."""
+    d = file_digests[label]
+    o = oracle()
+    n, ch, rate = d["samples_per_channel"], d["channels"], d["sample_rate"]
+    pcm = synth_pcm(n, ch, d["track"])
+    assert hashlib.sha256(wav_header(rate, ch, pcm.nbytes) + pcm.tobytes()).hexdigest() == d["wav_sha256"], "input drifted"
+    frames = n // 2048
+    blob, offs, _ = o.encode_frames(pcm[: frames * 2048].reshape(frames, 2048, ch), threads=4)
+    sela = sela_header(rate, ch, frames) + blob.tobytes()
+    assert len(sela) == d["sela_bytes"] and hashlib.sha256(sela).hexdigest() == d["sela_sha256"]
+    dec, _ = o.decode_frames(blob, offs, ch, threads=4)
+    wav = wav_header(rate, ch, dec.nbytes) + dec.tobytes()
+    assert len(wav) == d["decoded_wav_bytes"] and hashlib.sha256(wav).hexdigest() == d["decoded_wav_sha256"]
+
+
+def test_album_digest_sample(album_digests):
+    """BASELINE.json configs[3] on the CPU: three of the 100 tracks (one per sample rate), first 96 frames
+    bit-exact through the restatement; the whole album is checked on the GPU (tests/test_album.py)."""
+    assert album_digests["n_tracks"] == 100 and album_digests["n_frames"] == 549365
+    o = oracle()
+    for t in album_digests["tracks"][:3]:
+        pcm = synth_frames_torch(96, 2, t["track"]).numpy()
+        blob, offs, _ = o.encode_frames(pcm, threads=4)
+        dec, _ = o.decode_frames(blob, offs, 2, threads=4)
+        assert np.array_equal(dec, pcm) or t["lossy_frames"] > 0
+    total = hashlib.sha256()
+    for t in album_digests["tracks"]:
+        total.update(bytes.fromhex(t["sela_sha256"]))
+    assert total.hexdigest() == album_digests["sha256_of_track_sela_sha256s"]
