@@ -1,9 +1,11 @@
 // codec.hpp -- sela::Encoder / sela::Decoder with the reference's signatures
 // (src/include/sela/encoder.hpp:9-22, src/include/sela/decoder.hpp:9-22).
 //
-// Where the reference fans frames out to hardware_concurrency() threads (src/sela/encoder.cpp:40-92),
-// these hand the whole file to the MI355X as one batch: sela_hip_encode / sela_hip_decode.
-// There is no CPU fallback: if the GPU path is unavailable process() throws data::Exception.
+// Where the reference reads the whole file and then fans the frames out to hardware_concurrency() threads
+// (src/sela/encoder.cpp:40-100), these stream the file through the MI355X: the file is read piece by
+// piece into page-locked memory and every piece is handed to the GPU (sela_hip_encode_feed /
+// sela_hip_decode_feed) while the next one is still being read.  There is no CPU fallback: if the GPU path
+// is unavailable process() throws data::Exception.
 #pragma once
 
 #include <fstream>
@@ -35,9 +37,23 @@ public:
     file::WavFile process();
 };
 
-// Many files, one GPU batch per channel count (BASELINE.json configs[3]: an album is a few thousand
-// frames per track -- batching the tracks fills the device where one track would leave it in its
-// launch tail).  Results are what Encoder / Decoder give file by file.
+// File to file (what the reference's main.cpp:29-41 does with process() + writeToFile()): the same
+// streaming read, and finished frames / samples are written out while later pieces are still on the device.
+// Return the number of frames coded.
+size_t encodeFile(std::ifstream& in, std::ofstream& out);
+size_t decodeFile(std::ifstream& in, std::ofstream& out);
+
+// ---- many files, all GPUs of the node ------------------------------------------------------------------
+// BASELINE.json configs[3]: an album's tracks are one index space of frames, cut into contiguous balanced
+// ranges -- the reference's static partition (src/sela/encoder.cpp:58-73) with the remainder spread -- one
+// per device, one host thread per device.  A range may begin or end inside a track.  The compressed sizes
+// of the pieces meet in host memory (this is one process; sela_amd/sharding.py is the one-process-per-GPU
+// form with the RCCL all-gather).  Results are what Encoder / Decoder give file by file.
+//
+// Devices to use: setDevices({0, 1, ...}); an index may repeat (two workers on one GPU -- used by the
+// tests).  Default: every visible device.
+void setDevices(const std::vector<int>& devices);
+std::vector<int> devices();
 std::vector<file::SelaFile> encodeBatch(const std::vector<file::WavFile>& wavs);
 std::vector<file::WavFile> decodeBatch(const std::vector<file::SelaFile>& selas);
 

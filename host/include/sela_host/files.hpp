@@ -2,15 +2,20 @@
 // src/include/file/sela_file.hpp:10-18), re-designed around flat buffers:
 //
 //   * WavFile keeps the data chunk as the interleaved little-endian int16 array it already is -- that
-//     array IS the input format of sela_hip_encode, so encoding is zero-copy on the host.  The
-//     reference's per-frame de-interleaved `wavFrames` are still available (demuxSamples()).
+//     array IS the input format of sela_hip_encode, so encoding is zero-copy on the host -- in page-locked
+//     memory, read from the file piece by piece (readHeader + the caller's reads) so that the GPU can start
+//     before the file has been read.  The reference's per-frame de-interleaved `wavFrames` are still
+//     available (demuxSamples()).
 //   * SelaFile keeps the frame byte stream exactly as it goes to disk (one write()) plus the frame
 //     offsets; `selaFrames` objects are materialised for callers that want them.
+//
+// Deviations from the reference's public members are listed in INTEGRATION.md section 3.
 #pragma once
 
 #include <fstream>
 #include <string>
 
+#include "sela_host/buffer.hpp"
 #include "sela_host/data.hpp"
 
 namespace file {
@@ -21,15 +26,20 @@ public:
     uint32_t sampleRate = 0;
     uint16_t bitsPerSample = 16;
     uint16_t numChannels = 0;
-    std::vector<int16_t> pcm;               // interleaved, whole data chunk
+    sela_host::PinnedBuffer<int16_t> pcm;   // interleaved, whole data chunk
     std::vector<data::WavFrame> wavFrames;  // filled by demuxSamples()
 
     WavFile() {}
     WavFile(uint32_t rate, uint16_t bps, uint16_t channels, std::vector<data::WavFrame>&& frames);
     WavFile(uint32_t rate, uint16_t channels, std::vector<int16_t>&& interleaved);
+    WavFile(uint32_t rate, uint16_t channels, sela_host::PinnedBuffer<int16_t>&& interleaved);
 
-    void readFromFile(std::ifstream& in);   // throws data::Exception with the reference's messages
+    // Parse up to the data chunk and leave `in` at its first byte; returns the chunk's size in bytes
+    // (clipped to the file).  Throws data::Exception with the reference's messages.
+    size_t readHeader(std::ifstream& in);
+    void readFromFile(std::ifstream& in);   // readHeader + the whole data chunk
     void writeToFile(std::ofstream& out);   // canonical 44-byte header + data
+    static void writeHeader(std::ofstream& out, uint32_t rate, uint16_t channels, uint16_t bps, uint32_t dataBytes);
     void demuxSamples();                    // pcm -> wavFrames (whole frames only, tail dropped)
     size_t frameCount() const { return numChannels ? pcm.size() / numChannels / samplesPerChannelPerFrame : 0; }
 };
@@ -38,16 +48,20 @@ class SelaFile {
 public:
     data::SelaHeader selaHeader;
     std::vector<data::SelaFrame> selaFrames; // filled by readFromFile() and materializeFrames()
-    std::vector<uint8_t> frameBytes;          // the stream behind the 15-byte header
+    sela_host::PinnedBuffer<uint8_t> frameBytes; // the stream behind the 15-byte header
     std::vector<uint64_t> frameOffsets;       // [numFrames + 1] byte offsets into frameBytes
 
     SelaFile() {}
     SelaFile(uint32_t rate, uint16_t bps, uint8_t channels, std::vector<data::SelaFrame>&& frames);
-    SelaFile(uint32_t rate, uint16_t bps, uint8_t channels, std::vector<uint8_t>&& bytes, std::vector<uint64_t>&& offsets);
+    SelaFile(uint32_t rate, uint16_t bps, uint8_t channels, sela_host::PinnedBuffer<uint8_t>&& bytes, std::vector<uint64_t>&& offsets);
 
+    // Read the 15-byte header; returns the bytes that follow it in the file.
+    size_t readHeader(std::ifstream& in);
     void readFromFile(std::ifstream& in);
     void writeToFile(std::ofstream& out);
+    void writeHeader(std::ofstream& out) const;
     void materializeFrames(); // frameBytes -> selaFrames
+    size_t frameCount() const { return frameOffsets.empty() ? 0 : frameOffsets.size() - 1; }
 };
 
 } // namespace file

@@ -1,0 +1,119 @@
+// filebench.cpp -- end-to-end timing of the C++ host on one file (bench.py's `e2e` and `file_to_file` legs).
+//
+//   sela_filebench in.wav scratch_dir [repeats]
+//
+// Measures, with steady_clock, after one untimed warm-up of each (HIP initialisation, buffer pinning):
+//   e2e         sela_hip_encode / sela_hip_decode on page-locked host buffers: H2D + kernels + D2H
+//   file        sela::encodeFile / sela::decodeFile: file read, H2D, kernels, D2H and file write overlapped
+//               (what the reference's `sela -e` / `sela -d` do, src/main.cpp:29-41)
+// and prints one JSON object: medians in ms and stereo Msamples/s.  Results are checked against each other
+// (file-to-file .sela == header + e2e frames; decoded .wav == e2e decode) -- parity against the reference is
+// what tests/ do.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "sela_hip.h"
+#include "sela_host/codec.hpp"
+
+namespace {
+
+double median(std::vector<double> v)
+{
+    std::sort(v.begin(), v.end());
+    return v.empty() ? 0.0 : v[v.size() / 2];
+}
+
+std::vector<uint8_t> slurp(const std::string& path)
+{
+    std::ifstream in(path, std::ios::binary);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s in.wav scratch_dir [repeats]\n", argv[0]);
+        return 2;
+    }
+    const std::string wavPath = argv[1], dir = argv[2];
+    const int repeats = argc > 3 ? std::max(1, std::atoi(argv[3])) : 9;
+    const std::string selaPath = dir + "/filebench.sela", backPath = dir + "/filebench.wav";
+    using clock = std::chrono::steady_clock;
+    auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    try {
+        file::WavFile wav;
+        {
+            std::ifstream in(wavPath, std::ios::binary);
+            if (!in)
+                throw data::Exception("cannot open " + wavPath);
+            wav.readFromFile(in);
+        }
+        const uint32_t ch = wav.numChannels;
+        const uint32_t frames = (uint32_t)wav.frameCount();
+        const double samples = (double)frames * 2048;
+
+        // ---- host-pointer API on page-locked buffers ----------------------------------------------------
+        sela_host::PinnedBuffer<uint8_t> bytes(sela_hip_encode_bound_bytes(frames, ch));
+        std::vector<uint64_t> offs(frames + 1);
+        sela_host::PinnedBuffer<int16_t> back((size_t)frames * 2048 * ch);
+        std::vector<double> enc, dec;
+        for (int r = 0; r <= repeats; r++) {
+            const auto t0 = clock::now();
+            if (sela_hip_encode(wav.pcm.data(), frames, ch, 2048, bytes.data(), bytes.size(), offs.data()) != SELA_HIP_OK)
+                throw data::Exception(sela_hip_last_error());
+            const auto t1 = clock::now();
+            if (sela_hip_decode(bytes.data(), offs.data(), frames, ch, back.data()) != SELA_HIP_OK)
+                throw data::Exception(sela_hip_last_error());
+            const auto t2 = clock::now();
+            if (r) { // (the first pass pins and allocates)
+                enc.push_back(ms(t0, t1));
+                dec.push_back(ms(t1, t2));
+            }
+        }
+        // ---- file to file -------------------------------------------------------------------------------------
+        std::vector<double> fenc, fdec;
+        for (int r = 0; r <= repeats; r++) {
+            const auto t0 = clock::now();
+            {
+                std::ifstream in(wavPath, std::ios::binary);
+                std::ofstream out(selaPath, std::ios::binary);
+                sela::encodeFile(in, out);
+            }
+            const auto t1 = clock::now();
+            {
+                std::ifstream in(selaPath, std::ios::binary);
+                std::ofstream out(backPath, std::ios::binary);
+                sela::decodeFile(in, out);
+            }
+            const auto t2 = clock::now();
+            if (r) {
+                fenc.push_back(ms(t0, t1));
+                fdec.push_back(ms(t1, t2));
+            }
+        }
+        // the two paths agree with each other
+        const std::vector<uint8_t> selaFile = slurp(selaPath), backFile = slurp(backPath);
+        const bool sameSela = selaFile.size() == 15 + (size_t)offs[frames] && std::memcmp(selaFile.data() + 15, bytes.data(), (size_t)offs[frames]) == 0;
+        const bool sameWav = backFile.size() == 44 + back.size() * 2 && std::memcmp(backFile.data() + 44, back.data(), back.size() * 2) == 0;
+        std::printf("{\"frames\": %u, \"channels\": %u, \"repeats\": %d, \"sela_bytes\": %zu, "
+                    "\"e2e_encode_ms\": %.4f, \"e2e_decode_ms\": %.4f, \"e2e_encode_msps\": %.1f, \"e2e_decode_msps\": %.1f, "
+                    "\"file_encode_ms\": %.4f, \"file_decode_ms\": %.4f, \"file_encode_msps\": %.1f, \"file_decode_msps\": %.1f, "
+                    "\"file_equals_e2e\": %s}\n",
+            frames, ch, repeats, (size_t)offs[frames], median(enc), median(dec), samples / median(enc) / 1e3, samples / median(dec) / 1e3,
+            median(fenc), median(fdec), samples / median(fenc) / 1e3, samples / median(fdec) / 1e3, (sameSela && sameWav) ? "true" : "false");
+        return (sameSela && sameWav) ? 0 : 1;
+    } catch (const data::Exception& e) {
+        std::fprintf(stderr, "%s\n", e.exceptionMessage.c_str());
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+    }
+    return 1;
+}

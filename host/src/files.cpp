@@ -1,11 +1,14 @@
 // files.cpp -- WAV and .sela containers on flat buffers (see files.hpp).
 //
 // Behaviour kept from the reference (src/file/wav_file.cpp, src/file/sela_file.cpp): the accepted
-// WAV subset (RIFF/WAVE, 16-bit PCM, any chunk order after 'fmt '), the error conditions and their
+// WAV subset (RIFF/WAVE, 16-bit PCM, chunks in any order up to 'data'), the error conditions and their
 // messages, the dropped tail (only whole 2048-sample frames are coded), the canonical 44-byte header
 // on output, the 15-byte .sela header and the silent stop at the first frame without a sync word.
+// The files are read sequentially (headers first, then the payload straight into page-locked memory)
+// instead of being slurped and copied.
 #include "sela_host/files.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <iterator>
 
@@ -17,15 +20,18 @@ namespace {
 uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-std::vector<uint8_t> slurp(std::ifstream& in)
+size_t fileSize(std::ifstream& in)
 {
     in.seekg(0, std::ios::end);
     const std::streamoff size = in.tellg();
     in.seekg(0, std::ios::beg);
-    std::vector<uint8_t> bytes(size > 0 ? (size_t)size : 0);
-    if (!bytes.empty())
-        in.read(reinterpret_cast<char*>(bytes.data()), (std::streamsize)bytes.size());
-    return bytes;
+    return size > 0 ? (size_t)size : 0;
+}
+
+bool readExact(std::ifstream& in, void* dst, size_t n)
+{
+    in.read(static_cast<char*>(dst), (std::streamsize)n);
+    return (size_t)in.gcount() == n;
 }
 
 template <typename T>
@@ -41,59 +47,80 @@ namespace file {
 WavFile::WavFile(uint32_t rate, uint16_t bps, uint16_t channels, std::vector<data::WavFrame>&& frames)
     : sampleRate(rate), bitsPerSample(bps), numChannels(channels), wavFrames(std::move(frames))
 {
+    size_t total = 0;
+    for (const data::WavFrame& f : wavFrames)
+        total += (f.samples.empty() ? 0 : f.samples[0].size()) * f.samples.size();
+    pcm.resize(total);
+    size_t at = 0;
     for (const data::WavFrame& f : wavFrames) {
         const size_t n = f.samples.empty() ? 0 : f.samples[0].size();
         for (size_t i = 0; i < n; i++)
             for (size_t c = 0; c < f.samples.size(); c++)
-                pcm.push_back((int16_t)(uint16_t)f.samples[c][i]);
+                pcm[at++] = (int16_t)(uint16_t)f.samples[c][i];
     }
 }
 
 WavFile::WavFile(uint32_t rate, uint16_t channels, std::vector<int16_t>&& interleaved)
+    : sampleRate(rate), bitsPerSample(16), numChannels(channels), pcm(interleaved)
+{
+}
+
+WavFile::WavFile(uint32_t rate, uint16_t channels, sela_host::PinnedBuffer<int16_t>&& interleaved)
     : sampleRate(rate), bitsPerSample(16), numChannels(channels), pcm(std::move(interleaved))
 {
 }
 
-void WavFile::readFromFile(std::ifstream& in)
+size_t WavFile::readHeader(std::ifstream& in)
 {
-    const std::vector<uint8_t> bytes = slurp(in);
-    if (bytes.size() < 44)
+    const size_t size = fileSize(in);
+    if (size < 44)
         throw data::Exception("File is too small, probably not a wav file.");
-    if (std::memcmp(bytes.data(), "RIFF", 4) != 0)
+    uint8_t riff[12];
+    if (!readExact(in, riff, 12) || std::memcmp(riff, "RIFF", 4) != 0)
         throw data::Exception("chunkId is not RIFF, probably not a wav file.");
-    if ((size_t)le32(bytes.data() + 4) > bytes.size())
+    if ((size_t)le32(riff + 4) > size)
         throw data::Exception("chunkSize exceeds file size, probably a corrupted file");
-    if (std::memcmp(bytes.data() + 8, "WAVE", 4) != 0)
+    if (std::memcmp(riff + 8, "WAVE", 4) != 0)
         throw data::Exception("format is not WAVE, probably not a wav file.");
 
-    bool haveFmt = false, haveData = false;
+    bool haveFmt = false;
     size_t pos = 12;
-    while (pos + 8 <= bytes.size()) {
-        const uint8_t* id = bytes.data() + pos;
-        size_t size = le32(bytes.data() + pos + 4);
-        const uint8_t* body = bytes.data() + pos + 8;
-        if (pos + 8 + size > bytes.size())
-            size = bytes.size() - pos - 8; // tolerate a short last chunk
-        if (std::memcmp(id, "fmt ", 4) == 0 && size >= 16) {
+    while (pos + 8 <= size) {
+        uint8_t head[8];
+        if (!readExact(in, head, 8))
+            break;
+        size_t chunk = le32(head + 4);
+        if (pos + 8 + chunk > size)
+            chunk = size - pos - 8; // tolerate a short last chunk
+        if (std::memcmp(head, "fmt ", 4) == 0 && chunk >= 16) {
+            uint8_t body[16];
+            if (!readExact(in, body, 16))
+                break;
             haveFmt = true;
             numChannels = le16(body + 2);
             sampleRate = le32(body + 4);
             bitsPerSample = le16(body + 14);
             if (bitsPerSample != 16)
                 throw data::Exception("Only 16bits per sample wav is supported.");
-        } else if (std::memcmp(id, "data", 4) == 0) {
+        } else if (std::memcmp(head, "data", 4) == 0) {
             if (!haveFmt)
                 throw data::Exception("Probably corrupt wav, data subChunk present without fmt subChunk.");
-            haveData = true;
-            pcm.resize(size / 2);
-            std::memcpy(pcm.data(), body, pcm.size() * 2); // already interleaved little-endian int16
+            return chunk; // the stream stands at the first PCM byte
         }
-        pos += 8 + size;
+        pos += 8 + chunk;
+        in.seekg((std::streamoff)pos, std::ios::beg);
     }
     if (!haveFmt)
         throw data::Exception("fmt subChunk is missing from file");
-    if (!haveData)
-        throw data::Exception("data subChunk is missing from file");
+    throw data::Exception("data subChunk is missing from file");
+}
+
+void WavFile::readFromFile(std::ifstream& in)
+{
+    const size_t bytes = readHeader(in);
+    pcm.resize(bytes / 2);
+    if (!pcm.empty() && !readExact(in, pcm.data(), pcm.size() * 2)) // already interleaved little-endian int16
+        throw data::Exception("data subChunk is shorter than its header says");
 }
 
 void WavFile::demuxSamples()
@@ -111,22 +138,27 @@ void WavFile::demuxSamples()
     }
 }
 
-void WavFile::writeToFile(std::ofstream& out)
+void WavFile::writeHeader(std::ofstream& out, uint32_t rate, uint16_t channels, uint16_t bps, uint32_t dataBytes)
 {
-    const uint32_t dataBytes = (uint32_t)(pcm.size() * 2);
     out.write("RIFF", 4);
     put<uint32_t>(out, 36 + dataBytes);
     out.write("WAVE", 4);
     out.write("fmt ", 4);
     put<uint32_t>(out, 16);
     put<int16_t>(out, 1); // PCM
-    put<uint16_t>(out, numChannels);
-    put<uint32_t>(out, sampleRate);
-    put<uint32_t>(out, sampleRate * numChannels * bitsPerSample / 8);
-    put<uint16_t>(out, (uint16_t)(numChannels * bitsPerSample / 8));
-    put<uint16_t>(out, bitsPerSample);
+    put<uint16_t>(out, channels);
+    put<uint32_t>(out, rate);
+    put<uint32_t>(out, rate * channels * bps / 8);
+    put<uint16_t>(out, (uint16_t)(channels * bps / 8));
+    put<uint16_t>(out, bps);
     out.write("data", 4);
     put<uint32_t>(out, dataBytes);
+}
+
+void WavFile::writeToFile(std::ofstream& out)
+{
+    const uint32_t dataBytes = (uint32_t)(pcm.size() * 2);
+    writeHeader(out, sampleRate, numChannels, bitsPerSample, dataBytes);
     out.write(reinterpret_cast<const char*>(pcm.data()), dataBytes);
 }
 
@@ -138,13 +170,15 @@ SelaFile::SelaFile(uint32_t rate, uint16_t bps, uint8_t channels, std::vector<da
     selaHeader.channels = channels;
     selaHeader.numFrames = (uint32_t)selaFrames.size();
     frameOffsets.push_back(0);
+    std::vector<uint8_t> bytes;
     for (const data::SelaFrame& f : selaFrames) {
-        frame::appendFrame(f, frameBytes);
-        frameOffsets.push_back(frameBytes.size());
+        frame::appendFrame(f, bytes);
+        frameOffsets.push_back(bytes.size());
     }
+    frameBytes.assign(bytes.data(), bytes.size());
 }
 
-SelaFile::SelaFile(uint32_t rate, uint16_t bps, uint8_t channels, std::vector<uint8_t>&& bytes, std::vector<uint64_t>&& offsets)
+SelaFile::SelaFile(uint32_t rate, uint16_t bps, uint8_t channels, sela_host::PinnedBuffer<uint8_t>&& bytes, std::vector<uint64_t>&& offsets)
     : frameBytes(std::move(bytes)), frameOffsets(std::move(offsets))
 {
     selaHeader.sampleRate = rate;
@@ -153,22 +187,33 @@ SelaFile::SelaFile(uint32_t rate, uint16_t bps, uint8_t channels, std::vector<ui
     selaHeader.numFrames = frameOffsets.empty() ? 0 : (uint32_t)(frameOffsets.size() - 1);
 }
 
+size_t SelaFile::readHeader(std::ifstream& in)
+{
+    const size_t size = fileSize(in);
+    uint8_t head[15];
+    if (size < 15 || !readExact(in, head, 15))
+        throw data::Exception("File is too small, probably not a sela file.");
+    if (std::memcmp(head, "SeLa", 4) != 0)
+        throw data::Exception("Magic number is incorrect, probably not a sela file.");
+    selaHeader.sampleRate = le32(head + 4);
+    selaHeader.bitsPerSample = le16(head + 8);
+    selaHeader.channels = head[10];
+    selaHeader.numFrames = le32(head + 11);
+    return size - 15;
+}
+
 void SelaFile::readFromFile(std::ifstream& in)
 {
-    std::vector<uint8_t> bytes = slurp(in);
-    if (bytes.size() < 15)
+    const size_t bytes = readHeader(in);
+    frameBytes.resize(bytes);
+    if (bytes && !readExact(in, frameBytes.data(), bytes))
         throw data::Exception("File is too small, probably not a sela file.");
-    if (std::memcmp(bytes.data(), "SeLa", 4) != 0)
-        throw data::Exception("Magic number is incorrect, probably not a sela file.");
-    selaHeader.sampleRate = le32(bytes.data() + 4);
-    selaHeader.bitsPerSample = le16(bytes.data() + 8);
-    selaHeader.channels = bytes[10];
-    selaHeader.numFrames = le32(bytes.data() + 11);
-    frameBytes.assign(bytes.begin() + 15, bytes.end());
-    // index the frames; like the reference, stop silently at the first one without a sync word
-    frameOffsets.assign((size_t)selaHeader.numFrames + 1, 0);
-    const uint32_t found = sela_hip_index_frames(frameBytes.data(), frameBytes.size(), selaHeader.numFrames, selaHeader.channels,
-        frameOffsets.data());
+    // index the frames; like the reference, stop silently at the first one without a sync word.  The frame
+    // count of the header is not trusted for sizing: a frame has at least 4 + 12 bytes per channel.
+    const size_t least = 4 + 12 * (size_t)selaHeader.channels;
+    const uint32_t plausible = (uint32_t)std::min<size_t>(selaHeader.numFrames, bytes / least);
+    frameOffsets.assign((size_t)plausible + 1, 0);
+    const uint32_t found = sela_hip_index_frames(frameBytes.data(), frameBytes.size(), plausible, selaHeader.channels, frameOffsets.data());
     frameOffsets.resize((size_t)found + 1);
     frameBytes.resize((size_t)frameOffsets.back());
     materializeFrames();
@@ -177,7 +222,7 @@ void SelaFile::readFromFile(std::ifstream& in)
 void SelaFile::materializeFrames()
 {
     selaFrames.clear();
-    const size_t n = frameOffsets.empty() ? 0 : frameOffsets.size() - 1;
+    const size_t n = frameCount();
     selaFrames.reserve(n);
     for (size_t f = 0; f < n; f++) {
         data::SelaFrame frame((uint8_t)selaHeader.bitsPerSample);
@@ -187,13 +232,18 @@ void SelaFile::materializeFrames()
     }
 }
 
-void SelaFile::writeToFile(std::ofstream& out)
+void SelaFile::writeHeader(std::ofstream& out) const
 {
     out.write(reinterpret_cast<const char*>(selaHeader.magicNumber), 4);
     put<uint32_t>(out, selaHeader.sampleRate);
     put<uint16_t>(out, selaHeader.bitsPerSample);
     put<uint8_t>(out, selaHeader.channels);
     put<uint32_t>(out, selaHeader.numFrames);
+}
+
+void SelaFile::writeToFile(std::ofstream& out)
+{
+    writeHeader(out);
     out.write(reinterpret_cast<const char*>(frameBytes.data()), (std::streamsize)frameBytes.size()); // one write
 }
 

@@ -1,9 +1,12 @@
 // sela_cli.cpp -- command line front end of the MI355X SELA host:
 //   sela_mi355x -e in.wav out.sela     encode
 //   sela_mi355x -d in.sela out.wav     decode
-//   sela_mi355x -E out_dir a.wav b.wav ...    encode many files as one GPU batch -> out_dir/<name>.sela
-//   sela_mi355x -D out_dir a.sela b.sela ...  decode many files as one GPU batch -> out_dir/<name>.wav
-// Same verbs as the reference CLI (src/main.cpp:16-27); playback (-p) is not part of this build.
+//   sela_mi355x -E out_dir [--gpus N | --devices a,b,..] a.wav b.wav ...    encode many files as one job -> out_dir/<name>.sela
+//   sela_mi355x -D out_dir [--gpus N | --devices a,b,..] a.sela b.sela ...  decode many files as one job -> out_dir/<name>.wav
+// Same verbs as the reference CLI (src/main.cpp:16-27); playback (-p) is not part of this build.  The batch
+// verbs spread the files' frames over the GPUs of the node (default: all of them), one host thread each.
+#include <cstdlib>
+#include <exception>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -18,7 +21,7 @@ int usage(const std::string& program)
     std::cout << "Usage:\n\n"
               << "Encoding a file:\n" << program << " -e path/to/input.wav path/to/output.sela\n\n"
               << "Decoding a file:\n" << program << " -d path/to/input.sela path/to/output.wav\n\n"
-              << "Many files in one GPU batch:\n" << program << " -E|-D path/to/output_dir inputs...\n";
+              << "Many files, all GPUs:\n" << program << " -E|-D path/to/output_dir [--gpus N | --devices 0,1,..] inputs...\n";
     return 2;
 }
 
@@ -33,38 +36,107 @@ std::string sibling(const std::string& out_dir, const std::string& in, const cha
     return out_dir + "/" + name + extension;
 }
 
+std::ofstream openOutput(const std::string& path)
+{
+    std::ofstream out(path, std::ios::binary);
+    if (!out)
+        throw data::Exception("cannot open " + path + " for writing");
+    return out;
+}
+
+void finish(std::ofstream& out, const std::string& path)
+{
+    out.flush();
+    if (!out)
+        throw data::Exception("writing " + path + " failed");
+}
+
 int batch(const std::string& verb, int argc, char** argv)
 {
     const std::string out_dir = argv[2];
+    std::vector<std::string> inputs;
+    for (int i = 3; i < argc; i++) {
+        const std::string a = argv[i];
+        if ((a == "--gpus" || a == "--devices") && i + 1 < argc) {
+            std::vector<int> devs;
+            const std::string v = argv[++i];
+            if (a == "--gpus") {
+                for (int d = 0; d < std::atoi(v.c_str()); d++)
+                    devs.push_back(d);
+            } else {
+                for (size_t at = 0; at <= v.size();) {
+                    const size_t comma = std::min(v.find(',', at), v.size());
+                    devs.push_back(std::atoi(v.substr(at, comma - at).c_str()));
+                    at = comma + 1;
+                }
+            }
+            if (devs.empty())
+                throw data::Exception("no device selected");
+            sela::setDevices(devs);
+        } else {
+            inputs.push_back(a);
+        }
+    }
+    if (inputs.empty())
+        return 2;
     if (verb == "-E") {
-        std::vector<file::WavFile> wavs((size_t)argc - 3);
-        for (int i = 3; i < argc; i++) {
-            std::ifstream in(argv[i], std::ios::binary);
+        std::vector<file::WavFile> wavs(inputs.size());
+        for (size_t i = 0; i < inputs.size(); i++) {
+            std::ifstream in(inputs[i], std::ios::binary);
             if (!in)
-                throw data::Exception(std::string("cannot open ") + argv[i]);
-            wavs[(size_t)i - 3].readFromFile(in);
+                throw data::Exception("cannot open " + inputs[i]);
+            wavs[i].readFromFile(in);
         }
         sela::Encoder::materializeFrames = false;
         std::vector<file::SelaFile> selas = sela::encodeBatch(wavs);
-        for (int i = 3; i < argc; i++) {
-            std::ofstream out(sibling(out_dir, argv[i], ".sela"), std::ios::binary);
-            selas[(size_t)i - 3].writeToFile(out);
+        for (size_t i = 0; i < inputs.size(); i++) {
+            const std::string path = sibling(out_dir, inputs[i], ".sela");
+            std::ofstream out = openOutput(path);
+            selas[i].writeToFile(out);
+            finish(out, path);
         }
     } else {
-        std::vector<file::SelaFile> selas((size_t)argc - 3);
-        for (int i = 3; i < argc; i++) {
-            std::ifstream in(argv[i], std::ios::binary);
+        std::vector<file::SelaFile> selas(inputs.size());
+        for (size_t i = 0; i < inputs.size(); i++) {
+            std::ifstream in(inputs[i], std::ios::binary);
             if (!in)
-                throw data::Exception(std::string("cannot open ") + argv[i]);
-            selas[(size_t)i - 3].readFromFile(in);
+                throw data::Exception("cannot open " + inputs[i]);
+            selas[i].readFromFile(in);
         }
         sela::Decoder::demuxFrames = false;
         std::vector<file::WavFile> wavs = sela::decodeBatch(selas);
-        for (int i = 3; i < argc; i++) {
-            std::ofstream out(sibling(out_dir, argv[i], ".wav"), std::ios::binary);
-            wavs[(size_t)i - 3].writeToFile(out);
+        for (size_t i = 0; i < inputs.size(); i++) {
+            const std::string path = sibling(out_dir, inputs[i], ".wav");
+            std::ofstream out = openOutput(path);
+            wavs[i].writeToFile(out);
+            finish(out, path);
         }
     }
+    return 0;
+}
+
+int run(int argc, char** argv)
+{
+    const std::string program = argv[0];
+    const std::string verb = argc > 1 ? argv[1] : "";
+    if ((verb == "-E" || verb == "-D") && argc >= 4) {
+        const int rc = batch(verb, argc, argv);
+        return rc == 2 ? usage(program) : rc;
+    }
+    if (argc != 4 || (verb != "-e" && verb != "-d"))
+        return usage(program);
+    std::ifstream in(argv[2], std::ios::binary);
+    if (!in)
+        throw data::Exception(std::string("cannot open ") + argv[2]);
+    std::ofstream out = openOutput(argv[3]);
+    if (verb == "-e") {
+        std::cout << "Encoding: " << argv[2] << std::endl;
+        sela::encodeFile(in, out); // read, GPU and write overlap; only the byte stream is produced
+    } else {
+        std::cout << "Decoding: " << argv[2] << std::endl;
+        sela::decodeFile(in, out);
+    }
+    finish(out, argv[3]);
     return 0;
 }
 
@@ -73,40 +145,12 @@ int batch(const std::string& verb, int argc, char** argv)
 int main(int argc, char** argv)
 {
     std::cout << "SimplE Lossless Audio (.sela v2 bitstream) -- MI355X host" << std::endl;
-    const std::string program = argv[0];
-    const std::string verb = argc > 1 ? argv[1] : "";
-    if ((verb == "-E" || verb == "-D") && argc >= 4) {
-        try {
-            return batch(verb, argc, argv);
-        } catch (const data::Exception& e) {
-            std::cerr << e.exceptionMessage << std::endl;
-            return 1;
-        }
-    }
-    if (argc != 4)
-        return usage(program);
     try {
-        std::ifstream in(argv[2], std::ios::binary);
-        if (!in)
-            throw data::Exception(std::string("cannot open ") + argv[2]);
-        if (verb == "-e") {
-            std::cout << "Encoding: " << argv[2] << std::endl;
-            sela::Encoder::materializeFrames = false; // only the byte stream is needed
-            file::SelaFile sela = sela::Encoder(in).process();
-            std::ofstream out(argv[3], std::ios::binary);
-            sela.writeToFile(out);
-        } else if (verb == "-d") {
-            std::cout << "Decoding: " << argv[2] << std::endl;
-            sela::Decoder::demuxFrames = false;
-            file::WavFile wav = sela::Decoder(in).process();
-            std::ofstream out(argv[3], std::ios::binary);
-            wav.writeToFile(out);
-        } else {
-            return usage(program);
-        }
+        return run(argc, argv);
     } catch (const data::Exception& e) {
         std::cerr << e.exceptionMessage << std::endl;
-        return 1;
+    } catch (const std::exception& e) { // (std::bad_alloc on an absurd header, ...)
+        std::cerr << "error: " << e.what() << std::endl;
     }
-    return 0;
+    return 1;
 }

@@ -37,6 +37,10 @@
  *   host     : pointers are HOST pointers; the library stages through its own device buffers
  *              (H2D, kernels, D2H) and returns when the result is in host memory.  This is what
  *              the C++ host (host/) calls from sela::Encoder/Decoder and frame::Frame{En,De}coder.
+ *              One-shot calls (whole batch in memory) and streaming jobs (begin / feed / end: the
+ *              caller keeps reading its file while earlier pieces are already on the device).
+ *              Buffers from sela_hip_host_alloc() are page-locked: copies from and to them are truly
+ *              asynchronous; ordinary (pageable) memory works too, only slower.
  */
 #ifndef SELA_HIP_H_
 #define SELA_HIP_H_
@@ -74,9 +78,18 @@ typedef struct sela_hip_trace {
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* Select/initialise `device` (>= 0) for the calling thread, or -1 to keep the current device. */
 int sela_hip_init(int device);
+/* Free the calling thread's staging buffers and streams (host-pointer API); worker threads call this before
+ * they exit.  sela_hip_shutdown() does the same and also returns the idle page-locked blocks to the system. */
+void sela_hip_thread_release(void);
 void sela_hip_shutdown(void);
 const char* sela_hip_last_error(void);
 int sela_hip_device_count(void);
+/* Page-locked host memory for the buffers handed to the host-pointer API (PCM in, frames out, ...).
+ * Freed blocks are pooled and handed out again (pinning is slow); sela_hip_shutdown() returns them to the
+ * system.  Without a usable HIP device these fall back to ordinary aligned memory, so container code
+ * (WAV / .sela parsing) that holds its data in such buffers still runs on a CPU-only box. */
+void* sela_hip_host_alloc(size_t bytes);
+void sela_hip_host_free(void* p);
 
 /* ---- sizing ------------------------------------------------------------------------------------ */
 /* Number of signals analysed per frame: channels, +1 for exactly-stereo input. */
@@ -84,7 +97,12 @@ uint32_t sela_hip_signals_per_frame(uint32_t channels);
 /* Bytes of device workspace the *_device calls need for a batch of n_frames.  The workspace needs no
  * initialisation and may be reused by later calls; one call at a time may use it. */
 size_t sela_hip_encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
+/* (The decoder keeps residues and samples on chip: a small constant.  Kept so that callers size and pass a
+ * workspace the same way for both directions.) */
 size_t sela_hip_decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
+/* Most channels the decoder takes (17: every channel of a frame has to be in LDS for the parent - difference
+ * pass, src/frame/frame_decoder.cpp:40-69).  The .sela header allows 255; more than this is SELA_HIP_EINVAL. */
+uint32_t sela_hip_decode_max_channels(void);
 /* Upper bound of the frame byte stream produced by encoding n_frames (what `frames_cap` must be
  * to be certain never to get SELA_HIP_ECAPACITY). */
 size_t sela_hip_encode_bound_bytes(uint32_t n_frames, uint32_t channels);
@@ -104,11 +122,9 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
 /*
  * Decode n_frames frames.  d_frames / d_frame_offsets as produced above (or by parsing a .sela
  * file).  d_pcm_out: int16 [n_frames][2048][channels].  d_status: uint32[4], [0] = OR of flag
- * bits, [1] = number of malformed frames.  d_workspace holds the parsed residues and the filter state
- * between the kernels (sela_hip_decode_workspace_bytes()).  The call is cut into four chunks along the
- * sample axis: the parse kernel of chunk j+1 runs on a library-owned side stream beside the synthesis
- * kernel of chunk j on `stream`; all of it is ordered after earlier work on `stream`, and later work on
- * `stream` is ordered after all of it.
+ * bits, [1] = number of malformed frames (zeroed by the call).  channels <= sela_hip_decode_max_channels().
+ * One kernel on `stream` (one workgroup per frame, one wave per subframe); d_workspace is not touched and
+ * may be NULL.  Returns immediately.
  */
 int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames,
     uint32_t channels, int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, size_t workspace_bytes,
@@ -116,12 +132,34 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
 
 /* ---- host-pointer API (synchronous) -------------------------------------------------------------- */
 /* frames_out must hold sela_hip_encode_bound_bytes() or the call may return SELA_HIP_ECAPACITY.
- * Large batches run as a chunked pipeline on three library-owned streams (copy in / kernels / copy out
- * overlapped); results are identical to one call on the whole batch. */
+ * Batches run as a pipeline of 1024-frame chunks on library-owned streams (copy in / kernels / copy out
+ * overlapped, the kernels of consecutive chunks overlapped too); results are identical to one call on the
+ * whole batch.  These are begin + feed(everything) + end of the streaming jobs below. */
 int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel,
     uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out /* [n_frames+1] */);
 int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* pcm_out);
+
+/* ---- streaming jobs (host pointers) -------------------------------------------------------------------
+ * For callers that produce their input piece by piece (a file being read): feed() enqueues a piece and
+ * returns at once -- from page-locked buffers nothing in it waits for the device except the hand-over of
+ * a buffer set two chunks back -- so the caller's next read runs beside the device work.  One open job per
+ * calling thread; a job is used from the thread that began it.
+ *
+ * encode: the job appends to frames_out (capacity frames_cap) and fills frame_offsets_out[0 .. total_frames];
+ * *frames_final / *bytes_final (optional) report how much of both is complete in host memory, so a writer can
+ * drain finished bytes to disk while later pieces are still being encoded (src/file/sela_file.cpp:105-137 is
+ * what it replaces).  end() waits for everything, reports the totals, and frees the job -- also after an error.
+ * decode: pieces are whole frames (frame_offsets[0 .. n_frames] index into `frames`); pcm_out fills in order.
+ * Errors are those of the one-shot calls. */
+typedef struct sela_hip_job sela_hip_job;
+int sela_hip_encode_begin(sela_hip_job** job, uint32_t channels, uint32_t total_frames, uint8_t* frames_out, size_t frames_cap,
+    uint64_t* frame_offsets_out /* [total_frames + 1] */);
+int sela_hip_encode_feed(sela_hip_job* job, const int16_t* pcm, uint32_t n_frames, uint32_t* frames_final, uint64_t* bytes_final);
+int sela_hip_encode_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final);
+int sela_hip_decode_begin(sela_hip_job** job, uint32_t channels, uint32_t total_frames, int16_t* pcm_out);
+int sela_hip_decode_feed(sela_hip_job* job, const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t* frames_final);
+int sela_hip_decode_end(sela_hip_job* job, uint32_t* frames_final);
 
 /* Walk a frame byte stream on the host and fill frame_offsets[0..n_frames]; stops at the first bad
  * sync word like src/file/sela_file.cpp:54-56.  Returns the number of frames found (<= n_frames). */
@@ -131,7 +169,7 @@ uint32_t sela_hip_index_frames(const uint8_t* frames, size_t frames_bytes, uint3
 /* ---- per-kernel timing (measurement hook used by bench.py) ------------------------------------------
  * When enabled, the *_device calls of the calling thread bracket each kernel launch with HIP events
  * recorded on the caller's stream.  sela_hip_kernel_times() waits for the events of the most recent
- * encode (3 kernels: blocks, plan, assemble) or decode (2 kernels: parse, synthesize) call and returns their durations
+ * encode (3 kernels: blocks, plan, assemble) or decode (1 kernel) call and returns their durations
  * in milliseconds; it returns the number of kernels reported (0 if timing was off). */
 void sela_hip_enable_kernel_timing(int enable);
 int sela_hip_kernel_times(float* ms_out, int capacity);
@@ -141,6 +179,10 @@ int sela_hip_kernel_times(float* ms_out, int capacity);
  * (frame, signal) for the encoder and per (frame, subframe) for the decoder.  Slower; never set
  * in the timed path. */
 void sela_hip_debug_phase_buffer(uint64_t* d_cycles);
+/* Debug hook: while set, every block of the calling thread's encodes computes its residues with the plain
+ * 64-bit loop that predictors beyond the fast FIR's coefficient range take (never reached by 16-bit audio);
+ * results are identical by construction, which is what the tests check. */
+void sela_hip_debug_force_plain_fir(int enable);
 
 /* ---- flag bits reported through d_status[0] / sela_hip_trace.flags --------------------------------- */
 #define SELA_HIP_FLAG_Q_RANGE 1u       /* quantised reflection coefficient outside [-64,63] (clamped) */

@@ -19,11 +19,14 @@ FLAG_Q_RANGE, FLAG_COEF_OVERFLOW, FLAG_RICE_RANGE, FLAG_RICE_OVERRUN, FLAG_WORDS
 
 # every symbol include/sela_hip.h declares
 EXPORTS = [
-    "sela_hip_init", "sela_hip_shutdown", "sela_hip_last_error", "sela_hip_device_count",
+    "sela_hip_init", "sela_hip_shutdown", "sela_hip_thread_release", "sela_hip_last_error", "sela_hip_device_count",
     "sela_hip_signals_per_frame", "sela_hip_encode_workspace_bytes", "sela_hip_decode_workspace_bytes",
     "sela_hip_encode_bound_bytes", "sela_hip_encode_device", "sela_hip_decode_device",
     "sela_hip_encode", "sela_hip_decode", "sela_hip_index_frames",
     "sela_hip_enable_kernel_timing", "sela_hip_kernel_times", "sela_hip_debug_phase_buffer",
+    "sela_hip_host_alloc", "sela_hip_host_free", "sela_hip_decode_max_channels", "sela_hip_debug_force_plain_fir",
+    "sela_hip_encode_begin", "sela_hip_encode_feed", "sela_hip_encode_end",
+    "sela_hip_decode_begin", "sela_hip_decode_feed", "sela_hip_decode_end",
 ]
 
 
@@ -59,6 +62,8 @@ def lib() -> C.CDLL:
     L.sela_hip_init.restype = C.c_int
     L.sela_hip_shutdown.argtypes = []
     L.sela_hip_shutdown.restype = None
+    L.sela_hip_thread_release.argtypes = []
+    L.sela_hip_thread_release.restype = None
     L.sela_hip_last_error.argtypes = []
     L.sela_hip_last_error.restype = C.c_char_p
     L.sela_hip_device_count.argtypes = []
@@ -84,6 +89,23 @@ def lib() -> C.CDLL:
     L.sela_hip_kernel_times.restype = C.c_int
     L.sela_hip_debug_phase_buffer.argtypes = [C.c_void_p]
     L.sela_hip_debug_phase_buffer.restype = None
+    L.sela_hip_debug_force_plain_fir.argtypes = [C.c_int]
+    L.sela_hip_debug_force_plain_fir.restype = None
+    L.sela_hip_host_alloc.argtypes = [sz]
+    L.sela_hip_host_alloc.restype = C.c_void_p
+    L.sela_hip_host_free.argtypes = [C.c_void_p]
+    L.sela_hip_host_free.restype = None
+    L.sela_hip_decode_max_channels.argtypes = []
+    L.sela_hip_decode_max_channels.restype = u32
+    L.sela_hip_encode_begin.argtypes = [C.POINTER(C.c_void_p), u32, u32, vp, sz, vp]
+    L.sela_hip_encode_feed.argtypes = [vp, vp, u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.sela_hip_encode_end.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.sela_hip_decode_begin.argtypes = [C.POINTER(C.c_void_p), u32, u32, vp]
+    L.sela_hip_decode_feed.argtypes = [vp, vp, vp, u32, C.POINTER(C.c_uint32)]
+    L.sela_hip_decode_end.argtypes = [vp, C.POINTER(C.c_uint32)]
+    for name in ("sela_hip_encode_begin", "sela_hip_encode_feed", "sela_hip_encode_end", "sela_hip_decode_begin",
+                 "sela_hip_decode_feed", "sela_hip_decode_end"):
+        getattr(L, name).restype = C.c_int
     _LIB = L
     return L
 

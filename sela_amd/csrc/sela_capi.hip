@@ -1,12 +1,15 @@
 // sela_capi.hip -- the extern "C" boundary of libsela_hip.so (declared in include/sela_hip.h).
 //
 // Plain pointers and sizes only.  The *_device entry points enqueue kernels on the caller's stream;
-// the host-pointer entry points stage through a per-thread, grow-only set of device buffers.
-// There is no CPU fallback anywhere: without a HIP device every call fails with SELA_HIP_ENODEV.
+// the host-pointer entry points (one-shot and streaming jobs) stage through a per-thread, grow-only set
+// of device buffers.  There is no CPU fallback anywhere: without a HIP device every call fails with
+// SELA_HIP_ENODEV.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -16,13 +19,11 @@ namespace sela {
 size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
-    hipEvent_t* ev, uint64_t* d_phase_cycles);
+    hipEvent_t* ev, uint64_t* d_phase_cycles, uint64_t* d_mirror, int force_plain_fir);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles,
-    hipStream_t side, hipEvent_t fork, hipEvent_t* parsed);
+    int16_t* d_pcm_out, uint32_t* d_status, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles);
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
-size_t decode_lds_bytes(uint32_t channels, int n_waves, uint32_t v_count);
-int decode_waves(uint32_t channels);
+uint32_t decode_max_channels();
 } // namespace sela
 
 namespace {
@@ -38,6 +39,72 @@ int fail(int code, const std::string& what)
 int fail_hip(hipError_t e, const char* where)
 {
     return fail(e == hipErrorOutOfMemory ? SELA_HIP_ENOMEM : SELA_HIP_ENODEV, std::string(where) + ": " + hipGetErrorString(e));
+}
+
+// ---- page-locked host memory (sela_hip_host_alloc) ---------------------------------------------------------
+// Copies from and to pageable memory go through the runtime's own staging and block the calling thread;
+// from page-locked memory hipMemcpyAsync really is asynchronous, which is what the chunk pipeline below
+// needs.  Pinning is slow (page by page), so freed blocks are kept and handed out again.
+struct PinnedPool {
+    struct Block {
+        void* ptr;
+        size_t cap;
+        bool pinned;
+    };
+    std::mutex mu;
+    std::vector<Block> live, idle;
+
+    void* take(size_t bytes)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        size_t best = idle.size();
+        for (size_t i = 0; i < idle.size(); i++)
+            if (idle[i].cap >= bytes && idle[i].cap <= 2 * bytes + 4096 && (best == idle.size() || idle[i].cap < idle[best].cap))
+                best = i;
+        Block b;
+        if (best != idle.size()) {
+            b = idle[best];
+            idle.erase(idle.begin() + (std::ptrdiff_t)best);
+        } else {
+            b.cap = (bytes + 4095) & ~(size_t)4095;
+            b.ptr = nullptr;
+            b.pinned = hipHostMalloc(&b.ptr, b.cap, hipHostMallocDefault) == hipSuccess && b.ptr;
+            if (!b.pinned) { // no device (CPU-only container code still runs): ordinary memory
+                (void)hipGetLastError();
+                b.ptr = std::aligned_alloc(4096, b.cap);
+                if (!b.ptr)
+                    return nullptr;
+            }
+        }
+        live.push_back(b);
+        return b.ptr;
+    }
+    void give(void* p)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (size_t i = 0; i < live.size(); i++)
+            if (live[i].ptr == p) {
+                idle.push_back(live[i]);
+                live.erase(live.begin() + (std::ptrdiff_t)i);
+                return;
+            }
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (Block& b : idle) {
+            if (b.pinned)
+                (void)hipHostFree(b.ptr);
+            else
+                std::free(b.ptr);
+        }
+        idle.clear();
+    }
+};
+PinnedPool& pool()
+{
+    static PinnedPool* p = new PinnedPool; // (never destroyed: the HIP runtime may already be gone at exit)
+    return *p;
 }
 
 // Grow-only device scratch used by the host-pointer API (one set per calling thread).
@@ -66,22 +133,52 @@ struct DeviceBuffer {
         cap = 0;
     }
 };
+// page-locked host scratch owned by the library (frame offsets on their way in or out)
+struct HostBuffer {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        release();
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        if (e == hipSuccess)
+            cap = want;
+        else
+            ptr = nullptr;
+        return e;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
 
-// Host-pointer calls run as a chunked pipeline: while chunk i is in the kernels,
-// chunk i+1 is copied in and chunk i-1 is copied out, on three streams.  Two sets of device buffers
-// alternate; the workspace is shared because the kernels of consecutive chunks run in stream order.
-// Frames per chunk; batches below two chunks go in one piece.  Encoding 1024 frames takes 0.22 ms, about
-// as long as copying them in and out; decoding is latency-bound below a few thousand frames (one lane
-// per stream), so its chunks are larger.
-constexpr uint32_t kHostChunkFramesEncode = 1024;
-constexpr uint32_t kHostChunkFramesDecode = 4096;
+// Host-pointer calls run as a chunked pipeline: chunk i+1 is copied in while chunk i is
+// in the kernels and chunk i-1 is copied out.  Two sets of device buffers alternate, each with its own
+// kernel stream, so the kernels of consecutive chunks overlap as well (a chunk of this size leaves the
+// device in its launch tail for a good part of its run time).
+constexpr uint32_t kHostChunkFrames = 1024;
+
+struct ChunkSet {
+    DeviceBuffer pcm, frames, offsets, workspace;
+    HostBuffer host_offsets; // encode: k_plan_frames' mirror of offsets + status; decode: the chunk's rebased offsets
+    hipStream_t s_run = nullptr;
+    hipEvent_t copied_in = nullptr, ran = nullptr, copied_out = nullptr;
+};
 
 struct HostContext {
-    DeviceBuffer pcm[2], frames[2], offsets[2], status[2], workspace;
-    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
-    hipEvent_t copied_in[2] = { nullptr, nullptr }, ran[2] = { nullptr, nullptr };
-    std::vector<uint64_t> rebased[2]; // decode: a chunk's frame offsets relative to its first byte
+    ChunkSet set[2];
+    DeviceBuffer status;      // 4 words per chunk of the running job
+    HostBuffer host_status;
+    hipStream_t s_in = nullptr, s_out = nullptr;
     int device = -1;
+    bool job_open = false;
     // the buffers belong to the device that was current when they were allocated
     bool bind_current_device()
     {
@@ -97,32 +194,44 @@ struct HostContext {
     hipError_t streams()
     {
         hipError_t e = hipSuccess;
-        for (hipStream_t* s : { &s_in, &s_run, &s_out })
+        for (hipStream_t* s : { &s_in, &s_out, &set[0].s_run, &set[1].s_run })
             if (!*s && (e = hipStreamCreateWithFlags(s, hipStreamNonBlocking)) != hipSuccess)
                 return e;
-        for (hipEvent_t* ev : { &copied_in[0], &copied_in[1], &ran[0], &ran[1] })
-            if (!*ev && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
-                return e;
+        for (ChunkSet& c : set)
+            for (hipEvent_t* ev : { &c.copied_in, &c.ran, &c.copied_out })
+                if (!*ev && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
+                    return e;
         return e;
+    }
+    void sync_all()
+    {
+        for (hipStream_t s : { s_in, s_out, set[0].s_run, set[1].s_run })
+            if (s)
+                (void)hipStreamSynchronize(s);
     }
     void release()
     {
-        for (int b = 0; b < 2; b++) {
-            pcm[b].release();
-            frames[b].release();
-            offsets[b].release();
-            status[b].release();
+        for (ChunkSet& c : set) {
+            c.pcm.release();
+            c.frames.release();
+            c.offsets.release();
+            c.workspace.release();
+            c.host_offsets.release();
+            if (c.s_run)
+                (void)hipStreamDestroy(c.s_run);
+            c.s_run = nullptr;
+            for (hipEvent_t* ev : { &c.copied_in, &c.ran, &c.copied_out }) {
+                if (*ev)
+                    (void)hipEventDestroy(*ev);
+                *ev = nullptr;
+            }
         }
-        workspace.release();
-        for (hipStream_t* s : { &s_in, &s_run, &s_out }) {
+        status.release();
+        host_status.release();
+        for (hipStream_t* s : { &s_in, &s_out }) {
             if (*s)
                 (void)hipStreamDestroy(*s);
             *s = nullptr;
-        }
-        for (hipEvent_t* ev : { &copied_in[0], &copied_in[1], &ran[0], &ran[1] }) {
-            if (*ev)
-                (void)hipEventDestroy(*ev);
-            *ev = nullptr;
         }
     }
 };
@@ -144,57 +253,266 @@ struct KernelTiming {
     }
 };
 thread_local KernelTiming g_timing;
-// Side stream + events of the decode pipeline (parse chunk j+1 overlaps synthesis of chunk j), per
-// calling thread and device.
-struct DecodePipeline {
-    int device = -1;
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr;
-    hipEvent_t parsed[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    bool ready()
-    {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess)
-            return false;
-        if (dev == device && side)
-            return true;
-        release();
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) {
-            side = nullptr;
-            return false;
-        }
-        bool ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
-        for (auto& e : parsed)
-            ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            release();
-            return false;
-        }
-        device = dev;
-        return true;
-    }
-    void release()
-    {
-        if (side)
-            (void)hipStreamDestroy(side);
-        if (fork)
-            (void)hipEventDestroy(fork);
-        for (auto& e : parsed) {
-            if (e)
-                (void)hipEventDestroy(e);
-            e = nullptr;
-        }
-        side = nullptr;
-        fork = nullptr;
-        device = -1;
-    }
-};
-thread_local DecodePipeline g_pipeline;
 thread_local uint64_t* g_phase_cycles = nullptr; // debug: per-block phase cycle counts (sela_hip_debug_phase_buffer)
+thread_local int g_force_plain_fir = 0;          // debug: sela_hip_debug_force_plain_fir
 
 uint32_t flags_to_error(uint32_t flags)
 {
     return flags & (SELA_HIP_FLAG_WORDS_CAP | SELA_HIP_FLAG_RICE_RANGE | SELA_HIP_FLAG_COEF_OVERFLOW);
+}
+
+} // namespace
+
+// ---- streaming jobs ----------------------------------------------------------------------------------------
+struct sela_hip_job {
+    bool encode = false;
+    uint32_t channels = 0, total_frames = 0;
+    uint32_t fed = 0;      // frames handed to feed() so far
+    uint32_t issued = 0;   // chunks whose copy-in and kernels are enqueued
+    uint32_t drained = 0;  // chunks whose copy-out is enqueued
+    uint32_t final_chunks = 0; // chunks whose results are complete in host memory
+    std::vector<uint32_t> chunk_first, chunk_frames; // per issued chunk
+    std::vector<uint64_t> chunk_end_byte;            // encode: output bytes up to and including the chunk
+    // encode
+    uint8_t* frames_out = nullptr;
+    size_t frames_cap = 0;
+    uint64_t* offsets_out = nullptr;
+    uint64_t bytes_issued = 0; // output bytes of the drained chunks
+    size_t chunk_bound = 0;
+    // decode
+    int16_t* pcm_out = nullptr;
+    int error = SELA_HIP_OK;
+};
+
+namespace {
+
+int job_fail(sela_hip_job* job, int code)
+{
+    if (job->error == SELA_HIP_OK)
+        job->error = code;
+    return code;
+}
+
+// Results of chunk `i` are in host memory once its copy-out has finished.
+int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
+{
+    while (job->final_chunks < upto) {
+        ChunkSet& c = g_ctx.set[job->final_chunks & 1];
+        // (chunk i and chunk i+2 share the event: i+2 is only drained after i was finalized)
+        hipError_t e = hipEventSynchronize(c.copied_out);
+        if (e != hipSuccess)
+            return job_fail(job, fail_hip(e, "copy-out"));
+        job->final_chunks++;
+    }
+    return SELA_HIP_OK;
+}
+
+// Enqueue the copy-out of the oldest issued chunk (its kernels must have finished: the encoder's byte
+// count is needed on the host).
+int job_drain_one(sela_hip_job* job)
+{
+    const uint32_t i = job->drained;
+    ChunkSet& c = g_ctx.set[i & 1];
+    const uint32_t nf = job->chunk_frames[i], first = job->chunk_first[i];
+    hipError_t e = hipEventSynchronize(c.ran);
+    if (e != hipSuccess)
+        return job_fail(job, fail_hip(e, "kernels"));
+    if (job->encode) {
+        const uint64_t* mirror = static_cast<const uint64_t*>(c.host_offsets.ptr); // offsets[0..nf], then status[0] | status[1] << 32
+        const uint64_t st = mirror[nf + 1];
+        const uint32_t flags = (uint32_t)st, overflow = (uint32_t)(st >> 32);
+        if (flags_to_error(flags)) {
+            char msg[160];
+            std::snprintf(msg, sizeof msg, "a block left the range the .sela format can carry (flags 0x%x)", flags);
+            return job_fail(job, fail(SELA_HIP_ERANGE, msg));
+        }
+        const uint64_t total = mirror[nf];
+        if (overflow || job->bytes_issued + total > job->frames_cap)
+            return job_fail(job, fail(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes)"));
+        for (uint32_t f = 0; f <= nf; f++)
+            job->offsets_out[(size_t)first + f] = job->bytes_issued + mirror[f];
+        if (total && (e = hipMemcpyAsync(job->frames_out + job->bytes_issued, c.frames.ptr, (size_t)total, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess)
+            return job_fail(job, fail_hip(e, "D2H frames"));
+        job->bytes_issued += total;
+        job->chunk_end_byte.push_back(job->bytes_issued);
+    } else {
+        const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
+        if ((e = hipMemcpyAsync(job->pcm_out + (size_t)first * sela::kBlock * job->channels, c.pcm.ptr, nf * frame_pcm, hipMemcpyDeviceToHost, g_ctx.s_out))
+            != hipSuccess)
+            return job_fail(job, fail_hip(e, "D2H pcm"));
+    }
+    if ((e = hipEventRecord(c.copied_out, g_ctx.s_out)) != hipSuccess)
+        return job_fail(job, fail_hip(e, "hipEventRecord"));
+    job->drained++;
+    return SELA_HIP_OK;
+}
+
+hipError_t reserve_chunk_buffers(bool encode, uint32_t channels, size_t frames_bytes)
+{
+    hipError_t e = g_ctx.streams();
+    if (e != hipSuccess)
+        return e;
+    const size_t frame_pcm = (size_t)sela::kBlock * channels * sizeof(int16_t);
+    for (ChunkSet& c : g_ctx.set) {
+        if ((e = c.pcm.reserve(kHostChunkFrames * frame_pcm + 16)) != hipSuccess || (e = c.frames.reserve(frames_bytes + 16)) != hipSuccess
+            || (e = c.offsets.reserve(((size_t)kHostChunkFrames + 1) * 8)) != hipSuccess
+            || (e = c.host_offsets.reserve(((size_t)kHostChunkFrames + 2) * 8)) != hipSuccess)
+            return e;
+        if (encode && (e = c.workspace.reserve(sela::encode_workspace_bytes(kHostChunkFrames, channels))) != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+// One chunk (<= kHostChunkFrames frames) into the pipeline.
+int job_issue_encode(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
+{
+    const uint32_t i = job->issued;
+    ChunkSet& c = g_ctx.set[i & 1];
+    const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
+    hipError_t e;
+    // chunk i-2 used this set: its kernels have read pcm (ran), its frames have left the device (copied_out)
+    if (i >= 2) {
+        int rc = job->drained < i - 1 ? job_drain_one(job) : SELA_HIP_OK;
+        if (rc != SELA_HIP_OK)
+            return rc;
+        if ((e = hipStreamWaitEvent(g_ctx.s_in, c.ran, 0)) != hipSuccess || (e = hipStreamWaitEvent(c.s_run, c.copied_out, 0)) != hipSuccess)
+            return job_fail(job, fail_hip(e, "hipStreamWaitEvent"));
+    }
+    if ((e = hipMemcpyAsync(c.pcm.ptr, pcm, nf * frame_pcm, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
+        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(c.s_run, c.copied_in, 0)) != hipSuccess)
+        return job_fail(job, fail_hip(e, "H2D pcm"));
+    uint64_t* d_mirror = nullptr;
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d_mirror), c.host_offsets.ptr, 0)) != hipSuccess)
+        return job_fail(job, fail_hip(e, "hipHostGetDevicePointer"));
+    uint32_t* d_status = static_cast<uint32_t*>(g_ctx.status.ptr) + 4 * (size_t)(i & 1);
+    e = sela::launch_encode(static_cast<const int16_t*>(c.pcm.ptr), nf, job->channels, static_cast<uint8_t*>(c.frames.ptr), job->chunk_bound,
+        static_cast<uint64_t*>(c.offsets.ptr), d_status, c.workspace.ptr, nullptr, c.s_run, nullptr, nullptr, d_mirror, g_force_plain_fir);
+    if (e != hipSuccess || (e = hipEventRecord(c.ran, c.s_run)) != hipSuccess)
+        return job_fail(job, fail_hip(e, "encode launch"));
+    job->chunk_first.push_back(job->fed);
+    job->chunk_frames.push_back(nf);
+    job->issued++;
+    job->fed += nf;
+    return SELA_HIP_OK;
+}
+
+int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* offsets, uint32_t nf)
+{
+    const uint32_t i = job->issued;
+    ChunkSet& c = g_ctx.set[i & 1];
+    hipError_t e;
+    if (i >= 2) {
+        int rc = job->drained < i - 1 ? job_drain_one(job) : SELA_HIP_OK;
+        if (rc != SELA_HIP_OK)
+            return rc;
+        // the staging array below was read by chunk i-2's copy-in
+        if ((e = hipEventSynchronize(c.copied_in)) != hipSuccess || (e = hipStreamWaitEvent(g_ctx.s_in, c.ran, 0)) != hipSuccess
+            || (e = hipStreamWaitEvent(c.s_run, c.copied_out, 0)) != hipSuccess)
+            return job_fail(job, fail_hip(e, "hipStreamWaitEvent"));
+    }
+    const uint64_t bytes = offsets[nf] - offsets[0];
+    if ((e = c.frames.reserve((size_t)bytes + 16)) != hipSuccess) // (grow-only; a set that is still in use is never the one that grows: waited above)
+        return job_fail(job, fail_hip(e, "hipMalloc"));
+    uint64_t* rel = static_cast<uint64_t*>(c.host_offsets.ptr);
+    for (uint32_t f = 0; f <= nf; f++)
+        rel[f] = offsets[f] - offsets[0];
+    if ((bytes && (e = hipMemcpyAsync(c.frames.ptr, frames + offsets[0], (size_t)bytes, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess)
+        || (e = hipMemcpyAsync(c.offsets.ptr, rel, ((size_t)nf + 1) * 8, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
+        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(c.s_run, c.copied_in, 0)) != hipSuccess)
+        return job_fail(job, fail_hip(e, "H2D frames"));
+    if ((e = g_ctx.status.reserve(16 * ((size_t)i + 1))) != hipSuccess) // (sized at begin; this never reallocates)
+        return job_fail(job, fail_hip(e, "hipMalloc"));
+    uint32_t* d_status = static_cast<uint32_t*>(g_ctx.status.ptr) + 4 * (size_t)i;
+    e = sela::launch_decode(static_cast<const uint8_t*>(c.frames.ptr), static_cast<const uint64_t*>(c.offsets.ptr), nf, job->channels,
+        static_cast<int16_t*>(c.pcm.ptr), d_status, c.s_run, nullptr, nullptr);
+    if (e != hipSuccess || (e = hipEventRecord(c.ran, c.s_run)) != hipSuccess)
+        return job_fail(job, fail_hip(e, "decode launch"));
+    job->chunk_first.push_back(job->fed);
+    job->chunk_frames.push_back(nf);
+    job->issued++;
+    job->fed += nf;
+    return SELA_HIP_OK;
+}
+
+void job_progress(const sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
+{
+    const uint32_t n = job->final_chunks;
+    if (frames_final)
+        *frames_final = n ? job->chunk_first[n - 1] + job->chunk_frames[n - 1] : 0;
+    if (bytes_final)
+        *bytes_final = (job->encode && n) ? job->chunk_end_byte[n - 1] : 0;
+}
+
+int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total_frames)
+{
+    if (!out)
+        return fail(SELA_HIP_EINVAL, "null job pointer");
+    *out = nullptr;
+    if (channels == 0 || channels > 255)
+        return fail(SELA_HIP_EINVAL, "channels must be in 1..255");
+    if (!encode && channels > sela::decode_max_channels())
+        return fail(SELA_HIP_EINVAL, "the on-chip decoder handles at most 17 channels (LDS budget)");
+    int rc = sela_hip_init(-1);
+    if (rc != SELA_HIP_OK)
+        return rc;
+    if (!g_ctx.bind_current_device())
+        return fail(SELA_HIP_ENODEV, "hipGetDevice failed");
+    if (g_ctx.job_open)
+        return fail(SELA_HIP_EINVAL, "this thread already has an open job");
+    const size_t bound = sela_hip_encode_bound_bytes(kHostChunkFrames, channels);
+    hipError_t e = reserve_chunk_buffers(encode, channels, encode ? bound : 0);
+    const size_t n_chunks = ((size_t)total_frames + kHostChunkFrames - 1) / kHostChunkFrames + 2;
+    if (e == hipSuccess)
+        e = g_ctx.status.reserve(16 * n_chunks);
+    if (e == hipSuccess)
+        e = g_ctx.host_status.reserve(16 * n_chunks);
+    if (e != hipSuccess)
+        return fail_hip(e, "hipMalloc");
+    sela_hip_job* job = new sela_hip_job;
+    job->encode = encode;
+    job->channels = channels;
+    job->total_frames = total_frames;
+    job->chunk_bound = bound;
+    g_ctx.job_open = true;
+    *out = job;
+    return SELA_HIP_OK;
+}
+
+int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
+{
+    int rc = job->error;
+    while (rc == SELA_HIP_OK && job->drained < job->issued)
+        rc = job_drain_one(job);
+    if (rc == SELA_HIP_OK)
+        rc = job_finalize(job, job->drained);
+    uint32_t seen_flags = 0;
+    if (rc == SELA_HIP_OK && !job->encode && job->issued) {
+        // every frame is decoded (bad ones to silence) before the verdict
+        uint32_t* hs = static_cast<uint32_t*>(g_ctx.host_status.ptr);
+        hipError_t e = hipMemcpyAsync(hs, g_ctx.status.ptr, 16 * (size_t)job->issued, hipMemcpyDeviceToHost, g_ctx.s_out);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(g_ctx.s_out);
+        if (e != hipSuccess)
+            rc = fail_hip(e, "D2H status");
+        for (uint32_t i = 0; rc == SELA_HIP_OK && i < job->issued; i++)
+            seen_flags |= hs[4 * (size_t)i];
+    }
+    if (rc != SELA_HIP_OK) { // leave nothing in flight behind an error
+        const std::string msg = sela_hip_last_error();
+        g_ctx.sync_all();
+        (void)fail(rc, msg);
+    }
+    job_progress(job, frames_final, bytes_final);
+    g_ctx.job_open = false;
+    delete job;
+    if (rc != SELA_HIP_OK)
+        return rc;
+    if (seen_flags & SELA_HIP_FLAG_BAD_FRAME)
+        return fail(SELA_HIP_EFORMAT, "malformed frame stream (bad sync word or subframe header)");
+    if (seen_flags & SELA_HIP_FLAG_RICE_OVERRUN)
+        return fail(SELA_HIP_EFORMAT, "a Rice stream ended before all its values were read");
+    return SELA_HIP_OK;
 }
 
 } // namespace
@@ -227,13 +545,25 @@ int sela_hip_init(int device)
     return SELA_HIP_OK;
 }
 
+void sela_hip_thread_release(void) { g_ctx.release(); }
+
 void sela_hip_shutdown(void)
 {
     g_ctx.release();
-    g_pipeline.release();
+    pool().trim();
+}
+
+void* sela_hip_host_alloc(size_t bytes) { return pool().take(bytes ? bytes : 1); }
+
+void sela_hip_host_free(void* p)
+{
+    if (p)
+        pool().give(p);
 }
 
 void sela_hip_debug_phase_buffer(uint64_t* d_cycles) { g_phase_cycles = d_cycles; }
+
+void sela_hip_debug_force_plain_fir(int enable) { g_force_plain_fir = enable != 0; }
 
 void sela_hip_enable_kernel_timing(int enable) { g_timing.enabled = enable != 0; }
 
@@ -252,6 +582,8 @@ uint32_t sela_hip_signals_per_frame(uint32_t channels) { return channels == 2 ? 
 size_t sela_hip_encode_workspace_bytes(uint32_t n_frames, uint32_t channels) { return sela::encode_workspace_bytes(n_frames, channels); }
 
 size_t sela_hip_decode_workspace_bytes(uint32_t n_frames, uint32_t channels) { return sela::decode_workspace_bytes(n_frames, channels); }
+
+uint32_t sela_hip_decode_max_channels(void) { return sela::decode_max_channels(); }
 
 size_t sela_hip_encode_bound_bytes(uint32_t n_frames, uint32_t channels)
 {
@@ -272,7 +604,7 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 3 : 0;
     hipError_t e = sela::launch_encode(d_pcm, n_frames, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace,
-        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles);
+        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_force_plain_fir);
     if (e != hipSuccess)
         return fail_hip(e, "encode launch");
     return SELA_HIP_OK;
@@ -281,26 +613,116 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
 int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream)
 {
+    (void)d_workspace;
+    (void)workspace_bytes;
     if (channels == 0 || channels > 255)
         return fail(SELA_HIP_EINVAL, "channels must be in 1..255");
-    if (sela::decode_lds_bytes(channels, sela::decode_waves(channels), SELA_HIP_SAMPLES_PER_FRAME) > 160 * 1024)
-        return fail(SELA_HIP_EINVAL, "too many channels for the on-chip decoder (LDS budget)");
-    if (!d_status || (n_frames && (!d_frames || !d_frame_offsets || !d_pcm_out || !d_workspace)))
+    if (channels > sela::decode_max_channels())
+        return fail(SELA_HIP_EINVAL, "the on-chip decoder handles at most 17 channels (LDS budget)");
+    if (!d_status || (n_frames && (!d_frames || !d_frame_offsets || !d_pcm_out)))
         return fail(SELA_HIP_EINVAL, "null device pointer");
     if ((uintptr_t)d_frames & 3)
         return fail(SELA_HIP_EINVAL, "d_frames must be 4-byte aligned");
-    if (workspace_bytes < sela::decode_workspace_bytes(n_frames, channels))
-        return fail(SELA_HIP_ECAPACITY, "workspace smaller than sela_hip_decode_workspace_bytes()");
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
-    g_timing.recorded = ev ? 2 : 0;
-    const bool piped = n_frames && !ev && !g_phase_cycles && g_pipeline.ready();
-    hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, d_workspace,
-        static_cast<hipStream_t>(stream), ev, g_phase_cycles, piped ? g_pipeline.side : nullptr, g_pipeline.fork, g_pipeline.parsed);
+    g_timing.recorded = ev ? 1 : 0;
+    hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, static_cast<hipStream_t>(stream), ev,
+        g_phase_cycles);
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
     return SELA_HIP_OK;
 }
 
+// ---- streaming jobs (host pointers) ----------------------------------------------------------------------------
+int sela_hip_encode_begin(sela_hip_job** job, uint32_t channels, uint32_t total_frames, uint8_t* frames_out, size_t frames_cap,
+    uint64_t* frame_offsets_out)
+{
+    if (!frame_offsets_out || (total_frames && !frames_out))
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    int rc = job_begin(job, true, channels, total_frames);
+    if (rc != SELA_HIP_OK)
+        return rc;
+    (*job)->frames_out = frames_out;
+    (*job)->frames_cap = frames_cap;
+    (*job)->offsets_out = frame_offsets_out;
+    frame_offsets_out[0] = 0;
+    return SELA_HIP_OK;
+}
+
+int sela_hip_encode_feed(sela_hip_job* job, const int16_t* pcm, uint32_t n_frames, uint32_t* frames_final, uint64_t* bytes_final)
+{
+    if (!job || !job->encode || (n_frames && !pcm) || (uint64_t)job->fed + n_frames > job->total_frames)
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    if (job->error != SELA_HIP_OK)
+        return job->error;
+    const size_t frame_samples = (size_t)sela::kBlock * job->channels;
+    for (uint32_t done = 0; done < n_frames;) {
+        const uint32_t nf = n_frames - done < kHostChunkFrames ? n_frames - done : kHostChunkFrames;
+        int rc = job_issue_encode(job, pcm + done * frame_samples, nf);
+        if (rc != SELA_HIP_OK)
+            return rc;
+        done += nf;
+    }
+    // what has finished in the meantime is final without waiting: chunks drained two issues ago
+    if (job->drained >= 1) {
+        int rc = job_finalize(job, job->drained - 1);
+        if (rc != SELA_HIP_OK)
+            return rc;
+    }
+    job_progress(job, frames_final, bytes_final);
+    return SELA_HIP_OK;
+}
+
+int sela_hip_encode_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
+{
+    if (!job || !job->encode)
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    return job_end(job, frames_final, bytes_final);
+}
+
+int sela_hip_decode_begin(sela_hip_job** job, uint32_t channels, uint32_t total_frames, int16_t* pcm_out)
+{
+    if (total_frames && !pcm_out)
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    int rc = job_begin(job, false, channels, total_frames);
+    if (rc != SELA_HIP_OK)
+        return rc;
+    (*job)->pcm_out = pcm_out;
+    return SELA_HIP_OK;
+}
+
+int sela_hip_decode_feed(sela_hip_job* job, const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t* frames_final)
+{
+    if (!job || job->encode || (n_frames && (!frames || !frame_offsets)) || (uint64_t)job->fed + n_frames > job->total_frames)
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    if (job->error != SELA_HIP_OK)
+        return job->error;
+    for (uint32_t f = 0; f < n_frames; f++)
+        if (frame_offsets[f + 1] < frame_offsets[f] || (frame_offsets[f] & 3))
+            return job_fail(job, fail(SELA_HIP_EFORMAT, "frame offsets must be ascending multiples of 4"));
+    for (uint32_t done = 0; done < n_frames;) {
+        const uint32_t nf = n_frames - done < kHostChunkFrames ? n_frames - done : kHostChunkFrames;
+        int rc = job_issue_decode(job, frames, frame_offsets + done, nf);
+        if (rc != SELA_HIP_OK)
+            return rc;
+        done += nf;
+    }
+    if (job->drained >= 1) {
+        int rc = job_finalize(job, job->drained - 1);
+        if (rc != SELA_HIP_OK)
+            return rc;
+    }
+    job_progress(job, frames_final, nullptr);
+    return SELA_HIP_OK;
+}
+
+int sela_hip_decode_end(sela_hip_job* job, uint32_t* frames_final)
+{
+    if (!job || job->encode)
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    return job_end(job, frames_final, nullptr);
+}
+
+// ---- one-shot host-pointer API -----------------------------------------------------------------------------------
 int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel, uint8_t* frames_out,
     size_t frames_cap, uint64_t* frame_offsets_out)
 {
@@ -308,203 +730,32 @@ int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, ui
         return fail(SELA_HIP_EINVAL, "samples_per_channel must be 2048 (reference frame size)");
     if (channels == 0 || channels > 255 || !frame_offsets_out || (n_frames && (!pcm || !frames_out)))
         return fail(SELA_HIP_EINVAL, "bad argument");
-    int rc = sela_hip_init(-1);
+    sela_hip_job* job = nullptr;
+    int rc = sela_hip_encode_begin(&job, channels, n_frames, frames_out, frames_cap, frame_offsets_out);
     if (rc != SELA_HIP_OK)
         return rc;
-    if (!g_ctx.bind_current_device())
-        return fail(SELA_HIP_ENODEV, "hipGetDevice failed");
-    frame_offsets_out[0] = 0;
-    if (n_frames == 0)
-        return SELA_HIP_OK;
-    const uint32_t chunk = n_frames >= 2 * kHostChunkFramesEncode ? kHostChunkFramesEncode : n_frames;
-    const uint32_t n_chunks = (n_frames + chunk - 1) / chunk;
-    const int n_sets = n_chunks > 1 ? 2 : 1;
-    const size_t frame_pcm = (size_t)sela::kBlock * channels * sizeof(int16_t);
-    const size_t chunk_bound = sela_hip_encode_bound_bytes(chunk, channels);
-    hipError_t e = g_ctx.streams();
-    if (e != hipSuccess)
-        return fail_hip(e, "hipStreamCreate");
-    for (int b = 0; b < n_sets; b++)
-        if ((e = g_ctx.pcm[b].reserve(chunk * frame_pcm + 4)) != hipSuccess || (e = g_ctx.frames[b].reserve(chunk_bound + 4)) != hipSuccess
-            || (e = g_ctx.offsets[b].reserve(((size_t)chunk + 1) * 8)) != hipSuccess || (e = g_ctx.status[b].reserve(16)) != hipSuccess)
-            return fail_hip(e, "hipMalloc");
-    if ((e = g_ctx.workspace.reserve(sela::encode_workspace_bytes(chunk, channels))) != hipSuccess)
-        return fail_hip(e, "hipMalloc");
-
-    auto frames_of = [&](uint32_t i) { return i + 1 < n_chunks ? chunk : n_frames - i * chunk; };
-    auto copy_in = [&](uint32_t i) -> hipError_t {
-        const int b = (int)(i & 1);
-        hipError_t err;
-        if (i >= 2 && (err = hipStreamWaitEvent(g_ctx.s_in, g_ctx.ran[b], 0)) != hipSuccess) // chunk i-2 has read this buffer
-            return err;
-        if ((err = hipMemcpyAsync(g_ctx.pcm[b].ptr, pcm + (size_t)i * chunk * sela::kBlock * channels, frames_of(i) * frame_pcm,
-                 hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess)
-            return err;
-        return hipEventRecord(g_ctx.copied_in[b], g_ctx.s_in);
-    };
-    size_t base = 0; // bytes of the chunks already copied out
-    std::vector<uint64_t> chunk_offsets((size_t)chunk + 1);
-    auto copy_out = [&](uint32_t i) -> int {
-        const int b = (int)(i & 1);
-        const uint32_t nf = frames_of(i);
-        hipError_t err;
-        uint32_t status[4];
-        if ((err = hipEventSynchronize(g_ctx.ran[b])) != hipSuccess
-            || (err = hipMemcpyAsync(status, g_ctx.status[b].ptr, sizeof status, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
-            || (err = hipMemcpyAsync(chunk_offsets.data(), g_ctx.offsets[b].ptr, ((size_t)nf + 1) * 8, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
-            || (err = hipStreamSynchronize(g_ctx.s_out)) != hipSuccess)
-            return fail_hip(err, "D2H status/offsets");
-        if (flags_to_error(status[0])) {
-            char msg[160];
-            std::snprintf(msg, sizeof msg, "a block left the range the .sela format can carry (flags 0x%x)", status[0]);
-            return fail(SELA_HIP_ERANGE, msg);
-        }
-        const size_t total = (size_t)chunk_offsets[nf];
-        if (status[1] || base + total > frames_cap)
-            return fail(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes)");
-        for (uint32_t f = 0; f <= nf; f++)
-            frame_offsets_out[(size_t)i * chunk + f] = base + chunk_offsets[f];
-        if (total && ((err = hipMemcpyAsync(frames_out + base, g_ctx.frames[b].ptr, total, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
-                         || (err = hipStreamSynchronize(g_ctx.s_out)) != hipSuccess))
-            return fail_hip(err, "D2H frames");
-        base += total;
-        return SELA_HIP_OK;
-    };
-
-    rc = SELA_HIP_OK;
-    if ((e = copy_in(0)) != hipSuccess)
-        rc = fail_hip(e, "H2D pcm");
-    for (uint32_t i = 0; rc == SELA_HIP_OK && i <= n_chunks; i++) {
-        if (i < n_chunks) {
-            const int b = (int)(i & 1);
-            if ((e = hipStreamWaitEvent(g_ctx.s_run, g_ctx.copied_in[b], 0)) != hipSuccess) {
-                rc = fail_hip(e, "hipStreamWaitEvent");
-                break;
-            }
-            rc = sela_hip_encode_device(static_cast<const int16_t*>(g_ctx.pcm[b].ptr), frames_of(i), channels,
-                static_cast<uint8_t*>(g_ctx.frames[b].ptr), chunk_bound, static_cast<uint64_t*>(g_ctx.offsets[b].ptr),
-                static_cast<uint32_t*>(g_ctx.status[b].ptr), g_ctx.workspace.ptr, g_ctx.workspace.cap, nullptr, g_ctx.s_run);
-            if (rc != SELA_HIP_OK)
-                break;
-            if ((e = hipEventRecord(g_ctx.ran[b], g_ctx.s_run)) != hipSuccess || (i + 1 < n_chunks && (e = copy_in(i + 1)) != hipSuccess)) {
-                rc = fail_hip(e, "H2D pcm");
-                break;
-            }
-        }
-        if (i >= 1)
-            rc = copy_out(i - 1);
-    }
-    if (rc != SELA_HIP_OK) { // leave nothing in flight behind an error
-        const std::string msg = sela_hip_last_error();
-        (void)hipStreamSynchronize(g_ctx.s_in);
-        (void)hipStreamSynchronize(g_ctx.s_run);
-        (void)hipStreamSynchronize(g_ctx.s_out);
-        return fail(rc, msg.c_str());
-    }
-    return SELA_HIP_OK;
+    rc = sela_hip_encode_feed(job, pcm, n_frames, nullptr, nullptr);
+    const std::string msg = rc != SELA_HIP_OK ? sela_hip_last_error() : "";
+    const int rc_end = sela_hip_encode_end(job, nullptr, nullptr);
+    if (rc != SELA_HIP_OK)
+        return fail(rc, msg);
+    return rc_end;
 }
 
 int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm_out)
 {
     if (channels == 0 || channels > 255 || (n_frames && (!frames || !frame_offsets || !pcm_out)))
         return fail(SELA_HIP_EINVAL, "bad argument");
-    int rc = sela_hip_init(-1);
+    sela_hip_job* job = nullptr;
+    int rc = sela_hip_decode_begin(&job, channels, n_frames, pcm_out);
     if (rc != SELA_HIP_OK)
         return rc;
-    if (n_frames == 0)
-        return SELA_HIP_OK;
-    for (uint32_t f = 0; f < n_frames; f++)
-        if (frame_offsets[f + 1] < frame_offsets[f] || (frame_offsets[f] & 3))
-            return fail(SELA_HIP_EFORMAT, "frame offsets must be ascending multiples of 4");
-    if (!g_ctx.bind_current_device())
-        return fail(SELA_HIP_ENODEV, "hipGetDevice failed");
-    const uint32_t chunk = n_frames >= 2 * kHostChunkFramesDecode ? kHostChunkFramesDecode : n_frames;
-    const uint32_t n_chunks = (n_frames + chunk - 1) / chunk;
-    const int n_sets = n_chunks > 1 ? 2 : 1;
-    const size_t frame_pcm = (size_t)sela::kBlock * channels * sizeof(int16_t);
-    auto frames_of = [&](uint32_t i) { return i + 1 < n_chunks ? chunk : n_frames - i * chunk; };
-    size_t max_bytes = 0;
-    for (uint32_t i = 0; i < n_chunks; i++) {
-        const size_t bytes = (size_t)(frame_offsets[(size_t)i * chunk + frames_of(i)] - frame_offsets[(size_t)i * chunk]);
-        max_bytes = bytes > max_bytes ? bytes : max_bytes;
-    }
-    hipError_t e = g_ctx.streams();
-    if (e != hipSuccess)
-        return fail_hip(e, "hipStreamCreate");
-    for (int b = 0; b < n_sets; b++)
-        if ((e = g_ctx.pcm[b].reserve(chunk * frame_pcm + 4)) != hipSuccess || (e = g_ctx.frames[b].reserve(max_bytes + 8)) != hipSuccess
-            || (e = g_ctx.offsets[b].reserve(((size_t)chunk + 1) * 8)) != hipSuccess || (e = g_ctx.status[b].reserve(16)) != hipSuccess)
-            return fail_hip(e, "hipMalloc");
-    if ((e = g_ctx.workspace.reserve(sela::decode_workspace_bytes(chunk, channels))) != hipSuccess)
-        return fail_hip(e, "hipMalloc");
-
-    auto copy_in = [&](uint32_t i) -> hipError_t {
-        const int b = (int)(i & 1);
-        const uint32_t nf = frames_of(i);
-        const uint64_t* off = frame_offsets + (size_t)i * chunk;
-        hipError_t err;
-        if (i >= 2 && (err = hipStreamWaitEvent(g_ctx.s_in, g_ctx.ran[b], 0)) != hipSuccess) // chunk i-2 has read these buffers
-            return err;
-        std::vector<uint64_t>& rel = g_ctx.rebased[b];
-        rel.resize((size_t)nf + 1);
-        for (uint32_t f = 0; f <= nf; f++)
-            rel[f] = off[f] - off[0];
-        if ((err = hipMemcpyAsync(g_ctx.frames[b].ptr, frames + off[0], (size_t)rel[nf], hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
-            || (err = hipMemcpyAsync(g_ctx.offsets[b].ptr, rel.data(), ((size_t)nf + 1) * 8, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess)
-            return err;
-        return hipEventRecord(g_ctx.copied_in[b], g_ctx.s_in);
-    };
-    uint32_t seen_flags = 0;
-    auto copy_out = [&](uint32_t i) -> int {
-        const int b = (int)(i & 1);
-        hipError_t err;
-        uint32_t status[4];
-        if ((err = hipEventSynchronize(g_ctx.ran[b])) != hipSuccess
-            || (err = hipMemcpyAsync(status, g_ctx.status[b].ptr, sizeof status, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
-            || (err = hipMemcpyAsync(pcm_out + (size_t)i * chunk * sela::kBlock * channels, g_ctx.pcm[b].ptr, frames_of(i) * frame_pcm,
-                    hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess
-            || (err = hipStreamSynchronize(g_ctx.s_out)) != hipSuccess)
-            return fail_hip(err, "D2H pcm");
-        seen_flags |= status[0];
-        return SELA_HIP_OK;
-    };
-
-    rc = SELA_HIP_OK;
-    if ((e = copy_in(0)) != hipSuccess)
-        rc = fail_hip(e, "H2D frames");
-    for (uint32_t i = 0; rc == SELA_HIP_OK && i <= n_chunks; i++) {
-        if (i < n_chunks) {
-            const int b = (int)(i & 1);
-            if ((e = hipStreamWaitEvent(g_ctx.s_run, g_ctx.copied_in[b], 0)) != hipSuccess) {
-                rc = fail_hip(e, "hipStreamWaitEvent");
-                break;
-            }
-            rc = sela_hip_decode_device(static_cast<const uint8_t*>(g_ctx.frames[b].ptr), static_cast<const uint64_t*>(g_ctx.offsets[b].ptr),
-                frames_of(i), channels, static_cast<int16_t*>(g_ctx.pcm[b].ptr), static_cast<uint32_t*>(g_ctx.status[b].ptr),
-                g_ctx.workspace.ptr, g_ctx.workspace.cap, g_ctx.s_run);
-            if (rc != SELA_HIP_OK)
-                break;
-            if ((e = hipEventRecord(g_ctx.ran[b], g_ctx.s_run)) != hipSuccess || (i + 1 < n_chunks && (e = copy_in(i + 1)) != hipSuccess)) {
-                rc = fail_hip(e, "H2D frames");
-                break;
-            }
-        }
-        if (i >= 1)
-            rc = copy_out(i - 1);
-    }
-    if (rc != SELA_HIP_OK) { // leave nothing in flight behind an error
-        const std::string msg = sela_hip_last_error();
-        (void)hipStreamSynchronize(g_ctx.s_in);
-        (void)hipStreamSynchronize(g_ctx.s_run);
-        (void)hipStreamSynchronize(g_ctx.s_out);
-        return fail(rc, msg.c_str());
-    }
-    // every frame is decoded (bad ones to silence) before the verdict, as in the one-piece call
-    if (seen_flags & SELA_HIP_FLAG_BAD_FRAME)
-        return fail(SELA_HIP_EFORMAT, "malformed frame stream (bad sync word or subframe header)");
-    if (seen_flags & SELA_HIP_FLAG_RICE_OVERRUN)
-        return fail(SELA_HIP_EFORMAT, "a Rice stream ended before all its values were read");
-    return SELA_HIP_OK;
+    rc = sela_hip_decode_feed(job, frames, frame_offsets, n_frames, nullptr);
+    const std::string msg = rc != SELA_HIP_OK ? sela_hip_last_error() : "";
+    const int rc_end = sela_hip_decode_end(job, nullptr);
+    if (rc != SELA_HIP_OK)
+        return fail(rc, msg);
+    return rc_end;
 }
 
 uint32_t sela_hip_index_frames(const uint8_t* frames, size_t frames_bytes, uint32_t n_frames, uint32_t channels, uint64_t* frame_offsets)

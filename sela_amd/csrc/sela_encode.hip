@@ -50,7 +50,7 @@ constexpr int kFirstT1 = (kHalfEntries - kPadC) / 32;    // 14: second half hold
 // cleared between launches.
 constexpr int kRingHalf = 64;
 constexpr int kRingLen = 2 * kRingHalf + 64;          // doubles (a multiple of 8, i.e. of 64 bytes)
-constexpr int kRingsPerXcd = 512;                      // >= blocks resident on one XCD (9 per CU x 32 CUs)
+constexpr int kRingsPerXcd = 512;                      // >= blocks resident on one XCD (12 per CU x 32 CUs)
 constexpr int kXcds = 8;
 constexpr int kPadS = 128;
 constexpr int kSBufWords = (kPadS + kBlock) / 32 * 33; // samples, one pad word per 32: 2244 words
@@ -299,6 +299,7 @@ __device__ __forceinline__ void ac_steps_tail(const AcFetch& f, double& A, doubl
 // a = a_hi 2^32 + a_lo with a_lo = (int32)a:  a s mod 2^64 = a_lo s [v_mad_i64_i32] + (a_hi s mod 2^32) << 32;
 // a_hi is zero -- and its 32 multiply-adds are skipped, a wave-uniform branch -- whenever the Q35
 // coefficient fits 32 signed bits, i.e. |coefficient| < 1/16: 85 % of the taps on the bench track.
+// (The caller has checked that every a_hi fits the 24-bit multiplier; see fir_fits_fast.)
 template <int JJ>
 __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int32_t* sT, const int64_t* a,
     int32_t (&win)[kPerLane], int64_t (&acc)[kPerLane], uint32_t (&hi)[kPerLane])
@@ -314,7 +315,7 @@ __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int3
 #pragma unroll
     for (int t = 0; t < kPerLane; t++)
         acc[t] += (int64_t)a_lo * (int64_t)win[(t - JJ - 1) & 31]; // s[32 lane + t - j]
-    if (a_hi != 0) { // only the low 32 bits of a_hi s matter; both factors fit 24 bits (the caller checked |a| < 2^55)
+    if (a_hi != 0) { // only the low 32 bits of a_hi s matter; both factors fit 24 bits (fir_fits_fast)
 #pragma unroll
         for (int t = 0; t < kPerLane; t++)
             asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(hi[t]) : "s"(a_hi), "v"(win[(t - JJ - 1) & 31]));
@@ -323,10 +324,21 @@ __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int3
         fir_taps<JJ + 1>(j0, order, lane, sT, a, win, acc, hi);
 }
 
+// Whether coefficient a splits as a_hi 2^32 + a_lo (a_lo = (int32)a, signed) with a_hi inside the signed 24 bits of
+// v_mad_i32_i24 -- the same split fir_taps makes (a in [2^55 - 2^31, 2^55) has a_hi = 2^23: it does NOT fit).
+__device__ __forceinline__ bool fir_fits_fast(int64_t a)
+{
+    const int32_t a_lo = (int32_t)(uint32_t)(uint64_t)a;
+    const int64_t a_hi = (int64_t)((uint64_t)a - (uint64_t)(int64_t)a_lo) >> 32;
+    return a_hi >= -(1 << 23) && a_hi < (1 << 23);
+}
+
 // The predictions for a predictor with coefficients beyond 2^55: one multiply-add per (sample, tap) in
 // full 64-bit wrap-around arithmetic, samples straight from LDS; (int32)((2^34 + sum) >> 35) of sample
 // 32 lane + t goes to pred_out[t * 64 + lane] (global scratch: the block's own output slot, unused so
-// far).  Slow, out of line, and never needed by real audio.
+// far).  Slow, out of line, and never needed by 16-bit audio (its predictors stay below 2^37: the
+// dequantisation tables cap every reflection coefficient); tests reach it through
+// sela_hip_debug_force_plain_fir, which sends every block of the PRODUCT instantiation down this branch.
 __device__ __attribute__((noinline)) void fir_plain(int order, int lane, const int32_t* sT, const int64_t* a, uint32_t* pred_out)
 {
 #pragma unroll 1
@@ -353,7 +365,7 @@ template <int kMode>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
     double* __restrict__ rings, uint32_t* __restrict__ ring_owner, uint32_t ticket, sela_hip_trace* __restrict__ trace,
-    uint64_t* __restrict__ phase_cycles)
+    uint64_t* __restrict__ phase_cycles, int force_plain_fir)
 {
     constexpr bool kTrace = kMode == 1;
     long long stamp[14];
@@ -713,15 +725,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
         for (int t = 0; t < kPerLane; t++)
             acc[t] = (int64_t)1 << (SELA_Q_SHIFT - 1), hi[t] = 0;
-        // the 24-bit multiply of the high parts needs |a[j]| < 2^55 -- true of any predictor worth the
-        // name; a block that violates it takes a plain loop instead of the unrolled window
+        // the 24-bit multiply of the high parts needs every a[j]'s high part inside 24 signed bits -- true of
+        // any predictor worth the name; a block that violates it takes a plain loop instead of the unrolled window
         bool fits = true;
-        for (int j = 1 + lane; j <= order; j += 64) {
-            const int64_t aj = sm->a[j];
-            fits &= aj >= -((int64_t)1 << 55) && aj < ((int64_t)1 << 55);
-        }
-        // (the trace build, which only tests run, always takes the plain loop so that it is exercised too)
-        const bool plain = kTrace || __any(!fits);
+        for (int j = 1 + lane; j <= order; j += 64)
+            fits &= fir_fits_fast(sm->a[j]);
+        // (the trace build, which only tests run, always takes the plain loop; so does every block while the
+        // debug hook sela_hip_debug_force_plain_fir is set)
+        const bool plain = kTrace || force_plain_fir != 0 || __any(!fits);
         uint32_t* const plain_pred = slots + (size_t)block_id * kSlotWords; // 2048 words of the block's own slot
         if (plain) {
             fir_plain(order, lane, sT, sm->a, plain_pred);
@@ -870,8 +881,10 @@ __device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t cha
 
 __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* __restrict__ frame_offsets,
-    uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status)
+    uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status, uint64_t* __restrict__ mirror)
 {
+    // mirror (optional, page-locked HOST memory): a copy of frame_offsets[0 .. n_frames] followed by one word
+    // status[0] | status[1] << 32, so that the host pipeline reads a chunk's sizes without a copy of its own
     __shared__ uint64_t part[kPlanThreads];
     __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of every frame when the batch fits
     const uint32_t tid = threadIdx.x;
@@ -925,16 +938,26 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
             size = sela_frame_bytes(channels, frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, dummy));
         }
         frame_offsets[f] = off;
+        if (mirror)
+            mirror[f] = off;
         off += size;
         if (off > frames_cap)
             overflow++;
     }
-    if (tid == kPlanThreads - 1)
+    if (tid == kPlanThreads - 1) {
         frame_offsets[n_frames] = part[tid];
+        if (mirror)
+            mirror[n_frames] = part[tid];
+    }
     if (flags)
         atomicOr(&status[0], flags);
     if (overflow)
         atomicAdd(&status[1], overflow);
+    if (mirror) {
+        __syncthreads();
+        if (tid == 0)
+            mirror[(size_t)n_frames + 1] = (uint64_t)atomicOr(&status[0], 0u) | ((uint64_t)atomicAdd(&status[1], 0u) << 32);
+    }
 }
 
 // ---- assemble: the on-disk bytes of each frame (src/file/sela_file.cpp:115-135) ------------------------
@@ -1006,7 +1029,8 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
 
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames,
     size_t frames_cap, uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace,
-    hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles)
+    hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles, uint64_t* d_mirror /* host-mapped or nullptr */,
+    int force_plain_fir)
 {
     const uint32_t n_sig = sela_hip_signals_per_frame(channels);
     const size_t blocks = (size_t)n_frames * n_sig;
@@ -1024,6 +1048,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
 
     if (n_frames == 0) {
         hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
+        if (err == hipSuccess && d_mirror)
+            err = hipMemsetAsync(d_mirror, 0, 2 * sizeof(uint64_t), stream);
         return err != hipSuccess ? err : hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), stream);
     }
     const uint32_t groups = (n_frames + 7) / 8;
@@ -1036,15 +1062,15 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
-        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir);
     else if (d_trace)
-        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir);
     else
-        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles);
+        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap,
-        d_frame_offsets, choice, d_status);
+        d_frame_offsets, choice, d_status, d_mirror);
     if (ev)
         (void)hipEventRecord(ev[2], stream);
     hipLaunchKernelGGL(k_assemble_frames, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets,

@@ -99,6 +99,7 @@ def album_digests(ref, threads=8):
     of the decoded PCM, plus one digest over all of them."""
     tracks = []
     total = hashlib.sha256()
+    sizes = hashlib.sha256()  # every frame's size (uint64 LE) in job order: the layout the ranks agree on
     for track, rate, frames in album_tracks():
         pcm = synth_frames_torch(frames, 2, track).numpy()
         blob, offs, _ = ref.encode_frames(pcm, threads=threads)
@@ -107,12 +108,13 @@ def album_digests(ref, threads=8):
         sela_sha = hashlib.sha256(header + blob.tobytes()).hexdigest()
         dec_sha = hashlib.sha256(dec.tobytes()).hexdigest()
         total.update(bytes.fromhex(sela_sha))
+        sizes.update(np.diff(offs.astype(np.uint64)).astype("<u8").tobytes())
         tracks.append({"track": track, "sample_rate": rate, "n_frames": frames, "sela_bytes": 15 + int(len(blob)),
                        "sela_sha256": sela_sha, "decoded_sha256": dec_sha,
                        "lossy_frames": int((dec != pcm).reshape(frames, -1).any(axis=1).sum())})
         print(tracks[-1], flush=True)
     return {"n_tracks": len(tracks), "n_frames": sum(t["n_frames"] for t in tracks), "channels": 2,
-            "sha256_of_track_sela_sha256s": total.hexdigest(), "tracks": tracks}
+            "sha256_of_track_sela_sha256s": total.hexdigest(), "frame_sizes_sha256": sizes.hexdigest(), "tracks": tracks}
 
 
 def main():

@@ -71,7 +71,11 @@ def _kat_block_frames(kats):
 
 
 def test_analysis_stages_bit_exact(gpu, kats):
-    """mean / autocorrelation / reflection coefficients / order / q / a against the oracle's trace."""
+    """mean / autocorrelation / reflection coefficients / order / q / a against the oracle's trace.
+
+    The trace comes from k_encode_blocks<1>, a different instantiation (register allocation) from the timed
+    k_encode_blocks<0>; the product instantiation's correctness rests on the frame bytes and digests compared
+    everywhere else in this file -- every FP64 intermediate feeds them through q[] and the order."""
     o = oracle()
     names, mono = _kat_block_frames(kats)
     pcm_sets = [mono, synth_frames(24, 2, 3), synth_frames(5, 3, 4)]
@@ -338,26 +342,21 @@ def test_long_unary_runs_round_trip(gpu):
 
 
 def test_decode_only_10k_frames(gpu):
-    """BASELINE.json configs[4] at full size (10k pre-encoded stereo frames): frame sizes consistent with
-    the stream, the decode of the whole batch bit-exact against the oracle's decode, and a random sample
-    of 96 frames bit-exact against the oracle's encode.  (Not "== pcm": the reference is off by one LSB
-    per sample in frames 635 and 946 of this track -- half-up/half-down rounding, SURVEY.md App. E.)"""
+    """BASELINE.json configs[4] at full size (10k pre-encoded stereo frames): the whole encoded batch bit-exact
+    against the oracle's encode, the decode of the whole batch bit-exact against the oracle's decode.  (Not
+    "== pcm": the reference is off by one LSB per sample in frames 635 and 946 of this track -- half-up/half-down
+    rounding, SURVEY.md App. E.)"""
     o = oracle()
     n = 10000
     pcm = synth_frames(n, 2, 2)
     frames, offsets, _, out = _encode(gpu, pcm)
-    assert offsets[0] == 0 and np.all(np.diff(offsets.astype(np.int64)) > 28) and offsets[-1] == len(frames)
-    assert np.all(frames[offsets[:-1].astype(np.int64)] == 0x00) and np.all(frames[offsets[:-1].astype(np.int64) + 3] == 0xAA)
+    threads = os.cpu_count() or 1
+    ref_frames, ref_offsets, _ = o.encode_frames(pcm, threads=threads)
+    assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames)
     back = _decode(gpu, frames, offsets, 2)
-    ref_back, _ = o.decode_frames(frames, offsets, 2, threads=os.cpu_count() or 1)
+    ref_back, _ = o.decode_frames(frames, offsets, 2, threads=threads)
     assert np.array_equal(back, ref_back)
     assert (back != pcm).reshape(n, -1).any(axis=1).sum() <= 4
-    pick = np.random.default_rng(0).choice(n, 96, replace=False)
-    ref_frames, ref_offsets, _ = o.encode_frames(pcm[pick], threads=8)
-    for i, f in enumerate(pick):
-        a = frames[int(offsets[f]): int(offsets[f + 1])]
-        b = ref_frames[int(ref_offsets[i]): int(ref_offsets[i + 1])]
-        assert np.array_equal(a, b), int(f)
 
 
 def _rice_words(values, k):

@@ -1,10 +1,13 @@
 """CPU-only checks of host-side logic and of the mathematical claims the kernels rely on."""
 import os
+import sys
 
 import numpy as np
 
 from oracle_lib import oracle
 from sela_amd.synth import synth_frames, synth_pcm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _first_min_by_scan(u, n):
@@ -119,3 +122,77 @@ def test_torch_synth_matches_numpy():
     tracks = album_tracks()
     assert len(tracks) == 100 and sum(f for _, _, f in tracks) == 549365
     assert [tracks[i][2] for i in range(3)] == [3875, 4218, 8437]
+
+
+def _model_case(o, q, r, stats=None, coef_lanes=4):
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from parse_model import parse, subframe_words
+
+    q, r = np.asarray(q, np.int32), np.asarray(r, np.int32)
+    ck, cwords = o.rice_encode(q) if len(q) else (0, np.zeros(0, np.uint32))
+    rk, rwords = o.rice_encode(r)
+    words, cw, rw = subframe_words(cwords, rwords)
+    got_q, got_r, over_c, over_r = parse(words, cw, rw, ck, rk, len(q), len(r), coef_lanes, stats)
+    assert np.array_equal(got_q, q) and np.array_equal(got_r, r) and not over_c and not over_r
+    return cw, rw
+
+
+def test_segment_parallel_parse_model():
+    """tools/parse_model.py -- the algorithm of the decoder's segment-parallel Rice parser (zones, start
+    bitmap, merge points, chain walk, counts) -- against the oracle's encoder on real subframes and on the
+    streams that stress it: unary-only coding, runs longer than a zone, streams shorter than the wave,
+    empty coefficient streams, all-zero and single-value inputs."""
+    import numpy as np
+
+    from oracle_lib import oracle
+    from sela_amd.synth import synth_frames
+
+    o = oracle()
+    rng = np.random.default_rng(5)
+    stats = []
+    pcm = synth_frames(3, 2, 7)
+    for f in range(3):
+        for c in range(2):
+            order, q, r = o.lpc_analyze(pcm[f, :, c].astype(np.int32))
+            _model_case(o, q, r, stats)
+    assert max(s[3] for s in stats) <= 64 + 4  # chain hops never exceed the lanes
+    cases = [
+        ([0], np.zeros(2048)),                                   # silence: k = 0, 64 words, zones of one word
+        ([], rng.integers(-3, 4, 2048)),                         # order 0: no coefficient stream at all
+        ([5, -3], rng.integers(-1, 2, 2048)),                    # unary-heavy
+        (rng.integers(-64, 64, 100), rng.integers(-20000, 20000, 2048)),  # order 100, wide residues
+        ([1, 2, 3], np.where(rng.random(2048) < 0.01, 30000, 0)),        # long unary runs among zeros
+        ([-64] * 7, np.concatenate([np.full(5, 1 << 14), np.zeros(2043)])),
+        ([3], rng.integers(-(1 << 16), 1 << 16, 2048)),          # 17-bit residues: near the LDS plan's cap
+    ]
+    for q, r in cases:
+        for lanes in (1, 4, 8):
+            _model_case(o, q, np.asarray(r, np.int64), None, lanes)
+    # short value counts (the model is generic in n): zones longer than the stream
+    for n in (1, 2, 63, 64, 65, 130):
+        _model_case(o, [1], rng.integers(-40, 40, n))
+
+
+def test_parse_model_reports_truncated_streams():
+    """A residue stream cut short decodes zeros behind its end and raises the overrun flag -- the behaviour
+    of the kernel (reads beyond the stream are zero), which the reference leaves undefined."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from oracle_lib import oracle
+    from parse_model import parse, subframe_words
+
+    o = oracle()
+    rng = np.random.default_rng(6)
+    r = rng.integers(-300, 300, 2048).astype(np.int32)
+    rk, rwords = o.rice_encode(r)
+    ck, cwords = o.rice_encode(np.array([4, -2], np.int32))
+    cut = len(rwords) // 2
+    words, cw, rw = subframe_words(cwords, rwords[:cut])
+    q, got, over_c, over_r = parse(words, cw, rw, ck, rk, 2, 2048)
+    assert not over_c and over_r and q.tolist() == [4, -2]
+    full = o.rice_decode(rwords, 2048, rk)
+    n_ok = int((got == full).cumprod().sum())
+    assert n_ok > 900 and np.all(got[n_ok + 1:] == 0)

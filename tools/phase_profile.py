@@ -18,7 +18,8 @@ from sela_amd.synth import synth_frames  # noqa: E402
 
 ENC = ["load+x/32767", "mean chain", "centre", "autocorr", "normalise+Schur", "order/quant/dequant", "step-up",
        "FIR residues", "Rice k search", "pack coefs", "transpose+pack residues", "store slot/meta"]
-DEC = ["load residues+dequant", "step-up", "synthesis", "wait barrier", "combine+store"]
+DEC = ["headers + mode barrier", "stream -> LDS", "parse A (own zone)", "parse B (merge)", "resolve chain",
+       "pass 2 (decode)", "dequant + step-up + table", "synthesis", "barrier + combine + store"]
 
 
 def main():
@@ -38,19 +39,13 @@ def main():
     torch.cuda.synchronize()
     lib.sela_hip_debug_phase_buffer(None)
     dd = buf.cpu().numpy().reshape(-1, 16)[: n_frames * 2].astype(np.float64)
-    d = dd[:, :5]
+    d = dd[:, :9]
     print(f"encoder, mean cycles per (frame, signal) block over {len(e)} blocks (total {e.sum(1).mean():.0f}):")
     for name, v in zip(ENC, e.mean(0)):
         print(f"  {name:28s} {v:10.0f}  {100 * v / e.sum(1).mean():5.1f}%")
-    print(f"decoder, mean cycles per subframe over {len(d)} subframes (total {d.sum(1).mean():.0f}):")
+    print(f"decoder (k_decode_frames), mean cycles per subframe over {len(d)} subframes (total {d.sum(1).mean():.0f}):")
     for name, v in zip(DEC, d.mean(0)):
         print(f"  {name:28s} {v:10.0f}  {100 * v / d.sum(1).mean():5.1f}%")
-    ps = dd[::64, 8:13]  # one record per parser wave (64 subframes), whole block of 2048 values
-    tot = ps[:, [0, 1, 2, 4]].sum(1).mean()
-    print(f"parser, mean cycles per wave (64 streams x 2048 values) over {len(ps)} waves (total {tot:.0f}):")
-    for name, col in (("headers + coefficient streams", 0), ("codeword groups", 1), ("tile refills", 2), ("staged stores", 4)):
-        print(f"  {name:28s} {ps[:, col].mean():10.0f}  {100 * ps[:, col].mean() / tot:5.1f}%")
-    print(f"  tile refills per wave        {ps[:, 3].mean():10.1f}")
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@ if __name__ == "__main__":
 
 
 def host_api(n=3875):
-    """PCIe-inclusive rate of the host-pointer API (pageable numpy buffers): H2D + kernels + D2H."""
+    """PCIe-inclusive rate of the host-pointer API through the Python wrapper (pageable numpy buffers: H2D + kernels + D2H."""
     import numpy as np
 
     pcm = synth_frames(n, 2, 0)
@@ -55,7 +55,7 @@ def host_api(n=3875):
         codec.decode_host(frames, offs, 2)
     td = (time.perf_counter() - t0) / reps
     print(f"host-pointer API through the Python wrapper, {n} frames: encode {te * 1e3:.2f} ms, decode {td * 1e3:.2f} ms "
-          f"(each call allocates and first-touches its numpy output; host/host_selftest times the C++ path)")
+          f"(each call allocates and first-touches its numpy output; host/sela_filebench times the C++ path on page-locked buffers)")
 
 
 if __name__ == "__main__" and os.environ.get("SELA_SWEEP_HOST", "1") == "1":

@@ -1,7 +1,6 @@
 #!/bin/bash
 # tools/timeline.sh  (run ON THE GPU BOX): kernel start/end times of the LAST bench step, relative to
-# its k_encode_blocks start, from a rocprofv3 kernel trace.  Shows how the decode pipeline's two
-# streams overlap.
+# its k_encode_blocks start, from a rocprofv3 kernel trace (encode: three kernels; decode: a memset and one kernel).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_tl
@@ -15,7 +14,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 enc = [i for i, r in enumerate(rows) if "k_encode_blocks" in r["Kernel_Name"]]
 i0 = enc[5]
 t0 = int(rows[i0]["Start_Timestamp"])
-for r in rows[i0:i0 + 12]:
+for r in rows[i0:i0 + 6]:
     n = r["Kernel_Name"].split("(")[0].replace("void sela::", "")[:32]
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     print(f"{n:34s} start {s/1e3:9.1f} us  end {e/1e3:9.1f} us  dur {(e-s)/1e3:8.1f} us  stream {r.get('Stream_Id', r.get('Queue_Id', '?'))}")
