@@ -56,6 +56,13 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The SELA MI355X path has no CPU fallback.")
+    # PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever is loaded first serves both
+    # users; loaded second, torch would bring up a second HIP runtime in the process and this library's calls
+    # would land in one that sees no device.  So: torch first, when there is a torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64p, sz = C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t
     L.sela_hip_init.argtypes = [C.c_int]
