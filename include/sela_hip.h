@@ -97,10 +97,10 @@ uint32_t sela_hip_signals_per_frame(uint32_t channels);
 /* Bytes of device workspace the *_device calls need for a batch of n_frames.  The workspace needs no
  * initialisation and may be reused by later calls; one call at a time may use it. */
 size_t sela_hip_encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
-/* (The decoder keeps residues and samples on chip: a small constant.  Kept so that callers size and pass a
- * workspace the same way for both directions.) */
+/* (The decoder keeps positions and samples on chip; the workspace is only written for frames that take the
+ * kernel's generic mode -- Rice streams beyond what 16-bit audio produces, more than 8 channels.) */
 size_t sela_hip_decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
-/* Most channels the decoder takes (17: every channel of a frame has to be in LDS for the parent - difference
+/* Most channels the decoder takes (28: every channel of a frame has to be in LDS for the parent - difference
  * pass, src/frame/frame_decoder.cpp:40-69).  The .sela header allows 255; more than this is SELA_HIP_EINVAL. */
 uint32_t sela_hip_decode_max_channels(void);
 /* Upper bound of the frame byte stream produced by encoding n_frames (what `frames_cap` must be
@@ -123,8 +123,8 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
  * Decode n_frames frames.  d_frames / d_frame_offsets as produced above (or by parsing a .sela
  * file).  d_pcm_out: int16 [n_frames][2048][channels].  d_status: uint32[4], [0] = OR of flag
  * bits, [1] = number of malformed frames (zeroed by the call).  channels <= sela_hip_decode_max_channels().
- * One kernel on `stream` (one workgroup per frame, one wave per subframe); d_workspace is not touched and
- * may be NULL.  Returns immediately.
+ * One kernel on `stream` (one workgroup per frame, one wave per subframe); d_workspace as sized by
+ * sela_hip_decode_workspace_bytes().  Returns immediately.
  */
 int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames,
     uint32_t channels, int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, size_t workspace_bytes,

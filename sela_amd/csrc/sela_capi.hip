@@ -21,7 +21,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
     hipEvent_t* ev, uint64_t* d_phase_cycles, uint64_t* d_mirror, int force_plain_fir);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles);
+    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles);
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 uint32_t decode_max_channels();
 } // namespace sela
@@ -358,7 +358,8 @@ hipError_t reserve_chunk_buffers(bool encode, uint32_t channels, size_t frames_b
             || (e = c.offsets.reserve(((size_t)kHostChunkFrames + 1) * 8)) != hipSuccess
             || (e = c.host_offsets.reserve(((size_t)kHostChunkFrames + 2) * 8)) != hipSuccess)
             return e;
-        if (encode && (e = c.workspace.reserve(sela::encode_workspace_bytes(kHostChunkFrames, channels))) != hipSuccess)
+        if ((e = c.workspace.reserve(encode ? sela::encode_workspace_bytes(kHostChunkFrames, channels)
+                                            : sela::decode_workspace_bytes(kHostChunkFrames, channels))) != hipSuccess)
             return e;
     }
     return hipSuccess;
@@ -425,7 +426,7 @@ int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* o
         return job_fail(job, fail_hip(e, "hipMalloc"));
     uint32_t* d_status = static_cast<uint32_t*>(g_ctx.status.ptr) + 4 * (size_t)i;
     e = sela::launch_decode(static_cast<const uint8_t*>(c.frames.ptr), static_cast<const uint64_t*>(c.offsets.ptr), nf, job->channels,
-        static_cast<int16_t*>(c.pcm.ptr), d_status, c.s_run, nullptr, nullptr);
+        static_cast<int16_t*>(c.pcm.ptr), d_status, c.workspace.ptr, c.s_run, nullptr, nullptr);
     if (e != hipSuccess || (e = hipEventRecord(c.ran, c.s_run)) != hipSuccess)
         return job_fail(job, fail_hip(e, "decode launch"));
     job->chunk_first.push_back(job->fed);
@@ -452,7 +453,7 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
     if (channels == 0 || channels > 255)
         return fail(SELA_HIP_EINVAL, "channels must be in 1..255");
     if (!encode && channels > sela::decode_max_channels())
-        return fail(SELA_HIP_EINVAL, "the on-chip decoder handles at most 17 channels (LDS budget)");
+        return fail(SELA_HIP_EINVAL, "too many channels for the on-chip decoder (sela_hip_decode_max_channels)");
     int rc = sela_hip_init(-1);
     if (rc != SELA_HIP_OK)
         return rc;
@@ -613,20 +614,20 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
 int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream)
 {
-    (void)d_workspace;
-    (void)workspace_bytes;
     if (channels == 0 || channels > 255)
         return fail(SELA_HIP_EINVAL, "channels must be in 1..255");
     if (channels > sela::decode_max_channels())
-        return fail(SELA_HIP_EINVAL, "the on-chip decoder handles at most 17 channels (LDS budget)");
-    if (!d_status || (n_frames && (!d_frames || !d_frame_offsets || !d_pcm_out)))
+        return fail(SELA_HIP_EINVAL, "too many channels for the on-chip decoder (sela_hip_decode_max_channels)");
+    if (!d_status || (n_frames && (!d_frames || !d_frame_offsets || !d_pcm_out || !d_workspace)))
         return fail(SELA_HIP_EINVAL, "null device pointer");
     if ((uintptr_t)d_frames & 3)
         return fail(SELA_HIP_EINVAL, "d_frames must be 4-byte aligned");
+    if (workspace_bytes < sela::decode_workspace_bytes(n_frames, channels))
+        return fail(SELA_HIP_ECAPACITY, "workspace smaller than sela_hip_decode_workspace_bytes()");
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 1 : 0;
-    hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, static_cast<hipStream_t>(stream), ev,
-        g_phase_cycles);
+    hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, d_workspace,
+        static_cast<hipStream_t>(stream), ev, g_phase_cycles);
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
     return SELA_HIP_OK;

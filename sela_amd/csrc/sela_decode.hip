@@ -10,7 +10,15 @@
 //
 // then, after a workgroup barrier, frame::FrameDecoder's second pass (out[ch] = parent - difference,
 // src/frame/frame_decoder.cpp:40-69) and the int16 interleave of src/file/wav_file.cpp:244-257, stored
-// coalesced.  Residues and samples live in LDS only; nothing goes through a workspace.
+// coalesced.
+//
+// The synthesis recurrence is a dependent chain of ~90 cycles per sample, so the kernel lives on occupancy:
+// what a subframe keeps in LDS is cut to 7.4 KB (22 waves per CU).  The Rice stream is NOT copied on chip --
+// it is read where it lies through a bounds-checked buffer resource (reads past the subframe's words
+// return zero) -- the parser leaves one 16-bit POSITION per codeword instead of a 32-bit value, the
+// residues of a block of 64 samples are decoded from those positions just in time (the loads are in
+// flight during the previous block's 64 steps), and the finished samples go over the positions as int16
+// (the WAV writer truncates to 16 bits anyway, and (parent - difference) mod 2^16 only needs 16 bits).
 //
 // ---- Rice parsing across the lanes of a wave ------------------------------------------------------------
 // A Golomb-Rice stream is a serial bit parse -- where codeword i+1 starts depends on codeword i -- but it
@@ -25,35 +33,38 @@
 //   resolve  the true trajectory starts at the stream's first bit in its first lane; it follows that lane's
 //            path to m, which lies in the zone of a later lane j AND on lane j's path, then lane j's path to
 //            m_j, ... (a walk of <= 64 hops on the scalar unit).  Lanes the chain skips were never in step
-//            and decode nothing.  A lane on the chain counts its codewords from its true entry (popcount
+//            and list nothing.  A lane on the chain counts its codewords from its true entry (popcount
 //            of its bitmap words + what it parsed in phase B); an exclusive scan gives the index of its
 //            first value;
-//   pass 2   the lanes on the chain decode their codewords from their true entries, in parallel, straight
-//            into the LDS arrays the synthesis reads.
+//   pass 2   the lanes on the chain walk their codewords once more from their true entries, in parallel, and
+//            write every start position to pos[] (over the bitmap, which is dead by then).
 //
-// The first kCoefLanes lanes do the same for the coefficient stream (<= 100 codewords, its own k), in the
-// same loops: both streams are zones of ONE bit space, the subframe's aligned words.  tools/parse_model.py
-// is an executable model of this algorithm; tests/test_host_logic.py runs it against the CPU oracle.
+// All three walks take four codewords per memory round trip (a 160-bit window per lane) while every lane's
+// codewords are short, and one at a time otherwise (unary runs longer than the window, k = 31).  The first
+// kCoefLanes lanes do the same for the coefficient stream (<= 100 codewords, its own k), in the same loops:
+// both streams are zones of ONE bit space, the subframe's aligned words.  tools/parse_model.py is an
+// executable model of this algorithm; tests/test_host_logic.py runs it against the CPU oracle.
 //
 // A frame whose subframes do not fit the LDS plan (a Rice stream longer than any 16-bit audio produces,
-// or more than 8 channels) takes the GENERIC mode of the same kernel: a plain serial parse straight from
-// global memory, then the same synthesis.  Slow, complete, and never needed by files the encoder writes
+// or more than 8 channels) takes the GENERIC mode of the same kernel: a plain serial parse into the
+// workspace, then the same synthesis.  Slow, complete, and never needed by files the encoder writes
 // for 1..8 channels.
 #include "sela_device.h"
 
 namespace sela {
 
 constexpr int kDecMaxWaves = 8;     // waves per workgroup; frames with more channels loop (generic mode)
-constexpr int kDecMaxChannels = 17; // [channels][2048] int32 in LDS
+constexpr int kDecMaxChannels = 28; // one DecSubframeLds per channel + eight wave scratch records within 160 KB
 constexpr int kCoefLanes = 4;       // lanes of a wave that parse the coefficient stream
 constexpr int kResLanes = kWave - kCoefLanes;
-// Aligned words of one subframe the segment-parallel parser holds in LDS: coefficient words + 2 + residue
-// words.  With 8192 B of values, this and q[] a stereo workgroup needs 27,104 B: six per CU (12 waves).
+// Aligned words of one subframe the segment-parallel parser takes: coefficient words + 2 + residue words
+// (start bitmap: one bit per stream bit; positions must fit 16 bits).
 constexpr int kStreamCap = 1200;
-constexpr int kStreamMargin = 4;    // zero words behind the stream: a window may run this far past the end
+constexpr int kStreamMargin = 4;    // a window may run this many words past the end (they read as zero)
 constexpr uint32_t kEndOfStream = 0xFFFFFFFFu;
 
 typedef const volatile __attribute__((address_space(3))) uint64_t* LdsTable;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- per-wave LDS scratch --------------------------------------------------------------------------------
 struct SynthTables {
@@ -65,19 +76,18 @@ struct SynthTables {
         uint64_t tab[256];  // synthesis coefficient table (build_synth_table), replaces k[] and a[]
     };
 };
-struct DecWaveFast {
-    union {
-        uint32_t strm[kStreamCap + kStreamMargin]; // the subframe's aligned words (until the values are decoded)
-        SynthTables t;
-    };
-    int32_t q[128];
-};
-struct DecWaveGeneric {
+struct DecWaveScratch {
     SynthTables t;
     int32_t q[128];
 };
-static_assert(sizeof(SynthTables) == 2048 && sizeof(SynthTables) <= (kStreamCap + kStreamMargin) * 4, "tables overlay the stream words");
-static_assert(kStreamCap + kStreamMargin <= kBlock, "the start bitmap overlays the value array");
+// per subframe POSITION (not per wave: the combine pass reads every channel)
+union DecSubframeLds {
+    uint32_t marks[kStreamCap + kStreamMargin]; // start bitmap (parse)
+    uint16_t pos[kBlock];                       // bit position of every residue codeword (after the parse)
+    int16_t smp[kBlock];                        // finished samples, written over the positions block by block
+};
+static_assert(sizeof(DecSubframeLds) == (kStreamCap + kStreamMargin) * 4 && sizeof(DecSubframeLds) % 16 == 0, "LDS plan");
+static_assert(32 * (kStreamCap + kStreamMargin) <= 65536, "positions are 16-bit");
 
 __device__ __forceinline__ int32_t rice_value(uint32_t ones, uint32_t field, uint32_t k)
 {
@@ -86,25 +96,109 @@ __device__ __forceinline__ int32_t rice_value(uint32_t ones, uint32_t field, uin
     return (int32_t)((u >> 1) ^ (0u - (u & 1u)));               // un-zig-zag, src/rice/rice_decoder.cpp:49-50
 }
 
+// ---- the subframe's aligned words, where they lie ------------------------------------------------------------
+// A raw-dword buffer resource over [words, words + n_words): reads beyond return 0 (hardware bounds check),
+// which is exactly the zero padding the parser wants behind a stream.  Rebuilt from scalars at every use site
+// that a function call separates from its creation (a resource that travelled through arguments is no longer
+// known to be wave-uniform).
+struct StreamWords {
+    const uint32_t* words;
+    uint32_t n_words;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const StreamWords& s)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(read_first_lane(reinterpret_cast<uint64_t>(s.words))), 0,
+        4u * (uint32_t)__builtin_amdgcn_readfirstlane((int)s.n_words), 0x00020000);
+}
+// 64 stream bits at bit position p
+__device__ __forceinline__ void window64(__amdgpu_buffer_rsrc_t rs, uint32_t p, uint32_t& x0, uint32_t& x1)
+{
+    const uint32_t b = 4 * (p >> 5), sh = p & 31;
+    const uint32_t w0 = __builtin_amdgcn_raw_buffer_load_b32(rs, b, 0, 0), w1 = __builtin_amdgcn_raw_buffer_load_b32(rs, b + 4, 0, 0),
+                   w2 = __builtin_amdgcn_raw_buffer_load_b32(rs, b + 8, 0, 0);
+    x0 = __builtin_amdgcn_alignbit(w1, w0, sh);
+    x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+}
+
+// Four codewords at bit position p, provided they are all short: off[j] = offset of codeword j's start,
+// off[4] = offset behind the fourth.  simple = every run length < 31 and every codeword <= 31 bits (the
+// funnel shifts below take their amounts mod 32, and the 160-bit window then always covers the next start).
+__device__ __forceinline__ void analyse4(__amdgpu_buffer_rsrc_t rs, uint32_t p, uint32_t k, uint32_t (&off)[5], bool& simple)
+{
+    const uint32_t b = 4 * (p >> 5), sh = p & 31;
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, b, 0, 0);
+    const uint32_t w4 = __builtin_amdgcn_raw_buffer_load_b32(rs, b + 16, 0, 0);
+    uint32_t n0 = __builtin_amdgcn_alignbit(w.y, w.x, sh), n1 = __builtin_amdgcn_alignbit(w.z, w.y, sh);
+    uint32_t n2 = __builtin_amdgcn_alignbit(w.w, w.z, sh), n3 = __builtin_amdgcn_alignbit(w4, w.w, sh);
+    uint32_t used = 0;
+    simple = true;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t t = (uint32_t)__builtin_ctz(~n0 | 0x80000000u); // <= 31
+        const uint32_t len = t + 1 + k;
+        simple = simple && len <= 31;
+        off[j] = used;
+        used += len;
+        if (j < 3) { // (a codeword that is not simple garbles the rest of a group that is then not used)
+            n0 = __builtin_amdgcn_alignbit(n1, n0, len);
+            n1 = __builtin_amdgcn_alignbit(n2, n1, len);
+            if (j < 2)
+                n2 = __builtin_amdgcn_alignbit(n3, n2, len);
+            if (j < 1)
+                n3 >>= len & 31;
+        }
+    }
+    off[4] = used;
+}
+
+// One step of the careful walk: over (part of) one codeword at p.  A run of 32 ones and more is taken 32
+// bits at a time (in_run).
+__device__ __forceinline__ void single_step(__amdgpu_buffer_rsrc_t rs, uint32_t p, uint32_t k, uint32_t& adv, bool& full)
+{
+    const uint32_t b = 4 * (p >> 5), sh = p & 31;
+    const uint32_t x = __builtin_amdgcn_alignbit(__builtin_amdgcn_raw_buffer_load_b32(rs, b + 4, 0, 0), __builtin_amdgcn_raw_buffer_load_b32(rs, b, 0, 0), sh);
+    full = x == 0xFFFFFFFFu;
+    adv = full ? 32u : (uint32_t)__builtin_ctz(~x | 0x80000000u) + 1 + k;
+}
+
 // ---- segment-parallel parse of one subframe (fast mode) ------------------------------------------------
-// strm[0 .. cw + 2 + rw) = the subframe's aligned words from the one holding [coefficient word count |
-// order | first coefficient byte] on, followed by kStreamMargin zero words.  Bit space: stream bit t of the
-// array = bit t % 32 of word t / 32.  Coefficient stream = bits [24, 24 + 32 cw), residue stream = bits
-// [32 (cw + 2), 32 (cw + 2 + rw)).  marks[] overlays vals[] (it is dead before the first value is stored).
-// Outputs: q[0 .. order), vals[0 .. 2048); returns SELA_HIP_FLAG_RICE_OVERRUN or 0.
+// Bit space: stream bit t of the subframe's aligned words = bit t % 32 of word t / 32.  Coefficient stream =
+// bits [24, 24 + 32 cw), residue stream = bits [32 (cw + 2), 32 (cw + 2 + rw)).  marks[] and pos_out[] are the
+// same LDS bytes (the bitmap is dead before the first position is stored).  Outputs: pos_out[0 .. 2048) =
+// start of every residue codeword, q[0 .. order) = the coefficients (decoded here: there are few);
+// returns SELA_HIP_FLAG_RICE_OVERRUN or 0.  cpos: 128 uint16 of scratch.
 struct ParseProfile {
     long long t[4];
 };
 
-template <bool kProf>
-__device__ inline uint32_t parse_subframe(const uint32_t* strm, uint32_t* marks, int32_t* vals, int32_t* q, uint32_t cw, uint32_t rw,
-    uint32_t ck, uint32_t rk, uint32_t order, int lane, ParseProfile& prof)
+// The value of the codeword at bit position p (runs of 32 ones and more are followed word by word).
+__device__ __forceinline__ int32_t decode_at(__amdgpu_buffer_rsrc_t rs, uint32_t p, uint32_t k, uint32_t kmask, bool valid)
 {
+    uint32_t x0, x1, ones = 0;
+    window64(rs, p, x0, x1);
+    while (__any(valid && x0 == 0xFFFFFFFFu)) {
+        const bool more = valid && x0 == 0xFFFFFFFFu;
+        ones += more ? 32u : 0u;
+        p += more ? 32u : 0u;
+        window64(rs, p, x0, x1);
+    }
+    const uint32_t t = (uint32_t)__builtin_ctz(~x0 | 0x80000000u);
+    const uint32_t field = (uint32_t)(((((uint64_t)x1) << 32) | x0) >> (t + 1)) & kmask;
+    return rice_value(ones + t, field, k);
+}
+
+template <bool kProf>
+__device__ __forceinline__ uint32_t parse_subframe(const StreamWords& sw, uint32_t* marks, uint16_t* pos_out, uint16_t* cpos, int32_t* q,
+    uint32_t cw, uint32_t rw, uint32_t ck, uint32_t rk, uint32_t order, int lane, ParseProfile& prof)
+{
+    const __amdgpu_buffer_rsrc_t rs = stream_rsrc(sw);
     // ---- zones ---------------------------------------------------------------------------------------------
     const bool coef_lane = lane < kCoefLanes;
     const uint32_t zc = max(1u, (cw + 1 + kCoefLanes - 1) / kCoefLanes); // words per coefficient zone
     const uint32_t zr = max(1u, (rw + kResLanes - 1) / kResLanes);       // words per residue zone
     const uint32_t rs_word = cw + 2;
+    const uint32_t last_mark_word = cw + 2 + rw + kStreamMargin - 1;
     uint32_t first_word, end_word, stream_end, k, need;
     if (coef_lane) {
         first_word = min((uint32_t)lane * zc, cw + 1);
@@ -122,23 +216,35 @@ __device__ inline uint32_t parse_subframe(const uint32_t* strm, uint32_t* marks,
     }
     const uint32_t entry = lane == 0 ? 24u : 32 * first_word;
     const uint32_t zone_end = min(32 * end_word, stream_end);
-    const uint32_t kmask = k ? (0xFFFFFFFFu >> (32 - k)) : 0u;
 
     // ---- phase A: own zone, marking every codeword start ---------------------------------------------------
-    uint32_t pos = entry, n_own = 0;
-    bool in_run = false; // inside a unary run longer than the 32-bit window
-    // (predicated rather than branched: lanes that are through OR a zero into a word of the bitmap)
+    // (predicated rather than branched: lanes that are through OR a zero into the first word of the bitmap)
+    uint32_t pos = entry;
+    bool in_run = false; // inside a unary run longer than the window
     while (__any(pos < zone_end)) {
-        const uint32_t w = pos >> 5, sh = pos & 31;
-        const uint32_t x = __builtin_amdgcn_alignbit(strm[w + 1], strm[w], sh);
         const bool act = pos < zone_end;
-        const bool start = act && !in_run;
-        atomicOr(&marks[w], start ? 1u << sh : 0u); // (LDS ds_or_b32; a zone's words are marked by its lane alone)
-        n_own += start ? 1u : 0u;
-        const bool full = x == 0xFFFFFFFFu;
-        const uint32_t adv = full ? 32u : (uint32_t)__builtin_ctz(~x | 0x80000000u) + 1 + k;
-        pos += act ? adv : 0u;
-        in_run = act ? full : in_run;
+        uint32_t off[5];
+        bool simple;
+        analyse4(rs, pos, k, off, simple);
+        if (!__any(act && (in_run || !simple))) { // four codewords per round trip
+            uint32_t adv = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t p = pos + off[j];
+                const bool a = act && p < zone_end;
+                atomicOr(&marks[a ? p >> 5 : 0u], a ? 1u << (p & 31) : 0u); // (LDS ds_or_b32; a zone's words are marked by its lane alone)
+                adv = a ? off[j + 1] : adv;
+            }
+            pos += adv;
+        } else { // one (part of a) codeword at a time
+            uint32_t adv;
+            bool full;
+            single_step(rs, pos, k, adv, full);
+            const bool start = act && !in_run;
+            atomicOr(&marks[start ? pos >> 5 : 0u], start ? 1u << (pos & 31) : 0u);
+            pos += act ? adv : 0u;
+            in_run = act ? full : in_run;
+        }
     }
     wave_sync();
     if (kProf)
@@ -148,19 +254,40 @@ __device__ inline uint32_t parse_subframe(const uint32_t* strm, uint32_t* marks,
     uint32_t n_cont = 0, merged = 0;
     bool walking = true;
     while (__any(walking)) {
-        const uint32_t w = pos >> 5, sh = pos & 31;
-        const uint32_t x = __builtin_amdgcn_alignbit(strm[w + 1], strm[w], sh);
-        const uint32_t mk = marks[w];
-        const bool at_start = walking && !in_run;
-        const bool ended = at_start && pos >= stream_end;
-        const bool met = at_start && !ended && ((mk >> sh) & 1u);
-        merged = ended ? kEndOfStream : (met ? pos : merged);
-        walking = walking && !ended && !met;
-        n_cont += (at_start && walking) ? 1u : 0u;
-        const bool full = x == 0xFFFFFFFFu;
-        const uint32_t adv = full ? 32u : (uint32_t)__builtin_ctz(~x | 0x80000000u) + 1 + k;
-        pos += walking ? adv : 0u;
-        in_run = walking ? full : in_run;
+        uint32_t off[5];
+        bool simple;
+        analyse4(rs, pos, k, off, simple);
+        if (!__any(walking && (in_run || !simple))) {
+            uint32_t mk[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                mk[j] = marks[min((pos + off[j]) >> 5, last_mark_word)];
+            uint32_t adv = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t p = pos + off[j];
+                const bool ended = walking && p >= stream_end;
+                const bool met = walking && !ended && ((mk[j] >> (p & 31)) & 1u);
+                merged = ended ? kEndOfStream : (met ? p : merged);
+                walking = walking && !ended && !met;
+                n_cont += walking ? 1u : 0u;
+                adv = walking ? off[j + 1] : adv;
+            }
+            pos += adv;
+        } else {
+            uint32_t adv;
+            bool full;
+            single_step(rs, pos, k, adv, full);
+            const uint32_t mk = marks[min(pos >> 5, last_mark_word)];
+            const bool at_start = walking && !in_run;
+            const bool ended = at_start && pos >= stream_end;
+            const bool met = at_start && !ended && ((mk >> (pos & 31)) & 1u);
+            merged = ended ? kEndOfStream : (met ? pos : merged);
+            walking = walking && !ended && !met;
+            n_cont += (at_start && walking) ? 1u : 0u;
+            pos += walking ? adv : 0u;
+            in_run = walking ? full : in_run;
+        }
     }
     if (kProf)
         prof.t[1] = clock64();
@@ -205,7 +332,6 @@ __device__ inline uint32_t parse_subframe(const uint32_t* strm, uint32_t* marks,
         }
         count = on_chain ? count + n_cont : 0u;
     }
-    (void)n_own;
     uint32_t idx = wave_exclusive_scan(count, lane);
     const uint32_t coef_total = (uint32_t)__builtin_amdgcn_readlane((int)idx, kCoefLanes);
     const uint32_t all_total = (uint32_t)__builtin_amdgcn_readlane((int)(idx + count), kWave - 1);
@@ -213,39 +339,65 @@ __device__ inline uint32_t parse_subframe(const uint32_t* strm, uint32_t* marks,
     if (!coef_lane)
         idx -= coef_total;
     uint32_t remaining = idx < need ? min(count, need - idx) : 0u;
-    wave_sync(); // every lane has read the bitmap: the values may overwrite it
+    wave_sync(); // every lane has read the bitmap: the positions may overwrite it
     if (kProf)
         prof.t[2] = clock64();
 
-    // ---- pass 2: decode, every chain lane from its true entry -----------------------------------------------------
-    int32_t* out = (coef_lane ? q : vals) + idx;
+    // ---- pass 2: list the starts, every chain lane from its true entry -----------------------------------------------
+    uint16_t* out = (coef_lane ? cpos : pos_out) + idx;
     pos = on_chain ? e_true : 0u;
-    uint32_t ones = 0;
+    in_run = false;
     bool overrun = false;
     while (__any(remaining != 0)) {
-        const uint32_t w = pos >> 5, sh = pos & 31;
-        const uint32_t w0 = strm[w], w1 = strm[w + 1], w2 = strm[w + 2];
-        const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
         const bool act = remaining != 0;
-        const bool full = x0 == 0xFFFFFFFFu;
-        const uint32_t t = full ? 32u : (uint32_t)__builtin_ctz(~x0 | 0x80000000u);
-        const uint32_t field = (uint32_t)(((((uint64_t)x1) << 32) | x0) >> ((t + 1) & 63)) & kmask;
-        const bool emit = act && !full;
-        if (emit)
-            *out = rice_value(ones + t, field, k);
-        out += emit ? 1 : 0;
-        ones = emit ? 0u : (act ? ones + 32 : ones);
-        pos += act ? (full ? 32u : t + 1 + k) : 0u;
-        remaining -= emit ? 1u : 0u;
-        overrun |= emit && pos > stream_end;
+        uint32_t off[5];
+        bool simple;
+        analyse4(rs, pos, k, off, simple);
+        if (!__any(act && (in_run || !simple))) {
+            uint32_t adv = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool a = (uint32_t)j < remaining;
+                if (a)
+                    out[j] = (uint16_t)(pos + off[j]);
+                adv = a ? off[j + 1] : adv;
+            }
+            const uint32_t take = min(remaining, 4u);
+            out += take;
+            remaining -= take;
+            pos += adv;
+            overrun |= act && pos > stream_end;
+        } else {
+            uint32_t adv;
+            bool full;
+            single_step(rs, pos, k, adv, full);
+            const bool start = act && !in_run;
+            if (start)
+                *out = (uint16_t)pos;
+            out += start ? 1 : 0;
+            pos += act ? adv : 0u;
+            in_run = act ? full : in_run;
+            remaining -= (act && !full) ? 1u : 0u;
+            overrun |= act && !full && pos > stream_end;
+        }
     }
-    // a stream that ends before all its values were read yields zeros (reads beyond the end are zero)
-    if (coef_total < order)
-        for (uint32_t i = coef_total + lane; i < order; i += kWave)
-            q[i] = 0;
+    // a stream that ends before all its values were read: the missing codewords read as zero bits, i.e. they
+    // "start" behind the stream's end, where the resource returns zeros
     if (res_total < (uint32_t)kBlock)
         for (uint32_t i = res_total + lane; i < (uint32_t)kBlock; i += kWave)
-            vals[i] = 0;
+            pos_out[i] = (uint16_t)(32 * (rs_word + rw + 1));
+    wave_sync();
+    // the coefficients themselves (<= 100 values: two rounds)
+    {
+        const uint32_t ckmask = ck ? (0xFFFFFFFFu >> (32 - ck)) : 0u;
+        for (uint32_t i0 = 0; i0 < order; i0 += kWave) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool valid = i < min(order, coef_total);
+            const int32_t v = decode_at(rs, valid ? cpos[i] : 0u, ck, ckmask, valid);
+            if (i < order)
+                q[i] = valid ? v : 0;
+        }
+    }
     const bool bad = __any(overrun) || coef_total < order || res_total < (uint32_t)kBlock;
     wave_sync();
     if (kProf)
@@ -266,12 +418,10 @@ __device__ inline uint32_t parse_stream_serial(const uint32_t* __restrict__ word
 #pragma unroll 1
     for (uint32_t i = 0; i < count; i++) {
         uint32_t ones = 0;
-        for (;;) { // whole words of ones at a time, then bit by bit
-            const uint32_t w = pos >> 5, sh = pos & 31;
-            const uint32_t lo = word_at(w) >> sh;
-            const uint32_t have = 32 - sh;
-            const uint32_t run = (uint32_t)__builtin_ctz(~lo | (have < 32 ? 1u << have : 0u));
-            const uint32_t t = min(run, have);
+        for (;;) { // up to a whole word of ones at a time
+            const uint32_t sh = pos & 31, have = 32 - sh;
+            const uint32_t lo = word_at(pos >> 5) >> sh;
+            const uint32_t t = (uint32_t)__builtin_ctzll(~(uint64_t)lo | ((uint64_t)1 << have)); // <= have
             ones += t;
             pos += t;
             if (t < have || pos >= stream_end)
@@ -291,14 +441,14 @@ __device__ inline uint32_t parse_stream_serial(const uint32_t* __restrict__ word
 }
 
 // ---- synthesis filter ----------------------------------------------------------------------------------
-// lpc::SampleGenerator::generateSamples (src/lpc/sample_generator.cpp:11-30), in place over the
-// residues in LDS.  Transposed direct form without data movement: every sample that is still to come
-// owns a partial sum, and the sum of sample j lives in lane j mod 64 for its whole life (a ring over
-// the lanes; orders above 60 use two registers per lane = a ring of 128).  Once sample s_i is known,
-// the lane that owns sample i + d adds a[d] * s_i; its coefficient a[(lane - i) mod ring] comes out of
-// a doubled table in LDS at a compile-time offset (the 64 steps of a block are unrolled), so nothing is
-// shifted between lanes.  The recurrence itself (sum -> s_i) runs on the scalar unit: v_readlane of the
-// finished sum, two SALU ops, and s_i feeds the multiply-adds as a scalar operand.
+// lpc::SampleGenerator::generateSamples (src/lpc/sample_generator.cpp:11-30).  Transposed direct form
+// without data movement: every sample that is still to come owns a partial sum, and the sum of sample j
+// lives in lane j mod 64 for its whole life (a ring over the lanes; orders above 60 use two registers per
+// lane = a ring of 128).  Once sample s_i is known, the lane that owns sample i + d adds a[d] * s_i; its
+// coefficient a[(lane - i) mod ring] comes out of a doubled table in LDS at a compile-time offset (the 64
+// steps of a block are unrolled), so nothing is shifted between lanes.  The recurrence itself (sum -> s_i)
+// runs on the scalar unit: v_readlane of the finished sum, two SALU ops, and s_i feeds the multiply-adds
+// as a scalar operand.
 //
 // What is accumulated is N = 2^34 - sum(a_j s_(i-j)): the coefficients are negated once and every sum
 // starts at the rounding constant 2^34, so the prediction (int32)((2^34 - P) >> 35) is the arithmetic
@@ -377,11 +527,11 @@ __device__ __forceinline__ void synth_steps(uint32_t& cl, uint32_t& ch, uint32_t
         synth_steps<R, kFold, G, M + 1>(cl, ch, ol, oh, kept, tab_lane, r_block, four, zero, pf_c, pf_o);
 }
 
-// One block of 64 samples at rs[0..63].  The folded form returns false, with rs[] untouched, if a sample
-// of the block left its range.
+// One block of 64 samples with residues r_block (one per lane).  The folded form returns false if a sample
+// of the block left its range (s is then meaningless).
 template <int R, bool kFold, int G>
-__device__ __forceinline__ bool synth_block(int32_t* rs, uint32_t& cl, uint32_t& ch, uint32_t& ol, uint32_t& oh,
-    LdsTable tab_lane, int lane, uint32_t four, uint32_t zero)
+__device__ __forceinline__ bool synth_block(int32_t r_block, int32_t& s, uint32_t& cl, uint32_t& ch, uint32_t& ol, uint32_t& oh,
+    LdsTable tab_lane, uint32_t four, uint32_t zero)
 {
     uint64_t pf_c[kAhead], pf_o[kAhead];
 #pragma unroll
@@ -389,25 +539,30 @@ __device__ __forceinline__ bool synth_block(int32_t* rs, uint32_t& cl, uint32_t&
         pf_c[m] = tab_lane[64 * R - m];
         pf_o[m] = R == 2 ? tab_lane[64 - m] : 0;
     }
-    const int32_t r_block = rs[lane];
     if (kFold)
         ch -= (uint32_t)r_block << 3; // sample lane of this block: N -= r * 2^35
     uint32_t kept = 0;
     __builtin_amdgcn_sched_barrier(0);
     synth_steps<R, kFold, G, 0>(cl, ch, ol, oh, kept, tab_lane, r_block, four, zero, pf_c, pf_o);
-    const int32_t s = (int32_t)((kFold ? 0u : (uint32_t)r_block) - (uint32_t)((int32_t)kept >> 3));
-    if (kFold && __any((uint32_t)(s + (1 << 23)) >= (1u << 24)))
-        return false;
-    rs[lane] = s;
-    return true;
+    s = (int32_t)((kFold ? 0u : (uint32_t)r_block) - (uint32_t)((int32_t)kept >> 3));
+    return !kFold || !__any((uint32_t)(s + (1 << 23)) >= (1u << 24));
 }
 
 // All 2048 samples of a subframe.  R = ring / 64 (1: order <= 64 - G, 2: order <= 128 - G); G = recycling
-// group (4 or 16).  fold = start in the folded form (the coefficients fit it).
+// group (4 or 16).  fold = start in the folded form (the coefficients fit it).  Residues: decoded just in time
+// from the codeword positions in pos_smp[] (ws == nullptr), the words fetched one block ahead -- or read from
+// the workspace array ws[] (generic mode).  Samples go to pos_smp[] as int16, over the positions of the
+// block just consumed.
 template <int R, int G>
-__device__ inline void synthesize(int32_t* rs, const uint64_t* tab, bool fold, int lane)
+__device__ inline void synthesize(const uint32_t* words, uint32_t n_words, uint32_t k, uint16_t* pos_smp, const int32_t* ws,
+    const uint64_t* tab, bool fold, int lane)
 {
     static_assert(G == 4 || G == 16, "groups are DPP banks or rows");
+    const StreamWords sw = { words, n_words };
+    const __amdgpu_buffer_rsrc_t rs = stream_rsrc(sw);
+    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    const uint32_t kmask = k ? (0xFFFFFFFFu >> (32 - k)) : 0u;
+    const bool jit = read_first_lane(reinterpret_cast<uint64_t>(ws)) == 0;
     uint32_t zl[2], zh[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) { // every sum starts at 2^34
@@ -417,23 +572,61 @@ __device__ inline void synthesize(int32_t* rs, const uint64_t* tab, bool fold, i
     uint32_t four = 4, zero = 0;
     asm volatile("" : "+v"(four), "+v"(zero)); // DPP sources must be VGPRs
     const LdsTable tab_lane = (LdsTable)(tab + lane); // the table is in LDS: ds_read with immediate offsets
-#pragma unroll 1
-    for (int base = 0; base < kBlock; base += 64 * R) {
-#pragma unroll
-        for (int h = 0; h < R; h++) {
-            uint32_t& cl = zl[h];
-            uint32_t& ch = zh[h];
-            uint32_t& ol = zl[R - 1 - h];
-            uint32_t& oh = zh[R - 1 - h];
-            if (fold) {
-                const uint32_t s0 = zl[0], s1 = zh[0], s2 = zl[1], s3 = zh[1];
-                if (synth_block<R, true, G>(rs + base + 64 * h, cl, ch, ol, oh, tab_lane, lane, four, zero))
-                    continue;
-                zl[0] = s0, zh[0] = s1, zl[1] = s2, zh[1] = s3; // back to the block's start, exact form from here on
+    // the block ahead: its codeword's position and three stream words (or its residue, generic mode)
+    uint32_t p = 0, w0 = 0, w1 = 0, w2 = 0;
+    int32_t r_ws = 0;
+    auto issue = [&](int blk) {
+        if (jit) {
+            p = pos_smp[64 * blk + lane];
+            const uint32_t b = 4 * (p >> 5);
+            w0 = __builtin_amdgcn_raw_buffer_load_b32(rs, b, 0, 0);
+            w1 = __builtin_amdgcn_raw_buffer_load_b32(rs, b + 4, 0, 0);
+            w2 = __builtin_amdgcn_raw_buffer_load_b32(rs, b + 8, 0, 0);
+        } else {
+            r_ws = ws[64 * blk + lane];
+        }
+    };
+    auto land = [&]() -> int32_t {
+        if (!jit)
+            return r_ws;
+        uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, p & 31), x1 = __builtin_amdgcn_alignbit(w2, w1, p & 31), ones = 0;
+        while (__any(x0 == 0xFFFFFFFFu)) { // runs of 32 ones and more (rare): follow them word by word
+            const bool more = x0 == 0xFFFFFFFFu;
+            ones += more ? 32u : 0u;
+            p += more ? 32u : 0u;
+            window64(rs, p, x0, x1);
+        }
+        const uint32_t t = (uint32_t)__builtin_ctz(~x0);
+        const uint32_t field = (uint32_t)(((((uint64_t)x1) << 32) | x0) >> (t + 1)) & kmask;
+        return rice_value(ones + t, field, k);
+    };
+    // one block: (cl, ch) = the register whose sums finish in it, (ol, oh) = the other register of a ring of 128
+    auto run_block = [&](int blk, uint32_t& cl, uint32_t& ch, uint32_t& ol, uint32_t& oh) {
+        const int32_t r_block = land();
+        if (blk + 1 < kBlock / 64)
+            issue(blk + 1); // in flight during this block's 64 steps
+        int32_t s;
+        bool done = false;
+        if (fold) {
+            const uint32_t s0 = cl, s1 = ch, s2 = ol, s3 = oh;
+            done = synth_block<R, true, G>(r_block, s, cl, ch, ol, oh, tab_lane, four, zero);
+            if (!done) { // back to the block's start, exact form from here on
+                cl = s0, ch = s1;
+                if (R == 2)
+                    ol = s2, oh = s3;
                 fold = false;
             }
-            synth_block<R, false, G>(rs + base + 64 * h, cl, ch, ol, oh, tab_lane, lane, four, zero);
         }
+        if (!done)
+            synth_block<R, false, G>(r_block, s, cl, ch, ol, oh, tab_lane, four, zero);
+        reinterpret_cast<int16_t*>(pos_smp)[64 * blk + lane] = (int16_t)(uint16_t)(uint32_t)s;
+    };
+    issue(0);
+#pragma unroll 1
+    for (int pair = 0; pair < kBlock / 64; pair += R) {
+        run_block(pair, zl[0], zh[0], zl[R - 1], zh[R - 1]);
+        if (R == 2)
+            run_block(pair + 1, zl[1], zh[1], zl[0], zh[0]);
     }
     wave_sync();
 }
@@ -512,15 +705,18 @@ __device__ inline SubHeader walk_headers(const uint8_t* fb, uint64_t fbytes, uin
     return h;
 }
 
-// LDS plan of k_decode_frames (dynamic): [channels][2048] int32 values | one scratch record per wave |
-// sub_info[channels] | mode words.  Values are indexed by subframe POSITION; sub_info maps channels to them.
-__host__ __device__ inline size_t decode_scratch_stride(bool fast) { return fast ? sizeof(DecWaveFast) : sizeof(DecWaveGeneric); }
+// LDS plan of k_decode_frames (dynamic): one DecSubframeLds per subframe POSITION | one DecWaveScratch per wave |
+// sub_info[channels] (channel -> type | parent << 8 | position << 16) | too_big[n_waves].
+__host__ __device__ inline size_t decode_lds_bytes_for(uint32_t channels, int n_waves)
+{
+    return (size_t)channels * sizeof(DecSubframeLds) + (size_t)n_waves * sizeof(DecWaveScratch) + (size_t)channels * 4 + (size_t)n_waves * 4;
+}
 
 // kProf: also write per-phase cycle counts (debug hook sela_hip_debug_phase_buffer; 16 uint64 per subframe).
 template <bool kProf>
 __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* __restrict__ pcm_out,
-    uint32_t* __restrict__ status, uint64_t* __restrict__ phase_cycles)
+    uint32_t* __restrict__ status, int32_t* __restrict__ ws_residues, uint64_t* __restrict__ phase_cycles)
 {
     long long stamp[10];
     for (int i = 0; i < 10; i++)
@@ -531,10 +727,9 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     const int n_waves = blockDim.x / 64;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
-    const bool fast_plan = channels <= (uint32_t)kDecMaxWaves; // the scratch records are DecWaveFast (host: launch_decode)
-    int32_t* const vals_all = reinterpret_cast<int32_t*>(dyn);
-    unsigned char* const scratch = dyn + (size_t)channels * kBlock * 4 + (size_t)wave * decode_scratch_stride(fast_plan);
-    uint32_t* const sub_info = reinterpret_cast<uint32_t*>(dyn + (size_t)channels * kBlock * 4 + (size_t)n_waves * decode_scratch_stride(fast_plan));
+    DecSubframeLds* const sub = reinterpret_cast<DecSubframeLds*>(dyn);
+    DecWaveScratch* const scratch = reinterpret_cast<DecWaveScratch*>(dyn + (size_t)channels * sizeof(DecSubframeLds)) + wave;
+    uint32_t* const sub_info = reinterpret_cast<uint32_t*>(dyn + (size_t)channels * sizeof(DecSubframeLds) + (size_t)n_waves * sizeof(DecWaveScratch));
     uint32_t* const too_big = sub_info + channels; // [n_waves]: this wave's subframe does not fit the fast plan
 
     const uint32_t f = blockIdx.x;
@@ -547,9 +742,10 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
         sub_info[c] = 0xFFFFFFFFu; // "no subframe delivered this channel"
 
     // ---- mode: every subframe of the frame must fit the fast plan ----------------------------------------------
+    const bool fast_plan = channels <= (uint32_t)kDecMaxWaves;
     SubHeader hd = walk_headers(fb, fbytes, (uint32_t)wave < channels ? (uint32_t)wave : 0u, channels);
     if (lane == 0)
-        too_big[wave] = (fast_plan && (!hd.ok || (hd.cw + 2 + hd.rw <= (uint32_t)kStreamCap && hd.cw <= (uint32_t)kCoefWordsCap))) ? 0u : 1u;
+        too_big[wave] = (fast_plan && (!hd.ok || (hd.cw + 2 + hd.rw <= (uint32_t)kStreamCap && hd.order <= 2 * (uint32_t)kWave))) ? 0u : 1u;
     __syncthreads();
     bool fast = fast_plan;
     for (int w = 0; w < n_waves; w++)
@@ -564,44 +760,38 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
             flags |= SELA_HIP_FLAG_BAD_FRAME;
             continue;
         }
-        int32_t* const vals = vals_all + (size_t)c * kBlock;
-        SynthTables* tables;
-        int32_t* q;
+        DecSubframeLds* const sl = sub + c;
+        const uint32_t nw = hd.cw + 2 + hd.rw;
+        const uint32_t* const gw = reinterpret_cast<const uint32_t*>(fb + hd.p + 4); // the subframe's aligned words
+        const int32_t* ws_c = nullptr;
         ParseProfile pp;
         if (fast) {
-            DecWaveFast* const wl = reinterpret_cast<DecWaveFast*>(scratch);
-            tables = &wl->t;
-            q = wl->q;
-            // the subframe's aligned words -> LDS, the start bitmap (over the value array) cleared
-            const uint32_t nw = hd.cw + 2 + hd.rw;
-            const uint32_t* const gw = reinterpret_cast<const uint32_t*>(fb + hd.p + 4);
-            uint32_t* const marks = reinterpret_cast<uint32_t*>(vals);
-            for (uint32_t w = lane; w < nw + kStreamMargin; w += kWave) {
-                wl->strm[w] = w < nw ? gw[w] : 0u;
-                marks[w] = 0;
-            }
+            for (uint32_t w = lane; w < nw + kStreamMargin; w += kWave) // the start bitmap
+                sl->marks[w] = 0;
             wave_sync();
             if (kProf)
                 stamp[2] = clock64(), prof_sub = c;
-            flags |= parse_subframe<kProf>(wl->strm, marks, vals, q, hd.cw, hd.rw, hd.ck, hd.rk, hd.order, lane, pp);
+            const StreamWords sw = { gw, nw };
+            flags |= parse_subframe<kProf>(sw, sl->marks, sl->pos, reinterpret_cast<uint16_t*>(&scratch->t), scratch->q, hd.cw, hd.rw, hd.ck, hd.rk,
+                hd.order, lane, pp);
         } else {
-            DecWaveGeneric* const wl = reinterpret_cast<DecWaveGeneric*>(scratch);
-            tables = &wl->t;
-            q = wl->q;
             if (kProf)
                 stamp[2] = clock64(), prof_sub = c;
-            const uint32_t* const gw = reinterpret_cast<const uint32_t*>(fb + hd.p + 4);
+            int32_t* const wres = ws_residues + ((size_t)f * channels + c) * kBlock;
             const uint32_t n_frame_words = (uint32_t)((fbytes - hd.p - 4) / 4);
-            flags |= parse_stream_serial(gw, 24, 24 + 32 * hd.cw, n_frame_words, hd.ck, hd.order, q, lane);
-            flags |= parse_stream_serial(gw, 32 * (hd.cw + 2), 32 * (hd.cw + 2 + hd.rw), n_frame_words, hd.rk, (uint32_t)kBlock, vals, lane);
+            flags |= parse_stream_serial(gw, 24, 24 + 32 * hd.cw, n_frame_words, hd.ck, hd.order, scratch->q, lane);
+            flags |= parse_stream_serial(gw, 32 * (hd.cw + 2), 32 * (hd.cw + 2 + hd.rw), n_frame_words, hd.rk, (uint32_t)kBlock, wres, lane);
+            __threadfence(); // lane 0's stores to the workspace are read back by every lane
+            ws_c = wres;
             pp.t[0] = pp.t[1] = pp.t[2] = pp.t[3] = kProf ? clock64() : 0;
         }
         if (kProf)
             stamp[3] = pp.t[0], stamp[4] = pp.t[1], stamp[5] = pp.t[2], stamp[6] = pp.t[3];
 
-        // dequantise (src/lpc/linear_predictor.cpp:16-28) + step-up; the tables go over the dead stream words
+        // dequantise (src/lpc/linear_predictor.cpp:16-28) + step-up
+        SynthTables* const tables = &scratch->t;
         const uint32_t order = hd.order;
-        const int32_t q_lo = (uint32_t)lane < order ? q[lane] : 0, q_hi = (uint32_t)lane + 64 < order ? q[lane + 64] : 0;
+        const int32_t q_lo = (uint32_t)lane < order ? scratch->q[lane] : 0, q_hi = (uint32_t)lane + 64 < order ? scratch->q[lane + 64] : 0;
         wave_sync();
         if ((uint32_t)lane < order)
             tables->k[lane] = order <= 1 ? 0.0 : dequant(lane, q_lo, flags);
@@ -614,11 +804,11 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
             stamp[7] = clock64();
         // ring / recycling group by order: <= 48: 64 / 16, <= 60: 64 / 4, else 128 / 16
         if (order <= 48)
-            synthesize<1, 16>(vals, tables->tab, fits24, lane);
+            synthesize<1, 16>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
         else if (order <= 60)
-            synthesize<1, 4>(vals, tables->tab, fits24, lane);
+            synthesize<1, 4>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
         else
-            synthesize<2, 16>(vals, tables->tab, fits24, lane);
+            synthesize<2, 16>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
         if (kProf)
             stamp[8] = clock64();
         if (lane == 0)
@@ -628,46 +818,47 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
 
     // ---- second pass of frame::FrameDecoder + interleave to int16 ------------------------------------
     // dependent channels become parent - difference (parents are independent subframes); a channel
-    // that no valid subframe delivered decodes to silence and raises BAD_FRAME.
+    // that no valid subframe delivered decodes to silence and raises BAD_FRAME.  All of it mod 2^16: the
+    // reference truncates to int16 when it writes the WAV (src/file/wav_file.cpp:248-251).
     if (channels == 2) {
         // stereo: four samples of both channels per thread, one 16-byte store (wave-uniform case analysis)
         const uint32_t i0 = sub_info[0], i1 = sub_info[1];
         const bool have0 = i0 != 0xFFFFFFFFu, have1 = i1 != 0xFFFFFFFFu;
         const bool dep0 = have0 && (i0 & 0xFF) == 1, dep1 = have1 && (i1 & 0xFF) == 1;
         const uint32_t par0 = (i0 >> 8) & 0xFF, par1 = (i1 >> 8) & 0xFF; // parent channel of a dependent subframe (0 or 1, checked above)
-        const int4* s0 = reinterpret_cast<const int4*>(vals_all + (size_t)(have0 ? i0 >> 16 : 0) * kBlock);
-        const int4* s1 = reinterpret_cast<const int4*>(vals_all + (size_t)(have1 ? i1 >> 16 : 0) * kBlock);
+        const uint2* s0 = reinterpret_cast<const uint2*>(sub[have0 ? i0 >> 16 : 0].smp);
+        const uint2* s1 = reinterpret_cast<const uint2*>(sub[have1 ? i1 >> 16 : 0].smp);
         uint4* out = reinterpret_cast<uint4*>(pcm_out + (size_t)f * kBlock * 2);
         for (uint32_t i4 = threadIdx.x; i4 < (uint32_t)kBlock / 4; i4 += blockDim.x) {
-            const int4 zero = make_int4(0, 0, 0, 0);
-            const int4 r0 = have0 ? s0[i4] : zero, r1 = have1 ? s1[i4] : zero; // raw subframe outputs
-            int4 a = r0, b = r1;
-            if (dep0) { // parent - difference; the parent's own (independent) samples
-                const int4 pv = par0 == 0 ? r0 : r1;
-                a = make_int4((int)((uint32_t)pv.x - (uint32_t)r0.x), (int)((uint32_t)pv.y - (uint32_t)r0.y),
-                    (int)((uint32_t)pv.z - (uint32_t)r0.z), (int)((uint32_t)pv.w - (uint32_t)r0.w));
+            const uint2 zero = make_uint2(0, 0);
+            const uint2 r0 = have0 ? s0[i4] : zero, r1 = have1 ? s1[i4] : zero; // raw subframe outputs, two samples per word
+            // per 16-bit half: parent - difference (the parent's own, independent samples)
+            auto sub16 = [](uint32_t a, uint32_t b) -> uint32_t { return ((a - (b & 0xFFFFu)) & 0xFFFFu) | ((a & 0xFFFF0000u) - (b & 0xFFFF0000u)); };
+            uint2 a = r0, b = r1;
+            if (dep0) {
+                const uint2 pv = par0 == 0 ? r0 : r1;
+                a = make_uint2(sub16(pv.x, r0.x), sub16(pv.y, r0.y));
             }
             if (dep1) {
-                const int4 pv = par1 == 0 ? r0 : r1;
-                b = make_int4((int)((uint32_t)pv.x - (uint32_t)r1.x), (int)((uint32_t)pv.y - (uint32_t)r1.y),
-                    (int)((uint32_t)pv.z - (uint32_t)r1.z), (int)((uint32_t)pv.w - (uint32_t)r1.w));
+                const uint2 pv = par1 == 0 ? r0 : r1;
+                b = make_uint2(sub16(pv.x, r1.x), sub16(pv.y, r1.y));
             }
             uint4 w;
-            w.x = ((uint32_t)a.x & 0xFFFFu) | ((uint32_t)b.x << 16);
-            w.y = ((uint32_t)a.y & 0xFFFFu) | ((uint32_t)b.y << 16);
-            w.z = ((uint32_t)a.z & 0xFFFFu) | ((uint32_t)b.z << 16);
-            w.w = ((uint32_t)a.w & 0xFFFFu) | ((uint32_t)b.w << 16);
+            w.x = (a.x & 0xFFFFu) | (b.x << 16);
+            w.y = (a.x >> 16) | (b.x & 0xFFFF0000u);
+            w.z = (a.y & 0xFFFFu) | (b.y << 16);
+            w.w = (a.y >> 16) | (b.y & 0xFFFF0000u);
             out[i4] = w;
         }
     } else {
         for (uint32_t i = threadIdx.x; i < (uint32_t)kBlock; i += blockDim.x) {
             for (uint32_t c = 0; c < channels; c++) {
                 const uint32_t info = sub_info[c];
-                int32_t v = info == 0xFFFFFFFFu ? 0 : vals_all[(size_t)(info >> 16) * kBlock + i];
+                uint32_t v = info == 0xFFFFFFFFu ? 0u : (uint32_t)(uint16_t)sub[info >> 16].smp[i];
                 if (info != 0xFFFFFFFFu && (info & 0xFF) == 1) {
                     const uint32_t pinfo = sub_info[(info >> 8) & 0xFF];
-                    const int32_t pv = pinfo == 0xFFFFFFFFu ? 0 : vals_all[(size_t)(pinfo >> 16) * kBlock + i];
-                    v = (int32_t)((uint32_t)pv - (uint32_t)v);
+                    const uint32_t pv = pinfo == 0xFFFFFFFFu ? 0u : (uint32_t)(uint16_t)sub[pinfo >> 16].smp[i];
+                    v = pv - v;
                 }
                 pcm_out[((size_t)f * kBlock + i) * channels + c] = (int16_t)(uint16_t)v;
             }
@@ -686,17 +877,10 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
         }
     }
     flags = wave_or(flags);
-    if (lane == 0 && flags)
+    if (lane == 0 && flags) {
         atomicOr(&status[0], flags);
-    __syncthreads(); // (orders the flag words below after every wave's atomicOr only loosely; they are counted per frame)
-    if (threadIdx.x == 0) {
-        bool bad = (flags & SELA_HIP_FLAG_BAD_FRAME) != 0;
-        for (int w = 1; w < n_waves; w++)
-            bad = bad || too_big[w] == 2;
-        if (bad)
+        if (wave == 0 && (flags & SELA_HIP_FLAG_BAD_FRAME))
             atomicAdd(&status[1], 1u);
-    } else if (lane == 0 && (flags & SELA_HIP_FLAG_BAD_FRAME)) {
-        too_big[wave] = 2; // (read by thread 0 after the barrier below would be cleaner; see comment)
     }
     if (kProf && lane == 0 && prof_sub != 0xFFFFFFFFu) { // (one subframe per wave is reported)
         stamp[9] = clock64();
@@ -710,26 +894,19 @@ int decode_waves(uint32_t channels)
     return channels < (uint32_t)kDecMaxWaves ? (int)channels : kDecMaxWaves;
 }
 
-size_t decode_lds_bytes(uint32_t channels)
-{
-    const int n_waves = decode_waves(channels);
-    const bool fast_plan = channels <= (uint32_t)kDecMaxWaves;
-    return (size_t)channels * kBlock * 4 + (size_t)n_waves * decode_scratch_stride(fast_plan) + (size_t)channels * 4 + (size_t)n_waves * 4;
-}
+size_t decode_lds_bytes(uint32_t channels) { return decode_lds_bytes_for(channels, decode_waves(channels)); }
 
 uint32_t decode_max_channels() { return (uint32_t)kDecMaxChannels; }
 
-// The decoder keeps everything on chip; the workspace argument of the C ABI is kept for callers written
-// against the first version of the interface.
+// Generic mode parks the residues of a subframe here (int32[2048]); the usual path never touches it.
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels)
 {
-    (void)n_frames;
-    (void)channels;
-    return 256;
+    return (size_t)n_frames * channels * kBlock * sizeof(int32_t) + 256;
 }
 
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, hipStream_t stream, hipEvent_t* ev /* 2 events or nullptr */, uint64_t* d_phase_cycles)
+    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev /* 2 events or nullptr */,
+    uint64_t* d_phase_cycles)
 {
     hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
     if (err != hipSuccess || n_frames == 0)
@@ -738,21 +915,22 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
     const size_t lds = decode_lds_bytes(channels);
     if (channels > (uint32_t)kDecMaxChannels || lds > 160 * 1024)
         return hipErrorInvalidValue;
-    if (lds > 64 * 1024) { // above the default dynamic-LDS limit (five channels and more)
+    if (lds > 64 * 1024) { // above the default dynamic-LDS limit
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess)
             return err;
     }
+    int32_t* ws = reinterpret_cast<int32_t*>(((uintptr_t)d_workspace + 255) & ~(uintptr_t)255);
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
         hipLaunchKernelGGL(k_decode_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
-            d_pcm_out, d_status, d_phase_cycles);
+            d_pcm_out, d_status, ws, d_phase_cycles);
     else
         hipLaunchKernelGGL(k_decode_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
-            d_pcm_out, d_status, d_phase_cycles);
+            d_pcm_out, d_status, ws, d_phase_cycles);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     return hipGetLastError();
