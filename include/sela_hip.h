@@ -183,6 +183,11 @@ void sela_hip_debug_phase_buffer(uint64_t* d_cycles);
  * 64-bit loop that predictors beyond the fast FIR's coefficient range take (never reached by 16-bit audio);
  * results are identical by construction, which is what the tests check. */
 void sela_hip_debug_force_plain_fir(int enable);
+/* Debug hook: the encoder hands the sequential mean of every block beyond the first `self_blocks` of a launch
+ * to "mean worker" workgroups (normally self_blocks = what the device holds at once, so small batches never use
+ * workers).  Setting a small value makes small test batches take the worker path; -1 restores the default.
+ * Results are identical by construction, which is what the tests check. */
+void sela_hip_debug_mean_workers(int self_blocks);
 
 /* ---- flag bits reported through d_status[0] / sela_hip_trace.flags --------------------------------- */
 #define SELA_HIP_FLAG_Q_RANGE 1u       /* quantised reflection coefficient outside [-64,63] (clamped) */

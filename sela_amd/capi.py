@@ -24,7 +24,7 @@ EXPORTS = [
     "sela_hip_encode_bound_bytes", "sela_hip_encode_device", "sela_hip_decode_device",
     "sela_hip_encode", "sela_hip_decode", "sela_hip_index_frames",
     "sela_hip_enable_kernel_timing", "sela_hip_kernel_times", "sela_hip_debug_phase_buffer",
-    "sela_hip_host_alloc", "sela_hip_host_free", "sela_hip_decode_max_channels", "sela_hip_debug_force_plain_fir",
+    "sela_hip_host_alloc", "sela_hip_host_free", "sela_hip_decode_max_channels", "sela_hip_debug_force_plain_fir", "sela_hip_debug_mean_workers",
     "sela_hip_encode_begin", "sela_hip_encode_feed", "sela_hip_encode_end",
     "sela_hip_decode_begin", "sela_hip_decode_feed", "sela_hip_decode_end",
 ]
@@ -98,6 +98,8 @@ def lib() -> C.CDLL:
     L.sela_hip_debug_phase_buffer.restype = None
     L.sela_hip_debug_force_plain_fir.argtypes = [C.c_int]
     L.sela_hip_debug_force_plain_fir.restype = None
+    L.sela_hip_debug_mean_workers.argtypes = [C.c_int]
+    L.sela_hip_debug_mean_workers.restype = None
     L.sela_hip_host_alloc.argtypes = [sz]
     L.sela_hip_host_alloc.restype = C.c_void_p
     L.sela_hip_host_free.argtypes = [C.c_void_p]

@@ -19,7 +19,7 @@ namespace sela {
 size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
-    hipEvent_t* ev, uint64_t* d_phase_cycles, uint64_t* d_mirror, int force_plain_fir);
+    hipEvent_t* ev, uint64_t* d_phase_cycles, uint64_t* d_mirror, int force_plain_fir, int self_blocks_override);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles);
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
@@ -255,6 +255,7 @@ struct KernelTiming {
 thread_local KernelTiming g_timing;
 thread_local uint64_t* g_phase_cycles = nullptr; // debug: per-block phase cycle counts (sela_hip_debug_phase_buffer)
 thread_local int g_force_plain_fir = 0;          // debug: sela_hip_debug_force_plain_fir
+thread_local int g_self_blocks = -1;             // debug: sela_hip_debug_mean_workers
 
 uint32_t flags_to_error(uint32_t flags)
 {
@@ -388,7 +389,7 @@ int job_issue_encode(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
         return job_fail(job, fail_hip(e, "hipHostGetDevicePointer"));
     uint32_t* d_status = static_cast<uint32_t*>(g_ctx.status.ptr) + 4 * (size_t)(i & 1);
     e = sela::launch_encode(static_cast<const int16_t*>(c.pcm.ptr), nf, job->channels, static_cast<uint8_t*>(c.frames.ptr), job->chunk_bound,
-        static_cast<uint64_t*>(c.offsets.ptr), d_status, c.workspace.ptr, nullptr, c.s_run, nullptr, nullptr, d_mirror, g_force_plain_fir);
+        static_cast<uint64_t*>(c.offsets.ptr), d_status, c.workspace.ptr, nullptr, c.s_run, nullptr, nullptr, d_mirror, g_force_plain_fir, g_self_blocks);
     if (e != hipSuccess || (e = hipEventRecord(c.ran, c.s_run)) != hipSuccess)
         return job_fail(job, fail_hip(e, "encode launch"));
     job->chunk_first.push_back(job->fed);
@@ -566,6 +567,8 @@ void sela_hip_debug_phase_buffer(uint64_t* d_cycles) { g_phase_cycles = d_cycles
 
 void sela_hip_debug_force_plain_fir(int enable) { g_force_plain_fir = enable != 0; }
 
+void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks; }
+
 void sela_hip_enable_kernel_timing(int enable) { g_timing.enabled = enable != 0; }
 
 int sela_hip_kernel_times(float* ms_out, int capacity)
@@ -605,7 +608,7 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 3 : 0;
     hipError_t e = sela::launch_encode(d_pcm, n_frames, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace,
-        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_force_plain_fir);
+        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_force_plain_fir, g_self_blocks);
     if (e != hipSuccess)
         return fail_hip(e, "encode launch");
     return SELA_HIP_OK;

@@ -353,6 +353,75 @@ __device__ __attribute__((noinline)) void fir_plain(int order, int lane, const i
     }
 }
 
+// ---- mean workers -------------------------------------------------------------------------------------------
+// The mean of a block (src/lpc/residue_generator.cpp:27-30) is one strictly sequential 2048-term FP64 sum.  Inside
+// a block's own wave it is a chain that all 64 lanes walk redundantly: 2048 vector adds (plus the FP64 samples
+// written to LDS for it), 12 % of the block's instructions, for ONE number.  The same chain laid across lanes --
+// lane = block, 64 blocks per wave -- costs 2048 adds per 64 blocks.  So the first workgroups of the launch are
+// "mean workers": each sums the 64 blocks of encode indices [self_blocks + 64 w, +64) and publishes mean + a
+// ready word (= the launch's ticket, release / acquire at agent scope: consumer and worker may sit on different
+// XCDs).  Blocks below self_blocks -- the ones that start with the launch, before any worker could have finished --
+// walk their own chain as before; so does any block whose ready word has not turned up after a bounded wait, so
+// no block ever depends on another workgroup making progress.
+constexpr uint32_t kMeanWaitSpins = 4096; // x s_sleep 16 (~1000 cycles each): ~2 ms, then the block computes its own mean
+
+__device__ __forceinline__ void block_of(uint32_t e, uint32_t n_sig, uint32_t& frame, uint32_t& sig)
+{
+    // XCD-aware: hardware places workgroup b on XCD b % 8, so the signals of one frame are given encode indices
+    // that are equal mod 8 and share that XCD's L2 copy of the PCM (the worker prefix is a multiple of 8)
+    const uint32_t per_group = 8 * n_sig;
+    const uint32_t grp = e / per_group, rem = e % per_group;
+    sig = rem / 8;
+    frame = grp * 8 + (rem % 8);
+}
+
+__device__ __attribute__((noinline)) void mean_worker(const int16_t* __restrict__ pcm, uint32_t n_frames, uint32_t channels, uint32_t n_sig,
+    uint32_t first_e, uint32_t total_e, double* __restrict__ mean_out, uint32_t* __restrict__ mean_ready, uint32_t ticket)
+{
+    const uint32_t e = first_e + threadIdx.x;
+    uint32_t frame, sig;
+    block_of(e < total_e ? e : 0u, n_sig, frame, sig);
+    const bool live = e < total_e && frame < n_frames;
+    if (!live)
+        frame = 0, sig = 0; // idle lanes shadow a valid block, never publish
+    const int16_t* fp = pcm + (size_t)frame * kBlock * channels;
+    double sum = 0.0;
+    if (channels == 2) {
+        const uint4* p = reinterpret_cast<const uint4*>(fp); // 4 stereo pairs per load (dword-aligned: unaligned vector loads are fine)
+#pragma unroll 2
+        for (int j4 = 0; j4 < kBlock / 4; j4++) {
+            const uint4 v = p[j4];
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int32_t l = (int16_t)(w[i] & 0xFFFFu), r = (int16_t)(w[i] >> 16);
+                sum += scale_sample(sig == 0 ? l : (sig == 1 ? r : l - r));
+            }
+        }
+    } else if (channels == 1) {
+        const uint4* p = reinterpret_cast<const uint4*>(fp); // 8 samples per load
+#pragma unroll 2
+        for (int j8 = 0; j8 < kBlock / 8; j8++) {
+            const uint4 v = p[j8];
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                sum += scale_sample((int16_t)(w[i] & 0xFFFFu));
+                sum += scale_sample((int16_t)(w[i] >> 16));
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int j = 0; j < kBlock; j++)
+            sum += scale_sample(fp[(size_t)j * channels + sig]);
+    }
+    const double mean = sum / (double)kBlock;
+    if (live) {
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(mean_out) + e, __builtin_bit_cast(uint64_t, mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mean_ready + e, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts
 // (debug hook sela_hip_debug_phase_buffer; 16 uint64 per block).
 #define SELA_STAMP(n)                 \
@@ -365,9 +434,14 @@ template <int kMode>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
     double* __restrict__ rings, uint32_t* __restrict__ ring_owner, uint32_t ticket, sela_hip_trace* __restrict__ trace,
-    uint64_t* __restrict__ phase_cycles, int force_plain_fir)
+    uint64_t* __restrict__ phase_cycles, int force_plain_fir, double* __restrict__ mean_out, uint32_t* __restrict__ mean_ready,
+    uint32_t n_workers, uint32_t self_blocks, uint32_t total_e)
 {
     constexpr bool kTrace = kMode == 1;
+    if (blockIdx.x < n_workers) { // (the first workgroups of the launch: see mean_worker)
+        mean_worker(pcm, n_frames, channels, n_sig, self_blocks + 64 * blockIdx.x, total_e, mean_out, mean_ready, ticket);
+        return;
+    }
     long long stamp[14];
     SELA_STAMP(0);
     __shared__ __attribute__((aligned(16))) unsigned char big[kBigBytes];
@@ -375,12 +449,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     const int lane = threadIdx.x;
 
-    // XCD-aware block -> (frame, signal): hardware places workgroup b on XCD b % 8, so the signals
-    // of one frame are given ids that are equal mod 8 and share that XCD's L2 copy of the PCM.
-    const uint32_t per_group = 8 * n_sig;
-    const uint32_t grp = blockIdx.x / per_group, rem = blockIdx.x % per_group;
-    const uint32_t sig = rem / 8;
-    const uint32_t frame = grp * 8 + (rem % 8);
+    const uint32_t e = blockIdx.x - n_workers; // encode index
+    uint32_t frame, sig;
+    block_of(e, n_sig, frame, sig);
     if (frame >= n_frames)
         return;
     const uint32_t block_id = frame * n_sig + sig;
@@ -416,6 +487,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     double* const mine = (lane & 1) ? O : E;    // first half
     double* const mine1 = (lane & 1) ? O1 : E1; // second half
     const int half = lane >> 1;
+    // The mean: from a mean worker if this block starts late enough for one to have run (bounded wait) ...
+    double mean = 0.0;
+    bool have_mean = false;
+    if (e >= self_blocks) {
+        for (uint32_t spin = 0; spin < kMeanWaitSpins; spin++) {
+            if (__hip_atomic_load(mean_ready + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == ticket) {
+                have_mean = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (have_mean)
+            mean = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<uint64_t*>(mean_out) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        have_mean = __builtin_amdgcn_readfirstlane((int)have_mean) != 0;
+        mean = read_first_lane(mean);
+    }
+    SELA_STAMP(1);
+    if (!have_mean) { // ... else the chain, walked here
     for (int m = lane; m < kPadC; m += 64) { // zero pads in front of both parity arrays
         E[m - kPadC] = 0.0;
         O[m - kPadC] = 0.0;
@@ -425,7 +514,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         mine[half + 32 * t] = scale_sample(s[t]);
     wave_sync();
 
-    SELA_STAMP(1);
     // ---- mean (src/lpc/residue_generator.cpp:27-30): one strictly sequential sum -----------------
     // Every lane walks the same chain from broadcast LDS reads, so the result is wave-uniform.
     // (a pure dependency chain: run it at raised wave priority so that its adds issue the moment
@@ -458,8 +546,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
         mean_wait(f0, sum);
     }
-    const double mean = sum / (double)kBlock;
+    mean = sum / (double)kBlock;
     __builtin_amdgcn_s_setprio(0);
+    }
 
     SELA_STAMP(2);
     // c[j] = x[j] - mean (same value at every use): the first half again
@@ -495,7 +584,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if (lane == 0) {
             // workgroups that run together have nearby indices within their XCD: each starts at its own
             // ring (index mod 512), so that in the common case one atomic takes a ring without a retry
-            slot = (blockIdx.x >> 3) & (kRingsPerXcd - 1);
+            slot = (e >> 3) & (kRingsPerXcd - 1);
             while (atomicExch(pool + slot, ticket) == ticket)
                 slot = (slot + 1) & (kRingsPerXcd - 1);
         }
@@ -886,77 +975,67 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
     // mirror (optional, page-locked HOST memory): a copy of frame_offsets[0 .. n_frames] followed by one word
     // status[0] | status[1] << 32, so that the host pipeline reads a chunk's sizes without a copy of its own
     __shared__ uint64_t part[kPlanThreads];
-    __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of every frame when the batch fits
+    __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of the frames of one tile
+    __shared__ uint32_t acc[2];                      // flags, frames that do not fit frames_cap
     const uint32_t tid = threadIdx.x;
-    if (tid < 4)
-        status[tid] = 0; // this single workgroup is the only writer of the encode status words
-    __syncthreads();
-    const uint32_t per = (n_frames + kPlanThreads - 1) / kPlanThreads;
-    const uint32_t begin = tid * per, end = min(begin + per, n_frames);
-    const bool staged = n_frames <= (uint32_t)kPlanLdsFrames;
-    uint64_t bytes = 0;
-    uint32_t flags = 0;
-    if (staged) {
-        // frame f by thread f mod 1024: the metadata loads of one pass are independent and coalesced,
-        // and the passes do not depend on each other (a thread that walks `per` consecutive frames waits
-        // for memory `per` times)
+    if (tid < 2)
+        acc[tid] = 0;
+    uint64_t base = 0; // bytes of the tiles before this one (the same value in every thread)
+    uint32_t flags = 0, overflow = 0;
+    // Tiles of kPlanLdsFrames frames.  Within a tile, frame f is sized by thread f mod 1024: the metadata loads of
+    // one pass are independent and coalesced, and the passes do not depend on each other (a thread that walks
+    // consecutive frames waits for memory once per frame: 0.45 ms for 61 k frames, against 10 us per tile).
+    for (uint32_t tile0 = 0; tile0 < n_frames; tile0 += kPlanLdsFrames) {
+        const uint32_t tile_n = min((uint32_t)kPlanLdsFrames, n_frames - tile0);
+        __syncthreads(); // the previous tile's sizes have been read
 #pragma unroll 4
-        for (uint32_t f = tid; f < n_frames; f += kPlanThreads) {
+        for (uint32_t i = tid; i < tile_n; i += kPlanThreads) {
             uint32_t choice;
-            const uint32_t words = frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, flags);
-            choice_out[f] = (uint8_t)choice;
-            frame_size[f] = (uint32_t)sela_frame_bytes(channels, words);
+            const uint32_t words = frame_words(meta + (size_t)(tile0 + i) * n_sig, channels, n_sig, choice, flags);
+            choice_out[tile0 + i] = (uint8_t)choice;
+            frame_size[i] = (uint32_t)sela_frame_bytes(channels, words);
         }
         __syncthreads();
-        for (uint32_t f = begin; f < end; f++)
-            bytes += frame_size[f];
-    } else {
-        for (uint32_t f = begin; f < end; f++) {
-            uint32_t choice;
-            const uint32_t words = frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, flags);
-            choice_out[f] = (uint8_t)choice;
-            bytes += sela_frame_bytes(channels, words);
+        const uint32_t per = (tile_n + kPlanThreads - 1) / kPlanThreads;
+        const uint32_t begin = min(tid * per, tile_n), end = min(begin + per, tile_n);
+        uint64_t bytes = 0;
+        for (uint32_t i = begin; i < end; i++)
+            bytes += frame_size[i];
+        part[tid] = bytes;
+        __syncthreads();
+        for (uint32_t d = 1; d < kPlanThreads; d <<= 1) { // Hillis-Steele inclusive scan
+            const uint64_t v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
         }
+        uint64_t off = base + part[tid] - bytes;
+        for (uint32_t i = begin; i < end; i++) {
+            frame_offsets[tile0 + i] = off;
+            if (mirror)
+                mirror[tile0 + i] = off;
+            off += frame_size[i];
+            if (off > frames_cap)
+                overflow++;
+        }
+        base += part[kPlanThreads - 1];
     }
-    part[tid] = bytes;
-    __syncthreads();
-    for (uint32_t d = 1; d < kPlanThreads; d <<= 1) { // Hillis-Steele inclusive scan
-        const uint64_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint64_t off = part[tid] - bytes;
-    uint32_t overflow = 0;
-    for (uint32_t f = begin; f < end; f++) {
-        uint64_t size;
-        if (staged) {
-            size = frame_size[f];
-        } else {
-            uint32_t choice;
-            uint32_t dummy = 0;
-            size = sela_frame_bytes(channels, frame_words(meta + (size_t)f * n_sig, channels, n_sig, choice, dummy));
-        }
-        frame_offsets[f] = off;
+    if (tid == 0) {
+        frame_offsets[n_frames] = base;
         if (mirror)
-            mirror[f] = off;
-        off += size;
-        if (off > frames_cap)
-            overflow++;
-    }
-    if (tid == kPlanThreads - 1) {
-        frame_offsets[n_frames] = part[tid];
-        if (mirror)
-            mirror[n_frames] = part[tid];
+            mirror[n_frames] = base;
     }
     if (flags)
-        atomicOr(&status[0], flags);
+        atomicOr(&acc[0], flags);
     if (overflow)
-        atomicAdd(&status[1], overflow);
-    if (mirror) {
-        __syncthreads();
-        if (tid == 0)
-            mirror[(size_t)n_frames + 1] = (uint64_t)atomicOr(&status[0], 0u) | ((uint64_t)atomicAdd(&status[1], 0u) << 32);
+        atomicAdd(&acc[1], overflow);
+    __syncthreads();
+    if (tid == 0) { // this single workgroup is the only writer of the encode status words
+        status[0] = acc[0];
+        status[1] = acc[1];
+        status[2] = status[3] = 0;
+        if (mirror)
+            mirror[(size_t)n_frames + 1] = (uint64_t)acc[0] | ((uint64_t)acc[1] << 32);
     }
 }
 
@@ -1024,13 +1103,33 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
     bytes += ((size_t)n_frames + 255) & ~(size_t)255; // choice
     bytes += (size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 256; // scalar-operand rings (L2-resident) ...
     bytes += (size_t)kXcds * kRingsPerXcd * 4 + 256;                          // ... and their owner words
+    const size_t padded = (((size_t)n_frames + 7) / 8) * 8 * n_sig;           // encode indices (frames rounded up to 8)
+    bytes += ((padded * sizeof(double) + 255) & ~(size_t)255) + ((padded * 4 + 255) & ~(size_t)255); // worker means + ready words
     return bytes + 256;
+}
+
+// Workgroups of k_encode_blocks the current device holds at once: 12 per CU (LDS), cached per device.
+static uint32_t resident_encode_blocks()
+{
+    static std::atomic<uint32_t> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 256 * 12;
+    uint32_t v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        v = (uint32_t)cus * 12;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames,
     size_t frames_cap, uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace,
     hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles, uint64_t* d_mirror /* host-mapped or nullptr */,
-    int force_plain_fir)
+    int force_plain_fir, int self_blocks_override)
 {
     const uint32_t n_sig = sela_hip_signals_per_frame(channels);
     const size_t blocks = (size_t)n_frames * n_sig;
@@ -1045,6 +1144,11 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     double* rings = reinterpret_cast<double*>(ws);
     ws += ((size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 255) & ~(size_t)255;
     uint32_t* ring_owner = reinterpret_cast<uint32_t*>(ws);
+    ws += ((size_t)kXcds * kRingsPerXcd * 4 + 255) & ~(size_t)255;
+    const size_t padded = (((size_t)n_frames + 7) / 8) * 8 * n_sig;
+    double* mean_out = reinterpret_cast<double*>(ws);
+    ws += (padded * sizeof(double) + 255) & ~(size_t)255;
+    uint32_t* mean_ready = reinterpret_cast<uint32_t*>(ws);
 
     if (n_frames == 0) {
         hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
@@ -1053,7 +1157,21 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         return err != hipSuccess ? err : hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), stream);
     }
     const uint32_t groups = (n_frames + 7) / 8;
-    const dim3 grid(groups * 8 * n_sig), wg(64);
+    const uint32_t total_e = groups * 8 * n_sig;
+    // mean workers (see mean_worker): blocks that cannot start before the first ones retire get their mean from
+    // a worker.  self_blocks = what the device holds at once (12 workgroups per CU) less the workers themselves.
+    uint32_t self_blocks = self_blocks_override >= 0 ? (uint32_t)self_blocks_override : resident_encode_blocks();
+    uint32_t n_workers = 0;
+    if (total_e > self_blocks) {
+        n_workers = (total_e - self_blocks + 63) / 64;
+        if (self_blocks_override < 0) { // the workers take slots of the first fill too
+            const uint32_t resident = self_blocks;
+            self_blocks = resident > n_workers + 64 ? resident - n_workers : 64;
+            n_workers = (total_e - self_blocks + 63) / 64;
+        }
+        n_workers = (n_workers + 7) & ~7u; // keeps encode index == workgroup index mod 8 (XCD placement)
+    }
+    const dim3 grid(n_workers + total_e), wg(64);
     // ring ticket: unique per launch in this process, never 0 (see kRingLen)
     static std::atomic<uint32_t> next_ticket{ 0x5E1A0001u };
     uint32_t ticket = next_ticket.fetch_add(1, std::memory_order_relaxed);
@@ -1062,11 +1180,11 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
-        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir);
+        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
     else if (d_trace)
-        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir);
+        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
     else
-        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir);
+        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap,

@@ -322,3 +322,37 @@ def test_sharded_encode_over_rccl_world_of_one(gpu, tmp_path):
         assert pieces[1].file_offset == sharding.SELA_HEADER_BYTES and pieces[1].n_bytes == int(offsets[65] - offsets[40])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3])
+def test_mean_workers_give_the_same_means(gpu, channels):
+    """sela_hip_debug_mean_workers(self_blocks): all but the first `self_blocks` blocks of a launch take their
+    2048-term sequential mean from the "mean worker" workgroups (lane = block) instead of walking the chain in
+    their own wave.  Small batches never do by default, so the hook forces it: the means (bit patterns), every
+    later intermediate and the frame bytes must not change.  Large batches (the configs[1] digest test, the
+    10k-frame test, the album) take the worker path without the hook."""
+    from sela_amd import capi
+    from test_gpu_parity import _bits
+
+    o = oracle()
+    pcm = synth_frames(70, channels, 90 + channels)
+    want_frames, want_offsets, _ = o.encode_frames(pcm, threads=4)
+    lib = capi.lib()
+    n_sig = 3 if channels == 2 else channels
+    for self_blocks in (0, 8, 40):
+        lib.sela_hip_debug_mean_workers(self_blocks)
+        try:
+            frames, offsets, enc, _ = _encode(gpu, pcm, with_trace=True)
+            plain_frames, plain_offsets, _, _ = _encode(gpu, pcm)  # the product instantiation
+        finally:
+            lib.sela_hip_debug_mean_workers(-1)
+        assert np.array_equal(offsets, want_offsets) and np.array_equal(frames, want_frames), self_blocks
+        assert np.array_equal(plain_offsets, want_offsets) and np.array_equal(plain_frames, want_frames), self_blocks
+        traces = enc.traces(pcm.shape[0])
+        for f in (0, 1, 7, 33, 69):
+            for sig in range(n_sig):
+                s = (pcm[f, :, 0].astype(np.int32) - pcm[f, :, 1]) if (channels == 2 and sig == 2) else pcm[f, :, sig].astype(np.int32)
+                _, _, _, _, tr, _ = o.lpc_analyze(s, with_trace=True)
+                g = traces[f * n_sig + sig]
+                assert np.array_equal(_bits(g.mean), _bits(tr.mean)), (self_blocks, f, sig)
+                assert np.array_equal(_bits(list(g.ac)), _bits(list(tr.ac))), (self_blocks, f, sig)
