@@ -363,7 +363,7 @@ __device__ __attribute__((noinline)) void fir_plain(int order, int lane, const i
 // XCDs).  Blocks below self_blocks -- the ones that start with the launch, before any worker could have finished --
 // walk their own chain as before; so does any block whose ready word has not turned up after a bounded wait, so
 // no block ever depends on another workgroup making progress.
-constexpr uint32_t kMeanWaitSpins = 4096; // x s_sleep 16 (~1000 cycles each): ~2 ms, then the block computes its own mean
+constexpr uint32_t kMeanWaitSpins = 24;   // x s_sleep 16 (~1000 cycles each): ~10 us, then the block computes its own mean
 
 __device__ __forceinline__ void block_of(uint32_t e, uint32_t n_sig, uint32_t& frame, uint32_t& sig)
 {
@@ -385,17 +385,22 @@ __device__ __attribute__((noinline)) void mean_worker(const int16_t* __restrict_
     if (!live)
         frame = 0, sig = 0; // idle lanes shadow a valid block, never publish
     const int16_t* fp = pcm + (size_t)frame * kBlock * channels;
+    // the blocks that wait for these means hold CU slots: take the issue slots the co-resident block waves would
+    // otherwise win (their phases are throughput-bound, this one is a chain)
+    __builtin_amdgcn_s_setprio(3);
     double sum = 0.0;
     if (channels == 2) {
         const uint4* p = reinterpret_cast<const uint4*>(fp); // 4 stereo pairs per load (dword-aligned: unaligned vector loads are fine)
-#pragma unroll 2
+        const uint32_t first_shift = sig == 1 ? 16u : 0u;     // signal 0: l, 1: r, 2: l - r  as  a - (b & mask)
+        const uint32_t second_mask = sig == 2 ? 0xFFFFFFFFu : 0u;
+#pragma unroll 4
         for (int j4 = 0; j4 < kBlock / 4; j4++) {
             const uint4 v = p[j4];
             const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int32_t l = (int16_t)(w[i] & 0xFFFFu), r = (int16_t)(w[i] >> 16);
-                sum += scale_sample(sig == 0 ? l : (sig == 1 ? r : l - r));
+                const int32_t a = (int32_t)(w[i] << (16 - first_shift)) >> 16, b = ((int32_t)w[i] >> 16) & (int32_t)second_mask;
+                sum += scale_sample(a - b);
             }
         }
     } else if (channels == 1) {

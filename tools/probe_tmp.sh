@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02e
-SELA_BENCH_FORCE_EXCHANGE=1 timeout 600 python bench.py --workload album --steps 3 --warmup 1 > gpurun_out/r02e/album1.log 2>&1
-echo "album rc=$?"; tail -c 2500 gpurun_out/r02e/album1.log
-SELA_BENCH_FORCE_EXCHANGE=1 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-legs > gpurun_out/r02e/track_exch.log 2>&1
-echo "track+exchange rc=$?"; tail -c 600 gpurun_out/r02e/track_exch.log
+python -m pytest tests/test_gpu_round2.py -q -k "mean_workers" -p no:cacheprovider 2>&1 | tail -2
+python -m pytest tests/test_gpu_parity.py -q -k "digest or 10k" -p no:cacheprovider 2>&1 | tail -2
+python tools/sweep.py 1000 3875 10000 40000 2>&1 | grep -v amdgpu
+python tools/phase_profile.py 2>&1 | sed -n 1,8p
