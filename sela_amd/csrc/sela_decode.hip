@@ -912,13 +912,16 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
     if (err != hipSuccess || n_frames == 0)
         return err;
     const int n_waves = decode_waves(channels);
-    const size_t lds = decode_lds_bytes(channels);
-    if (channels > (uint32_t)kDecMaxChannels || lds > 160 * 1024)
+    const size_t need = decode_lds_bytes(channels);
+    if (channels > (uint32_t)kDecMaxChannels || need > 160 * 1024)
         return hipErrorInvalidValue;
-    if (lds > 64 * 1024) { // above the default dynamic-LDS limit
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err == hipSuccess)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // (Capping the occupancy so that a batch fills whole rounds of resident workgroups was tried -- extra dynamic
+    // LDS -- and lost at every batch size: the recurrence is latency-bound per wave, more waves always overlap more.)
+    const size_t lds = need;
+    if (lds > 64 * 1024) { // above the default dynamic-LDS limit (more than four channels); per device, so every time
+        err = d_phase_cycles
+            ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess)
             return err;
     }
