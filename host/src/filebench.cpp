@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "sela_hip.h"
 #include "sela_host/codec.hpp"
 
@@ -78,6 +80,31 @@ int main(int argc, char** argv)
                 dec.push_back(ms(t1, t2));
             }
         }
+        // ---- the PCIe transfers alone (page-locked <-> device), for scale: PCM one way, frames the other -------------
+        double h2d_pcm = 0, d2h_pcm = 0, h2d_sela = 0, d2h_sela = 0;
+        {
+            void* dev = nullptr;
+            const size_t pcmBytes = (size_t)frames * 2048 * ch * 2, selaBytes = (size_t)offs[frames];
+            if (hipMalloc(&dev, pcmBytes) == hipSuccess) {
+                std::vector<double> a, b, c, d;
+                for (int r = 0; r <= repeats; r++) {
+                    const auto t0 = clock::now();
+                    (void)hipMemcpy(dev, wav.pcm.data(), pcmBytes, hipMemcpyHostToDevice);
+                    const auto t1 = clock::now();
+                    (void)hipMemcpy(back.data(), dev, pcmBytes, hipMemcpyDeviceToHost);
+                    const auto t2 = clock::now();
+                    (void)hipMemcpy(dev, bytes.data(), selaBytes, hipMemcpyHostToDevice);
+                    const auto t3 = clock::now();
+                    (void)hipMemcpy(bytes.data(), dev, selaBytes, hipMemcpyDeviceToHost);
+                    const auto t4 = clock::now();
+                    if (r)
+                        a.push_back(ms(t0, t1)), b.push_back(ms(t1, t2)), c.push_back(ms(t2, t3)), d.push_back(ms(t3, t4));
+                }
+                h2d_pcm = median(a), d2h_pcm = median(b), h2d_sela = median(c), d2h_sela = median(d);
+                (void)hipFree(dev);
+                // (back and bytes were overwritten with the same contents they held)
+            }
+        }
         // ---- file to file -------------------------------------------------------------------------------------
         std::vector<double> fenc, fdec;
         for (int r = 0; r <= repeats; r++) {
@@ -106,9 +133,11 @@ int main(int argc, char** argv)
         std::printf("{\"frames\": %u, \"channels\": %u, \"repeats\": %d, \"sela_bytes\": %zu, "
                     "\"e2e_encode_ms\": %.4f, \"e2e_decode_ms\": %.4f, \"e2e_encode_msps\": %.1f, \"e2e_decode_msps\": %.1f, "
                     "\"file_encode_ms\": %.4f, \"file_decode_ms\": %.4f, \"file_encode_msps\": %.1f, \"file_decode_msps\": %.1f, "
+                    "\"pcie_h2d_pcm_ms\": %.4f, \"pcie_d2h_pcm_ms\": %.4f, \"pcie_h2d_sela_ms\": %.4f, \"pcie_d2h_sela_ms\": %.4f, "
                     "\"file_equals_e2e\": %s}\n",
             frames, ch, repeats, (size_t)offs[frames], median(enc), median(dec), samples / median(enc) / 1e3, samples / median(dec) / 1e3,
-            median(fenc), median(fdec), samples / median(fenc) / 1e3, samples / median(fdec) / 1e3, (sameSela && sameWav) ? "true" : "false");
+            median(fenc), median(fdec), samples / median(fenc) / 1e3, samples / median(fdec) / 1e3, h2d_pcm, d2h_pcm, h2d_sela, d2h_sela,
+            (sameSela && sameWav) ? "true" : "false");
         return (sameSela && sameWav) ? 0 : 1;
     } catch (const data::Exception& e) {
         std::fprintf(stderr, "%s\n", e.exceptionMessage.c_str());

@@ -159,24 +159,28 @@ struct HostBuffer {
     }
 };
 
-// Host-pointer calls run as a chunked pipeline: chunk i+1 is copied in while chunk i is
-// in the kernels and chunk i-1 is copied out.  Two sets of device buffers alternate, each with its own
-// kernel stream, so the kernels of consecutive chunks overlap as well (a chunk of this size leaves the
-// device in its launch tail for a good part of its run time).
-constexpr uint32_t kHostChunkFrames = 1024;
+// Host-pointer calls run as a chunked pipeline: the copy-in of every chunk is queued, in order
+// on one stream, as soon as the chunk is fed (kSets chunks deep); the kernels of consecutive chunks alternate
+// between streams (a chunk of this size leaves the device in its launch tail for a good part of its run time, so
+// neighbours overlap); a chunk is copied out as soon as its kernels have finished.  Nothing in the issue path
+// waits for the device until a buffer set comes round again.
+constexpr uint32_t kHostChunkFrames = 1024; // (buffers are sized for this; chunk_frames() may cut chunks shorter)
+constexpr uint32_t kSets = 8;
+constexpr uint32_t kRunStreams = 4;
 
 struct ChunkSet {
     DeviceBuffer pcm, frames, offsets, workspace;
     HostBuffer host_offsets; // encode: k_plan_frames' mirror of offsets + status; decode: the chunk's rebased offsets
-    hipStream_t s_run = nullptr;
+    uint64_t* mirror_dev = nullptr; // device address of host_offsets
+    void* mirror_host = nullptr;
     hipEvent_t copied_in = nullptr, ran = nullptr, copied_out = nullptr;
 };
 
 struct HostContext {
-    ChunkSet set[2];
+    ChunkSet set[kSets];
     DeviceBuffer status;      // 4 words per chunk of the running job
     HostBuffer host_status;
-    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipStream_t s_in = nullptr, s_out = nullptr, s_run[kRunStreams] = { nullptr, nullptr, nullptr, nullptr };
     int device = -1;
     bool job_open = false;
     // the buffers belong to the device that was current when they were allocated
@@ -194,7 +198,7 @@ struct HostContext {
     hipError_t streams()
     {
         hipError_t e = hipSuccess;
-        for (hipStream_t* s : { &s_in, &s_out, &set[0].s_run, &set[1].s_run })
+        for (hipStream_t* s : { &s_in, &s_out, &s_run[0], &s_run[1], &s_run[2], &s_run[3] })
             if (!*s && (e = hipStreamCreateWithFlags(s, hipStreamNonBlocking)) != hipSuccess)
                 return e;
         for (ChunkSet& c : set)
@@ -205,7 +209,7 @@ struct HostContext {
     }
     void sync_all()
     {
-        for (hipStream_t s : { s_in, s_out, set[0].s_run, set[1].s_run })
+        for (hipStream_t s : { s_in, s_out, s_run[0], s_run[1], s_run[2], s_run[3] })
             if (s)
                 (void)hipStreamSynchronize(s);
     }
@@ -217,9 +221,7 @@ struct HostContext {
             c.offsets.release();
             c.workspace.release();
             c.host_offsets.release();
-            if (c.s_run)
-                (void)hipStreamDestroy(c.s_run);
-            c.s_run = nullptr;
+            c.mirror_host = nullptr;
             for (hipEvent_t* ev : { &c.copied_in, &c.ran, &c.copied_out }) {
                 if (*ev)
                     (void)hipEventDestroy(*ev);
@@ -228,7 +230,7 @@ struct HostContext {
         }
         status.release();
         host_status.release();
-        for (hipStream_t* s : { &s_in, &s_out }) {
+        for (hipStream_t* s : { &s_in, &s_out, &s_run[0], &s_run[1], &s_run[2], &s_run[3] }) {
             if (*s)
                 (void)hipStreamDestroy(*s);
             *s = nullptr;
@@ -256,6 +258,42 @@ thread_local KernelTiming g_timing;
 thread_local uint64_t* g_phase_cycles = nullptr; // debug: per-block phase cycle counts (sela_hip_debug_phase_buffer)
 thread_local int g_force_plain_fir = 0;          // debug: sela_hip_debug_force_plain_fir
 thread_local int g_self_blocks = -1;             // debug: sela_hip_debug_mean_workers
+
+uint32_t env_u32(const char* name, uint32_t lo, uint32_t hi, uint32_t fallback)
+{
+    const char* e = std::getenv(name);
+    const long n = e ? std::atol(e) : -1;
+    return (n >= (long)lo && n <= (long)hi) ? (uint32_t)n : fallback;
+}
+// Pipeline shape; the environment variables are for experiments.
+uint32_t chunk_frames()
+{
+    static const uint32_t v = env_u32("SELA_HOST_CHUNK_FRAMES", 8, kHostChunkFrames, kHostChunkFrames);
+    return v;
+}
+uint32_t run_streams()
+{
+    static const uint32_t v = env_u32("SELA_HOST_RUN_STREAMS", 1, kRunStreams, 2);
+    return v;
+}
+uint32_t edge_frames()
+{
+    static const uint32_t v = env_u32("SELA_HOST_EDGE_FRAMES", 0, kHostChunkFrames, 0);
+    return v;
+}
+// Size of the next chunk of a job that has `available` frames at hand.  With edge_frames() > 0 the job's first and
+// last chunks are short (the pipeline fills and drains faster), the ones between are full.
+uint32_t next_chunk_frames(uint32_t fed, uint32_t total, uint32_t available)
+{
+    const uint32_t full = chunk_frames(), edge = edge_frames() && edge_frames() < full ? edge_frames() : full;
+    const uint32_t rem = total - fed;
+    uint32_t want = full;
+    if (fed == 0 || rem <= edge)
+        want = edge;
+    else if (rem <= full + edge)
+        want = rem - edge; // leaves a short last chunk
+    return want < available ? want : available;
+}
 
 uint32_t flags_to_error(uint32_t flags)
 {
@@ -298,8 +336,8 @@ int job_fail(sela_hip_job* job, int code)
 int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
 {
     while (job->final_chunks < upto) {
-        ChunkSet& c = g_ctx.set[job->final_chunks & 1];
-        // (chunk i and chunk i+2 share the event: i+2 is only drained after i was finalized)
+        ChunkSet& c = g_ctx.set[job->final_chunks % kSets];
+        // (chunk i and chunk i + kSets share the event; waiting for the later record covers the earlier one)
         hipError_t e = hipEventSynchronize(c.copied_out);
         if (e != hipSuccess)
             return job_fail(job, fail_hip(e, "copy-out"));
@@ -313,7 +351,7 @@ int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
 int job_drain_one(sela_hip_job* job)
 {
     const uint32_t i = job->drained;
-    ChunkSet& c = g_ctx.set[i & 1];
+    ChunkSet& c = g_ctx.set[i % kSets];
     const uint32_t nf = job->chunk_frames[i], first = job->chunk_first[i];
     hipError_t e = hipEventSynchronize(c.ran);
     if (e != hipSuccess)
@@ -370,27 +408,36 @@ hipError_t reserve_chunk_buffers(bool encode, uint32_t channels, size_t frames_b
 int job_issue_encode(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
 {
     const uint32_t i = job->issued;
-    ChunkSet& c = g_ctx.set[i & 1];
+    ChunkSet& c = g_ctx.set[i % kSets];
+    const hipStream_t s_run = g_ctx.s_run[i % run_streams()];
     const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
     hipError_t e;
-    // chunk i-2 used this set: its kernels have read pcm (ran), its frames have left the device (copied_out)
-    if (i >= 2) {
-        int rc = job->drained < i - 1 ? job_drain_one(job) : SELA_HIP_OK;
-        if (rc != SELA_HIP_OK)
-            return rc;
-        if ((e = hipStreamWaitEvent(g_ctx.s_in, c.ran, 0)) != hipSuccess || (e = hipStreamWaitEvent(c.s_run, c.copied_out, 0)) != hipSuccess)
+    // chunk i - kSets used this set: drained (so its kernels have read pcm and the host has read its sizes);
+    // its frames must have left the device before the kernels overwrite them (copied_out)
+    if (i >= kSets) {
+        while (job->drained + kSets <= i) {
+            const int rc = job_drain_one(job);
+            if (rc != SELA_HIP_OK)
+                return rc;
+        }
+        if ((e = hipStreamWaitEvent(s_run, c.copied_out, 0)) != hipSuccess)
             return job_fail(job, fail_hip(e, "hipStreamWaitEvent"));
     }
+    // (copies in job order on ONE stream: spread over the kernel streams they share the link and every chunk
+    // arrives late)
     if ((e = hipMemcpyAsync(c.pcm.ptr, pcm, nf * frame_pcm, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
-        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(c.s_run, c.copied_in, 0)) != hipSuccess)
+        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s_run, c.copied_in, 0)) != hipSuccess)
         return job_fail(job, fail_hip(e, "H2D pcm"));
-    uint64_t* d_mirror = nullptr;
-    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d_mirror), c.host_offsets.ptr, 0)) != hipSuccess)
-        return job_fail(job, fail_hip(e, "hipHostGetDevicePointer"));
-    uint32_t* d_status = static_cast<uint32_t*>(g_ctx.status.ptr) + 4 * (size_t)(i & 1);
+    if (c.mirror_host != c.host_offsets.ptr) { // (looked up once per allocation)
+        if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c.mirror_dev), c.host_offsets.ptr, 0)) != hipSuccess)
+            return job_fail(job, fail_hip(e, "hipHostGetDevicePointer"));
+        c.mirror_host = c.host_offsets.ptr;
+    }
+    uint64_t* d_mirror = c.mirror_dev;
+    uint32_t* d_status = static_cast<uint32_t*>(g_ctx.status.ptr) + 4 * (size_t)(i % kSets);
     e = sela::launch_encode(static_cast<const int16_t*>(c.pcm.ptr), nf, job->channels, static_cast<uint8_t*>(c.frames.ptr), job->chunk_bound,
-        static_cast<uint64_t*>(c.offsets.ptr), d_status, c.workspace.ptr, nullptr, c.s_run, nullptr, nullptr, d_mirror, g_force_plain_fir, g_self_blocks);
-    if (e != hipSuccess || (e = hipEventRecord(c.ran, c.s_run)) != hipSuccess)
+        static_cast<uint64_t*>(c.offsets.ptr), d_status, c.workspace.ptr, nullptr, s_run, nullptr, nullptr, d_mirror, g_force_plain_fir, g_self_blocks);
+    if (e != hipSuccess || (e = hipEventRecord(c.ran, s_run)) != hipSuccess)
         return job_fail(job, fail_hip(e, "encode launch"));
     job->chunk_first.push_back(job->fed);
     job->chunk_frames.push_back(nf);
@@ -402,15 +449,17 @@ int job_issue_encode(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
 int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* offsets, uint32_t nf)
 {
     const uint32_t i = job->issued;
-    ChunkSet& c = g_ctx.set[i & 1];
+    ChunkSet& c = g_ctx.set[i % kSets];
+    const hipStream_t s_run = g_ctx.s_run[i % run_streams()];
     hipError_t e;
-    if (i >= 2) {
-        int rc = job->drained < i - 1 ? job_drain_one(job) : SELA_HIP_OK;
-        if (rc != SELA_HIP_OK)
-            return rc;
-        // the staging array below was read by chunk i-2's copy-in
-        if ((e = hipEventSynchronize(c.copied_in)) != hipSuccess || (e = hipStreamWaitEvent(g_ctx.s_in, c.ran, 0)) != hipSuccess
-            || (e = hipStreamWaitEvent(c.s_run, c.copied_out, 0)) != hipSuccess)
+    if (i >= kSets) {
+        while (job->drained + kSets <= i) {
+            const int rc = job_drain_one(job);
+            if (rc != SELA_HIP_OK)
+                return rc;
+        }
+        // (drained: the set's kernels are done, so its copy-in -- which read the staging array below -- is too)
+        if ((e = hipStreamWaitEvent(s_run, c.copied_out, 0)) != hipSuccess)
             return job_fail(job, fail_hip(e, "hipStreamWaitEvent"));
     }
     const uint64_t bytes = offsets[nf] - offsets[0];
@@ -421,19 +470,35 @@ int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* o
         rel[f] = offsets[f] - offsets[0];
     if ((bytes && (e = hipMemcpyAsync(c.frames.ptr, frames + offsets[0], (size_t)bytes, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess)
         || (e = hipMemcpyAsync(c.offsets.ptr, rel, ((size_t)nf + 1) * 8, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
-        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(c.s_run, c.copied_in, 0)) != hipSuccess)
+        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s_run, c.copied_in, 0)) != hipSuccess)
         return job_fail(job, fail_hip(e, "H2D frames"));
     if ((e = g_ctx.status.reserve(16 * ((size_t)i + 1))) != hipSuccess) // (sized at begin; this never reallocates)
         return job_fail(job, fail_hip(e, "hipMalloc"));
     uint32_t* d_status = static_cast<uint32_t*>(g_ctx.status.ptr) + 4 * (size_t)i;
     e = sela::launch_decode(static_cast<const uint8_t*>(c.frames.ptr), static_cast<const uint64_t*>(c.offsets.ptr), nf, job->channels,
-        static_cast<int16_t*>(c.pcm.ptr), d_status, c.workspace.ptr, c.s_run, nullptr, nullptr);
-    if (e != hipSuccess || (e = hipEventRecord(c.ran, c.s_run)) != hipSuccess)
+        static_cast<int16_t*>(c.pcm.ptr), d_status, c.workspace.ptr, s_run, nullptr, nullptr);
+    if (e != hipSuccess || (e = hipEventRecord(c.ran, s_run)) != hipSuccess)
         return job_fail(job, fail_hip(e, "decode launch"));
     job->chunk_first.push_back(job->fed);
     job->chunk_frames.push_back(nf);
     job->issued++;
     job->fed += nf;
+    return SELA_HIP_OK;
+}
+
+// Copy out every chunk whose kernels have already finished, without waiting for any that has not; what has
+// arrived in host memory by now is final.
+int job_drain_ready(sela_hip_job* job)
+{
+    while (job->drained < job->issued && hipEventQuery(g_ctx.set[job->drained % kSets].ran) == hipSuccess) {
+        const int rc = job_drain_one(job);
+        if (rc != SELA_HIP_OK)
+            return rc;
+    }
+    (void)hipGetLastError(); // (hipErrorNotReady from the query is not an error)
+    while (job->final_chunks < job->drained && hipEventQuery(g_ctx.set[job->final_chunks % kSets].copied_out) == hipSuccess)
+        job->final_chunks++;
+    (void)hipGetLastError();
     return SELA_HIP_OK;
 }
 
@@ -464,7 +529,7 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
         return fail(SELA_HIP_EINVAL, "this thread already has an open job");
     const size_t bound = sela_hip_encode_bound_bytes(kHostChunkFrames, channels);
     hipError_t e = reserve_chunk_buffers(encode, channels, encode ? bound : 0);
-    const size_t n_chunks = ((size_t)total_frames + kHostChunkFrames - 1) / kHostChunkFrames + 2;
+    const size_t n_chunks = (size_t)total_frames + kSets + 4; // (a caller may feed one frame at a time)
     if (e == hipSuccess)
         e = g_ctx.status.reserve(16 * n_chunks);
     if (e == hipSuccess)
@@ -660,18 +725,15 @@ int sela_hip_encode_feed(sela_hip_job* job, const int16_t* pcm, uint32_t n_frame
         return job->error;
     const size_t frame_samples = (size_t)sela::kBlock * job->channels;
     for (uint32_t done = 0; done < n_frames;) {
-        const uint32_t nf = n_frames - done < kHostChunkFrames ? n_frames - done : kHostChunkFrames;
+        const uint32_t nf = next_chunk_frames(job->fed, job->total_frames, n_frames - done);
         int rc = job_issue_encode(job, pcm + done * frame_samples, nf);
         if (rc != SELA_HIP_OK)
             return rc;
         done += nf;
     }
-    // what has finished in the meantime is final without waiting: chunks drained two issues ago
-    if (job->drained >= 1) {
-        int rc = job_finalize(job, job->drained - 1);
-        if (rc != SELA_HIP_OK)
-            return rc;
-    }
+    const int rc = job_drain_ready(job);
+    if (rc != SELA_HIP_OK)
+        return rc;
     job_progress(job, frames_final, bytes_final);
     return SELA_HIP_OK;
 }
@@ -704,17 +766,15 @@ int sela_hip_decode_feed(sela_hip_job* job, const uint8_t* frames, const uint64_
         if (frame_offsets[f + 1] < frame_offsets[f] || (frame_offsets[f] & 3))
             return job_fail(job, fail(SELA_HIP_EFORMAT, "frame offsets must be ascending multiples of 4"));
     for (uint32_t done = 0; done < n_frames;) {
-        const uint32_t nf = n_frames - done < kHostChunkFrames ? n_frames - done : kHostChunkFrames;
+        const uint32_t nf = next_chunk_frames(job->fed, job->total_frames, n_frames - done);
         int rc = job_issue_decode(job, frames, frame_offsets + done, nf);
         if (rc != SELA_HIP_OK)
             return rc;
         done += nf;
     }
-    if (job->drained >= 1) {
-        int rc = job_finalize(job, job->drained - 1);
-        if (rc != SELA_HIP_OK)
-            return rc;
-    }
+    const int rc = job_drain_ready(job);
+    if (rc != SELA_HIP_OK)
+        return rc;
     job_progress(job, frames_final, nullptr);
     return SELA_HIP_OK;
 }
