@@ -1,0 +1,21 @@
+#!/bin/bash
+# tools/collect_all.sh <round-tag>  (run ON THE GPU BOX through gpurun): everything profiles/<tag>/ holds.
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+bash tools/collect_profiles.sh "$TAG" > "$OUT/collect.log" 2>&1
+bash tools/valu_counters.sh > "$OUT/valu_counters.txt" 2>&1
+bash tools/timeline.sh > "$OUT/timeline.txt" 2>&1
+python tools/phase_profile.py > "$OUT/phase_cycles.txt" 2>&1
+python tools/phase_profile.py 1000 > "$OUT/phase_cycles_1000_frames.txt" 2>&1
+SELA_SWEEP_HOST=0 python tools/sweep.py > "$OUT/sweep.txt" 2>&1
+python bench.py > "$OUT/bench.log" 2>&1
+tail -1 "$OUT/bench.log" > "$OUT/bench_line.json"
+SELA_BENCH_FORCE_EXCHANGE=1 python bench.py --workload album --steps 3 --warmup 1 > "$OUT/bench_album.log" 2>&1
+tail -1 "$OUT/bench_album.log" > "$OUT/bench_album_1gpu_line.json"
+ls -la "$OUT"
+cat "$OUT/valu_counters.txt" "$OUT/timeline.txt" | grep -v amdgpu.ids
+cat "$OUT/traffic.json"
+head -20 "$OUT/kernel_stats.csv"
