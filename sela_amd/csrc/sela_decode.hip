@@ -298,24 +298,39 @@ __device__ __forceinline__ uint32_t parse_subframe(const StreamWords& sw, uint32
         const uint32_t wm = merged >> 5;
         succ = wm < rs_word ? min(wm / zc, (uint32_t)kCoefLanes - 1) : (uint32_t)kCoefLanes + (wm - rs_word) / zr;
     }
-    uint32_t e_true = kEndOfStream; // this lane's true entry; kEndOfStream = not on a chain
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
-        uint32_t cur = h ? (uint32_t)kCoefLanes : 0u;
-        const uint32_t limit = h ? (uint32_t)kWave : (uint32_t)kCoefLanes;
-        uint32_t e = h ? 32 * rs_word : 24u;
-#pragma unroll 1
-        for (int hop = 0; hop < kWave; hop++) {
-            e_true = (uint32_t)lane == cur ? e : e_true;
-            const uint32_t m_cur = (uint32_t)__builtin_amdgcn_readlane((int)merged, (int)cur);
-            const uint32_t s_cur = (uint32_t)__builtin_amdgcn_readlane((int)succ, (int)cur);
-            if (m_cur == kEndOfStream || s_cur <= cur || s_cur >= limit)
-                break;
-            e = m_cur;
-            cur = s_cur;
-        }
+    // The lanes a chain runs through = the orbit of its first lane under succ.  Pointer doubling: after round r
+    // the set holds every lane within 2^(r+1) hops (six rounds cover the wave); a lane joins when a member's
+    // pointer lands on it (a byte flag in LDS), and the pointers are squared with ds_bpermute.  (The walk
+    // hop by hop on the scalar unit, 64 x readlane -> compare -> branch, cost 19 k cycles of latency.)
+    if (coef_lane ? succ >= (uint32_t)kCoefLanes : false)
+        succ = 64;
+    succ = succ > (uint32_t)lane ? succ : 64u; // (always true of a zone further on; keeps the orbit finite whatever the stream holds)
+    uint8_t* const flag = reinterpret_cast<uint8_t*>(cpos) + 512;   // 65 bytes of the scratch (the tables' space, dead until the parse is over)
+    uint32_t* const entry_of = reinterpret_cast<uint32_t*>(cpos) + 160; // 64 words behind them
+    flag[lane] = 0;
+    if (lane == 0)
+        flag[64] = 0;
+    bool on_chain = lane == 0 || lane == kCoefLanes;
+    uint32_t jump = succ;
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        if (on_chain && jump < 64)
+            flag[jump] = 1;
+        wave_sync();
+        on_chain = on_chain || flag[lane] != 0;
+        const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * min(jump, 63u)), (int)jump);
+        jump = jump < 64 ? next : 64u;
+        wave_sync();
     }
-    const bool on_chain = e_true != kEndOfStream;
+    // a chain lane's true entry = where its predecessor merged
+    if (on_chain && succ < 64)
+        entry_of[succ] = merged;
+    wave_sync();
+    uint32_t e_true = kEndOfStream; // this lane's true entry; kEndOfStream = not on a chain
+    if (on_chain)
+        e_true = lane == 0 ? 24u : (lane == kCoefLanes ? 32 * rs_word : entry_of[lane]);
+    wave_sync();
     // codewords of this lane's path from its true entry: the marked starts at or behind the entry + phase B's
     uint32_t count = 0;
     {

@@ -690,11 +690,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         double g0a = sm->ac[lane + 1], g1a = g0a;
         double g0b = lane < 36 ? sm->ac[lane + 65] : 0.0, g1b = g0b;
         double err = 1.0; // ac[0]
+        // k_i is wave-uniform: every lane stores the same value to sm->k[i] (one LDS write) instead of
+        // selecting it into the lane that keeps it (two compares + four selects per stage)
         double g = read_first_lane(g1a);
         double ki = -g / err;
         err += g * ki;
-        if (lane == 0)
-            k_lo = ki;
+        sm->k[0] = ki;
         // stage i only needs columns j < 100 - i: the second register (columns 64..99) is dead from
         // stage 37 on, and with it the value shifted into lane 63
         constexpr int kTwoRegs = kMaxOrder - 64 + 1; // 37
@@ -709,8 +710,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             g = read_first_lane(g1a);
             ki = -g / err;
             err += g * ki;
-            if (lane == i)
-                k_lo = ki;
+            sm->k[i] = ki;
         }
 #pragma unroll 1
         for (int i = kTwoRegs; i < kMaxOrder; i++) {
@@ -720,11 +720,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             g = read_first_lane(g1a);
             ki = -g / err;
             err += g * ki;
-            if (lane == i)
-                k_lo = ki;
-            if (lane + 64 == i)
-                k_hi = ki;
+            sm->k[i] = ki;
         }
+        wave_sync();
+        k_lo = sm->k[lane];
+        k_hi = lane < kMaxOrder - 64 ? sm->k[lane + 64] : 0.0;
+        wave_sync(); // (sm->k is overwritten with the dequantised coefficients below)
     }
 
     SELA_STAMP(5);
