@@ -18,7 +18,8 @@ One "step" = one pass of the hot path over synthetic PCM that is already residen
           digest of the one-GPU (reference) layout.  `--workload album` runs the same job on one GPU.
 
 K steps are timed, bracketed by barrier + torch.cuda.synchronize(), MAX over ranks; that measurement is
-repeated until at least ~0.5 s has been timed and `value` is the median repetition (min / max reported).
+repeated until at least ~0.5 s has been timed and `value` is the median repetition (min / max reported; the
+first repetition, which runs while the clocks still settle, is reported separately).
 
 Rank 0 prints ONE JSON line: metric/value as BASELINE.json names them (Msamples/s, a sample = one stereo pair
 that went through encode AND decode), plus
@@ -301,7 +302,10 @@ def main():
     for _ in range(args.warmup):
         step()
     reps, (out, back) = timed_repetitions(step, barrier, args.steps, dist)
-    per_step = sorted(r / args.steps for r in reps)
+    # the first K-step measurement runs a few % slow while the clocks settle behind the W warm-up steps: with four
+    # measurements or more it is reported (ms_per_step_first) but kept out of median / min / max
+    settled = reps[1:] if len(reps) >= 4 else reps
+    per_step = sorted(r / args.steps for r in settled)
     median_s = per_step[len(per_step) // 2]
 
     # ---- correctness of what was timed ------------------------------------------------------------------------
@@ -385,7 +389,8 @@ def main():
                 "sharding": f"contiguous frame ranges x{world}" if workload == "album" else "single track",
                 "batch_frames": max_batch, "sela_bytes_total": payload_bytes, "pcm_bytes_total": n_total * 2048 * CHANNELS * 2,
             },
-            "repetitions": {"count": len(per_step), "timed_s": sum(reps), "ms_per_step_min": per_step[0] * 1e3,
+            "repetitions": {"count": len(reps), "timed_s": sum(reps), "ms_per_step_first": reps[0] / args.steps * 1e3,
+                            "ms_per_step_min": per_step[0] * 1e3,
                             "ms_per_step_median": median_s * 1e3, "ms_per_step_max": per_step[-1] * 1e3,
                             "spread_frac": (per_step[-1] - per_step[0]) / median_s},
             "encode_msps": samples0 / (enc_ms * 1e-3) / 1e6,   # kernels of the first batch, HBM resident

@@ -196,3 +196,39 @@ def test_parse_model_reports_truncated_streams():
     full = o.rice_decode(rwords, 2048, rk)
     n_ok = int((got == full).cumprod().sum())
     assert n_ok > 900 and np.all(got[n_ok + 1:] == 0)
+
+
+def test_album_ranges_tile_the_album():
+    """bench.py --gpus N (N > 1) gives every rank a contiguous range of the album's (track, frame) space and has
+    it synthesise just that: the ranks' pieces, in rank order, must be the tracks' frames in job order -- for
+    every world size the driver uses -- and rank_track_pieces must place them in the right files."""
+    import numpy as np
+
+    from sela_amd import sharding
+    from sela_amd.synth import album_tracks, synth_frames_torch
+
+    tracks = album_tracks(9, seconds=0.5)  # 10 / 11 / 23 frames per track at 44.1 / 48 / 96 kHz
+    frames = [f for _, _, f in tracks]
+    starts = np.concatenate([[0], np.cumsum(frames)])
+    n_total = int(starts[-1])
+    whole = np.concatenate([synth_frames_torch(f, 2, t).numpy() for t, _, f in tracks])
+    for world in (1, 2, 4, 8):
+        got = []
+        for rank in range(world):
+            b0, e0 = sharding.my_range(n_total, rank, world)
+            for track, _, nf in tracks:  # (the loop of bench.py)
+                b, e = max(b0, int(starts[track])), min(e0, int(starts[track + 1]))
+                if b < e:
+                    got.append(synth_frames_torch(e - b, 2, track, first_frame=b - int(starts[track])).numpy())
+        assert np.array_equal(np.concatenate(got), whole), world
+        sizes = np.arange(1, n_total + 1, dtype=np.uint64) * 4  # any sizes: the layout arithmetic is what is checked
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        layout = sharding.FileLayout(sizes, offsets, sharding.partition(n_total, world))
+        covered = np.zeros(n_total, bool)
+        for rank in range(world):
+            for p in sharding.rank_track_pieces(layout, frames, rank):
+                assert p.job_frame == int(starts[p.track]) + p.first_frame
+                assert p.file_offset == sharding.SELA_HEADER_BYTES + int(offsets[p.job_frame] - offsets[int(starts[p.track])])
+                assert not covered[p.job_frame: p.job_frame + p.n_frames].any()
+                covered[p.job_frame: p.job_frame + p.n_frames] = True
+        assert covered.all()
