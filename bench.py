@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--workload", choices=["track", "album"], default=None, help="default: track for --gpus 1, album otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2, help="batches in flight: independent encode->decode chains on their own HIP streams")
     args = ap.parse_args()
 
     import numpy as np
@@ -265,43 +266,55 @@ def main():
         pcm_host = None
     n_local = my_end - my_begin
     max_batch = max(int(b.shape[0]) for b in batches)
-    enc = codec.Encoder(max(max_batch, 1), CHANNELS)
-    dec = codec.Decoder(max(max_batch, 1), CHANNELS)
+    # Lanes: consecutive batches (N = 1: consecutive steps) are independent encode -> decode chains, so they run on
+    # alternating HIP streams with their own buffers: the decode of one batch fills the launch tail of the next
+    # batch's encode and the other way round.  Everything issued inside the timed region completes inside it
+    # (device-wide synchronize on both sides); `--lanes 1` is the strictly serial form, reported beside it.
+    n_lanes = max(1, args.lanes)
+    lanes = [{"enc": codec.Encoder(max(max_batch, 1), CHANNELS), "dec": codec.Decoder(max(max_batch, 1), CHANNELS),
+              "stream": torch.cuda.Stream()} for _ in range(n_lanes)]
+    enc, dec = lanes[0]["enc"], lanes[0]["dec"]
+    slot = {"next": 0}
     max_local = max(e - b for b, e in sharding.partition(n_total, world))
     local_sizes = torch.zeros(max_local, dtype=torch.int64, device="cuda")
     all_sizes = torch.zeros(world * max_local, dtype=torch.int64, device="cuda")
     state = {"lossy": 0, "bytes": 0}
 
-    def step(check=False):
+    def step(check=False, serial=False):
         at = 0
         for i, pcm in enumerate(batches):
             nb = int(pcm.shape[0])
-            out = enc.encode(pcm)
-            if dist is not None:
-                local_sizes[at: at + nb] = out.offsets[1:] - out.offsets[:-1]
-                if i == len(batches) - 1:
-                    # the path's only exchange: every rank learns the size of every frame of the
-                    # job, i.e. where its bytes land in every output file (8 bytes x frames, latency bound -- RCCL
-                    # over xGMI).  Decoding does not need the layout, so the collective runs beside the last
-                    # decode on its own stream and is joined at the end of the step, inside the timed region.
-                    exchange.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(exchange):
-                        dist.all_gather_into_tensor(all_sizes, local_sizes)
-            back = dec.decode(out.frames, out.offsets, nb)
+            lane = lanes[0 if serial else slot["next"] % n_lanes]
+            slot["next"] += 1
+            with torch.cuda.stream(lane["stream"]):
+                out = lane["enc"].encode(pcm)
+                if dist is not None:
+                    local_sizes[at: at + nb] = out.offsets[1:] - out.offsets[:-1]
+                    if i == len(batches) - 1:
+                        # the path's only exchange: every rank learns the size of every frame of the
+                        # job, i.e. where its bytes land in every output file (8 bytes x frames, latency bound -- RCCL
+                        # over xGMI).  Decoding does not need the layout, so the collective runs beside the last
+                        # decode on its own stream and is joined at the end of the step, inside the timed region.
+                        for other in lanes:  # (the sizes of the earlier batches were written on the other lanes' streams)
+                            exchange.wait_stream(other["stream"])
+                        with torch.cuda.stream(exchange):
+                            dist.all_gather_into_tensor(all_sizes, local_sizes)
+                back = lane["dec"].decode(out.frames, out.offsets, nb)
+                if dist is not None and i == len(batches) - 1:
+                    lane["stream"].wait_stream(exchange)
             if check:  # (outside the timed region) status words + round trip of every batch
                 torch.cuda.synchronize()
                 out.check()
-                dec.check()
+                lane["dec"].check()
                 state["lossy"] += int((back != pcm).reshape(nb, -1).any(dim=1).sum().item()) if nb else 0
                 state["bytes"] += out.total_bytes()
             at += nb
-        if dist is not None:
-            torch.cuda.current_stream().wait_stream(exchange)
         return out, back
 
     for _ in range(args.warmup):
         step()
     reps, (out, back) = timed_repetitions(step, barrier, args.steps, dist)
+    serial_reps, _ = timed_repetitions(lambda: step(serial=True), barrier, args.steps, dist, min_total_s=0.15) if n_lanes > 1 else (reps, None)
     # the first K-step measurement runs a few % slow while the clocks settle behind the W warm-up steps: with four
     # measurements or more it is reported (ms_per_step_first) but kept out of median / min / max
     settled = reps[1:] if len(reps) >= 4 else reps
@@ -389,6 +402,9 @@ def main():
                 "sharding": f"contiguous frame ranges x{world}" if workload == "album" else "single track",
                 "batch_frames": max_batch, "sela_bytes_total": payload_bytes, "pcm_bytes_total": n_total * 2048 * CHANNELS * 2,
             },
+            "lanes": {"in_flight": n_lanes, "ms_per_step_one_lane": sorted(serial_reps)[len(serial_reps) // 2] / args.steps * 1e3,
+                      "value_one_lane": samples / (sorted(serial_reps)[len(serial_reps) // 2] / args.steps) / 1e6,
+                      "what": "consecutive batches are independent encode->decode chains on alternating HIP streams; one lane = strictly serial"},
             "repetitions": {"count": len(reps), "timed_s": sum(reps), "ms_per_step_first": reps[0] / args.steps * 1e3,
                             "ms_per_step_min": per_step[0] * 1e3,
                             "ms_per_step_median": median_s * 1e3, "ms_per_step_max": per_step[-1] * 1e3,

@@ -356,3 +356,36 @@ def test_mean_workers_give_the_same_means(gpu, channels):
                 g = traces[f * n_sig + sig]
                 assert np.array_equal(_bits(g.mean), _bits(tr.mean)), (self_blocks, f, sig)
                 assert np.array_equal(_bits(list(g.ac)), _bits(list(tr.ac))), (self_blocks, f, sig)
+
+
+def test_parser_on_random_valid_streams(gpu, kats):
+    """300 hand-built mono subframes with random Rice parameters (0..15 for the residues, whatever the oracle picks
+    for the coefficients), random orders and residue distributions from near-silence to spiky: all valid streams
+    inside the decoder's LDS plan, every decoded sample against the oracle's decoder.  (What the segment-parallel
+    parser must get right is where codewords start; these streams vary zone sizes, resynchronisation distances and
+    chain shapes far beyond what the encoder's own output does.)"""
+    rng = np.random.default_rng(2024)
+    q_pool = [kats["blk/sine_deg/q"], kats["blk/white_fullscale/q"], np.zeros(1, np.int32), kats["blk/square_p64/q"]]
+    frames = []
+    while len(frames) < 300:
+        k = int(rng.integers(0, 16))
+        kind = int(rng.integers(0, 4))
+        scale = (1 << k) * float(rng.choice([0.3, 1.0, 2.5]))
+        if kind == 0:
+            r = rng.normal(0, scale + 0.5, 2048)
+        elif kind == 1:
+            r = rng.laplace(0, scale + 0.5, 2048)
+        elif kind == 2:
+            r = np.where(rng.random(2048) < 0.02, rng.normal(0, 40 * (scale + 1), 2048), rng.normal(0, 0.3 * scale + 0.2, 2048))
+        else:
+            r = rng.integers(-int(scale) - 1, int(scale) + 2, 2048).astype(np.float64)
+        r = np.clip(np.round(r), -(1 << 20), 1 << 20).astype(np.int64)
+        q = q_pool[int(rng.integers(0, len(q_pool)))]
+        q = np.asarray(q[: int(rng.integers(1, len(q) + 1))], np.int32)
+        words = _rice_words(r, k)
+        ck, cw = oracle().rice_encode(q)
+        if len(cw) + 2 + len(words) > 1200:  # keep it inside the fast plan (generic mode has its own tests)
+            continue
+        frames.append(struct.pack("<I", 0xAA55FF00) + struct.pack("<BBBBHB", 0, 0, 0, ck, len(cw), len(q)) + cw.astype("<u4").tobytes()
+                      + struct.pack("<BHH", k, len(words), 2048) + words.astype("<u4").tobytes())
+    _decode_frames_vs_oracle(gpu, frames)
