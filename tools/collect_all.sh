@@ -8,6 +8,7 @@ cd "$ROOT"
 bash tools/collect_profiles.sh "$TAG" > "$OUT/collect.log" 2>&1
 bash tools/valu_counters.sh > "$OUT/valu_counters.txt" 2>&1
 bash tools/timeline.sh > "$OUT/timeline.txt" 2>&1
+LANES=2 bash tools/timeline.sh > "$OUT/timeline_two_lanes.txt" 2>&1
 python tools/phase_profile.py > "$OUT/phase_cycles.txt" 2>&1
 python tools/phase_profile.py 1000 > "$OUT/phase_cycles_1000_frames.txt" 2>&1
 SELA_SWEEP_HOST=0 python tools/sweep.py > "$OUT/sweep.txt" 2>&1
