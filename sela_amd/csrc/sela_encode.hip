@@ -497,7 +497,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     bool have_mean = false;
     if (e >= self_blocks) {
         for (uint32_t spin = 0; spin < kMeanWaitSpins; spin++) {
-            if (__hip_atomic_load(mean_ready + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == ticket) {
+            // (polled relaxed: an acquire per poll invalidates the vector cache under every co-resident wave)
+            if (__hip_atomic_load(mean_ready + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ticket) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 have_mean = true;
                 break;
             }
