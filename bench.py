@@ -412,7 +412,8 @@ def main():
             "repetitions": {"count": len(reps), "timed_s": sum(reps), "ms_per_step_first": reps[0] / args.steps * 1e3,
                             "ms_per_step_min": per_step[0] * 1e3,
                             "ms_per_step_median": median_s * 1e3, "ms_per_step_max": per_step[-1] * 1e3,
-                            "spread_frac": (per_step[-1] - per_step[0]) / median_s},
+                            "spread_frac": (per_step[-1] - per_step[0]) / median_s,
+                            "spread_frac_p10_p90": (per_step[(9 * len(per_step)) // 10 - (1 if len(per_step) >= 10 else 0)] - per_step[len(per_step) // 10]) / median_s},
             "encode_msps": samples0 / (enc_ms * 1e-3) / 1e6,   # kernels of the first batch, HBM resident
             "decode_msps": samples0 / (dec_ms * 1e-3) / 1e6,
             "encode_target": {"msps": ENCODE_TARGET_MSPS, "met": bool(samples0 / (enc_ms * 1e-3) / 1e6 >= ENCODE_TARGET_MSPS),
