@@ -276,23 +276,12 @@ uint32_t run_streams()
     static const uint32_t v = env_u32("SELA_HOST_RUN_STREAMS", 1, kRunStreams, 2);
     return v;
 }
-uint32_t edge_frames()
+// Size of the next chunk of a job that has `available` frames at hand.  (Short first / last chunks and chunk sizes
+// halving towards the end of a job were tried: more chunks cost more in per-chunk handshakes and in kernel
+// efficiency than the shorter fill and drain save.)
+uint32_t next_chunk_frames(uint32_t available)
 {
-    static const uint32_t v = env_u32("SELA_HOST_EDGE_FRAMES", 0, kHostChunkFrames, 0);
-    return v;
-}
-// Size of the next chunk of a job that has `available` frames at hand.  With edge_frames() > 0 the job's first and
-// last chunks are short (the pipeline fills and drains faster), the ones between are full.
-uint32_t next_chunk_frames(uint32_t fed, uint32_t total, uint32_t available)
-{
-    const uint32_t full = chunk_frames(), edge = edge_frames() && edge_frames() < full ? edge_frames() : full;
-    const uint32_t rem = total - fed;
-    uint32_t want = full;
-    if (fed == 0 || rem <= edge)
-        want = edge;
-    else if (rem <= full + edge)
-        want = rem - edge; // leaves a short last chunk
-    return want < available ? want : available;
+    return chunk_frames() < available ? chunk_frames() : available;
 }
 
 uint32_t flags_to_error(uint32_t flags)
@@ -725,7 +714,7 @@ int sela_hip_encode_feed(sela_hip_job* job, const int16_t* pcm, uint32_t n_frame
         return job->error;
     const size_t frame_samples = (size_t)sela::kBlock * job->channels;
     for (uint32_t done = 0; done < n_frames;) {
-        const uint32_t nf = next_chunk_frames(job->fed, job->total_frames, n_frames - done);
+        const uint32_t nf = next_chunk_frames(n_frames - done);
         int rc = job_issue_encode(job, pcm + done * frame_samples, nf);
         if (rc != SELA_HIP_OK)
             return rc;
@@ -766,7 +755,7 @@ int sela_hip_decode_feed(sela_hip_job* job, const uint8_t* frames, const uint64_
         if (frame_offsets[f + 1] < frame_offsets[f] || (frame_offsets[f] & 3))
             return job_fail(job, fail(SELA_HIP_EFORMAT, "frame offsets must be ascending multiples of 4"));
     for (uint32_t done = 0; done < n_frames;) {
-        const uint32_t nf = next_chunk_frames(job->fed, job->total_frames, n_frames - done);
+        const uint32_t nf = next_chunk_frames(n_frames - done);
         int rc = job_issue_decode(job, frames, frame_offsets + done, nf);
         if (rc != SELA_HIP_OK)
             return rc;
