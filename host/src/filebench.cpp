@@ -42,11 +42,12 @@ std::vector<uint8_t> slurp(const std::string& path)
 int main(int argc, char** argv)
 {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s in.wav scratch_dir [repeats]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s in.wav scratch_dir [repeats] [e2e]   (e2e: only the host-pointer leg, for traces)\n", argv[0]);
         return 2;
     }
     const std::string wavPath = argv[1], dir = argv[2];
     const int repeats = argc > 3 ? std::max(1, std::atoi(argv[3])) : 9;
+    const bool onlyE2e = argc > 4 && std::string(argv[4]) == "e2e";
     const std::string selaPath = dir + "/filebench.sela", backPath = dir + "/filebench.wav";
     using clock = std::chrono::steady_clock;
     auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -79,6 +80,10 @@ int main(int argc, char** argv)
                 enc.push_back(ms(t0, t1));
                 dec.push_back(ms(t1, t2));
             }
+        }
+        if (onlyE2e) {
+            std::printf("{\"frames\": %u, \"e2e_encode_ms\": %.4f, \"e2e_decode_ms\": %.4f}\n", frames, median(enc), median(dec));
+            return 0;
         }
         // ---- the PCIe transfers alone (page-locked <-> device), for scale: PCM one way, frames the other -------------
         double h2d_pcm = 0, d2h_pcm = 0, h2d_sela = 0, d2h_sela = 0;

@@ -6,6 +6,8 @@
 // SELA_HIP_ENODEV.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,7 +23,9 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
     hipEvent_t* ev, uint64_t* d_phase_cycles, uint64_t* d_mirror, int force_plain_fir, int self_blocks_override);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
-    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles);
+    int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles,
+    uint8_t* frame_flags);
+int decode_waves(uint32_t channels);
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 uint32_t decode_max_channels();
 } // namespace sela
@@ -166,7 +170,7 @@ struct HostBuffer {
 // waits for the device until a buffer set comes round again.
 constexpr uint32_t kHostChunkFrames = 1024; // (buffers are sized for this; chunk_frames() may cut chunks shorter)
 constexpr uint32_t kSets = 8;
-constexpr uint32_t kRunStreams = 4;
+constexpr uint32_t kRunStreams = 2;
 
 struct ChunkSet {
     DeviceBuffer pcm, frames, offsets, workspace;
@@ -178,9 +182,12 @@ struct ChunkSet {
 
 struct HostContext {
     ChunkSet set[kSets];
-    DeviceBuffer status;      // 4 words per chunk of the running job
-    HostBuffer host_status;
-    hipStream_t s_in = nullptr, s_out = nullptr, s_run[kRunStreams] = { nullptr, nullptr, nullptr, nullptr };
+    DeviceBuffer status;      // encode: 4 words per buffer set
+    HostBuffer job_offsets_host; // decode: the frame offsets of every feed of the running job, where the kernels read them
+    HostBuffer job_flags;     // decode: one byte per (frame, wave), zeroed by the host, written by the kernels (over the link) on errors only
+    const uint64_t* job_offsets_mapped = nullptr; // device addresses of the two host buffers
+    uint8_t* job_flags_mapped = nullptr;
+    hipStream_t s_in = nullptr, s_out = nullptr, s_run[kRunStreams] = { nullptr, nullptr };
     int device = -1;
     bool job_open = false;
     // the buffers belong to the device that was current when they were allocated
@@ -195,10 +202,13 @@ struct HostContext {
         }
         return true;
     }
+    // Four streams, because the runtime multiplexes streams onto four hardware queues and two streams on one queue
+    // serialise (an event record of one sits in front of the other's kernels).  Encode jobs use them as copy-in,
+    // two kernel streams and copy-out; decode jobs as copy-in and three kernel + copy-out streams.
     hipError_t streams()
     {
         hipError_t e = hipSuccess;
-        for (hipStream_t* s : { &s_in, &s_out, &s_run[0], &s_run[1], &s_run[2], &s_run[3] })
+        for (hipStream_t* s : { &s_in, &s_run[0], &s_run[1], &s_out })
             if (!*s && (e = hipStreamCreateWithFlags(s, hipStreamNonBlocking)) != hipSuccess)
                 return e;
         for (ChunkSet& c : set)
@@ -207,9 +217,15 @@ struct HostContext {
                     return e;
         return e;
     }
+    // decode: a chunk's kernel and copy-out share a stream, three streams in turn (the fourth copies in)
+    hipStream_t decode_stream(uint32_t chunk) const
+    {
+        const hipStream_t run[3] = { s_run[0], s_run[1], s_out };
+        return run[chunk % 3];
+    }
     void sync_all()
     {
-        for (hipStream_t s : { s_in, s_out, s_run[0], s_run[1], s_run[2], s_run[3] })
+        for (hipStream_t s : { s_in, s_out, s_run[0], s_run[1] })
             if (s)
                 (void)hipStreamSynchronize(s);
     }
@@ -229,8 +245,9 @@ struct HostContext {
             }
         }
         status.release();
-        host_status.release();
-        for (hipStream_t* s : { &s_in, &s_out, &s_run[0], &s_run[1], &s_run[2], &s_run[3] }) {
+        job_offsets_host.release();
+        job_flags.release();
+        for (hipStream_t* s : { &s_in, &s_out, &s_run[0], &s_run[1] }) {
             if (*s)
                 (void)hipStreamDestroy(*s);
             *s = nullptr;
@@ -276,12 +293,35 @@ uint32_t run_streams()
     static const uint32_t v = env_u32("SELA_HOST_RUN_STREAMS", 1, kRunStreams, 2);
     return v;
 }
-// Size of the next chunk of a job that has `available` frames at hand.  (Short first / last chunks and chunk sizes
-// halving towards the end of a job were tried: more chunks cost more in per-chunk handshakes and in kernel
-// efficiency than the shorter fill and drain save.)
-uint32_t next_chunk_frames(uint32_t available)
+// Size of chunk number `index` of a job that has `available` frames at hand.  A decode job opens with two shorter
+// chunks: its copy-outs run back to back from the moment the first chunk is done, so the job is as long as the way
+// to that moment plus the bare copy of the PCM -- provided every later chunk is decoded by the time the copy-out
+// before it ends, which is what keeps the first chunks from being shorter still.  (For encode jobs short first / last chunks and sizes halving towards
+// the end were tried: more chunks cost more in kernel efficiency than the shorter fill and drain save.)
+// SELA_HOST_CHUNK_PLAN="a,b,c" sets the sizes of the first chunks of every job (experiments).
+uint32_t next_chunk_frames(bool encode, uint32_t index, uint32_t available)
 {
-    return chunk_frames() < available ? chunk_frames() : available;
+    static const std::vector<uint32_t> plan = [] {
+        std::vector<uint32_t> v;
+        if (const char* e = std::getenv("SELA_HOST_CHUNK_PLAN"))
+            for (const char* p = e; *p;) {
+                char* end = nullptr;
+                const long n = std::strtol(p, &end, 10);
+                if (end == p)
+                    break;
+                v.push_back((uint32_t)std::min<long>(std::max<long>(n, 8), kHostChunkFrames));
+                p = *end ? end + 1 : end;
+            }
+        return v;
+    }();
+    uint32_t want = chunk_frames();
+    if (index < plan.size())
+        want = plan[index];
+    else if (plan.empty() && !encode && index < 2)
+        want = std::min<uint32_t>(want, index ? 640u : 384u);
+    if (want < available && available - want < want / 4) // (no stub of a last chunk: split what is left in two)
+        want = (available + 1) / 2;
+    return want < available ? want : available;
 }
 
 uint32_t flags_to_error(uint32_t flags)
@@ -309,6 +349,7 @@ struct sela_hip_job {
     size_t chunk_bound = 0;
     // decode
     int16_t* pcm_out = nullptr;
+    size_t offsets_used = 0; // entries of g_ctx.job_offsets taken by the feeds so far
     int error = SELA_HIP_OK;
 };
 
@@ -335,8 +376,8 @@ int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
     return SELA_HIP_OK;
 }
 
-// Enqueue the copy-out of the oldest issued chunk (its kernels must have finished: the encoder's byte
-// count is needed on the host).
+// Encode jobs: enqueue the copy-out of the oldest issued chunk (its kernels must have finished: the byte count
+// is needed on the host).  A decode chunk's copy-out is queued with the chunk (job_issue_decode).
 int job_drain_one(sela_hip_job* job)
 {
     const uint32_t i = job->drained;
@@ -345,7 +386,7 @@ int job_drain_one(sela_hip_job* job)
     hipError_t e = hipEventSynchronize(c.ran);
     if (e != hipSuccess)
         return job_fail(job, fail_hip(e, "kernels"));
-    if (job->encode) {
+    {
         const uint64_t* mirror = static_cast<const uint64_t*>(c.host_offsets.ptr); // offsets[0..nf], then status[0] | status[1] << 32
         const uint64_t st = mirror[nf + 1];
         const uint32_t flags = (uint32_t)st, overflow = (uint32_t)(st >> 32);
@@ -363,11 +404,6 @@ int job_drain_one(sela_hip_job* job)
             return job_fail(job, fail_hip(e, "D2H frames"));
         job->bytes_issued += total;
         job->chunk_end_byte.push_back(job->bytes_issued);
-    } else {
-        const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
-        if ((e = hipMemcpyAsync(job->pcm_out + (size_t)first * sela::kBlock * job->channels, c.pcm.ptr, nf * frame_pcm, hipMemcpyDeviceToHost, g_ctx.s_out))
-            != hipSuccess)
-            return job_fail(job, fail_hip(e, "D2H pcm"));
     }
     if ((e = hipEventRecord(c.copied_out, g_ctx.s_out)) != hipSuccess)
         return job_fail(job, fail_hip(e, "hipEventRecord"));
@@ -414,8 +450,9 @@ int job_issue_encode(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
     }
     // (copies in job order on ONE stream: spread over the kernel streams they share the link and every chunk
     // arrives late)
-    if ((e = hipMemcpyAsync(c.pcm.ptr, pcm, nf * frame_pcm, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
-        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s_run, c.copied_in, 0)) != hipSuccess)
+    const hipStream_t s_copy = g_ctx.s_in;
+    if ((e = hipMemcpyAsync(c.pcm.ptr, pcm, nf * frame_pcm, hipMemcpyHostToDevice, s_copy)) != hipSuccess
+        || (e = hipEventRecord(c.copied_in, s_copy)) != hipSuccess || (e = hipStreamWaitEvent(s_run, c.copied_in, 0)) != hipSuccess)
         return job_fail(job, fail_hip(e, "H2D pcm"));
     if (c.mirror_host != c.host_offsets.ptr) { // (looked up once per allocation)
         if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c.mirror_dev), c.host_offsets.ptr, 0)) != hipSuccess)
@@ -435,43 +472,75 @@ int job_issue_encode(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
     return SELA_HIP_OK;
 }
 
-int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* offsets, uint32_t nf)
+// A decode chunk needs nothing from the host once it is queued (its output size is known): copy-in on the copy
+// stream; then, on one of three streams in turn, the kernel and right behind it -- no event in between -- the
+// copy-out, so that the copy-outs of neighbouring chunks come from different streams (on ONE stream the copy engine
+// idles ~20 us between two copies).  The kernels read the frame offsets where the host staged them (page-locked
+// memory, two words per workgroup over the link): the first kernel starts as soon as the first chunk's frames are on
+// the device.  (Measured and dropped: copy-in on the chunk's own stream as well -- the runtime keeps about three
+// copies in flight and starts them in the order they were queued, so a copy-out that waits for its kernel holds up
+// the copy-ins queued behind it: 0.90 -> 1.11 ms.)
+// `k_offsets` = the chunk's first entry of the feed's staged offsets (absolute in `frames`), as the device sees it.
+int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* offsets, const uint64_t* k_offsets, uint32_t nf)
 {
     const uint32_t i = job->issued;
     ChunkSet& c = g_ctx.set[i % kSets];
-    const hipStream_t s_run = g_ctx.s_run[i % run_streams()];
+    const hipStream_t s = g_ctx.decode_stream(i);
     hipError_t e;
     if (i >= kSets) {
-        while (job->drained + kSets <= i) {
-            const int rc = job_drain_one(job);
-            if (rc != SELA_HIP_OK)
-                return rc;
-        }
-        // (drained: the set's kernels are done, so its copy-in -- which read the staging array below -- is too)
-        if ((e = hipStreamWaitEvent(s_run, c.copied_out, 0)) != hipSuccess)
+        // chunk i - kSets used this set.  The host goes no further ahead than that chunk's kernel (which also keeps
+        // the queues short); the copy-in must not overwrite frames that kernel reads, the kernel not PCM on its way out.
+        if ((e = hipEventSynchronize(c.ran)) != hipSuccess)
+            return job_fail(job, fail_hip(e, "kernels"));
+        if ((e = hipStreamWaitEvent(s, c.copied_out, 0)) != hipSuccess)
             return job_fail(job, fail_hip(e, "hipStreamWaitEvent"));
     }
     const uint64_t bytes = offsets[nf] - offsets[0];
-    if ((e = c.frames.reserve((size_t)bytes + 16)) != hipSuccess) // (grow-only; a set that is still in use is never the one that grows: waited above)
-        return job_fail(job, fail_hip(e, "hipMalloc"));
-    uint64_t* rel = static_cast<uint64_t*>(c.host_offsets.ptr);
-    for (uint32_t f = 0; f <= nf; f++)
-        rel[f] = offsets[f] - offsets[0];
+    if ((size_t)bytes + 16 > c.frames.cap) {
+        if (i >= kSets && (e = hipEventSynchronize(c.copied_out)) != hipSuccess) // (nothing of the set's last use is in flight)
+            return job_fail(job, fail_hip(e, "copy-out"));
+        if ((e = c.frames.reserve((size_t)bytes + 16)) != hipSuccess)
+            return job_fail(job, fail_hip(e, "hipMalloc"));
+    }
     if ((bytes && (e = hipMemcpyAsync(c.frames.ptr, frames + offsets[0], (size_t)bytes, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess)
-        || (e = hipMemcpyAsync(c.offsets.ptr, rel, ((size_t)nf + 1) * 8, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
-        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s_run, c.copied_in, 0)) != hipSuccess)
+        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s, c.copied_in, 0)) != hipSuccess)
         return job_fail(job, fail_hip(e, "H2D frames"));
-    if ((e = g_ctx.status.reserve(16 * ((size_t)i + 1))) != hipSuccess) // (sized at begin; this never reallocates)
-        return job_fail(job, fail_hip(e, "hipMalloc"));
-    uint32_t* d_status = static_cast<uint32_t*>(g_ctx.status.ptr) + 4 * (size_t)i;
-    e = sela::launch_decode(static_cast<const uint8_t*>(c.frames.ptr), static_cast<const uint64_t*>(c.offsets.ptr), nf, job->channels,
-        static_cast<int16_t*>(c.pcm.ptr), d_status, c.workspace.ptr, s_run, nullptr, nullptr);
-    if (e != hipSuccess || (e = hipEventRecord(c.ran, s_run)) != hipSuccess)
+    // the kernel adds the feed's absolute offsets to its base: bias the base so that offsets[0] lands on the chunk's copy
+    const uint8_t* d_base = static_cast<const uint8_t*>(c.frames.ptr) - offsets[0];
+    uint8_t* flags = g_ctx.job_flags_mapped + (size_t)job->fed * sela::decode_waves(job->channels);
+    e = sela::launch_decode(d_base, k_offsets, nf, job->channels, static_cast<int16_t*>(c.pcm.ptr), static_cast<uint32_t*>(g_ctx.status.ptr),
+        c.workspace.ptr, s, nullptr, nullptr, flags);
+    if (e != hipSuccess || (e = hipEventRecord(c.ran, s)) != hipSuccess)
         return job_fail(job, fail_hip(e, "decode launch"));
+    const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
+    if ((e = hipMemcpyAsync(job->pcm_out + (size_t)job->fed * sela::kBlock * job->channels, c.pcm.ptr, nf * frame_pcm, hipMemcpyDeviceToHost, s)) != hipSuccess
+        || (e = hipEventRecord(c.copied_out, s)) != hipSuccess)
+        return job_fail(job, fail_hip(e, "D2H pcm"));
     job->chunk_first.push_back(job->fed);
     job->chunk_frames.push_back(nf);
     job->issued++;
+    job->drained = job->issued;
     job->fed += nf;
+    return SELA_HIP_OK;
+}
+
+// One feed of a decode job: stage its offsets, queue its chunks.
+int job_feed_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames)
+{
+    if (n_frames == 0)
+        return SELA_HIP_OK;
+    // (sized at begin for the whole job: total_frames entries + one more per feed, and a feed has at least a frame)
+    uint64_t* staged = static_cast<uint64_t*>(g_ctx.job_offsets_host.ptr) + job->offsets_used;
+    const uint64_t* mapped = g_ctx.job_offsets_mapped + job->offsets_used;
+    std::memcpy(staged, offsets, ((size_t)n_frames + 1) * 8);
+    job->offsets_used += (size_t)n_frames + 1;
+    for (uint32_t done = 0; done < n_frames;) {
+        const uint32_t nf = next_chunk_frames(false, job->issued, n_frames - done);
+        const int rc = job_issue_decode(job, frames, offsets + done, mapped + done, nf);
+        if (rc != SELA_HIP_OK)
+            return rc;
+        done += nf;
+    }
     return SELA_HIP_OK;
 }
 
@@ -518,11 +587,16 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
         return fail(SELA_HIP_EINVAL, "this thread already has an open job");
     const size_t bound = sela_hip_encode_bound_bytes(kHostChunkFrames, channels);
     hipError_t e = reserve_chunk_buffers(encode, channels, encode ? bound : 0);
-    const size_t n_chunks = (size_t)total_frames + kSets + 4; // (a caller may feed one frame at a time)
     if (e == hipSuccess)
-        e = g_ctx.status.reserve(16 * n_chunks);
-    if (e == hipSuccess)
-        e = g_ctx.host_status.reserve(16 * n_chunks);
+        e = g_ctx.status.reserve(16 * (size_t)kSets); // (encode: four words per buffer set, mirrored to the host by k_plan_frames)
+    if (e == hipSuccess && !encode) {
+        const size_t n_flags = (size_t)total_frames * sela::decode_waves(channels) + 1;
+        if ((e = g_ctx.job_offsets_host.reserve((2 * (size_t)total_frames + 2) * 8)) == hipSuccess
+            && (e = g_ctx.job_flags.reserve(n_flags)) == hipSuccess
+            && (e = hipHostGetDevicePointer((void**)&g_ctx.job_offsets_mapped, g_ctx.job_offsets_host.ptr, 0)) == hipSuccess
+            && (e = hipHostGetDevicePointer((void**)&g_ctx.job_flags_mapped, g_ctx.job_flags.ptr, 0)) == hipSuccess)
+            std::memset(g_ctx.job_flags.ptr, 0, n_flags);
+    }
     if (e != hipSuccess)
         return fail_hip(e, "hipMalloc");
     sela_hip_job* job = new sela_hip_job;
@@ -544,15 +618,11 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
         rc = job_finalize(job, job->drained);
     uint32_t seen_flags = 0;
     if (rc == SELA_HIP_OK && !job->encode && job->issued) {
-        // every frame is decoded (bad ones to silence) before the verdict
-        uint32_t* hs = static_cast<uint32_t*>(g_ctx.host_status.ptr);
-        hipError_t e = hipMemcpyAsync(hs, g_ctx.status.ptr, 16 * (size_t)job->issued, hipMemcpyDeviceToHost, g_ctx.s_out);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(g_ctx.s_out);
-        if (e != hipSuccess)
-            rc = fail_hip(e, "D2H status");
-        for (uint32_t i = 0; rc == SELA_HIP_OK && i < job->issued; i++)
-            seen_flags |= hs[4 * (size_t)i];
+        // every frame is decoded (bad ones to silence) before the verdict; the kernels left their flags in host memory
+        const uint8_t* flags = static_cast<const uint8_t*>(g_ctx.job_flags.ptr);
+        const size_t n = (size_t)job->fed * sela::decode_waves(job->channels);
+        for (size_t i = 0; i < n; i++)
+            seen_flags |= flags[i];
     }
     if (rc != SELA_HIP_OK) { // leave nothing in flight behind an error
         const std::string msg = sela_hip_last_error();
@@ -684,7 +754,7 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 1 : 0;
     hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, d_workspace,
-        static_cast<hipStream_t>(stream), ev, g_phase_cycles);
+        static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr);
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
     return SELA_HIP_OK;
@@ -714,7 +784,7 @@ int sela_hip_encode_feed(sela_hip_job* job, const int16_t* pcm, uint32_t n_frame
         return job->error;
     const size_t frame_samples = (size_t)sela::kBlock * job->channels;
     for (uint32_t done = 0; done < n_frames;) {
-        const uint32_t nf = next_chunk_frames(n_frames - done);
+        const uint32_t nf = next_chunk_frames(true, job->issued, n_frames - done);
         int rc = job_issue_encode(job, pcm + done * frame_samples, nf);
         if (rc != SELA_HIP_OK)
             return rc;
@@ -754,14 +824,10 @@ int sela_hip_decode_feed(sela_hip_job* job, const uint8_t* frames, const uint64_
     for (uint32_t f = 0; f < n_frames; f++)
         if (frame_offsets[f + 1] < frame_offsets[f] || (frame_offsets[f] & 3))
             return job_fail(job, fail(SELA_HIP_EFORMAT, "frame offsets must be ascending multiples of 4"));
-    for (uint32_t done = 0; done < n_frames;) {
-        const uint32_t nf = next_chunk_frames(n_frames - done);
-        int rc = job_issue_decode(job, frames, frame_offsets + done, nf);
-        if (rc != SELA_HIP_OK)
-            return rc;
-        done += nf;
-    }
-    const int rc = job_drain_ready(job);
+    int rc = job_feed_decode(job, frames, frame_offsets, n_frames);
+    if (rc != SELA_HIP_OK)
+        return rc;
+    rc = job_drain_ready(job);
     if (rc != SELA_HIP_OK)
         return rc;
     job_progress(job, frames_final, nullptr);

@@ -731,7 +731,8 @@ __host__ __device__ inline size_t decode_lds_bytes_for(uint32_t channels, int n_
 template <bool kProf>
 __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* __restrict__ pcm_out,
-    uint32_t* __restrict__ status, int32_t* __restrict__ ws_residues, uint64_t* __restrict__ phase_cycles)
+    uint32_t* __restrict__ status, int32_t* __restrict__ ws_residues, uint64_t* __restrict__ phase_cycles,
+    uint8_t* __restrict__ frame_flags /* or null: one byte per (frame, wave), written only when not zero */)
 {
     long long stamp[10];
     for (int i = 0; i < 10; i++)
@@ -893,9 +894,13 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
     }
     flags = wave_or(flags);
     if (lane == 0 && flags) {
-        atomicOr(&status[0], flags);
-        if (wave == 0 && (flags & SELA_HIP_FLAG_BAD_FRAME))
-            atomicAdd(&status[1], 1u);
+        if (frame_flags) // (the host pipeline: page-locked host memory, zeroed by the host; a plain store, no atomics over the link)
+            frame_flags[(size_t)f * n_waves + wave] = (uint8_t)flags;
+        else {
+            atomicOr(&status[0], flags);
+            if (wave == 0 && (flags & SELA_HIP_FLAG_BAD_FRAME))
+                atomicAdd(&status[1], 1u);
+        }
     }
     if (kProf && lane == 0 && prof_sub != 0xFFFFFFFFu) { // (one subframe per wave is reported)
         stamp[9] = clock64();
@@ -921,9 +926,9 @@ size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels)
 
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev /* 2 events or nullptr */,
-    uint64_t* d_phase_cycles)
+    uint64_t* d_phase_cycles, uint8_t* frame_flags /* null: flags go to d_status, which is zeroed here */)
 {
-    hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
+    hipError_t err = frame_flags ? hipSuccess : hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
     if (err != hipSuccess || n_frames == 0)
         return err;
     const int n_waves = decode_waves(channels);
@@ -945,10 +950,10 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
         hipLaunchKernelGGL(k_decode_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
-            d_pcm_out, d_status, ws, d_phase_cycles);
+            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags);
     else
         hipLaunchKernelGGL(k_decode_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
-            d_pcm_out, d_status, ws, d_phase_cycles);
+            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     return hipGetLastError();
