@@ -196,7 +196,6 @@ void sela_hip_debug_mean_workers(int self_blocks);
 #define SELA_HIP_FLAG_RICE_OVERRUN 8u  /* decoder ran past the end of a Rice stream */
 #define SELA_HIP_FLAG_WORDS_CAP 16u    /* a Rice stream exceeded the per-block slot (encoder) */
 #define SELA_HIP_FLAG_BAD_FRAME 32u    /* bad sync word / inconsistent subframe header (decoder) */
-#define SELA_HIP_FLAG_INTERNAL 64u     /* a bounded wait inside a kernel ran out (never expected; reported as SELA_HIP_ENODEV) */
 
 #ifdef __cplusplus
 }

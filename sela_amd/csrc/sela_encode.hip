@@ -1,21 +1,18 @@
 // sela_encode.hip -- MI355X (gfx950) encoder kernels of the SELA frame path.
 //
-// ONE launch for a batch of frames, k_encode_blocks:
+// Pipeline for a batch of frames (three launches on one stream):
 //
-//   a block           one WAVE per (frame, signal): the whole of lpc::ResidueGenerator +
+//   k_encode_blocks   one WAVE per (frame, signal): the whole of lpc::ResidueGenerator +
 //                     rice::RiceEncoder x2 for that signal (reference src/lpc/residue_generator.cpp:
 //                     121-134, src/rice/rice_encoder.cpp:73-81).  A stereo frame has three signals
 //                     (ch0, ch1, ch0-ch1; src/frame/frame_encoder.cpp:18-60); all three are coded and
 //                     the loser is simply not copied out.  Output: a fixed-stride slot of Rice
 //                     words + an 8-byte BlockMeta per signal.
-//   a group's last    the block that finishes LAST among those of 16 consecutive frames (finish_group):
-//   block             per frame the stereo decision of src/frame/frame_encoder.cpp:64-72 (strict < on
-//                     u32 word counts) and the frame's on-disk size; the group's place in the stream by a
-//                     decoupled look-back over the groups before it; then the exact bytes that
-//                     file::SelaFile::writeToFile emits for its frames (src/file/sela_file.cpp:115-135),
-//                     written where they belong -- device memory, or the caller's page-locked buffer.
-//   mean workers,     the first workgroups of the launch (mean_worker, stage_in).
-//   stagers
+//   k_plan_frames     one workgroup: per frame, the stereo decision of src/frame/frame_encoder.cpp:
+//                     64-72 (strict < on u32 word counts) and the frame's on-disk size, then an
+//                     exclusive scan of the sizes -> frame_offsets[].
+//   k_assemble_frames one workgroup per frame: writes the exact byte stream that
+//                     file::SelaFile::writeToFile emits for the frame (src/file/sela_file.cpp:115-135).
 //
 // Arithmetic contract: this file must be compiled with -ffp-contract=off.  Every
 // FP64 accumulator is updated in the reference's order: the lanes of a wave carry *independent*
@@ -430,250 +427,6 @@ __device__ __attribute__((noinline)) void mean_worker(const int16_t* __restrict_
     }
 }
 
-// ---- a group's last block: sizes, place in the stream, on-disk bytes ---------------------------------------------
-// Round 2 had two more kernels behind k_encode_blocks (a one-workgroup plan: stereo decision, sizes, scan; an
-// assembler, one workgroup per frame).  Between two batches they cost two launch hand-overs; in the host pipeline
-// they waited behind the next chunk's blocks for a free CU (80-95 us per chunk, traced) and forced a host
-// hand-over (sizes) before every copy-out.  Now the blocks do it: frames are grouped by 16; every block, when its
-// slot and BlockMeta are written, counts itself in; the one that completes the count finishes the group.
-constexpr int kGroupFrames = 16;
-constexpr uint32_t kFuseSpinLimit = 1u << 21; // x s_sleep 8 (~0.25 us): ~0.5 s, then the launch flags an error instead of hanging
-
-struct GroupState {         // decoupled look-back cell; `tag` = launch ticket << 2 | kind, written last (release)
-    uint64_t agg_bytes;     // kind >= 1: bytes of this group's frames
-    uint64_t prefix_bytes;  // kind == 2: stream offset behind this group's last frame
-    uint32_t agg_info;      // flags | frames that do not fit frames_cap << 8   (this group / all groups up to it)
-    uint32_t prefix_info;
-    uint32_t tag;
-    uint32_t pad;
-};
-static_assert(sizeof(GroupState) == 32, "GroupState");
-
-struct FuseArgs {
-    const BlockMeta* meta;
-    const uint32_t* slots;
-    uint64_t* group_count;   // [n_groups]: launch ticket << 32 | blocks that have arrived
-    GroupState* group_state; // [n_groups]
-    uint8_t* frames;         // the stream (device memory, or page-locked host memory as the device sees it)
-    size_t frames_cap;
-    uint64_t* frame_offsets; // [n_frames + 1] or null
-    uint64_t* mirror;        // host copy of frame_offsets, + one word status[0] | status[1] << 32; or null
-    uint32_t* status;
-    uint64_t* stream_pos;    // in: offset of this launch's first frame (null: 0); out: offset behind its last frame
-    uint32_t* group_done;    // [n_groups] host-visible: ticket once the group's bytes are written; or null
-    uint32_t n_frames, channels, n_sig, ticket;
-};
-
-__device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t channels, uint32_t& choice, uint32_t& flags)
-{
-    uint32_t words = 0;
-    choice = 0;
-    for (uint32_t c = 0; c < channels; c++) {
-        BlockMeta b = m[c];
-        if (c == 1 && channels == 2) { // exactly-stereo only, src/frame/frame_encoder.cpp:18
-            const BlockMeta d = m[2];
-            const uint32_t dsz = (uint32_t)d.coef_words + d.res_words, asz = (uint32_t)b.coef_words + b.res_words;
-            flags |= d.flags;
-            if (dsz < asz) { // strict <, src/frame/frame_encoder.cpp:64
-                choice = 1;
-                b = d;
-            }
-        }
-        flags |= b.flags;
-        words += (uint32_t)b.coef_words + b.res_words;
-    }
-    return words;
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
-{
-    for (int d = 32; d >= 1; d >>= 1)
-        v += (uint64_t)__shfl_xor((unsigned long long)v, d, 64);
-    return v;
-}
-
-// The on-disk bytes of one frame (src/file/sela_file.cpp:115-135), by one wave.  Frame sizes are multiples of 4
-// and the stream base is 4-byte aligned, so everything is written as aligned u32.  Within a subframe the 7 header
-// bytes push the coefficient words 3 bytes off word alignment (funnel shift below); the 5 bytes of the residue
-// header realign the residue words.
-__device__ __forceinline__ void assemble_frame(const FuseArgs& fa, uint32_t f, uint32_t choice, uint32_t* __restrict__ out, int lane)
-{
-    if (lane == 0)
-        out[0] = SELA_SYNC_WORD;
-    uint32_t p = 1; // word cursor inside the frame
-    for (uint32_t c = 0; c < fa.channels; c++) {
-        uint32_t sig = c, type = 0, parent = c;
-        if (c == 1 && fa.channels == 2 && choice) {
-            sig = 2;
-            type = 1;
-            parent = 0;
-        }
-        const BlockMeta b = fa.meta[(size_t)f * fa.n_sig + sig];
-        const uint32_t* __restrict__ slot = fa.slots + ((size_t)f * fa.n_sig + sig) * kSlotWords;
-        const uint32_t cw = b.coef_words, rw = b.res_words;
-        if (lane == 0)
-            out[p] = c | (type << 8) | (parent << 16) | ((uint32_t)b.coef_k << 24);
-        // words p+1 .. p+1+cw: [cw:16 | order:8] then the coefficient words shifted by 3 bytes, then res_k
-        if ((uint32_t)lane <= cw) { // (cw <= kCoefWordsCap = 32)
-            const uint32_t low = lane == 0 ? (cw | ((uint32_t)b.order << 16)) : (slot[lane - 1] >> 8);
-            const uint32_t top = (uint32_t)lane < cw ? slot[lane] : (uint32_t)b.res_k;
-            out[p + 1 + lane] = (low & 0x00FFFFFFu) | (top << 24);
-        }
-        if (lane == 0)
-            out[p + 2 + cw] = rw | ((uint32_t)kBlock << 16);
-        // the residue words: 16-byte loads (the slot is 16-byte aligned), four loads in flight, word stores
-        const uint4* __restrict__ rs = reinterpret_cast<const uint4*>(slot + kCoefWordsCap);
-        uint32_t* __restrict__ ro = out + p + 3 + cw;
-        for (uint32_t base = 0; base < rw; base += 4 * 256) {
-            uint4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t w = base + 256 * u + 4 * lane;
-                v[u] = w < rw ? rs[w / 4] : make_uint4(0, 0, 0, 0); // (reads inside the slot: rw <= kResWordsCap, a multiple of 4 words)
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t w = base + 256 * u + 4 * lane;
-                if (w < rw)
-                    ro[w] = v[u].x;
-                if (w + 1 < rw)
-                    ro[w + 1] = v[u].y;
-                if (w + 2 < rw)
-                    ro[w + 2] = v[u].z;
-                if (w + 3 < rw)
-                    ro[w + 3] = v[u].w;
-            }
-        }
-        p += 3 + cw + rw;
-    }
-}
-
-// Count one finished block into its group; true for the block that completes the group.  The counter carries the
-// launch ticket, so nothing is cleared between launches (a stale or uninitialised counter reads as "nobody yet").
-__device__ __forceinline__ bool group_arrive(uint64_t* cell, uint32_t ticket, uint32_t blocks_in_group)
-{
-    uint64_t old = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        const uint64_t neu = (uint32_t)(old >> 32) == ticket ? old + 1 : (((uint64_t)ticket << 32) | 1u);
-        if (__hip_atomic_compare_exchange_strong(cell, &old, neu, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            return (uint32_t)neu == blocks_in_group;
-    }
-}
-
-__device__ __attribute__((noinline)) void finish_group(const FuseArgs& fa, uint32_t g, int lane)
-{
-    const uint32_t f0 = g * kGroupFrames;
-    const uint32_t nfg = min((uint32_t)kGroupFrames, fa.n_frames - f0);
-    const uint32_t n_groups = (fa.n_frames + kGroupFrames - 1) / kGroupFrames;
-    const uint32_t my_tag = fa.ticket << 2;
-    // ---- sizes ----
-    uint32_t size = 0, choice = 0, flags = 0;
-    if ((uint32_t)lane < nfg) {
-        const uint32_t words = frame_words(fa.meta + (size_t)(f0 + lane) * fa.n_sig, fa.channels, choice, flags);
-        size = sela_frame_bytes(fa.channels, words);
-    }
-    const uint32_t excl = wave_exclusive_scan(size, lane);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(excl + size), 63);
-    flags = wave_or(flags);
-    GroupState* const st = fa.group_state;
-    if (lane == 0) {
-        st[g].agg_bytes = total;
-        st[g].agg_info = flags;
-        __hip_atomic_store(&st[g].tag, my_tag | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- decoupled look-back: sum the groups before this one, nearest first, until one knows its prefix ----
-    uint64_t base = 0;
-    uint32_t over_before = 0, timed_out = 0;
-    bool reached_start = true;
-    for (int64_t p = (int64_t)g - 1; p >= 0; p -= 64) {
-        const int64_t mine = p - lane;
-        uint32_t kind = 0, info = 0;
-        uint64_t bytes = 0;
-        if (mine >= 0) {
-            uint32_t tag = 0, spins = 0;
-            for (;;) {
-                tag = __hip_atomic_load(&st[mine].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((tag & ~3u) == my_tag && (tag & 3u))
-                    break;
-                if (++spins > kFuseSpinLimit) {
-                    timed_out = 1;
-                    tag = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE); // (agent scope is what the HIP fence gives)
-            kind = tag & 3u;
-            if (kind == 2u) {
-                bytes = st[mine].prefix_bytes;
-                info = st[mine].prefix_info;
-            } else if (kind == 1u) {
-                bytes = st[mine].agg_bytes;
-                info = st[mine].agg_info;
-            }
-        }
-        const uint64_t knows = __ballot(kind == 2u);
-        const int first = knows ? __builtin_ctzll(knows) : 64;
-        const bool take = mine >= 0 && lane <= first;
-        base += wave_sum_u64(take ? bytes : 0);
-        flags |= wave_or(take ? (info & 0xFFu) : 0u);
-        over_before += wave_sum_small(take ? (info >> 8) : 0u);
-        if (knows) {
-            reached_start = false;
-            break;
-        }
-    }
-    if (reached_start && fa.stream_pos) // (the launch before this one on the stream left its end here)
-        base += *fa.stream_pos;
-    timed_out = wave_or(timed_out);
-    if (timed_out)
-        flags |= SELA_HIP_FLAG_INTERNAL;
-    // ---- this group's frames in the stream ----
-    const uint64_t begin = base + excl, end = begin + size;
-    const bool fits = end <= fa.frames_cap;
-    const uint32_t over = over_before + (uint32_t)__popcll(__ballot((uint32_t)lane < nfg && !fits));
-    if (lane == 0) {
-        st[g].prefix_bytes = base + total;
-        st[g].prefix_info = (flags & 0xFFu) | (over << 8);
-        __hip_atomic_store(&st[g].tag, my_tag | 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if ((uint32_t)lane < nfg) {
-        if (fa.frame_offsets) {
-            fa.frame_offsets[f0 + lane + 1] = end;
-            if (f0 + lane == 0)
-                fa.frame_offsets[0] = begin;
-        }
-        if (fa.mirror) {
-            fa.mirror[f0 + lane + 1] = end;
-            if (f0 + lane == 0)
-                fa.mirror[0] = begin;
-        }
-    }
-    if (g + 1 == n_groups && lane == 0) { // (every group before this one has been counted in: the launch's verdict)
-        fa.status[0] = flags & 0xFFu;
-        fa.status[1] = over;
-        fa.status[2] = fa.status[3] = 0;
-        if (fa.mirror)
-            fa.mirror[(size_t)fa.n_frames + 1] = (uint64_t)(flags & 0xFFu) | ((uint64_t)over << 32);
-        if (fa.stream_pos)
-            *fa.stream_pos = base + total;
-    }
-    // ---- the bytes ----
-    for (uint32_t i = 0; i < nfg; i++) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)begin, (int)i);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(begin >> 32), (int)i);
-        const bool ok = __builtin_amdgcn_readlane((int)fits, (int)i) != 0;
-        const uint32_t ch = (uint32_t)__builtin_amdgcn_readlane((int)choice, (int)i);
-        if (ok && !timed_out)
-            assemble_frame(fa, f0 + i, ch, reinterpret_cast<uint32_t*>(fa.frames + (((uint64_t)hi << 32) | lo)), lane);
-    }
-    if (fa.group_done) { // (host pipeline: the group's bytes and offsets are on their way before the word that says so)
-        __threadfence_system();
-        if (lane == 0)
-            __hip_atomic_store(fa.group_done + g, fa.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 // kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts
 // (debug hook sela_hip_debug_phase_buffer; 16 uint64 per block).
 #define SELA_STAMP(n)                 \
@@ -687,7 +440,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
     double* __restrict__ rings, uint32_t* __restrict__ ring_owner, uint32_t ticket, sela_hip_trace* __restrict__ trace,
     uint64_t* __restrict__ phase_cycles, int force_plain_fir, double* __restrict__ mean_out, uint32_t* __restrict__ mean_ready,
-    uint32_t n_workers, uint32_t self_blocks, uint32_t total_e, const FuseArgs fa)
+    uint32_t n_workers, uint32_t self_blocks, uint32_t total_e)
 {
     constexpr bool kTrace = kMode == 1;
     if (blockIdx.x < n_workers) { // (the first workgroups of the launch: see mean_worker)
@@ -1190,23 +943,157 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
     }
     SELA_STAMP(12);
-    // ---- count this block into its group; the group's last block places and writes the group's frames ----------
-    {
-        const uint32_t g = frame / kGroupFrames;
-        const uint32_t blocks_in_group = min((uint32_t)kGroupFrames, n_frames - g * kGroupFrames) * n_sig;
-        __threadfence(); // the slot and the BlockMeta of every lane, before the count
-        uint32_t last = 0;
-        if (lane == 0)
-            last = group_arrive(fa.group_count + g, ticket, blocks_in_group) ? 1u : 0u;
-        if (__builtin_amdgcn_readfirstlane((int)last)) {
-            __threadfence(); // (acquire side: the other blocks' slots and metas)
-            finish_group(fa, g, lane);
-        }
-    }
-    SELA_STAMP(13);
     if (kMode == 2 && lane == 0)
-        for (int i = 0; i < 13; i++)
+        for (int i = 0; i < 12; i++)
             phase_cycles[(size_t)block_id * 16 + i] = (uint64_t)(stamp[i + 1] - stamp[i]);
+}
+
+// ---- plan: stereo decision + frame sizes + exclusive scan (one workgroup of 1024) -------------------
+// choice[f] = 1 when the second channel of an exactly-stereo frame is stored as the difference
+// signal (src/frame/frame_encoder.cpp:64-72).
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanLdsFrames = 12288; // frame sizes staged in LDS up to this batch size (48 KB)
+
+__device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t channels, uint32_t n_sig, uint32_t& choice,
+    uint32_t& flags)
+{
+    uint32_t words = 0;
+    choice = 0;
+    for (uint32_t c = 0; c < channels; c++) {
+        BlockMeta b = m[c];
+        if (c == 1 && channels == 2) { // exactly-stereo only, src/frame/frame_encoder.cpp:18
+            const BlockMeta d = m[2];
+            const uint32_t dsz = (uint32_t)d.coef_words + d.res_words, asz = (uint32_t)b.coef_words + b.res_words;
+            flags |= d.flags;
+            if (dsz < asz) {
+                choice = 1;
+                b = d;
+            }
+        }
+        flags |= b.flags;
+        words += (uint32_t)b.coef_words + b.res_words;
+    }
+    return words;
+}
+
+__global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
+    uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* __restrict__ frame_offsets,
+    uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status, uint64_t* __restrict__ mirror)
+{
+    // mirror (optional, page-locked HOST memory): a copy of frame_offsets[0 .. n_frames] followed by one word
+    // status[0] | status[1] << 32, so that the host pipeline reads a chunk's sizes without a copy of its own
+    __shared__ uint64_t part[kPlanThreads];
+    __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of the frames of one tile
+    __shared__ uint32_t acc[2];                      // flags, frames that do not fit frames_cap
+    const uint32_t tid = threadIdx.x;
+    if (tid < 2)
+        acc[tid] = 0;
+    uint64_t base = 0; // bytes of the tiles before this one (the same value in every thread)
+    uint32_t flags = 0, overflow = 0;
+    // Tiles of kPlanLdsFrames frames.  Within a tile, frame f is sized by thread f mod 1024: the metadata loads of
+    // one pass are independent and coalesced, and the passes do not depend on each other (a thread that walks
+    // consecutive frames waits for memory once per frame: 0.45 ms for 61 k frames, against 10 us per tile).
+    for (uint32_t tile0 = 0; tile0 < n_frames; tile0 += kPlanLdsFrames) {
+        const uint32_t tile_n = min((uint32_t)kPlanLdsFrames, n_frames - tile0);
+        __syncthreads(); // the previous tile's sizes have been read
+#pragma unroll 4
+        for (uint32_t i = tid; i < tile_n; i += kPlanThreads) {
+            uint32_t choice;
+            const uint32_t words = frame_words(meta + (size_t)(tile0 + i) * n_sig, channels, n_sig, choice, flags);
+            choice_out[tile0 + i] = (uint8_t)choice;
+            frame_size[i] = (uint32_t)sela_frame_bytes(channels, words);
+        }
+        __syncthreads();
+        const uint32_t per = (tile_n + kPlanThreads - 1) / kPlanThreads;
+        const uint32_t begin = min(tid * per, tile_n), end = min(begin + per, tile_n);
+        uint64_t bytes = 0;
+        for (uint32_t i = begin; i < end; i++)
+            bytes += frame_size[i];
+        part[tid] = bytes;
+        __syncthreads();
+        for (uint32_t d = 1; d < kPlanThreads; d <<= 1) { // Hillis-Steele inclusive scan
+            const uint64_t v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        uint64_t off = base + part[tid] - bytes;
+        for (uint32_t i = begin; i < end; i++) {
+            frame_offsets[tile0 + i] = off;
+            if (mirror)
+                mirror[tile0 + i] = off;
+            off += frame_size[i];
+            if (off > frames_cap)
+                overflow++;
+        }
+        base += part[kPlanThreads - 1];
+    }
+    if (tid == 0) {
+        frame_offsets[n_frames] = base;
+        if (mirror)
+            mirror[n_frames] = base;
+    }
+    if (flags)
+        atomicOr(&acc[0], flags);
+    if (overflow)
+        atomicAdd(&acc[1], overflow);
+    __syncthreads();
+    if (tid == 0) { // this single workgroup is the only writer of the encode status words
+        status[0] = acc[0];
+        status[1] = acc[1];
+        status[2] = status[3] = 0;
+        if (mirror)
+            mirror[(size_t)n_frames + 1] = (uint64_t)acc[0] | ((uint64_t)acc[1] << 32);
+    }
+}
+
+// ---- assemble: the on-disk bytes of each frame (src/file/sela_file.cpp:115-135) ------------------------
+// Frame sizes are multiples of 4 and the stream base is 4-byte aligned, so everything is written as
+// aligned u32.  Within a subframe the 7 header bytes push the coefficient words 3 bytes off word
+// alignment (funnel shift below); the 5 bytes of the residue header realign the residue words.
+constexpr int kAsmThreads = 256;
+
+__global__ __launch_bounds__(kAsmThreads) void k_assemble_frames(const BlockMeta* __restrict__ meta,
+    const uint32_t* __restrict__ slots, const uint8_t* __restrict__ choice, const uint64_t* __restrict__ frame_offsets,
+    uint32_t n_frames, uint32_t channels, uint32_t n_sig, size_t frames_cap, uint8_t* __restrict__ frames)
+{
+    const uint32_t f = blockIdx.x;
+    if (f >= n_frames)
+        return;
+    const uint64_t begin = frame_offsets[f], end = frame_offsets[f + 1];
+    if (end > frames_cap)
+        return; // reported through status[1] by k_plan_frames
+    uint32_t* out = reinterpret_cast<uint32_t*>(frames + begin);
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0)
+        out[0] = SELA_SYNC_WORD;
+    uint32_t p = 1; // word cursor inside the frame
+    for (uint32_t c = 0; c < channels; c++) {
+        uint32_t sig = c, type = 0, parent = c;
+        if (c == 1 && channels == 2 && choice[f]) {
+            sig = 2;
+            type = 1;
+            parent = 0;
+        }
+        const BlockMeta b = meta[(size_t)f * n_sig + sig];
+        const uint32_t* slot = slots + ((size_t)f * n_sig + sig) * kSlotWords;
+        const uint32_t cw = b.coef_words, rw = b.res_words;
+        if (tid == 0)
+            out[p] = c | (type << 8) | (parent << 16) | ((uint32_t)b.coef_k << 24);
+        // words p+1 .. p+1+cw: [cw:16 | order:8] then the coefficient words shifted by 3 bytes, then res_k
+        for (uint32_t i = tid; i <= cw; i += kAsmThreads) {
+            const uint32_t low = i == 0 ? (cw | ((uint32_t)b.order << 16)) : (slot[i - 1] >> 8);
+            const uint32_t top = i < cw ? slot[i] : (uint32_t)b.res_k;
+            out[p + 1 + i] = (low & 0x00FFFFFFu) | (top << 24);
+        }
+        if (tid == 0)
+            out[p + 2 + cw] = rw | ((uint32_t)kBlock << 16);
+        const uint32_t* rs = slot + kCoefWordsCap;
+        uint32_t* ro = out + p + 3 + cw;
+        for (uint32_t i = tid; i < rw; i += kAsmThreads)
+            ro[i] = rs[i];
+        p += 3 + cw + rw;
+    }
 }
 
 } // namespace sela
@@ -1221,8 +1108,7 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
     size_t bytes = 0;
     bytes += (blocks * sizeof(BlockMeta) + 255) & ~(size_t)255;
     bytes += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
-    const size_t n_groups = ((size_t)n_frames + kGroupFrames - 1) / kGroupFrames;
-    bytes += ((n_groups * sizeof(uint64_t) + 255) & ~(size_t)255) + ((n_groups * sizeof(GroupState) + 255) & ~(size_t)255); // finish_group
+    bytes += ((size_t)n_frames + 255) & ~(size_t)255; // choice
     bytes += (size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 256; // scalar-operand rings (L2-resident) ...
     bytes += (size_t)kXcds * kRingsPerXcd * 4 + 256;                          // ... and their owner words
     const size_t padded = (((size_t)n_frames + 7) / 8) * 8 * n_sig;           // encode indices (frames rounded up to 8)
@@ -1250,22 +1136,19 @@ static uint32_t resident_encode_blocks()
 
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames,
     size_t frames_cap, uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace,
-    hipStream_t stream, hipEvent_t* ev /* 2 events or nullptr */, uint64_t* d_phase_cycles, const EncodeHostLink* link /* or nullptr */,
+    hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles, uint64_t* d_mirror /* host-mapped or nullptr */,
     int force_plain_fir, int self_blocks_override)
 {
     const uint32_t n_sig = sela_hip_signals_per_frame(channels);
     const size_t blocks = (size_t)n_frames * n_sig;
-    const size_t n_groups = ((size_t)n_frames + kGroupFrames - 1) / kGroupFrames;
     unsigned char* ws = static_cast<unsigned char*>(d_workspace);
     ws = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     BlockMeta* meta = reinterpret_cast<BlockMeta*>(ws);
     ws += (blocks * sizeof(BlockMeta) + 255) & ~(size_t)255;
     uint32_t* slots = reinterpret_cast<uint32_t*>(ws);
     ws += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
-    uint64_t* group_count = reinterpret_cast<uint64_t*>(ws);
-    ws += (n_groups * sizeof(uint64_t) + 255) & ~(size_t)255;
-    GroupState* group_state = reinterpret_cast<GroupState*>(ws);
-    ws += (n_groups * sizeof(GroupState) + 255) & ~(size_t)255;
+    uint8_t* choice = ws;
+    ws += ((size_t)n_frames + 255) & ~(size_t)255;
     double* rings = reinterpret_cast<double*>(ws);
     ws += ((size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 255) & ~(size_t)255;
     uint32_t* ring_owner = reinterpret_cast<uint32_t*>(ws);
@@ -1275,11 +1158,11 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     ws += (padded * sizeof(double) + 255) & ~(size_t)255;
     uint32_t* mean_ready = reinterpret_cast<uint32_t*>(ws);
 
-    if (n_frames == 0) { // (nothing to launch; a job's stream position stays where it is)
+    if (n_frames == 0) {
         hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
-        if (err == hipSuccess && d_frame_offsets)
-            err = hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), stream);
-        return err;
+        if (err == hipSuccess && d_mirror)
+            err = hipMemsetAsync(d_mirror, 0, 2 * sizeof(uint64_t), stream);
+        return err != hipSuccess ? err : hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), stream);
     }
     const uint32_t groups = (n_frames + 7) / 8;
     const uint32_t total_e = groups * 8 * n_sig;
@@ -1297,40 +1180,29 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         n_workers = (n_workers + 7) & ~7u; // keeps encode index == workgroup index mod 8 (XCD placement)
     }
     const dim3 grid(n_workers + total_e), wg(64);
-    // launch ticket: unique per launch in this process, never 0 (rings, worker means, group counters and look-back
-    // cells all carry it, so nothing in the workspace is cleared between launches)
+    // ring ticket: unique per launch in this process, never 0 (see kRingLen)
     static std::atomic<uint32_t> next_ticket{ 0x5E1A0001u };
     uint32_t ticket = next_ticket.fetch_add(1, std::memory_order_relaxed);
     if (ticket == 0)
         ticket = next_ticket.fetch_add(1, std::memory_order_relaxed);
-    FuseArgs fa;
-    fa.meta = meta;
-    fa.slots = slots;
-    fa.group_count = group_count;
-    fa.group_state = group_state;
-    fa.frames = d_frames;
-    fa.frames_cap = frames_cap;
-    fa.frame_offsets = d_frame_offsets;
-    fa.mirror = link ? link->mirror : nullptr;
-    fa.status = d_status;
-    fa.stream_pos = link ? link->stream_pos : nullptr;
-    fa.group_done = link ? link->group_done : nullptr;
-    fa.n_frames = n_frames;
-    fa.channels = channels;
-    fa.n_sig = n_sig;
-    fa.ticket = ticket;
-    if (link)
-        *link->ticket_out = ticket;
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
-        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
+        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
     else if (d_trace)
-        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
+        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
     else
-        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
+        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
+    hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap,
+        d_frame_offsets, choice, d_status, d_mirror);
+    if (ev)
+        (void)hipEventRecord(ev[2], stream);
+    hipLaunchKernelGGL(k_assemble_frames, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets,
+        n_frames, channels, n_sig, frames_cap, d_frames);
+    if (ev)
+        (void)hipEventRecord(ev[3], stream);
     return hipGetLastError();
 }
 
