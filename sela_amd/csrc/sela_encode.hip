@@ -953,6 +953,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 // signal (src/frame/frame_encoder.cpp:64-72).
 constexpr int kPlanThreads = 1024;
 constexpr int kPlanLdsFrames = 12288; // frame sizes staged in LDS up to this batch size (48 KB)
+// The host pipeline's chunks (<= 1024 frames) get a plan of one wave and 4.5 KB of LDS: while the next chunk's blocks
+// fill the device (145 of a CU's 160 KB of LDS, 504 of a SIMD's 512 VGPRs) nothing larger finds a place -- the
+// 1024-thread, 57 KB plan waited 80-95 us for one (traced), the copy-out of the chunk behind it.
+constexpr int kSmallPlanThreads = 64;
+constexpr int kSmallPlanFrames = 1024;
 
 __device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t channels, uint32_t n_sig, uint32_t& choice,
     uint32_t& flags)
@@ -976,14 +981,15 @@ __device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t cha
     return words;
 }
 
-__global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
+template <int kThreads, int kTileFrames>
+__global__ __launch_bounds__(kThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* __restrict__ frame_offsets,
     uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status, uint64_t* __restrict__ mirror)
 {
     // mirror (optional, page-locked HOST memory): a copy of frame_offsets[0 .. n_frames] followed by one word
     // status[0] | status[1] << 32, so that the host pipeline reads a chunk's sizes without a copy of its own
-    __shared__ uint64_t part[kPlanThreads];
-    __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of the frames of one tile
+    __shared__ uint64_t part[kThreads];
+    __shared__ uint32_t frame_size[kTileFrames]; // bytes of the frames of one tile
     __shared__ uint32_t acc[2];                      // flags, frames that do not fit frames_cap
     const uint32_t tid = threadIdx.x;
     if (tid < 2)
@@ -993,25 +999,25 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
     // Tiles of kPlanLdsFrames frames.  Within a tile, frame f is sized by thread f mod 1024: the metadata loads of
     // one pass are independent and coalesced, and the passes do not depend on each other (a thread that walks
     // consecutive frames waits for memory once per frame: 0.45 ms for 61 k frames, against 10 us per tile).
-    for (uint32_t tile0 = 0; tile0 < n_frames; tile0 += kPlanLdsFrames) {
-        const uint32_t tile_n = min((uint32_t)kPlanLdsFrames, n_frames - tile0);
+    for (uint32_t tile0 = 0; tile0 < n_frames; tile0 += kTileFrames) {
+        const uint32_t tile_n = min((uint32_t)kTileFrames, n_frames - tile0);
         __syncthreads(); // the previous tile's sizes have been read
 #pragma unroll 4
-        for (uint32_t i = tid; i < tile_n; i += kPlanThreads) {
+        for (uint32_t i = tid; i < tile_n; i += kThreads) {
             uint32_t choice;
             const uint32_t words = frame_words(meta + (size_t)(tile0 + i) * n_sig, channels, n_sig, choice, flags);
             choice_out[tile0 + i] = (uint8_t)choice;
             frame_size[i] = (uint32_t)sela_frame_bytes(channels, words);
         }
         __syncthreads();
-        const uint32_t per = (tile_n + kPlanThreads - 1) / kPlanThreads;
+        const uint32_t per = (tile_n + kThreads - 1) / kThreads;
         const uint32_t begin = min(tid * per, tile_n), end = min(begin + per, tile_n);
         uint64_t bytes = 0;
         for (uint32_t i = begin; i < end; i++)
             bytes += frame_size[i];
         part[tid] = bytes;
         __syncthreads();
-        for (uint32_t d = 1; d < kPlanThreads; d <<= 1) { // Hillis-Steele inclusive scan
+        for (uint32_t d = 1; d < (uint32_t)kThreads; d <<= 1) { // Hillis-Steele inclusive scan
             const uint64_t v = tid >= d ? part[tid - d] : 0;
             __syncthreads();
             part[tid] += v;
@@ -1026,7 +1032,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
             if (off > frames_cap)
                 overflow++;
         }
-        base += part[kPlanThreads - 1];
+        base += part[kThreads - 1];
     }
     if (tid == 0) {
         frame_offsets[n_frames] = base;
@@ -1053,7 +1059,8 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
 // alignment (funnel shift below); the 5 bytes of the residue header realign the residue words.
 constexpr int kAsmThreads = 256;
 
-__global__ __launch_bounds__(kAsmThreads) void k_assemble_frames(const BlockMeta* __restrict__ meta,
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void k_assemble_frames(const BlockMeta* __restrict__ meta,
     const uint32_t* __restrict__ slots, const uint8_t* __restrict__ choice, const uint64_t* __restrict__ frame_offsets,
     uint32_t n_frames, uint32_t channels, uint32_t n_sig, size_t frames_cap, uint8_t* __restrict__ frames)
 {
@@ -1081,7 +1088,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_frames(const BlockMeta
         if (tid == 0)
             out[p] = c | (type << 8) | (parent << 16) | ((uint32_t)b.coef_k << 24);
         // words p+1 .. p+1+cw: [cw:16 | order:8] then the coefficient words shifted by 3 bytes, then res_k
-        for (uint32_t i = tid; i <= cw; i += kAsmThreads) {
+        for (uint32_t i = tid; i <= cw; i += kThreads) {
             const uint32_t low = i == 0 ? (cw | ((uint32_t)b.order << 16)) : (slot[i - 1] >> 8);
             const uint32_t top = i < cw ? slot[i] : (uint32_t)b.res_k;
             out[p + 1 + i] = (low & 0x00FFFFFFu) | (top << 24);
@@ -1090,7 +1097,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_frames(const BlockMeta
             out[p + 2 + cw] = rw | ((uint32_t)kBlock << 16);
         const uint32_t* rs = slot + kCoefWordsCap;
         uint32_t* ro = out + p + 3 + cw;
-        for (uint32_t i = tid; i < rw; i += kAsmThreads)
+        for (uint32_t i = tid; i < rw; i += kThreads)
             ro[i] = rs[i];
         p += 3 + cw + rw;
     }
@@ -1195,11 +1202,20 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap,
-        d_frame_offsets, choice, d_status, d_mirror);
+    // (chunks of the host pipeline: a plan small enough to start beside the next chunk's blocks, see kSmallPlanThreads.
+    // Tried on top of it: plan + assemble on a stream of higher priority -- they then start 19 us after the blocks end and
+    // take 33 us together, but the copy-outs need a stream of their own as well, and a fifth stream shares a hardware
+    // queue with one of the others; one-wave assemble workgroups -- 100 us instead of 50 beside the next chunk's blocks.)
+    const bool small = d_mirror != nullptr && n_frames <= (uint32_t)kSmallPlanFrames;
+    if (small)
+        hipLaunchKernelGGL((k_plan_frames<kSmallPlanThreads, kSmallPlanFrames>), dim3(1), dim3(kSmallPlanThreads), 0, stream, meta, n_frames, channels,
+            n_sig, frames_cap, d_frame_offsets, choice, d_status, d_mirror);
+    else
+        hipLaunchKernelGGL((k_plan_frames<kPlanThreads, kPlanLdsFrames>), dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig,
+            frames_cap, d_frame_offsets, choice, d_status, d_mirror);
     if (ev)
         (void)hipEventRecord(ev[2], stream);
-    hipLaunchKernelGGL(k_assemble_frames, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets,
+    hipLaunchKernelGGL(k_assemble_frames<kAsmThreads>, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets,
         n_frames, channels, n_sig, frames_cap, d_frames);
     if (ev)
         (void)hipEventRecord(ev[3], stream);
