@@ -18,6 +18,7 @@
 // FP64 accumulator is updated in the reference's order: the lanes of a wave carry *independent*
 // accumulators (autocorrelation lags, Schur columns, step-up elements), never a split of one sum.
 #include <atomic>
+#include <random>
 
 #include "sela_device.h"
 
@@ -367,7 +368,8 @@ constexpr uint32_t kMeanWaitSpins = 24;   // x s_sleep 16 (~1000 cycles each): ~
 
 __device__ __forceinline__ void block_of(uint32_t e, uint32_t n_sig, uint32_t& frame, uint32_t& sig)
 {
-    // XCD-aware: hardware places workgroup b on XCD b % 8, so the signals of one frame are given encode indices
+    // XCD-aware: consecutive workgroups of a launch go round the eight XCDs in turn (where a launch starts on that round
+    // is not fixed: it continues from the launch before), so the signals of one frame are given encode indices
     // that are equal mod 8 and share that XCD's L2 copy of the PCM (the worker prefix is a multiple of 8)
     const uint32_t per_group = 8 * n_sig;
     const uint32_t grp = e / per_group, rem = e % per_group;
@@ -499,7 +501,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         for (uint32_t spin = 0; spin < kMeanWaitSpins; spin++) {
             // (polled relaxed: an acquire per poll invalidates the vector cache under every co-resident wave)
             if (__hip_atomic_load(mean_ready + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ticket) {
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                // (order only: the mean below is loaded past the L2 as well, and the worker's release -- an L2 write-back --
+                // put it in memory before the ready word.  An acquire fence here would drop this XCD's clean L2 lines once
+                // per block.)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 have_mean = true;
                 break;
             }
@@ -1187,8 +1192,14 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         n_workers = (n_workers + 7) & ~7u; // keeps encode index == workgroup index mod 8 (XCD placement)
     }
     const dim3 grid(n_workers + total_e), wg(64);
-    // ring ticket: unique per launch in this process, never 0 (see kRingLen)
-    static std::atomic<uint32_t> next_ticket{ 0x5E1A0001u };
+    // launch ticket: unique per launch in this process, never 0 (ring owner words and the mean workers' ready words carry
+    // it, so the workspace is never cleared).  The count starts at a random number: device memory keeps its contents from
+    // one process to the next, and with a fixed start another process's ready words -- and its means -- would carry the
+    // very tickets of this one.
+    static std::atomic<uint32_t> next_ticket{ [] {
+        std::random_device rd;
+        return ((uint32_t)rd() ^ ((uint32_t)rd() << 16)) | 1u;
+    }() };
     uint32_t ticket = next_ticket.fetch_add(1, std::memory_order_relaxed);
     if (ticket == 0)
         ticket = next_ticket.fetch_add(1, std::memory_order_relaxed);
