@@ -242,8 +242,8 @@ def test_host_pointer_api(gpu):
 
 
 def test_host_pointer_api_chunked_pipeline(gpu):
-    """Batches of two chunks and more go through the three-stream copy-in / kernels / copy-out pipeline
-    (sela_capi.hip: 1024 frames per chunk encoding, 4096 decoding): same bytes as the device-pointer call
+    """Batches of two chunks and more go through the copy-in / kernels / copy-out pipeline (sela_capi.hip:
+    chunks of <= 768 frames encoding, 384 / 640 / 1024 decoding): same bytes as the device-pointer call
     on the whole batch, including a short last chunk, and a corrupt frame in a later chunk is still reported."""
     from sela_amd import capi, codec
 
