@@ -142,8 +142,9 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
 
 /* ---- streaming jobs (host pointers) -------------------------------------------------------------------
  * For callers that produce their input piece by piece (a file being read): feed() enqueues a piece and
- * returns at once -- from page-locked buffers nothing in it waits for the device except the hand-over of
- * a buffer set two chunks back -- so the caller's next read runs beside the device work.  One open job per
+ * returns at once -- from page-locked buffers nothing in it waits for the device until one of the eight
+ * chunk buffer sets comes round again -- so the caller's next read runs beside the device work.  A piece's
+ * buffer must stay valid and unchanged until the job reports its frames final (or ends).  One open job per
  * calling thread; a job is used from the thread that began it.
  *
  * encode: the job appends to frames_out (capacity frames_cap) and fills frame_offsets_out[0 .. total_frames];
