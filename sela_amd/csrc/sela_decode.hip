@@ -59,7 +59,7 @@ constexpr int kCoefLanes = 4;       // lanes of a wave that parse the coefficien
 constexpr int kResLanes = kWave - kCoefLanes;
 // Aligned words of one subframe the segment-parallel parser takes: coefficient words + 2 + residue words
 // (start bitmap: one bit per stream bit; positions must fit 16 bits).
-constexpr int kStreamCap = 1200;
+constexpr int kStreamCap = 1144;
 constexpr int kStreamMargin = 4;    // a window may run this many words past the end (they read as zero)
 constexpr uint32_t kEndOfStream = 0xFFFFFFFFu;
 
@@ -78,8 +78,15 @@ struct SynthTables {
 };
 struct DecWaveScratch {
     SynthTables t;
-    int32_t q[128];
+    // (the parsed coefficient values q[0 .. order) live inside t, see coef_values(): between the parse, whose scratch lies
+    // in front of them, and the dequantisation, which reads them into registers before k[] and a[] are written)
 };
+constexpr int kCoefValuesAt = 1152; // byte offset in SynthTables: behind the parse's positions, chain table and flags, inside a[]
+static_assert(kCoefValuesAt + 128 * 4 <= 104 * 8 * 2, "the coefficient values must lie inside k[] / a[]");
+__device__ __forceinline__ int32_t* coef_values(DecWaveScratch* s)
+{
+    return reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(&s->t) + kCoefValuesAt);
+}
 // per subframe POSITION (not per wave: the combine pass reads every channel)
 union DecSubframeLds {
     uint32_t marks[kStreamCap + kStreamMargin]; // start bitmap (parse)
@@ -788,14 +795,14 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
             if (kProf)
                 stamp[2] = clock64(), prof_sub = c;
             const StreamWords sw = { gw, nw };
-            flags |= parse_subframe<kProf>(sw, sl->marks, sl->pos, reinterpret_cast<uint16_t*>(&scratch->t), scratch->q, hd.cw, hd.rw, hd.ck, hd.rk,
+            flags |= parse_subframe<kProf>(sw, sl->marks, sl->pos, reinterpret_cast<uint16_t*>(&scratch->t), coef_values(scratch), hd.cw, hd.rw, hd.ck, hd.rk,
                 hd.order, lane, pp);
         } else {
             if (kProf)
                 stamp[2] = clock64(), prof_sub = c;
             int32_t* const wres = ws_residues + ((size_t)f * channels + c) * kBlock;
             const uint32_t n_frame_words = (uint32_t)((fbytes - hd.p - 4) / 4);
-            flags |= parse_stream_serial(gw, 24, 24 + 32 * hd.cw, n_frame_words, hd.ck, hd.order, scratch->q, lane);
+            flags |= parse_stream_serial(gw, 24, 24 + 32 * hd.cw, n_frame_words, hd.ck, hd.order, coef_values(scratch), lane);
             flags |= parse_stream_serial(gw, 32 * (hd.cw + 2), 32 * (hd.cw + 2 + hd.rw), n_frame_words, hd.rk, (uint32_t)kBlock, wres, lane);
             __threadfence(); // lane 0's stores to the workspace are read back by every lane
             ws_c = wres;
@@ -807,7 +814,7 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
         // dequantise (src/lpc/linear_predictor.cpp:16-28) + step-up
         SynthTables* const tables = &scratch->t;
         const uint32_t order = hd.order;
-        const int32_t q_lo = (uint32_t)lane < order ? scratch->q[lane] : 0, q_hi = (uint32_t)lane + 64 < order ? scratch->q[lane + 64] : 0;
+        const int32_t q_lo = (uint32_t)lane < order ? coef_values(scratch)[lane] : 0, q_hi = (uint32_t)lane + 64 < order ? coef_values(scratch)[lane + 64] : 0;
         wave_sync();
         if ((uint32_t)lane < order)
             tables->k[lane] = order <= 1 ? 0.0 : dequant(lane, q_lo, flags);

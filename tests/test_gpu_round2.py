@@ -58,7 +58,7 @@ def _decode_frames_vs_oracle(gpu, frames, channels=1):
 
 
 def test_segment_parallel_parser_on_hard_streams(gpu, kats):
-    """Hand-built subframes that stay inside the decoder's LDS plan (<= 1200 aligned words), so they are
+    """Hand-built subframes that stay inside the decoder's LDS plan (<= 1144 aligned words), so they are
     parsed by the segment-parallel path: unary-only coding, residue streams shorter than the wave has zones,
     a unary run longer than several zones, orders 0 / 1 / 100, streams of exactly the plan's capacity and one
     word over it (generic mode), all against the oracle's decoder."""
@@ -83,7 +83,7 @@ def test_segment_parallel_parser_on_hard_streams(gpu, kats):
     rk = 7
     rw = _rice_words(base, rk)
     ck, cw = oracle().rice_encode(np.asarray(q_sine, np.int32))
-    for total in (1200, 1201):
+    for total in (1144, 1145):
         pad = total - (len(cw) + 2 + len(rw))
         assert pad > 0
         words = np.concatenate([rw, np.zeros(pad, np.uint32)])
@@ -429,7 +429,7 @@ def test_parser_on_random_valid_streams(gpu, kats):
         q = np.asarray(q[: int(rng.integers(1, len(q) + 1))], np.int32)
         words = _rice_words(r, k)
         ck, cw = oracle().rice_encode(q)
-        if len(cw) + 2 + len(words) > 1200:  # keep it inside the fast plan (generic mode has its own tests)
+        if len(cw) + 2 + len(words) > 1144:  # keep it inside the fast plan (generic mode has its own tests)
             continue
         frames.append(struct.pack("<I", 0xAA55FF00) + struct.pack("<BBBBHB", 0, 0, 0, ck, len(cw), len(q)) + cw.astype("<u4").tobytes()
                       + struct.pack("<BHH", k, len(words), 2048) + words.astype("<u4").tobytes())
