@@ -72,7 +72,8 @@ struct PinnedPool {
         } else {
             b.cap = (bytes + 4095) & ~(size_t)4095;
             b.ptr = nullptr;
-            b.pinned = hipHostMalloc(&b.ptr, b.cap, hipHostMallocDefault) == hipSuccess && b.ptr;
+            // (portable: the pool is shared by the worker threads of every device)
+            b.pinned = hipHostMalloc(&b.ptr, b.cap, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && b.ptr;
             if (!b.pinned) { // no device (CPU-only container code still runs): ordinary memory
                 (void)hipGetLastError();
                 b.ptr = std::aligned_alloc(4096, b.cap);
@@ -147,7 +148,7 @@ struct HostBuffer {
             return hipSuccess;
         release();
         const size_t want = bytes + bytes / 4 + 4096;
-        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocPortable | hipHostMallocMapped);
         if (e == hipSuccess)
             cap = want;
         else
