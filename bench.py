@@ -354,13 +354,18 @@ def main():
     k_enc, k_dec = [], []
     pcm0 = batches[0]
     n0 = int(pcm0.shape[0])
+    o2 = enc.encode(pcm0) if n0 else None
     for _ in range(max(5, min(args.steps, 20)) if n0 else 0):
-        # three launches back to back, the LAST one timed: its kernels start on a busy, clocked-up device like those of
-        # the timed region (a launch onto an idle device runs ~10 % slower and disagrees with the rocprofv3 averages)
-        for _ in range(3):
+        # The timed kernel runs where it runs in a step: the encoder behind a decode, the decoder behind an encode, two
+        # steps queued so that it starts on a busy, clocked-up device (a launch onto an idle device runs ~10 % slower;
+        # an encoder behind an encoder 6 % slower than behind a decoder -- the device's clock follows the power the last
+        # kernel drew -- and it is behind a decoder that the rocprofv3 averages of the timed loop see it).
+        for _ in range(2):
+            dec.decode(o2.frames, o2.offsets, n0)
             o2 = enc.encode(pcm0)
         k_enc.append(capi.kernel_times(3))
-        for _ in range(3):
+        for _ in range(2):
+            o2 = enc.encode(pcm0)
             dec.decode(o2.frames, o2.offsets, n0)
         k_dec.append(capi.kernel_times(1))
     lib.sela_hip_enable_kernel_timing(0)
