@@ -175,7 +175,7 @@ constexpr uint32_t kRunStreams = 2;
 
 struct ChunkSet {
     DeviceBuffer pcm, frames, offsets, workspace;
-    HostBuffer host_offsets; // encode: k_plan_frames' mirror of offsets + status; decode: the chunk's rebased offsets
+    HostBuffer host_offsets; // encode: k_plan_frames' mirror of offsets + status (a decode job stages its offsets in job_offsets_host)
     uint64_t* mirror_dev = nullptr; // device address of host_offsets
     void* mirror_host = nullptr;
     hipEvent_t copied_in = nullptr, ran = nullptr, copied_out = nullptr;
