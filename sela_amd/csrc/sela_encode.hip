@@ -375,12 +375,11 @@ constexpr uint32_t kMeanWaitSpins = 24;   // x s_sleep 16 (~1000 cycles each): ~
 
 __device__ __forceinline__ void block_of(uint32_t e, uint32_t n_sig, uint32_t& frame, uint32_t& sig)
 {
-    // XCD-aware: hardware places workgroup b on XCD b % 8 (and the worker / stager prefix is a multiple of 8), so encode
-    // index e runs on XCD e % 8.  ALL blocks of a group of eight frames (kGroupFrames) get indices that are equal mod 8:
-    // the signals of a frame share that XCD's L2 copy of the PCM, and -- what finish_group rests on -- everything the
-    // group's blocks write for its last block to read stays inside ONE L2, which is coherent for the CUs below it.  (The
-    // L2s of different XCDs are not coherent with each other: see the note at store_through.)  Eight groups, one per XCD,
-    // advance side by side: a "span" of 64 frames.
+    // XCD-aware, for speed only: as observed, workgroup b lands on XCD (b + where the launch started) % 8, so encode
+    // indices that are equal mod 8 (the worker prefix is a multiple of 8) run on one XCD.  ALL blocks of a group of
+    // eight frames (kGroupFrames) get such indices: the signals of a frame share that XCD's L2 copy of the PCM, and
+    // what the group's blocks hand to its last block does not cross the chip.  Nothing is correct because of this
+    // (see the note at store_through).  Eight groups, one per XCD, advance side by side: a "span" of 64 frames.
     const uint32_t per_group = 8 * n_sig, per_span = 8 * per_group;
     const uint32_t span = e / per_span, rem = e % per_span;
     const uint32_t xcd = rem % 8, j = rem / 8; // j: the block's number inside its group
@@ -389,16 +388,21 @@ __device__ __forceinline__ void block_of(uint32_t e, uint32_t n_sig, uint32_t& f
 }
 
 // ---- handing data to another workgroup -------------------------------------------------------------------------------
-// The eight XCDs' L2 caches are not coherent with each other.  The textbook hand-over -- plain stores, a release fence at
-// agent scope, a flag -- writes back EVERY dirty line of the writer's L2 (buffer_wbl2), and this kernel keeps its
-// scalar-operand rings dirty in L2 on purpose: with one such fence per block the launch took 2.36 ms instead of 0.41.
-// Storing the data through the L2 instead (sc1 stores, waited for with s_waitcnt before the flag) was fast and passed
-// every test but one run in some hundred, in which the reader got one stale word: a store's acknowledgement is not
-// a promise that another XCD's load sees it.  So bulk data is only ever handed over INSIDE one XCD (block_of puts a
-// group's blocks, and stage_in a frame's stager, on the XCD of the reader: one L2, coherent once a store is
-// acknowledged), and what crosses XCDs are single 64-bit words that carry their own validity (launch tag | payload,
-// written and read past the L2 by relaxed atomics): such a word is either there or not yet, there is no order between
-// two stores to rely on.
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility".)  The eight XCDs' L2 caches
+// are not coherent with each other and a CU's vector cache is never refreshed by another CU's stores.  The textbook
+// hand-over -- plain stores, a release fence at agent scope, a flag -- writes back EVERY dirty line of the writer's L2
+// (buffer_wbl2), and this kernel keeps its scalar-operand rings dirty in L2 on purpose: with one such fence per block
+// the launch took 2.36 ms instead of 0.41.  What the one-launch form hands from workgroup to workgroup therefore goes
+//   producer: stores THROUGH the L2 (relaxed atomic stores at agent scope = sc1) -> asm s_waitcnt vmcnt(0) (written
+//             out: a fence's own wait is dropped by the compiler when it believes nothing is outstanding -- the first
+//             version, with a workgroup-scope fence here, handed over one stale word in some hundred runs and stalled
+//             or not depending on an unrelated line of code) -> the mark, a relaxed atomic at agent scope;
+//   consumer: sees the mark with a relaxed atomic -> ONE acquire fence at agent scope (invalidates this CU's vector
+//             cache) -> plain loads: a group's last block, once per group.  Where every block would need one (the frame
+//             from the stagers) the consumer loads past the L2 as well, which the producer's write-through stores allow;
+// and the look-back cells are single 64-bit words that say themselves whether they are valid (launch mark | payload,
+// relaxed atomics on both sides): such a word is either there or not yet.  Where workgroups land (block_of keeps a
+// group's blocks on one XCD) is for speed only; nothing here is correct because of it.
 template <typename T>
 __device__ __forceinline__ void store_through(T* p, T v)
 {
@@ -409,16 +413,13 @@ __device__ __forceinline__ T load_through(const T* p)
 {
     return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void stores_done() // (this wave's stores have been acknowledged by the L2)
+__device__ __forceinline__ void stores_done() // (every store of this wave so far has been acknowledged)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ void drop_stale_lines() // (nothing older than now is served from this CU's vector cache)
 {
-    // The data was written inside this XCD, so only the CU's own cache could be behind (and hardly that: it allocates
-    // on loads only, and nothing here has loaded these lines before).  An acquire fence at agent scope would also
-    // drop every clean line of the L2 -- the other blocks' samples, and the rings once a write-back has cleaned them.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_inv sc0" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // ---- stagers: a second kernel fetches the PCM from page-locked host memory (host pipeline, stereo) ---------------
@@ -461,12 +462,17 @@ __global__ __launch_bounds__(kStageThreads) void k_stage_in(const int16_t* __res
     // with frames dealt out in advance (wave w: frames w, w + 128, ...) some waves were at their fifteenth frame when
     // others were at their third, and the blocks, which start in frame order, sat waiting for the slow waves' frames
     // while frames far ahead lay ready.
+    // Every lane adds 1 and the wave takes frame (lane 0's old value) / 64: the compiler folds the 64 additions into one
+    // fetch-and-add of 64 (and 64 of them would be as correct).  The obvious form -- lane 0 adds 1, readfirstlane hands
+    // the frame to the others -- is what the first version had, next to the flag store below, also lane 0's: the
+    // compiler fused the two lane-0 regions across the loop's back edge and sent lanes 1..63 round again with the 0
+    // they had been given "for now" -- a stager kernel that never ended, or not, depending on an unrelated line in the
+    // loop.  No value leaves a one-lane region here any more.
+    // (A compare-and-swap loop instead of the add: 128 waves took turns, a frame per 1.4 us.)
     uint64_t* const next = started + 1; // (zeroed by the launcher on this stream)
     for (;;) {
-        uint32_t f = 0;
-        if (lane == 0) // (one fetch-and-add each: with a compare-and-swap loop 128 waves took turns, a frame per 1.4 us)
-            f = (uint32_t)__hip_atomic_fetch_add(next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+        const uint64_t drawn = __hip_atomic_fetch_add(next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(drawn >> 6));
         if (f >= n_frames)
             break;
         const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(host_pcm) + (size_t)f * n16;
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(kStageThreads) void k_stage_in(const int16_t* __res
         }
         sum = wave_sum_small(sum); // (mod 2^32)
         stores_done();
-        if (lane == 0)
+        if (lane == 0) // (nothing comes back out of this one-lane region)
             store_through(pcm_ready + f, ((uint64_t)ticket << 32) | sum);
     }
 }
@@ -592,9 +598,10 @@ __device__ __attribute__((noinline)) void mean_worker(const int16_t* __restrict_
     }
     const double mean = sum / (double)kBlock;
     if (live) {
-        // (two words, for blocks on any XCD: a real release -- one L2 write-back per worker, not per block)
+        // (two words for blocks on any XCD, both past the L2 on both sides)
         store_through(reinterpret_cast<uint64_t*>(mean_out) + e, __builtin_bit_cast(uint64_t, mean));
-        __hip_atomic_store(mean_ready + e, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        stores_done();
+        store_through(mean_ready + e, tag);
     }
 }
 
@@ -849,14 +856,13 @@ __device__ __forceinline__ void assemble_group(const FuseArgs& fa, uint32_t f0, 
 // layout -- matches a tag with probability 2^-40 here and 2^-62 .. 2^-64 in the other cells).
 __device__ __forceinline__ bool group_arrive(uint64_t* cell, uint64_t tag, uint32_t blocks_in_group)
 {
-    // Every block of the group runs on one XCD (block_of), so the count lives in that XCD's L2: atomics at workgroup
-    // scope execute there.  (At agent scope they go out to memory, and the 11,625 of a 3,875-frame launch -- sixteen
-    // counters to a cache line -- added 77 us to it.)
+    // (agent scope: where the group's blocks run is not ours to rely on.  One counter per 128-byte line -- sixteen to
+    // a line, the 11,625 updates of a 3,875-frame launch added 77 us to it.)
     const uint64_t mark = (tag * 0x9E3779B97F4A7C15ull) & ~(uint64_t)0xFFFFFF; // (blocks_in_group <= 8 * 256 < 2^24)
-    uint64_t old = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint64_t old = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         const uint64_t neu = (old & ~(uint64_t)0xFFFFFF) == mark ? old + 1 : (mark | 1u);
-        if (__hip_atomic_compare_exchange_strong(cell, &old, neu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+        if (__hip_atomic_compare_exchange_strong(cell, &old, neu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             return (uint32_t)(neu & 0xFFFFFF) == blocks_in_group;
     }
 }
@@ -1031,7 +1037,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             const uint32_t* fp2 = reinterpret_cast<const uint32_t*>(fp);
 #pragma unroll
             for (int t = 0; t < kPerLane; t++) {
-                const uint32_t w = fp2[lane + 64 * t];
+                // (behind the stagers: past the L2 like await_frame's check -- an acquire fence here instead, one per block,
+                // cost the 3,875-frame call 0.24 ms)
+                const uint32_t w = fa.pcm_ready ? load_through(fp2 + lane + 64 * t) : fp2[lane + 64 * t];
                 const int32_t l = (int16_t)(w & 0xFFFFu), r = (int16_t)(w >> 16);
                 s[t] = sig == 0 ? l : (sig == 1 ? r : l - r); // src/frame/frame_encoder.cpp:22-24
             }
@@ -1473,12 +1481,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     SELA_STAMP(11);
     // ---- slot + meta -------------------------------------------------------------------------------------
-    // (plain stores: the group's last block, which reads them, runs on this XCD -- block_of)
     uint32_t* slot = slots + (size_t)block_id * kSlotWords;
-    if (lane < (int)coef_words && lane < kCoefWordsCap)
-        slot[lane] = cw_buf[lane];
-    for (uint32_t w = lane; w < res_words; w += 64)
-        slot[kCoefWordsCap + w] = out_words[w];
+    if (fa.group_count) { // host pipeline: the group's last block reads them in this launch -- through the L2 (store_through)
+        uint64_t* const slot2 = reinterpret_cast<uint64_t*>(slot);
+        if (lane < kCoefWordsCap / 2) // (all 32 coefficient words: what lies behind coef_words is never read)
+            store_through(slot2 + lane, (uint64_t)cw_buf[2 * lane] | ((uint64_t)cw_buf[2 * lane + 1] << 32));
+        const uint64_t* const out2 = reinterpret_cast<const uint64_t*>(out_words);
+        for (uint32_t w2 = lane; w2 < (res_words + 1) / 2; w2 += 64)
+            store_through(slot2 + kCoefWordsCap / 2 + w2, out2[w2]);
+    } else {
+        if (lane < (int)coef_words && lane < kCoefWordsCap)
+            slot[lane] = cw_buf[lane];
+        for (uint32_t w = lane; w < res_words; w += 64)
+            slot[kCoefWordsCap + w] = out_words[w];
+    }
     const uint32_t all_flags = wave_or(flags);
     if (lane == 0) {
         BlockMeta bm;
@@ -1488,7 +1504,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         bm.flags = (uint8_t)all_flags;
         bm.coef_words = (uint16_t)coef_words;
         bm.res_words = (uint16_t)res_words;
-        meta[block_id] = bm;
+        if (fa.group_count)
+            store_through(reinterpret_cast<uint64_t*>(meta + block_id), __builtin_bit_cast(uint64_t, bm));
+        else
+            meta[block_id] = bm;
         if (kTrace) {
             sela_hip_trace* tr = trace + block_id;
             tr->coef_k = coef_k;
@@ -1503,12 +1522,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (fa.group_count) {
         const uint32_t g = frame / kGroupFrames;
         const uint32_t blocks_in_group = min((uint32_t)kGroupFrames, n_frames - g * kGroupFrames) * n_sig;
-        stores_done(); // the slot and the BlockMeta of every lane are in this XCD's L2, before the count
+        stores_done(); // the slot and the BlockMeta of every lane, before the count
         uint32_t last = 0;
         if (lane == 0)
             last = group_arrive(fa.group_count + (size_t)g * kGroupCountStride, fa.tag, blocks_in_group) ? 1u : 0u;
         if (__builtin_amdgcn_readfirstlane((int)last)) {
-            drop_stale_lines(); // (the other blocks' slots and metas are in the L2 above this CU)
+            drop_stale_lines(); // (the other blocks' slots and metas are in memory: nothing older may come from this CU's cache)
             finish_group(fa, g, lane);
         }
     }
