@@ -994,7 +994,8 @@ __device__ __attribute__((noinline)) void finish_group(const FuseArgs& fa, uint3
             stamp[n] = clock64();     \
     } while (0)
 
-template <int kMode>
+// kFused: the host pipeline's one-launch form (await_frame, finish_group); compiled out of the device-pointer path's kernel
+template <int kMode, bool kFused>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
     double* __restrict__ rings, uint32_t* __restrict__ ring_owner, uint32_t ticket, sela_hip_trace* __restrict__ trace,
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         return;
     const uint32_t block_id = frame * n_sig + sig;
     uint32_t flags = 0;
-    if (fa.pcm_ready && !await_frame(fa.pcm_ready, pcm, frame, ticket))
+    if (kFused && fa.pcm_ready && !await_frame(fa.pcm_ready, pcm, frame, ticket))
         flags |= SELA_HIP_FLAG_INTERNAL;
 
     double* const E = reinterpret_cast<double*>(big) + kPadC;              // first half: E[-64 .. 575]
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for (int t = 0; t < kPerLane; t++) {
                 // (behind the stagers: past the L2 like await_frame's check -- an acquire fence here instead, one per block,
                 // cost the 3,875-frame call 0.24 ms)
-                const uint32_t w = fa.pcm_ready ? load_through(fp2 + lane + 64 * t) : fp2[lane + 64 * t];
+                const uint32_t w = (kFused && fa.pcm_ready) ? load_through(fp2 + lane + 64 * t) : fp2[lane + 64 * t];
                 const int32_t l = (int16_t)(w & 0xFFFFu), r = (int16_t)(w >> 16);
                 s[t] = sig == 0 ? l : (sig == 1 ? r : l - r); // src/frame/frame_encoder.cpp:22-24
             }
@@ -1482,7 +1483,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     SELA_STAMP(11);
     // ---- slot + meta -------------------------------------------------------------------------------------
     uint32_t* slot = slots + (size_t)block_id * kSlotWords;
-    if (fa.group_count) { // host pipeline: the group's last block reads them in this launch -- through the L2 (store_through)
+    if (kFused) { // host pipeline: the group's last block reads them in this launch -- through the L2 (store_through)
         uint64_t* const slot2 = reinterpret_cast<uint64_t*>(slot);
         if (lane < kCoefWordsCap / 2) // (all 32 coefficient words: what lies behind coef_words is never read)
             store_through(slot2 + lane, (uint64_t)cw_buf[2 * lane] | ((uint64_t)cw_buf[2 * lane + 1] << 32));
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         bm.flags = (uint8_t)all_flags;
         bm.coef_words = (uint16_t)coef_words;
         bm.res_words = (uint16_t)res_words;
-        if (fa.group_count)
+        if (kFused)
             store_through(reinterpret_cast<uint64_t*>(meta + block_id), __builtin_bit_cast(uint64_t, bm));
         else
             meta[block_id] = bm;
@@ -1519,7 +1520,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
     SELA_STAMP(12);
     // ---- host pipeline: count this block into its group; the group's last block places and writes the group's frames
-    if (fa.group_count) {
+    if (kFused) {
         const uint32_t g = frame / kGroupFrames;
         const uint32_t blocks_in_group = min((uint32_t)kGroupFrames, n_frames - g * kGroupFrames) * n_sig;
         stores_done(); // the slot and the BlockMeta of every lane, before the count
@@ -1734,6 +1735,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     ws += (padded * sizeof(double) + 255) & ~(size_t)255;
     uint64_t* mean_ready = reinterpret_cast<uint64_t*>(ws);
 
+    if (link && (d_trace || d_phase_cycles))
+        return hipErrorInvalidValue; // (the analysis trace and the phase counts are the device-pointer path's)
     if (n_frames == 0) { // (nothing to launch; a job's stream position stays where it is)
         hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
         if (err == hipSuccess && d_frame_offsets)
@@ -1799,11 +1802,13 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
-        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
+        hipLaunchKernelGGL((k_encode_blocks<2, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     else if (d_trace)
-        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
+        hipLaunchKernelGGL((k_encode_blocks<1, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
+    else if (link)
+        hipLaunchKernelGGL((k_encode_blocks<0, true>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     else
-        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
+        hipLaunchKernelGGL((k_encode_blocks<0, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     if (!link) {
