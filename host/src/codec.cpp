@@ -50,8 +50,10 @@ void streamEncode(std::ifstream* in, int16_t* pcm, size_t frames, uint32_t chann
         if (sela_hip_encode_begin(&job, channels, (uint32_t)frames, bytes.data(), bytes.size(), offsets.data()) != SELA_HIP_OK)
             gpuFailure("Encoder");
         int rc = SELA_HIP_OK;
-        for (size_t f0 = 0; f0 < frames && rc == SELA_HIP_OK; f0 += kPieceFrames) {
-            const size_t nf = std::min<size_t>(kPieceFrames, frames - f0);
+        // (a feed is one kernel launch: samples that are in memory already go in one piece)
+        const size_t piece = in ? kPieceFrames : std::max<size_t>(frames, 1);
+        for (size_t f0 = 0; f0 < frames && rc == SELA_HIP_OK; f0 += piece) {
+            const size_t nf = std::min<size_t>(piece, frames - f0);
             if (in && f0 + nf > readFrames) { // the device works on the earlier pieces while this one is read
                 if (!readExact(*in, pcm + f0 * frameSamples, nf * frameSamples * 2)) {
                     (void)sela_hip_encode_end(job, nullptr, nullptr);

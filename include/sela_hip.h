@@ -142,9 +142,10 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
 
 /* ---- streaming jobs (host pointers) -------------------------------------------------------------------
  * For callers that produce their input piece by piece (a file being read): feed() enqueues a piece and
- * returns at once -- from page-locked buffers nothing in it waits for the device until one of the eight
- * chunk buffer sets comes round again -- so the caller's next read runs beside the device work.  A piece's
- * buffer must stay valid and unchanged until the job reports its frames final (or ends).  One open job per
+ * returns at once -- from page-locked buffers nothing in it waits for the device (an encode feed is one kernel
+ * launch; a decode feed waits when one of its eight chunk buffer sets comes round again) -- so the caller's next
+ * read runs beside the device work.  A piece's buffer must stay valid and unchanged until the job reports its
+ * frames final (or ends); pieces in ordinary memory are copied to page-locked memory first.  One open job per
  * calling thread; a job is used from the thread that began it.
  *
  * encode: the job appends to frames_out (capacity frames_cap) and fills frame_offsets_out[0 .. total_frames];
@@ -197,6 +198,7 @@ void sela_hip_debug_mean_workers(int self_blocks);
 #define SELA_HIP_FLAG_RICE_OVERRUN 8u  /* decoder ran past the end of a Rice stream */
 #define SELA_HIP_FLAG_WORDS_CAP 16u    /* a Rice stream exceeded the per-block slot (encoder) */
 #define SELA_HIP_FLAG_BAD_FRAME 32u    /* bad sync word / inconsistent subframe header (decoder) */
+#define SELA_HIP_FLAG_INTERNAL 64u     /* a bounded wait inside a kernel ran out (never expected; reported as SELA_HIP_ENODEV) */
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ namespace sela {
 size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
-    hipEvent_t* ev, uint64_t* d_phase_cycles, uint64_t* d_mirror, int force_plain_fir, int self_blocks_override);
+    hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles,
     uint8_t* frame_flags);
@@ -72,8 +72,7 @@ struct PinnedPool {
         } else {
             b.cap = (bytes + 4095) & ~(size_t)4095;
             b.ptr = nullptr;
-            // (portable: the pool is shared by the worker threads of every device)
-            b.pinned = hipHostMalloc(&b.ptr, b.cap, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && b.ptr;
+            b.pinned = hipHostMalloc(&b.ptr, b.cap, hipHostMallocDefault) == hipSuccess && b.ptr;
             if (!b.pinned) { // no device (CPU-only container code still runs): ordinary memory
                 (void)hipGetLastError();
                 b.ptr = std::aligned_alloc(4096, b.cap);
@@ -148,10 +147,11 @@ struct HostBuffer {
             return hipSuccess;
         release();
         const size_t want = bytes + bytes / 4 + 4096;
-        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocPortable | hipHostMallocMapped);
-        if (e == hipSuccess)
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        if (e == hipSuccess) {
             cap = want;
-        else
+            std::memset(ptr, 0, want); // (tickets and flags the device leaves here are compared with what was there before)
+        } else
             ptr = nullptr;
         return e;
     }
@@ -173,17 +173,19 @@ constexpr uint32_t kHostChunkFrames = 1024; // (buffers are sized for this; chun
 constexpr uint32_t kSets = 8;
 constexpr uint32_t kRunStreams = 2;
 
-struct ChunkSet {
-    DeviceBuffer pcm, frames, offsets, workspace;
-    HostBuffer host_offsets; // encode: k_plan_frames' mirror of offsets + status (a decode job stages its offsets in job_offsets_host)
-    uint64_t* mirror_dev = nullptr; // device address of host_offsets
-    void* mirror_host = nullptr;
+struct ChunkSet { // one chunk of a decode job in flight
+    DeviceBuffer pcm, frames, workspace;
     hipEvent_t copied_in = nullptr, ran = nullptr, copied_out = nullptr;
 };
 
 struct HostContext {
     ChunkSet set[kSets];
-    DeviceBuffer status;      // encode: 4 words per buffer set
+    DeviceBuffer status;      // device-side status words (decode kernels of a job report through job_flags instead)
+    // encode jobs: one launch per feed (see job_feed_encode)
+    DeviceBuffer enc_pcm, enc_workspace, enc_ready, enc_words; // enc_words: the job's stream position (two cells in turn), 4 status words, the stagers' roll call
+    hipEvent_t enc_prev = nullptr; // behind the newest work on the encode stream
+    HostBuffer enc_mirror;                                     // page-locked: offsets + status per feed
+    uint64_t* enc_mirror_mapped = nullptr;
     HostBuffer job_offsets_host; // decode: the frame offsets of every feed of the running job, where the kernels read them
     HostBuffer job_flags;     // decode: one byte per (frame, wave), zeroed by the host, written by the kernels (over the link) on errors only
     const uint64_t* job_offsets_mapped = nullptr; // device addresses of the two host buffers
@@ -209,15 +211,15 @@ struct HostContext {
     hipError_t streams()
     {
         hipError_t e = hipSuccess;
-        for (hipStream_t* s : { &s_in, &s_run[0], &s_run[1] })
+        for (hipStream_t* s : { &s_in, &s_run[0], &s_run[1], &s_out })
             if (!*s && (e = hipStreamCreateWithFlags(s, hipStreamNonBlocking)) != hipSuccess)
                 return e;
-        if (!s_out && (e = hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking)) != hipSuccess)
-            return e;
         for (ChunkSet& c : set)
             for (hipEvent_t* ev : { &c.copied_in, &c.ran, &c.copied_out })
                 if (!*ev && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
                     return e;
+        if (!enc_prev)
+            e = hipEventCreateWithFlags(&enc_prev, hipEventDisableTiming);
         return e;
     }
     // decode: a chunk's kernel and copy-out share a stream, three streams in turn (the fourth copies in)
@@ -237,10 +239,7 @@ struct HostContext {
         for (ChunkSet& c : set) {
             c.pcm.release();
             c.frames.release();
-            c.offsets.release();
             c.workspace.release();
-            c.host_offsets.release();
-            c.mirror_host = nullptr;
             for (hipEvent_t* ev : { &c.copied_in, &c.ran, &c.copied_out }) {
                 if (*ev)
                     (void)hipEventDestroy(*ev);
@@ -248,6 +247,14 @@ struct HostContext {
             }
         }
         status.release();
+        if (enc_prev)
+            (void)hipEventDestroy(enc_prev);
+        enc_prev = nullptr;
+        enc_pcm.release();
+        enc_workspace.release();
+        enc_ready.release();
+        enc_words.release();
+        enc_mirror.release();
         job_offsets_host.release();
         job_flags.release();
         for (hipStream_t* s : { &s_in, &s_out, &s_run[0], &s_run[1] }) {
@@ -299,7 +306,8 @@ uint32_t run_streams()
 // Size of chunk number `index` of a job that has `available` frames at hand.  A decode job opens with two shorter
 // chunks: its copy-outs run back to back from the moment the first chunk is done, so the job is as long as the way
 // to that moment plus the bare copy of the PCM -- provided every later chunk is decoded by the time the copy-out
-// before it ends, which is what keeps the first chunks from being shorter still.
+// before it ends, which is what keeps the first chunks from being shorter still.  (For encode jobs short first / last chunks and sizes halving towards
+// the end were tried: more chunks cost more in kernel efficiency than the shorter fill and drain save.)
 // SELA_HOST_CHUNK_PLAN="a,b,c" sets the sizes of the first chunks of every job (experiments).
 uint32_t next_chunk_frames(bool encode, uint32_t index, uint32_t available)
 {
@@ -321,14 +329,6 @@ uint32_t next_chunk_frames(bool encode, uint32_t index, uint32_t available)
         want = plan[index];
     else if (plan.empty() && !encode && index < 2)
         want = std::min<uint32_t>(want, index ? 640u : 384u);
-    else if (plan.empty() && encode) {
-        // 768 frames, and shorter towards the end: what follows a chunk's last byte in -- its kernels, the hand-over of
-        // its sizes, its copy-out -- is the tail of the job (measured with every stream on a hardware queue of its own:
-        // 1.00 ms for 1024-frame chunks, 0.91-0.93 for this shape; below 512 frames a chunk's kernels do not get shorter)
-        want = std::min<uint32_t>(want, 768u);
-        if (available < 2 * want)
-            want = std::max<uint32_t>(384u, available * 11u / 20u);
-    }
     if (want < available && available - want < want / 4) // (no stub of a last chunk: split what is left in two)
         want = (available + 1) / 2;
     return want < available ? want : available;
@@ -342,25 +342,36 @@ uint32_t flags_to_error(uint32_t flags)
 } // namespace
 
 // ---- streaming jobs ----------------------------------------------------------------------------------------
+struct EncodeFeed {      // one feed of an encode job = one launch
+    uint32_t first = 0, n_frames = 0;
+    size_t mirror_at = 0;        // where the launch reports (offsets, status) in g_ctx.enc_mirror
+    hipEvent_t done = nullptr;   // recorded behind the launch
+    void* bounce_in = nullptr;   // page-locked copy of a feed that came from ordinary memory
+};
+
 struct sela_hip_job {
     bool encode = false;
     uint32_t channels = 0, total_frames = 0;
     uint32_t fed = 0;      // frames handed to feed() so far
-    uint32_t issued = 0;   // chunks whose copy-in and kernels are enqueued
-    uint32_t drained = 0;  // chunks whose copy-out is enqueued
+    int error = SELA_HIP_OK;
+    // ---- decode: chunks
+    uint32_t issued = 0;       // chunks whose copies and kernel are enqueued
     uint32_t final_chunks = 0; // chunks whose results are complete in host memory
     std::vector<uint32_t> chunk_first, chunk_frames; // per issued chunk
-    std::vector<uint64_t> chunk_end_byte;            // encode: output bytes up to and including the chunk
-    // encode
-    uint8_t* frames_out = nullptr;
+    int16_t* pcm_out = nullptr;
+    size_t offsets_used = 0; // entries of g_ctx.job_offsets_host taken by the feeds so far
+    // ---- encode: feeds
+    uint8_t* frames_out = nullptr; // the caller's buffer
     size_t frames_cap = 0;
     uint64_t* offsets_out = nullptr;
-    uint64_t bytes_issued = 0; // output bytes of the drained chunks
-    size_t chunk_bound = 0;
-    // decode
-    int16_t* pcm_out = nullptr;
-    size_t offsets_used = 0; // entries of g_ctx.job_offsets taken by the feeds so far
-    int error = SELA_HIP_OK;
+    uint8_t* out_host = nullptr;   // where the kernels' stores land as the host sees it: frames_out, or a page-locked bounce buffer
+    uint8_t* out_mapped = nullptr; // ... as the device sees it
+    bool out_bounce = false;
+    std::vector<EncodeFeed> feeds;
+    size_t mirror_used = 0;
+    uint32_t feeds_final = 0; // feeds whose launch has finished: their bytes and offsets are complete in host memory
+    uint32_t frames_final = 0;
+    uint64_t bytes_final = 0, bytes_copied = 0; // (bytes_copied: bounce buffer -> frames_out)
 };
 
 namespace {
@@ -372,7 +383,7 @@ int job_fail(sela_hip_job* job, int code)
     return code;
 }
 
-// Results of chunk `i` are in host memory once its copy-out has finished.
+// Results of decode chunk `i` are in host memory once its copy-out has finished.
 int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
 {
     while (job->final_chunks < upto) {
@@ -386,99 +397,174 @@ int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
     return SELA_HIP_OK;
 }
 
-// Encode jobs: enqueue the copy-out of the oldest issued chunk (its kernels must have finished: the byte count
-// is needed on the host).  A decode chunk's copy-out is queued with the chunk (job_issue_decode).
-int job_drain_one(sela_hip_job* job)
+hipError_t reserve_chunk_buffers(uint32_t channels)
 {
-    const uint32_t i = job->drained;
-    ChunkSet& c = g_ctx.set[i % kSets];
-    const uint32_t nf = job->chunk_frames[i], first = job->chunk_first[i];
-    hipError_t e = hipEventSynchronize(c.ran);
-    if (e != hipSuccess)
-        return job_fail(job, fail_hip(e, "kernels"));
-    {
-        const uint64_t* mirror = static_cast<const uint64_t*>(c.host_offsets.ptr); // offsets[0..nf], then status[0] | status[1] << 32
-        const uint64_t st = mirror[nf + 1];
-        const uint32_t flags = (uint32_t)st, overflow = (uint32_t)(st >> 32);
-        if (flags_to_error(flags)) {
-            char msg[160];
-            std::snprintf(msg, sizeof msg, "a block left the range the .sela format can carry (flags 0x%x)", flags);
-            return job_fail(job, fail(SELA_HIP_ERANGE, msg));
-        }
-        const uint64_t total = mirror[nf];
-        if (overflow || job->bytes_issued + total > job->frames_cap)
-            return job_fail(job, fail(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes)"));
-        for (uint32_t f = 0; f <= nf; f++)
-            job->offsets_out[(size_t)first + f] = job->bytes_issued + mirror[f];
-        if (total && (e = hipMemcpyAsync(job->frames_out + job->bytes_issued, c.frames.ptr, (size_t)total, hipMemcpyDeviceToHost, g_ctx.s_out)) != hipSuccess)
-            return job_fail(job, fail_hip(e, "D2H frames"));
-        job->bytes_issued += total;
-        job->chunk_end_byte.push_back(job->bytes_issued);
-    }
-    if ((e = hipEventRecord(c.copied_out, g_ctx.s_out)) != hipSuccess)
-        return job_fail(job, fail_hip(e, "hipEventRecord"));
-    job->drained++;
-    return SELA_HIP_OK;
-}
-
-hipError_t reserve_chunk_buffers(bool encode, uint32_t channels, size_t frames_bytes)
-{
-    hipError_t e = g_ctx.streams();
-    if (e != hipSuccess)
-        return e;
     const size_t frame_pcm = (size_t)sela::kBlock * channels * sizeof(int16_t);
     for (ChunkSet& c : g_ctx.set) {
-        if ((e = c.pcm.reserve(kHostChunkFrames * frame_pcm + 16)) != hipSuccess || (e = c.frames.reserve(frames_bytes + 16)) != hipSuccess
-            || (e = c.offsets.reserve(((size_t)kHostChunkFrames + 1) * 8)) != hipSuccess
-            || (e = c.host_offsets.reserve(((size_t)kHostChunkFrames + 2) * 8)) != hipSuccess)
-            return e;
-        if ((e = c.workspace.reserve(encode ? sela::encode_workspace_bytes(kHostChunkFrames, channels)
-                                            : sela::decode_workspace_bytes(kHostChunkFrames, channels))) != hipSuccess)
+        hipError_t e;
+        if ((e = c.pcm.reserve(kHostChunkFrames * frame_pcm + 16)) != hipSuccess
+            || (e = c.workspace.reserve(sela::decode_workspace_bytes(kHostChunkFrames, channels))) != hipSuccess)
             return e;
     }
     return hipSuccess;
 }
 
-// One chunk (<= kHostChunkFrames frames) into the pipeline.
-int job_issue_encode(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
+// The address the device uses for page-locked host memory, or null for ordinary (pageable) memory.
+void* device_view(const void* host)
 {
-    const uint32_t i = job->issued;
-    ChunkSet& c = g_ctx.set[i % kSets];
-    const hipStream_t s_run = g_ctx.s_run[i % run_streams()];
+    hipPointerAttribute_t attr;
+    void* dev = nullptr;
+    if (host && hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost
+        && hipHostGetDevicePointer(&dev, const_cast<void*>(host), 0) == hipSuccess)
+        return dev;
+    (void)hipGetLastError(); // (not an error: the caller falls back to a bounce buffer)
+    return nullptr;
+}
+
+// ---- encode jobs ---------------------------------------------------------------------------------------------------
+// One feed = one launch of k_encode_blocks, everything in it: the launch's first workgroups fetch the feed's PCM
+// from page-locked host memory frame by frame (stage_in), the blocks encode each frame as it lands, and the last
+// block of every group of frames (kGroupFrames) writes the group's finished bytes straight to their place in frames_out
+// and their offsets to page-locked memory (finish_group).  No copy engine, no hand-over: the host enqueues one kernel
+// per feed and an event behind it; a feed's bytes and offsets are final when its event has fired.  Feeds run one
+// after the other on one stream; the job's stream position passes from launch to launch in device memory
+// (enc_words).  Buffers that are not page-locked go through page-locked bounce buffers.
+constexpr uint32_t kStageWorkgroups = 8;         // of k_stage_in, 16 waves each: 128 waves copy in (55.9 GB/s from 128 waves up, tools/pcie_probe.hip)
+constexpr uint32_t kEncodeLaunchFrames = 1u << 16; // a feed larger than this is cut (device buffers are sized for it)
+
+int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
+{
     const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
+    const hipStream_t s = g_ctx.s_run[0];
     hipError_t e;
-    // chunk i - kSets used this set: drained (so its kernels have read pcm and the host has read its sizes);
-    // its frames must have left the device before the kernels overwrite them (copied_out)
-    if (i >= kSets) {
-        while (job->drained + kSets <= i) {
-            const int rc = job_drain_one(job);
-            if (rc != SELA_HIP_OK)
-                return rc;
+    EncodeFeed feed;
+    feed.first = job->fed;
+    feed.n_frames = nf;
+    feed.mirror_at = job->mirror_used;
+    const void* src = device_view(pcm);
+    if (!src) { // ordinary memory: through a page-locked copy (kept until the job ends)
+        feed.bounce_in = pool().take(nf * frame_pcm);
+        if (!feed.bounce_in)
+            return job_fail(job, fail(SELA_HIP_ENOMEM, "page-locked bounce buffer"));
+        std::memcpy(feed.bounce_in, pcm, nf * frame_pcm);
+        if (!(src = device_view(feed.bounce_in))) {
+            pool().give(feed.bounce_in);
+            return job_fail(job, fail(SELA_HIP_ENODEV, "page-locked memory is not visible to the device"));
         }
-        if ((e = hipStreamWaitEvent(s_run, c.copied_out, 0)) != hipSuccess)
-            return job_fail(job, fail_hip(e, "hipStreamWaitEvent"));
     }
-    // (copies in job order on ONE stream: spread over the kernel streams they share the link and every chunk
-    // arrives late)
-    const hipStream_t s_copy = g_ctx.s_in;
-    if ((e = hipMemcpyAsync(c.pcm.ptr, pcm, nf * frame_pcm, hipMemcpyHostToDevice, s_copy)) != hipSuccess
-        || (e = hipEventRecord(c.copied_in, s_copy)) != hipSuccess || (e = hipStreamWaitEvent(s_run, c.copied_in, 0)) != hipSuccess)
-        return job_fail(job, fail_hip(e, "H2D pcm"));
-    if (c.mirror_host != c.host_offsets.ptr) { // (looked up once per allocation)
-        if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c.mirror_dev), c.host_offsets.ptr, 0)) != hipSuccess)
-            return job_fail(job, fail_hip(e, "hipHostGetDevicePointer"));
-        c.mirror_host = c.host_offsets.ptr;
+    // (grow-only; the launches of a job run in order on one stream, so growing waits for the last one)
+    const size_t need_pcm = nf * frame_pcm + 16, need_ws = sela::encode_workspace_bytes(nf, job->channels), need_ready = (size_t)nf * 8;
+    if (need_pcm > g_ctx.enc_pcm.cap || need_ws > g_ctx.enc_workspace.cap || need_ready > g_ctx.enc_ready.cap) {
+        if ((e = hipStreamSynchronize(s)) != hipSuccess || (e = g_ctx.enc_pcm.reserve(need_pcm)) != hipSuccess
+            || (e = g_ctx.enc_workspace.reserve(need_ws)) != hipSuccess || (e = g_ctx.enc_ready.reserve(need_ready)) != hipSuccess
+            // (the "frame copied in" words carry the bare ticket -- and a checksum -- and another process's tickets count from the same start)
+            || (e = hipMemsetAsync(g_ctx.enc_ready.ptr, 0, g_ctx.enc_ready.cap, s)) != hipSuccess) {
+            if (feed.bounce_in)
+                pool().give(feed.bounce_in);
+            return job_fail(job, fail_hip(e, "hipMalloc"));
+        }
     }
-    uint64_t* d_mirror = c.mirror_dev;
-    uint32_t* d_status = static_cast<uint32_t*>(g_ctx.status.ptr) + 4 * (size_t)(i % kSets);
-    e = sela::launch_encode(static_cast<const int16_t*>(c.pcm.ptr), nf, job->channels, static_cast<uint8_t*>(c.frames.ptr), job->chunk_bound,
-        static_cast<uint64_t*>(c.offsets.ptr), d_status, c.workspace.ptr, nullptr, s_run, nullptr, nullptr, d_mirror, g_force_plain_fir, g_self_blocks);
-    if (e != hipSuccess || (e = hipEventRecord(c.ran, s_run)) != hipSuccess)
+    sela::EncodeHostLink link;
+    link.mirror = g_ctx.enc_mirror_mapped + feed.mirror_at;
+    // (two cells in turn: a launch reads where the one before left the stream and leaves its own end in the other)
+    uint64_t* const pos = static_cast<uint64_t*>(g_ctx.enc_words.ptr);
+    link.pos_in = pos + (job->feeds.size() & 1);
+    link.pos_out = pos + ((job->feeds.size() + 1) & 1);
+    link.host_pcm = static_cast<const int16_t*>(src);
+    link.pcm_ready = static_cast<uint64_t*>(g_ctx.enc_ready.ptr);
+    link.stage_workgroups = kStageWorkgroups;
+    link.stage_stream = g_ctx.s_in;
+    link.stage_started = pos + 4;
+    // what fills the device's copy of the PCM waits for the launch before this one, which reads it (and for the
+    // allocation that may just have cleared the marks)
+    if ((e = hipEventRecord(g_ctx.enc_prev, s)) != hipSuccess || (e = hipStreamWaitEvent(g_ctx.s_in, g_ctx.enc_prev, 0)) != hipSuccess) {
+        if (feed.bounce_in)
+            pool().give(feed.bounce_in);
+        return job_fail(job, fail_hip(e, "hipStreamWaitEvent"));
+    }
+    if (job->channels != 2) { // (the stagers copy stereo frames; anything else goes in by the copy engine, ahead of the launch)
+        if ((e = hipMemcpyAsync(g_ctx.enc_pcm.ptr, feed.bounce_in ? feed.bounce_in : pcm, nf * frame_pcm, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
+            || (e = hipEventRecord(g_ctx.enc_prev, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s, g_ctx.enc_prev, 0)) != hipSuccess) {
+            if (feed.bounce_in)
+                pool().give(feed.bounce_in);
+            return job_fail(job, fail_hip(e, "H2D pcm"));
+        }
+        link.host_pcm = nullptr;
+    }
+    uint32_t* d_status = reinterpret_cast<uint32_t*>(pos + 2);
+    e = sela::launch_encode(static_cast<const int16_t*>(g_ctx.enc_pcm.ptr), nf, job->channels, job->out_mapped, job->frames_cap, nullptr, d_status,
+        g_ctx.enc_workspace.ptr, nullptr, s, nullptr, nullptr, &link, g_force_plain_fir, g_self_blocks);
+    if (e == hipSuccess && (e = hipEventCreateWithFlags(&feed.done, hipEventDisableTiming)) == hipSuccess)
+        e = hipEventRecord(feed.done, s);
+    if (e != hipSuccess) {
+        if (feed.bounce_in)
+            pool().give(feed.bounce_in);
+        if (feed.done)
+            (void)hipEventDestroy(feed.done);
         return job_fail(job, fail_hip(e, "encode launch"));
-    job->chunk_first.push_back(job->fed);
-    job->chunk_frames.push_back(nf);
-    job->issued++;
+    }
+    job->mirror_used += (size_t)nf + 2;
     job->fed += nf;
+    job->feeds.push_back(feed);
+    return SELA_HIP_OK;
+}
+
+int job_feed_encode(sela_hip_job* job, const int16_t* pcm, uint32_t n_frames)
+{
+    const size_t frame_samples = (size_t)sela::kBlock * job->channels;
+    for (uint32_t done = 0; done < n_frames;) {
+        const uint32_t nf = std::min(kEncodeLaunchFrames, n_frames - done);
+        const int rc = job_feed_encode_launch(job, pcm + done * frame_samples, nf);
+        if (rc != SELA_HIP_OK)
+            return rc;
+        done += nf;
+    }
+    return SELA_HIP_OK;
+}
+
+// How far the stream has got in host memory: the feeds, in order, whose launch has finished.  Fills offsets_out for
+// their frames, and moves their bytes out of the bounce buffer if there is one.  (Finer steps -- a word per group of
+// frames written by the kernel behind the group's bytes -- were dropped with the release fence they need: it costs an
+// L2 write-back per group.)
+int job_encode_progress(sela_hip_job* job, bool wait)
+{
+    const uint64_t* mirror = static_cast<const uint64_t*>(g_ctx.enc_mirror.ptr);
+    while (job->feeds_final < job->feeds.size()) {
+        const EncodeFeed& f = job->feeds[job->feeds_final];
+        const hipError_t q = wait ? hipEventSynchronize(f.done) : hipEventQuery(f.done);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            break;
+        }
+        if (q != hipSuccess)
+            return job_fail(job, fail_hip(q, "encode kernels"));
+        const uint64_t* m = mirror + f.mirror_at;
+        const uint64_t st = m[f.n_frames + 1];
+        const uint32_t flags = (uint32_t)st, overflow = (uint32_t)(st >> 32);
+        if (flags & SELA_HIP_FLAG_INTERNAL)
+            return job_fail(job, fail(SELA_HIP_ENODEV, "a wait inside the encode kernel ran out (internal error)"));
+        if (flags_to_error(flags)) {
+            char msg[160];
+            std::snprintf(msg, sizeof msg, "a block left the range the .sela format can carry (flags 0x%x)", flags);
+            return job_fail(job, fail(SELA_HIP_ERANGE, msg));
+        }
+        for (uint32_t i = 0; i <= f.n_frames; i++)
+            job->offsets_out[(size_t)f.first + i] = m[i];
+        uint32_t fits = f.n_frames; // (a frame that ends beyond the capacity was not written, nor was any frame behind it)
+        while (fits > 0 && m[fits] > job->frames_cap)
+            fits--;
+        if (m[fits] <= job->frames_cap) {
+            job->frames_final = f.first + fits;
+            job->bytes_final = m[fits];
+        }
+        if (job->out_bounce && job->bytes_final > job->bytes_copied) {
+            std::memcpy(job->frames_out + job->bytes_copied, job->out_host + job->bytes_copied, (size_t)(job->bytes_final - job->bytes_copied));
+            job->bytes_copied = job->bytes_final;
+        }
+        if (overflow)
+            return job_fail(job, fail(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes)"));
+        job->feeds_final++;
+    }
     return SELA_HIP_OK;
 }
 
@@ -529,7 +615,6 @@ int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* o
     job->chunk_first.push_back(job->fed);
     job->chunk_frames.push_back(nf);
     job->issued++;
-    job->drained = job->issued;
     job->fed += nf;
     return SELA_HIP_OK;
 }
@@ -554,29 +639,31 @@ int job_feed_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* of
     return SELA_HIP_OK;
 }
 
-// Copy out every chunk whose kernels have already finished, without waiting for any that has not; what has
-// arrived in host memory by now is final.
+// Decode: which chunks have arrived in host memory by now (no waiting).
 int job_drain_ready(sela_hip_job* job)
 {
-    while (job->drained < job->issued && hipEventQuery(g_ctx.set[job->drained % kSets].ran) == hipSuccess) {
-        const int rc = job_drain_one(job);
-        if (rc != SELA_HIP_OK)
-            return rc;
-    }
-    (void)hipGetLastError(); // (hipErrorNotReady from the query is not an error)
-    while (job->final_chunks < job->drained && hipEventQuery(g_ctx.set[job->final_chunks % kSets].copied_out) == hipSuccess)
+    if (job->encode)
+        return job_encode_progress(job, false);
+    while (job->final_chunks < job->issued && hipEventQuery(g_ctx.set[job->final_chunks % kSets].copied_out) == hipSuccess)
         job->final_chunks++;
-    (void)hipGetLastError();
+    (void)hipGetLastError(); // (hipErrorNotReady from the query is not an error)
     return SELA_HIP_OK;
 }
 
 void job_progress(const sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
 {
+    if (job->encode) {
+        if (frames_final)
+            *frames_final = job->frames_final;
+        if (bytes_final)
+            *bytes_final = job->bytes_final;
+        return;
+    }
     const uint32_t n = job->final_chunks;
     if (frames_final)
         *frames_final = n ? job->chunk_first[n - 1] + job->chunk_frames[n - 1] : 0;
     if (bytes_final)
-        *bytes_final = (job->encode && n) ? job->chunk_end_byte[n - 1] : 0;
+        *bytes_final = 0;
 }
 
 int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total_frames)
@@ -595,13 +682,20 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
         return fail(SELA_HIP_ENODEV, "hipGetDevice failed");
     if (g_ctx.job_open)
         return fail(SELA_HIP_EINVAL, "this thread already has an open job");
-    const size_t bound = sela_hip_encode_bound_bytes(kHostChunkFrames, channels);
-    hipError_t e = reserve_chunk_buffers(encode, channels, encode ? bound : 0);
+    hipError_t e = g_ctx.streams();
     if (e == hipSuccess)
-        e = g_ctx.status.reserve(16 * (size_t)kSets); // (encode: four words per buffer set, mirrored to the host by k_plan_frames)
+        e = g_ctx.status.reserve(16);
+    if (e == hipSuccess && encode) {
+        // (offsets + status per feed, a feed has at least a frame)
+        if ((e = g_ctx.enc_mirror.reserve((3 * (size_t)total_frames + 4) * 8)) == hipSuccess
+            && (e = g_ctx.enc_words.reserve(16 + 16 + 16)) == hipSuccess
+            && (e = hipHostGetDevicePointer((void**)&g_ctx.enc_mirror_mapped, g_ctx.enc_mirror.ptr, 0)) == hipSuccess)
+            e = hipMemsetAsync(g_ctx.enc_words.ptr, 0, 16 + 16 + 16, g_ctx.s_run[0]); // the job's stream position: 0
+    }
     if (e == hipSuccess && !encode) {
         const size_t n_flags = (size_t)total_frames * sela::decode_waves(channels) + 1;
-        if ((e = g_ctx.job_offsets_host.reserve((2 * (size_t)total_frames + 2) * 8)) == hipSuccess
+        if ((e = reserve_chunk_buffers(channels)) == hipSuccess
+            && (e = g_ctx.job_offsets_host.reserve((2 * (size_t)total_frames + 2) * 8)) == hipSuccess
             && (e = g_ctx.job_flags.reserve(n_flags)) == hipSuccess
             && (e = hipHostGetDevicePointer((void**)&g_ctx.job_offsets_mapped, g_ctx.job_offsets_host.ptr, 0)) == hipSuccess
             && (e = hipHostGetDevicePointer((void**)&g_ctx.job_flags_mapped, g_ctx.job_flags.ptr, 0)) == hipSuccess)
@@ -613,7 +707,6 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
     job->encode = encode;
     job->channels = channels;
     job->total_frames = total_frames;
-    job->chunk_bound = bound;
     g_ctx.job_open = true;
     *out = job;
     return SELA_HIP_OK;
@@ -622,10 +715,23 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
 int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
 {
     int rc = job->error;
-    while (rc == SELA_HIP_OK && job->drained < job->issued)
-        rc = job_drain_one(job);
-    if (rc == SELA_HIP_OK)
-        rc = job_finalize(job, job->drained);
+    hipError_t e = hipSuccess;
+    if (job->encode) {
+        // (also after an error: nothing of the job may still be running when its buffers go back)
+        if ((e = hipStreamSynchronize(g_ctx.s_run[0])) != hipSuccess && rc == SELA_HIP_OK)
+            rc = fail_hip(e, "encode kernels");
+        if (rc == SELA_HIP_OK)
+            rc = job_encode_progress(job, true);
+        for (EncodeFeed& f : job->feeds) {
+            if (f.bounce_in)
+                pool().give(f.bounce_in);
+            if (f.done)
+                (void)hipEventDestroy(f.done);
+        }
+        if (job->out_bounce && job->out_host)
+            pool().give(job->out_host);
+    } else if (rc == SELA_HIP_OK)
+        rc = job_finalize(job, job->issued);
     uint32_t seen_flags = 0;
     if (rc == SELA_HIP_OK && !job->encode && job->issued) {
         // every frame is decoded (bad ones to silence) before the verdict; the kernels left their flags in host memory
@@ -779,10 +885,26 @@ int sela_hip_encode_begin(sela_hip_job** job, uint32_t channels, uint32_t total_
     int rc = job_begin(job, true, channels, total_frames);
     if (rc != SELA_HIP_OK)
         return rc;
-    (*job)->frames_out = frames_out;
-    (*job)->frames_cap = frames_cap;
-    (*job)->offsets_out = frame_offsets_out;
+    sela_hip_job* j = *job;
+    j->frames_out = frames_out;
+    j->frames_cap = frames_cap;
+    j->offsets_out = frame_offsets_out;
     frame_offsets_out[0] = 0;
+    // the kernels store the stream where the device can reach it: the caller's buffer if it is page-locked,
+    // otherwise a page-locked bounce buffer (no larger than the job can need)
+    j->out_host = frames_out;
+    j->out_mapped = static_cast<uint8_t*>(device_view(frames_out));
+    if (total_frames && !j->out_mapped) {
+        j->frames_cap = std::min(frames_cap, sela_hip_encode_bound_bytes(total_frames, channels));
+        j->out_host = static_cast<uint8_t*>(pool().take(j->frames_cap ? j->frames_cap : 1));
+        j->out_bounce = true;
+        j->out_mapped = j->out_host ? static_cast<uint8_t*>(device_view(j->out_host)) : nullptr;
+        if (!j->out_mapped) {
+            (void)job_end(j, nullptr, nullptr);
+            *job = nullptr;
+            return fail(SELA_HIP_ENOMEM, "page-locked bounce buffer");
+        }
+    }
     return SELA_HIP_OK;
 }
 
@@ -792,15 +914,10 @@ int sela_hip_encode_feed(sela_hip_job* job, const int16_t* pcm, uint32_t n_frame
         return fail(SELA_HIP_EINVAL, "bad argument");
     if (job->error != SELA_HIP_OK)
         return job->error;
-    const size_t frame_samples = (size_t)sela::kBlock * job->channels;
-    for (uint32_t done = 0; done < n_frames;) {
-        const uint32_t nf = next_chunk_frames(true, job->issued, n_frames - done);
-        int rc = job_issue_encode(job, pcm + done * frame_samples, nf);
-        if (rc != SELA_HIP_OK)
-            return rc;
-        done += nf;
-    }
-    const int rc = job_drain_ready(job);
+    int rc = job_feed_encode(job, pcm, n_frames);
+    if (rc != SELA_HIP_OK)
+        return rc;
+    rc = job_drain_ready(job);
     if (rc != SELA_HIP_OK)
         return rc;
     job_progress(job, frames_final, bytes_final);

@@ -22,6 +22,7 @@ constexpr int kMaxOrder = SELA_MAX_LPC_ORDER;
 constexpr int kCoefWordsCap = 32;           // 100 values * (1 + 6 + 1) bits = 25 words worst case
 constexpr int kResWordsCap = 2208;          // > 34 bits per sample; 16-bit audio needs <= ~1216
 constexpr int kSlotWords = kCoefWordsCap + kResWordsCap; // 2240 words per (frame, signal) slot
+constexpr int kGroupFrames = 8;             // frames whose bytes one block (the last of theirs to finish) places and writes
 
 // One record per (frame, signal) written by the block-encode kernel.
 struct BlockMeta {
@@ -33,6 +34,19 @@ struct BlockMeta {
     uint16_t res_words;
 };
 static_assert(sizeof(BlockMeta) == 8, "BlockMeta is read as one 8-byte word");
+
+// What the host pipeline hands an encode launch (launch_encode): where the launch reports to the host, where the
+// job's stream position lives, and -- when the PCM is still in page-locked host memory -- where to fetch it from.
+struct EncodeHostLink {
+    uint64_t* mirror;        // page-locked, as the device sees it: a copy of frame_offsets[0..n_frames] + one status word
+    const uint64_t* pos_in;  // device word: offset of the launch's first frame in the job's stream
+    uint64_t* pos_out;       // device word (another one): the launch leaves the offset behind its last frame here
+    const int16_t* host_pcm; // page-locked stereo PCM as the device sees it (k_stage_in copies it in), or null: the PCM is on the device
+    uint64_t* pcm_ready;     // device: [n_frames] <- launch ticket | checksum, frame copied in
+    uint32_t stage_workgroups; // of k_stage_in, each with a CU to itself
+    hipStream_t stage_stream;  // where k_stage_in runs (not the encode launch's stream: the two may run side by side)
+    uint64_t* stage_started;   // device word: launch ticket | stager workgroups that have a CU
+};
 
 // Order LDS traffic between the lanes of ONE wave (a wave executes in lockstep and the LDS serves a
 // wave's instructions in order, so this only has to stop the compiler from moving accesses and make

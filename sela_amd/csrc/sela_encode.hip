@@ -1,24 +1,29 @@
 // sela_encode.hip -- MI355X (gfx950) encoder kernels of the SELA frame path.
 //
-// Pipeline for a batch of frames (three launches on one stream):
+// ONE launch for a batch of frames, k_encode_blocks:
 //
-//   k_encode_blocks   one WAVE per (frame, signal): the whole of lpc::ResidueGenerator +
+//   a block           one WAVE per (frame, signal): the whole of lpc::ResidueGenerator +
 //                     rice::RiceEncoder x2 for that signal (reference src/lpc/residue_generator.cpp:
 //                     121-134, src/rice/rice_encoder.cpp:73-81).  A stereo frame has three signals
 //                     (ch0, ch1, ch0-ch1; src/frame/frame_encoder.cpp:18-60); all three are coded and
 //                     the loser is simply not copied out.  Output: a fixed-stride slot of Rice
 //                     words + an 8-byte BlockMeta per signal.
-//   k_plan_frames     one workgroup: per frame, the stereo decision of src/frame/frame_encoder.cpp:
-//                     64-72 (strict < on u32 word counts) and the frame's on-disk size, then an
-//                     exclusive scan of the sizes -> frame_offsets[].
-//   k_assemble_frames one workgroup per frame: writes the exact byte stream that
-//                     file::SelaFile::writeToFile emits for the frame (src/file/sela_file.cpp:115-135).
+//   a group's last    the block that finishes LAST among those of 16 consecutive frames (finish_group):
+//   block             per frame the stereo decision of src/frame/frame_encoder.cpp:64-72 (strict < on
+//                     u32 word counts) and the frame's on-disk size; the group's place in the stream by a
+//                     decoupled look-back over the groups before it; then the exact bytes that
+//                     file::SelaFile::writeToFile emits for its frames (src/file/sela_file.cpp:115-135),
+//                     written where they belong -- device memory, or the caller's page-locked buffer.
+//   mean workers,     the first workgroups of the launch (mean_worker, stage_in).
+//   stagers
 //
 // Arithmetic contract: this file must be compiled with -ffp-contract=off.  Every
 // FP64 accumulator is updated in the reference's order: the lanes of a wave carry *independent*
 // accumulators (autocorrelation lags, Schur columns, step-up elements), never a split of one sum.
+#include <algorithm>
 #include <atomic>
 #include <random>
+#include <vector>
 
 #include "sela_device.h"
 
@@ -364,21 +369,190 @@ __device__ __attribute__((noinline)) void fir_plain(int order, int lane, const i
 // XCDs).  Blocks below self_blocks -- the ones that start with the launch, before any worker could have finished --
 // walk their own chain as before; so does any block whose ready word has not turned up after a bounded wait, so
 // no block ever depends on another workgroup making progress.
+constexpr uint32_t kFuseSpinLimit = 1u << 18; // bounded waits on other groups: x (s_sleep 64 + a trip to memory, ~4 us) = ~1 s, then the launch flags an error instead of hanging
+constexpr uint32_t kFuseNapLimit = 600000;  // waits for the stagers: x 2048 cycles = ~0.5 s
 constexpr uint32_t kMeanWaitSpins = 24;   // x s_sleep 16 (~1000 cycles each): ~10 us, then the block computes its own mean
 
 __device__ __forceinline__ void block_of(uint32_t e, uint32_t n_sig, uint32_t& frame, uint32_t& sig)
 {
-    // XCD-aware: consecutive workgroups of a launch go round the eight XCDs in turn (where a launch starts on that round
-    // is not fixed: it continues from the launch before), so the signals of one frame are given encode indices
-    // that are equal mod 8 and share that XCD's L2 copy of the PCM (the worker prefix is a multiple of 8)
-    const uint32_t per_group = 8 * n_sig;
-    const uint32_t grp = e / per_group, rem = e % per_group;
-    sig = rem / 8;
-    frame = grp * 8 + (rem % 8);
+    // XCD-aware, for speed only: as observed, workgroup b lands on XCD (b + where the launch started) % 8, so encode
+    // indices that are equal mod 8 (the worker prefix is a multiple of 8) run on one XCD.  ALL blocks of a group of
+    // eight frames (kGroupFrames) get such indices: the signals of a frame share that XCD's L2 copy of the PCM, and
+    // what the group's blocks hand to its last block does not cross the chip.  Nothing is correct because of this
+    // (see the note at store_through).  Eight groups, one per XCD, advance side by side: a "span" of 64 frames.
+    const uint32_t per_group = 8 * n_sig, per_span = 8 * per_group;
+    const uint32_t span = e / per_span, rem = e % per_span;
+    const uint32_t xcd = rem % 8, j = rem / 8; // j: the block's number inside its group
+    sig = j / 8;
+    frame = (span * 8 + xcd) * 8 + (j % 8);
+}
+
+// ---- handing data to another workgroup -------------------------------------------------------------------------------
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility".)  The eight XCDs' L2 caches
+// are not coherent with each other and a CU's vector cache is never refreshed by another CU's stores.  The textbook
+// hand-over -- plain stores, a release fence at agent scope, a flag -- writes back EVERY dirty line of the writer's L2
+// (buffer_wbl2), and this kernel keeps its scalar-operand rings dirty in L2 on purpose: with one such fence per block
+// the launch took 2.36 ms instead of 0.41.  What the one-launch form hands from workgroup to workgroup therefore goes
+//   producer: stores THROUGH the L2 (relaxed atomic stores at agent scope = sc1) -> asm s_waitcnt vmcnt(0) (written
+//             out: a fence's own wait is dropped by the compiler when it believes nothing is outstanding -- the first
+//             version, with a workgroup-scope fence here, handed over one stale word in some hundred runs and stalled
+//             or not depending on an unrelated line of code) -> the mark, a relaxed atomic at agent scope;
+//   consumer: sees the mark with a relaxed atomic -> ONE acquire fence at agent scope (invalidates this CU's vector
+//             cache) -> plain loads: a group's last block, once per group.  Where every block would need one (the frame
+//             from the stagers) the consumer loads past the L2 as well, which the producer's write-through stores allow;
+// and the look-back cells are single 64-bit words that say themselves whether they are valid (launch mark | payload,
+// relaxed atomics on both sides): such a word is either there or not yet.  Where workgroups land (block_of keeps a
+// group's blocks on one XCD) is for speed only; nothing here is correct because of it.
+template <typename T>
+__device__ __forceinline__ void store_through(T* p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T load_through(const T* p)
+{
+    return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stores_done() // (every store of this wave so far has been acknowledged)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void drop_stale_lines() // (nothing older than now is served from this CU's vector cache)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// ---- stagers: a second kernel fetches the PCM from page-locked host memory (host pipeline, stereo) ---------------
+// A kernel reads host memory at the link's rate (55.9 GB/s measured with >= 128 waves of 16-byte loads,
+// tools/pcie_probe.hip) without the ~15 us the copy engine idles between two copies and without an event per chunk.
+// k_stage_in is launched before k_encode_blocks on a stream of its own; one wave copies one frame at a time.
+//  * Every workgroup asks for (nearly) all the LDS of a CU and so has the CU to itself.  A load from host memory
+//    takes microseconds and a CU returns its waves' loads in order: staged from the encode launch's own first
+//    workgroups (the first version), the blocks that shared a CU with a stager took 500 us instead of 110 -- with
+//    one stager per CU and 2 KB in flight each, all of them did.
+//  * Nothing makes two kernels run at the same time (streams share hardware queues, and then the second launch
+//    starts when the first has ended), so the stagers wait for nothing and the encode launch is correct either
+//    way: behind a finished stager kernel it finds everything in place; beside a running one, a block waits for its
+//    frame's word in pcm_ready.
+//  * Beside each other the two kernels' workgroups sit on whatever XCDs the dispatcher's round robin has reached,
+//    so a frame crosses from one L2 to another: the stager stores it through its L2 and then publishes ONE word, the
+//    launch ticket | a checksum of the frame; the block reads the frame past its own L2 and takes it when the
+//    checksum matches (await_frame) -- whatever the order in which the stores become visible (see store_through).
+constexpr int kStageThreads = 256; // four waves per CU: with sixteen, the waves of a CU took turns so unevenly that single frames took 240 us
+constexpr int kStageLdsBytes = 150 * 1024; // (with the 12.1 KB of a block that is more than a CU has)
+
+__device__ __forceinline__ uint32_t frame_check_term(uint32_t word, uint32_t index) { return word * (2u * index + 1u); }
+
+__global__ __launch_bounds__(kStageThreads) void k_stage_in(const int16_t* __restrict__ host_pcm, int16_t* __restrict__ pcm, uint32_t n_frames,
+    uint64_t* __restrict__ pcm_ready, uint32_t ticket, uint64_t* __restrict__ started)
+{
+    extern __shared__ unsigned char stage_lds[]; // (never touched: it keeps other workgroups off this CU)
+    if (threadIdx.x == 0) { // one more stager workgroup has its CU (k_stage_gate)
+        uint64_t old = __hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const uint64_t neu = (uint32_t)(old >> 32) == ticket ? old + 1 : (((uint64_t)ticket << 32) | 1u);
+            if (__hip_atomic_compare_exchange_strong(started, &old, neu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                break;
+        }
+    }
+    constexpr uint32_t n16 = kBlock * 2 * 2 / 16; // 16-byte pieces of a stereo frame: 512, eight per lane
+    const uint32_t lane = threadIdx.x % 64;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // The frames are handed out one by one (a counter next to the roll call): the link does not serve the CUs evenly --
+    // with frames dealt out in advance (wave w: frames w, w + 128, ...) some waves were at their fifteenth frame when
+    // others were at their third, and the blocks, which start in frame order, sat waiting for the slow waves' frames
+    // while frames far ahead lay ready.
+    // Every lane adds 1 and the wave takes frame (lane 0's old value) / 64: the compiler folds the 64 additions into one
+    // fetch-and-add of 64 (and 64 of them would be as correct).  The obvious form -- lane 0 adds 1, readfirstlane hands
+    // the frame to the others -- is what the first version had, next to the flag store below, also lane 0's: the
+    // compiler fused the two lane-0 regions across the loop's back edge and sent lanes 1..63 round again with the 0
+    // they had been given "for now" -- a stager kernel that never ended, or not, depending on an unrelated line in the
+    // loop.  No value leaves a one-lane region here any more.
+    // (A compare-and-swap loop instead of the add: 128 waves took turns, a frame per 1.4 us.)
+    uint64_t* const next = started + 1; // (zeroed by the launcher on this stream)
+    for (;;) {
+        const uint64_t drawn = __hip_atomic_fetch_add(next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(drawn >> 6));
+        if (f >= n_frames)
+            break;
+        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(host_pcm) + (size_t)f * n16;
+        uint64_t* __restrict__ dst = reinterpret_cast<uint64_t*>(pcm) + (size_t)f * n16 * 2;
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            v[u] = __builtin_nontemporal_load(src + 64 * u + lane);
+        uint32_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t q = 64 * u + lane;
+            sum += frame_check_term(v[u].x, 4 * q) + frame_check_term(v[u].y, 4 * q + 1) + frame_check_term(v[u].z, 4 * q + 2)
+                + frame_check_term(v[u].w, 4 * q + 3);
+            store_through(dst + 2 * q, (uint64_t)v[u].x | ((uint64_t)v[u].y << 32));
+            store_through(dst + 2 * q + 1, (uint64_t)v[u].z | ((uint64_t)v[u].w << 32));
+        }
+        sum = wave_sum_small(sum); // (mod 2^32)
+        stores_done();
+        if (lane == 0) // (nothing comes back out of this one-lane region)
+            store_through(pcm_ready + f, ((uint64_t)ticket << 32) | sum);
+    }
+}
+
+// The stagers need whole CUs, and blocks that wait for their frames never leave theirs: an encode launch that got
+// onto the device before the stagers would keep them off it.  So this one wave goes first on the encode launch's
+// stream and ends when every stager workgroup has a CU (or, after ~20 ms, regardless: then the blocks' own waits
+// decide).  If the two streams share a hardware queue the stager kernel, launched first, has ended by now.
+__global__ __launch_bounds__(64) void k_stage_gate(const uint64_t* __restrict__ started, uint32_t ticket, uint32_t n_workgroups)
+{
+    for (uint32_t spins = 0; spins < 20000; spins++) {
+        const uint64_t c = load_through(started);
+        if ((uint32_t)(c >> 32) == ticket && (uint32_t)c >= n_workgroups)
+            return;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// The PCM pointer as the code behind a wait must see it: the kernel argument is const and restrict-qualified, which
+// lets the compiler treat the samples as unchanging for the whole kernel and read them before the wait.  Passing the
+// pointer through an opaque asm cuts that knowledge off (and nothing moves across the asm's memory clobber).
+__device__ __forceinline__ const int16_t* pcm_after_wait(const int16_t* p)
+{
+    asm volatile("" : "+s"(p) : : "memory");
+    return p;
+}
+
+// Wait until stereo frame `f` has been copied in and can be read from here (no-op without stagers): its word in
+// pcm_ready carries this launch's ticket, and the frame, read past this XCD's L2, has the checksum that word gives.
+// Bounded: a wait that runs out flags the launch.
+__device__ __attribute__((noinline)) bool await_frame(const uint64_t* pcm_ready, const int16_t* pcm, uint32_t f, uint32_t ticket)
+{
+    // Most of a launch's resident blocks wait here for most of the copy, and these loads go to memory: polled every
+    // quarter microsecond by 3,000 waves, the ready words took the link's bandwidth from the stagers (4.7 ms for a
+    // 0.6 ms copy).  The pause doubles from ~0.9 us to ~7 us.
+    const uint32_t lane = threadIdx.x;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(pcm) + (size_t)f * kBlock;
+    uint32_t naps = 1, slept = 0;
+    for (;;) {
+        const uint64_t c = load_through(pcm_ready + f);
+        if ((uint32_t)(c >> 32) == ticket) {
+            uint32_t sum = 0;
+#pragma unroll 8
+            for (uint32_t t = 0; t < (uint32_t)kPerLane; t++)
+                sum += frame_check_term(load_through(words + lane + 64 * t), lane + 64 * t);
+            if (wave_sum_small(sum) == (uint32_t)c) {
+                return true;
+            }
+        }
+        if (slept > kFuseNapLimit)
+            return false;
+        for (uint32_t i = 0; i < naps; i++)
+            __builtin_amdgcn_s_sleep(32); // 2048 cycles
+        slept += naps;
+        naps = naps < 8 ? naps * 2 : 8;
+    }
 }
 
 __device__ __attribute__((noinline)) void mean_worker(const int16_t* __restrict__ pcm, uint32_t n_frames, uint32_t channels, uint32_t n_sig,
-    uint32_t first_e, uint32_t total_e, double* __restrict__ mean_out, uint32_t* __restrict__ mean_ready, uint32_t ticket)
+    uint32_t first_e, uint32_t total_e, double* __restrict__ mean_out, uint64_t* __restrict__ mean_ready, uint32_t ticket, uint64_t tag)
 {
     const uint32_t e = first_e + threadIdx.x;
     uint32_t frame, sig;
@@ -424,8 +598,391 @@ __device__ __attribute__((noinline)) void mean_worker(const int16_t* __restrict_
     }
     const double mean = sum / (double)kBlock;
     if (live) {
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(mean_out) + e, __builtin_bit_cast(uint64_t, mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mean_ready + e, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // (two words for blocks on any XCD, both past the L2 on both sides)
+        store_through(reinterpret_cast<uint64_t*>(mean_out) + e, __builtin_bit_cast(uint64_t, mean));
+        stores_done();
+        store_through(mean_ready + e, tag);
+    }
+}
+
+// ---- a group's last block: sizes, place in the stream, on-disk bytes ---------------------------------------------
+// Round 2 had two more kernels behind k_encode_blocks (a one-workgroup plan: stereo decision, sizes, scan; an
+// assembler, one workgroup per frame).  Between two batches they cost two launch hand-overs; in the host pipeline
+// they waited behind the next chunk's blocks for a free CU (80-95 us per chunk, traced) and forced a host
+// hand-over (sizes) before every copy-out.  Now the blocks do it: frames are grouped by kGroupFrames; every block, when its
+// slot and BlockMeta are written, counts itself in; the one that completes the count finishes the group.
+
+// Decoupled look-back cells of one group.  Groups finish on different XCDs, so every cell is ONE 64-bit word that says
+// itself whether it is valid: the launch's 32-bit mark (a hash of its tag) in the high half, the payload in the low half.
+struct GroupState {
+    uint64_t agg_bytes;  // bytes of this group's frames                              (known as soon as the group is complete)
+    uint64_t agg_flags;  // flag bits of its blocks
+    uint64_t prefix_lo;  // stream offset behind this group's last frame, bits 0..31  (known once every group before it is)
+    uint64_t prefix_hi;  // ... bits 32..63
+    uint64_t prefix_info; // flags | frames that do not fit frames_cap << 8, of all groups up to and including this one
+};
+static_assert(sizeof(GroupState) == 40, "GroupState");
+
+constexpr int kGroupCountStride = 16; // uint64 words: one counter per 128-byte line
+
+struct FuseArgs {
+    const BlockMeta* meta;
+    const uint32_t* slots;
+    uint64_t* group_count;   // [n_groups]: 40 bits of the launch's tag (hashed) << 24 | blocks that have arrived
+    GroupState* group_state; // [n_groups]
+    uint8_t* frames;         // the stream (device memory, or page-locked host memory as the device sees it)
+    size_t frames_cap;
+    uint64_t* frame_offsets; // [n_frames + 1] or null
+    uint64_t* mirror;        // host copy of frame_offsets, + one word status[0] | status[1] << 32; or null
+    uint32_t* status;
+    const uint64_t* pos_in;  // offset of this launch's first frame in the stream (null: 0) ...
+    uint64_t* pos_out;       // ... and where the launch leaves the offset behind its last frame (null: nowhere).  Two cells: groups
+                             // read the start long after the last group -- which only needs the others' sizes -- has written the end
+    const uint64_t* pcm_ready; // [n_frames]: launch ticket | checksum of every frame k_stage_in has copied in; or null (the PCM is there)
+    uint32_t n_frames, channels, n_sig, ticket;
+    uint64_t tag;            // process nonce << 32 | ticket (see launch_encode): what marks a cell as written by THIS launch
+};
+
+__device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t channels, uint32_t& choice, uint32_t& flags)
+{
+    uint32_t words = 0;
+    choice = 0;
+    for (uint32_t c = 0; c < channels; c++) {
+        BlockMeta b = m[c];
+        if (c == 1 && channels == 2) { // exactly-stereo only, src/frame/frame_encoder.cpp:18
+            const BlockMeta d = m[2];
+            const uint32_t dsz = (uint32_t)d.coef_words + d.res_words, asz = (uint32_t)b.coef_words + b.res_words;
+            flags |= d.flags;
+            if (dsz < asz) { // strict <, src/frame/frame_encoder.cpp:64
+                choice = 1;
+                b = d;
+            }
+        }
+        flags |= b.flags;
+        words += (uint32_t)b.coef_words + b.res_words;
+    }
+    return words;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
+{
+    for (int d = 32; d >= 1; d >>= 1)
+        v += (uint64_t)__shfl_xor((unsigned long long)v, d, 64);
+    return v;
+}
+
+// The on-disk bytes of one frame (src/file/sela_file.cpp:115-135), by one wave.  Frame sizes are multiples of 4
+// and the stream base is 4-byte aligned, so everything is written as aligned u32.  Within a subframe the 7 header
+// bytes push the coefficient words 3 bytes off word alignment (funnel shift below); the 5 bytes of the residue
+// header realign the residue words.
+__device__ __forceinline__ void assemble_frame(const FuseArgs& fa, uint32_t f, uint32_t choice, uint32_t* __restrict__ out, int lane)
+{
+    if (lane == 0)
+        out[0] = SELA_SYNC_WORD;
+    uint32_t p = 1; // word cursor inside the frame
+    for (uint32_t c = 0; c < fa.channels; c++) {
+        uint32_t sig = c, type = 0, parent = c;
+        if (c == 1 && fa.channels == 2 && choice) {
+            sig = 2;
+            type = 1;
+            parent = 0;
+        }
+        const BlockMeta b = fa.meta[(size_t)f * fa.n_sig + sig];
+        const uint32_t* __restrict__ slot = fa.slots + ((size_t)f * fa.n_sig + sig) * kSlotWords;
+        const uint32_t cw = b.coef_words, rw = b.res_words;
+        if (lane == 0)
+            out[p] = c | (type << 8) | (parent << 16) | ((uint32_t)b.coef_k << 24);
+        // words p+1 .. p+1+cw: [cw:16 | order:8] then the coefficient words shifted by 3 bytes, then res_k
+        if ((uint32_t)lane <= cw) { // (cw <= kCoefWordsCap = 32)
+            const uint32_t low = lane == 0 ? (cw | ((uint32_t)b.order << 16)) : (slot[lane - 1] >> 8);
+            const uint32_t top = (uint32_t)lane < cw ? slot[lane] : (uint32_t)b.res_k;
+            out[p + 1 + lane] = (low & 0x00FFFFFFu) | (top << 24);
+        }
+        if (lane == 0)
+            out[p + 2 + cw] = rw | ((uint32_t)kBlock << 16);
+        // the residue words: 16-byte loads (the slot is 16-byte aligned), four loads in flight, word stores
+        const uint4* __restrict__ rs = reinterpret_cast<const uint4*>(slot + kCoefWordsCap);
+        uint32_t* __restrict__ ro = out + p + 3 + cw;
+        for (uint32_t base = 0; base < rw; base += 4 * 256) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t w = base + 256 * u + 4 * lane;
+                v[u] = w < rw ? rs[w / 4] : make_uint4(0, 0, 0, 0); // (reads inside the slot: rw <= kResWordsCap, a multiple of 4 words)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t w = base + 256 * u + 4 * lane;
+                if (w < rw)
+                    ro[w] = v[u].x;
+                if (w + 1 < rw)
+                    ro[w + 1] = v[u].y;
+                if (w + 2 < rw)
+                    ro[w + 2] = v[u].z;
+                if (w + 3 < rw)
+                    ro[w + 3] = v[u].w;
+            }
+        }
+        p += 3 + cw + rw;
+    }
+}
+
+// The on-disk bytes of a whole group, when its subframes fit one per lane (<= 64: the usual case).  assemble_frame
+// walks a frame's subframes one behind the other, every load waiting for the one before it: ~6 us per subframe, 190 us
+// for 16 stereo frames, and the launch ended that much after its last block.  Here every subframe has a lane that
+// writes its headers and coefficient words (all of a subframe's coefficient words are fetched at once), and the
+// residue words are copied by all lanes, sixteen 16-byte loads in flight each.
+
+__device__ __forceinline__ void assemble_group(const FuseArgs& fa, uint32_t f0, uint32_t nfg, uint32_t choice, uint64_t begin, bool fits,
+    int lane)
+{
+    const uint32_t ch = fa.channels, n_sub = nfg * ch;
+    const uint32_t fi = (uint32_t)lane / ch, c = (uint32_t)lane % ch; // this lane's subframe: frame f0 + fi, channel c
+    const bool live = (uint32_t)lane < n_sub;
+    const int src_lane = live ? (int)fi : 0;
+    const uint32_t my_choice = (uint32_t)__shfl((int)choice, src_lane, 64);
+    const uint64_t my_begin = (uint64_t)__shfl((unsigned long long)begin, src_lane, 64);
+    const bool my_fits = __shfl((int)fits, src_lane, 64) != 0;
+    uint32_t sig = c, type = 0, parent = c;
+    if (c == 1 && ch == 2 && my_choice) {
+        sig = 2;
+        type = 1;
+        parent = 0;
+    }
+    BlockMeta b = {};
+    const uint32_t* slot = fa.slots;
+    if (live) {
+        const size_t block_id = (size_t)(f0 + fi) * fa.n_sig + sig;
+        b = fa.meta[block_id];
+        slot = fa.slots + block_id * kSlotWords;
+    }
+    const uint32_t cw = live ? b.coef_words : 0u, rw = live ? b.res_words : 0u;
+    const uint32_t sub_words = live ? 3u + cw + rw : 0u;
+    const uint32_t before = wave_exclusive_scan(sub_words, lane);
+    const uint32_t frame_start = (uint32_t)__shfl((int)before, live ? (int)(fi * ch) : 0, 64);
+    const uint32_t p = 1u + before - frame_start; // word cursor inside the frame
+    uint32_t* out = reinterpret_cast<uint32_t*>(fa.frames + my_begin);
+    const bool write = live && my_fits;
+    // ---- headers and coefficient words ----
+    uint4 cwv[kCoefWordsCap / 4];
+#pragma unroll
+    for (int i = 0; i < kCoefWordsCap / 4; i++)
+        cwv[i] = (write && 4u * i < cw) ? reinterpret_cast<const uint4*>(slot)[i] : make_uint4(0, 0, 0, 0);
+    if (write) {
+        if (c == 0)
+            out[0] = SELA_SYNC_WORD;
+        out[p] = c | (type << 8) | (parent << 16) | ((uint32_t)b.coef_k << 24);
+        // words p+1 .. p+1+cw: [cw:16 | order:8] then the coefficient words shifted by 3 bytes, then res_k
+        uint32_t prev = cw | ((uint32_t)b.order << 16);
+#pragma unroll
+        for (int i = 0; i <= kCoefWordsCap; i++) {
+            const uint4 q = cwv[(i < kCoefWordsCap ? i : 0) / 4];
+            const uint32_t word = i >= kCoefWordsCap ? 0u : ((i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w);
+            if ((uint32_t)i <= cw) {
+                const uint32_t top = (uint32_t)i < cw ? word : (uint32_t)b.res_k;
+                out[p + 1 + i] = (prev & 0x00FFFFFFu) | (top << 24);
+            }
+            prev = word >> 8;
+        }
+        out[p + 2 + cw] = rw | ((uint32_t)kBlock << 16);
+    }
+    // ---- residue words ----
+    // The destination of a subframe's residue words is 4-byte aligned, no more.  Its own lane writes the 0..3 words up to
+    // the first 16-byte boundary and the 0..3 behind the last one; everything between is 16-byte pieces, stored aligned
+    // (one instruction per piece, fully coalesced) and loaded from wherever that puts them in the slot (4-byte aligned
+    // 16-byte loads are fine).  The pieces of all subframes form one flat list, sixteen loads in flight per lane.
+    const uint32_t* res_src = slot + kCoefWordsCap;
+    uint32_t* res_dst = out + p + 3 + cw;
+    const uint32_t head = write ? min(rw, (uint32_t)((16u - ((uintptr_t)res_dst & 15u)) & 15u) / 4u) : 0u;
+    const uint32_t pieces = write ? (rw - head) / 4 : 0u;
+    const uint32_t tail = write ? rw - head - 4 * pieces : 0u;
+    if (write) {
+        uint32_t hw[3], tw[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            hw[j] = (uint32_t)j < head ? res_src[j] : 0u;
+            tw[j] = (uint32_t)j < tail ? res_src[head + 4 * pieces + j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if ((uint32_t)j < head)
+                res_dst[j] = hw[j];
+            if ((uint32_t)j < tail)
+                res_dst[head + 4 * pieces + j] = tw[j];
+        }
+    }
+    // The lanes split into teams, one per subframe (four lanes each for the sixteen subframes of eight stereo frames);
+    // a team copies its subframe's pieces in turn, every lane with sixteen loads in flight.  (First version: one flat
+    // list of pieces over all subframes, looked up in an LDS table -- the lookups, two dependent LDS reads per piece,
+    // took longer than the copies: 18 us per group.)
+    uint32_t team = 64;
+    while (team > 1 && 64u / team < n_sub)
+        team >>= 1; // lanes per subframe: the largest power of two with 64 / team >= n_sub
+    const int owner = (int)((uint32_t)lane / team); // the lane that did this subframe's headers above
+    const uint32_t l = (uint32_t)lane % team;
+    const uint64_t src0 = (uint64_t)__shfl((unsigned long long)(uintptr_t)(res_src + head), owner, 64);
+    const uint64_t dst0 = (uint64_t)__shfl((unsigned long long)(uintptr_t)(res_dst + head), owner, 64);
+    const uint32_t mine = (uint32_t)__shfl((int)pieces, owner, 64); // (0 beyond the last subframe: those lanes' `pieces` are 0)
+    uint32_t most = mine;
+    for (int d = 32; d >= 1; d >>= 1)
+        most = max(most, (uint32_t)__shfl_xor((int)most, d, 64));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
+    typedef u32x4 __attribute__((address_space(1))) * GlobalPieces;
+    constexpr int kFlight = 16;
+    for (uint32_t k0 = 0; k0 < most; k0 += team * kFlight) { // (wave-uniform trip count)
+        u32x4 v[kFlight];
+#pragma unroll
+        for (int u = 0; u < kFlight; u++) {
+            const uint32_t k = k0 + l + team * u;
+            v[u] = u32x4{ 0, 0, 0, 0 };
+            if (k < mine) {
+                const GlobalWords from = (GlobalWords)(uintptr_t)src0 + 4 * (size_t)k;
+                v[u] = u32x4{ from[0], from[1], from[2], from[3] };
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kFlight; u++) {
+            const uint32_t k = k0 + l + team * u;
+            if (k < mine)
+                *((GlobalPieces)(uintptr_t)dst0 + k) = v[u];
+        }
+    }
+}
+
+// Count one finished block into its group; true for the block that completes the group.  The counter carries 40
+// bits of the launch's tag, so nothing is cleared between launches (a stale or uninitialised counter reads as
+// "nobody yet"; whatever lay in the workspace before -- another process's cells, Rice words of a launch with another
+// layout -- matches a tag with probability 2^-40 here and 2^-62 .. 2^-64 in the other cells).
+__device__ __forceinline__ bool group_arrive(uint64_t* cell, uint64_t tag, uint32_t blocks_in_group)
+{
+    // (agent scope: where the group's blocks run is not ours to rely on.  One counter per 128-byte line -- sixteen to
+    // a line, the 11,625 updates of a 3,875-frame launch added 77 us to it.)
+    const uint64_t mark = (tag * 0x9E3779B97F4A7C15ull) & ~(uint64_t)0xFFFFFF; // (blocks_in_group <= 8 * 256 < 2^24)
+    uint64_t old = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const uint64_t neu = (old & ~(uint64_t)0xFFFFFF) == mark ? old + 1 : (mark | 1u);
+        if (__hip_atomic_compare_exchange_strong(cell, &old, neu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            return (uint32_t)(neu & 0xFFFFFF) == blocks_in_group;
+    }
+}
+
+__device__ __attribute__((noinline)) void finish_group(const FuseArgs& fa, uint32_t g, int lane)
+{
+    // (a chain of memory round trips that later groups and the end of the launch wait for: ahead of the co-resident
+    // blocks' throughput-bound phases)
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t f0 = g * kGroupFrames;
+    const uint32_t nfg = min((uint32_t)kGroupFrames, fa.n_frames - f0);
+    const uint32_t n_groups = (fa.n_frames + kGroupFrames - 1) / kGroupFrames;
+    // ---- sizes ----
+    uint32_t size = 0, choice = 0, flags = 0;
+    if ((uint32_t)lane < nfg) {
+        const uint32_t words = frame_words(fa.meta + (size_t)(f0 + lane) * fa.n_sig, fa.channels, choice, flags);
+        size = sela_frame_bytes(fa.channels, words);
+    }
+    const uint32_t excl = wave_exclusive_scan(size, lane);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(excl + size), 63);
+    flags = wave_or(flags);
+    GroupState* const st = fa.group_state;
+    const uint64_t mark = (fa.tag * 0x9E3779B97F4A7C15ull) & 0xFFFFFFFF00000000ull; // (what group_arrive uses, 32 bits of it)
+    if (lane == 0) {
+        store_through(&st[g].agg_bytes, mark | total);
+        store_through(&st[g].agg_flags, mark | flags);
+    }
+    // ---- decoupled look-back: sum the groups before this one, nearest first, until one knows its prefix ----
+    uint64_t base = 0;
+    uint32_t over_before = 0, timed_out = 0;
+    bool reached_start = true;
+    for (int64_t p = (int64_t)g - 1; p >= 0; p -= 64) {
+        const int64_t mine = p - lane;
+        uint32_t kind = 0, info = 0;
+        uint64_t bytes = 0;
+        if (mine >= 0) {
+            for (uint32_t spins = 0;;) {
+                // (all five at once: one trip to memory per poll)
+                const uint64_t lo = load_through(&st[mine].prefix_lo), hi = load_through(&st[mine].prefix_hi),
+                               pi = load_through(&st[mine].prefix_info);
+                const uint64_t ab = load_through(&st[mine].agg_bytes), af = load_through(&st[mine].agg_flags);
+                if ((lo & 0xFFFFFFFF00000000ull) == mark && (hi & 0xFFFFFFFF00000000ull) == mark && (pi & 0xFFFFFFFF00000000ull) == mark) {
+                    kind = 2;
+                    bytes = (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
+                    info = (uint32_t)pi;
+                    break;
+                }
+                if ((ab & 0xFFFFFFFF00000000ull) == mark && (af & 0xFFFFFFFF00000000ull) == mark) {
+                    kind = 1;
+                    bytes = (uint32_t)ab;
+                    info = (uint32_t)af & 0xFFu;
+                    break;
+                }
+                if (++spins > kFuseSpinLimit) {
+                    timed_out = 1;
+                    break;
+                }
+                // (each poll is five loads from memory per lane; up to a hundred groups wait at a time)
+                __builtin_amdgcn_s_sleep(64);
+            }
+        }
+        const uint64_t knows = __ballot(kind == 2u);
+        const int first = knows ? __builtin_ctzll(knows) : 64;
+        const bool take = mine >= 0 && lane <= first;
+        base += wave_sum_u64(take ? bytes : 0);
+        flags |= wave_or(take ? (info & 0xFFu) : 0u);
+        over_before += wave_sum_small(take ? (info >> 8) : 0u);
+        if (knows) {
+            reached_start = false;
+            break;
+        }
+    }
+    if (reached_start && fa.pos_in) // (the launch before this one on the stream left its end here)
+        base += *fa.pos_in;
+    timed_out = wave_or(timed_out);
+    if (timed_out)
+        flags |= SELA_HIP_FLAG_INTERNAL;
+    // ---- this group's frames in the stream ----
+    const uint64_t begin = base + excl, end = begin + size;
+    const bool fits = end <= fa.frames_cap;
+    const uint32_t over = over_before + (uint32_t)__popcll(__ballot((uint32_t)lane < nfg && !fits));
+    if (lane == 0) {
+        const uint64_t behind = base + total;
+        store_through(&st[g].prefix_lo, mark | (uint32_t)behind);
+        store_through(&st[g].prefix_hi, mark | (uint32_t)(behind >> 32));
+        store_through(&st[g].prefix_info, mark | ((flags & 0xFFu) | (over << 8)));
+    }
+    if ((uint32_t)lane < nfg) {
+        if (fa.frame_offsets) {
+            fa.frame_offsets[f0 + lane + 1] = end;
+            if (f0 + lane == 0)
+                fa.frame_offsets[0] = begin;
+        }
+        if (fa.mirror) {
+            fa.mirror[f0 + lane + 1] = end;
+            if (f0 + lane == 0)
+                fa.mirror[0] = begin;
+        }
+    }
+    if (g + 1 == n_groups && lane == 0) { // (every group before this one has been counted in: the launch's verdict)
+        fa.status[0] = flags & 0xFFu;
+        fa.status[1] = over;
+        fa.status[2] = fa.status[3] = 0;
+        if (fa.mirror)
+            fa.mirror[(size_t)fa.n_frames + 1] = (uint64_t)(flags & 0xFFu) | ((uint64_t)over << 32);
+        if (fa.pos_out)
+            *fa.pos_out = base + total;
+    }
+    // ---- the bytes ----
+    if (nfg * fa.channels <= 64u) {
+        if (!timed_out)
+            assemble_group(fa, f0, nfg, choice, begin, fits, lane);
+    } else
+    for (uint32_t i = 0; i < nfg; i++) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)begin, (int)i);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(begin >> 32), (int)i);
+        const bool ok = __builtin_amdgcn_readlane((int)fits, (int)i) != 0;
+        const uint32_t ch = (uint32_t)__builtin_amdgcn_readlane((int)choice, (int)i);
+        if (ok && !timed_out)
+            assemble_frame(fa, f0 + i, ch, reinterpret_cast<uint32_t*>(fa.frames + (((uint64_t)hi << 32) | lo)), lane);
     }
 }
 
@@ -437,16 +994,17 @@ __device__ __attribute__((noinline)) void mean_worker(const int16_t* __restrict_
             stamp[n] = clock64();     \
     } while (0)
 
-template <int kMode>
+// kFused: the host pipeline's one-launch form (await_frame, finish_group); compiled out of the device-pointer path's kernel
+template <int kMode, bool kFused>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta, uint32_t* __restrict__ slots,
     double* __restrict__ rings, uint32_t* __restrict__ ring_owner, uint32_t ticket, sela_hip_trace* __restrict__ trace,
-    uint64_t* __restrict__ phase_cycles, int force_plain_fir, double* __restrict__ mean_out, uint32_t* __restrict__ mean_ready,
-    uint32_t n_workers, uint32_t self_blocks, uint32_t total_e)
+    uint64_t* __restrict__ phase_cycles, int force_plain_fir, double* __restrict__ mean_out, uint64_t* __restrict__ mean_ready,
+    uint32_t n_workers, uint32_t self_blocks, uint32_t total_e, const FuseArgs fa)
 {
     constexpr bool kTrace = kMode == 1;
     if (blockIdx.x < n_workers) { // (the first workgroups of the launch: see mean_worker)
-        mean_worker(pcm, n_frames, channels, n_sig, self_blocks + 64 * blockIdx.x, total_e, mean_out, mean_ready, ticket);
+        mean_worker(pcm, n_frames, channels, n_sig, self_blocks + 64 * blockIdx.x, total_e, mean_out, mean_ready, ticket, fa.tag);
         return;
     }
     long long stamp[14];
@@ -463,6 +1021,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         return;
     const uint32_t block_id = frame * n_sig + sig;
     uint32_t flags = 0;
+    if (kFused && fa.pcm_ready && !await_frame(fa.pcm_ready, pcm, frame, ticket))
+        flags |= SELA_HIP_FLAG_INTERNAL;
 
     double* const E = reinterpret_cast<double*>(big) + kPadC;              // first half: E[-64 .. 575]
     double* const O = reinterpret_cast<double*>(big) + kParityLen + kPadC; // first half: O[-64 .. 575]
@@ -473,12 +1033,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // ---- load this signal: s[t] = sample lane + 64 t  (coalesced) ---------------------------------
     int32_t s[kPerLane];
     {
-        const int16_t* fp = pcm + (size_t)frame * kBlock * channels;
+        const int16_t* fp = pcm_after_wait(pcm) + (size_t)frame * kBlock * channels;
         if (channels == 2) {
             const uint32_t* fp2 = reinterpret_cast<const uint32_t*>(fp);
 #pragma unroll
             for (int t = 0; t < kPerLane; t++) {
-                const uint32_t w = fp2[lane + 64 * t];
+                // (behind the stagers: past the L2 like await_frame's check -- an acquire fence here instead, one per block,
+                // cost the 3,875-frame call 0.24 ms)
+                const uint32_t w = (kFused && fa.pcm_ready) ? load_through(fp2 + lane + 64 * t) : fp2[lane + 64 * t];
                 const int32_t l = (int16_t)(w & 0xFFFFu), r = (int16_t)(w >> 16);
                 s[t] = sig == 0 ? l : (sig == 1 ? r : l - r); // src/frame/frame_encoder.cpp:22-24
             }
@@ -500,11 +1062,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (e >= self_blocks) {
         for (uint32_t spin = 0; spin < kMeanWaitSpins; spin++) {
             // (polled relaxed: an acquire per poll invalidates the vector cache under every co-resident wave)
-            if (__hip_atomic_load(mean_ready + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ticket) {
-                // (order only: the mean below is loaded past the L2 as well, and the worker's release -- an L2 write-back --
-                // put it in memory before the ready word.  An acquire fence here would drop this XCD's clean L2 lines once
-                // per block.)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (__hip_atomic_load(mean_ready + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fa.tag) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // (the mean is loaded past the L2 as well: order only)
                 have_mean = true;
                 break;
             }
@@ -924,10 +1483,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     SELA_STAMP(11);
     // ---- slot + meta -------------------------------------------------------------------------------------
     uint32_t* slot = slots + (size_t)block_id * kSlotWords;
-    if (lane < (int)coef_words && lane < kCoefWordsCap)
-        slot[lane] = cw_buf[lane];
-    for (uint32_t w = lane; w < res_words; w += 64)
-        slot[kCoefWordsCap + w] = out_words[w];
+    if (kFused) { // host pipeline: the group's last block reads them in this launch -- through the L2 (store_through)
+        uint64_t* const slot2 = reinterpret_cast<uint64_t*>(slot);
+        if (lane < kCoefWordsCap / 2) // (all 32 coefficient words: what lies behind coef_words is never read)
+            store_through(slot2 + lane, (uint64_t)cw_buf[2 * lane] | ((uint64_t)cw_buf[2 * lane + 1] << 32));
+        const uint64_t* const out2 = reinterpret_cast<const uint64_t*>(out_words);
+        for (uint32_t w2 = lane; w2 < (res_words + 1) / 2; w2 += 64)
+            store_through(slot2 + kCoefWordsCap / 2 + w2, out2[w2]);
+    } else {
+        if (lane < (int)coef_words && lane < kCoefWordsCap)
+            slot[lane] = cw_buf[lane];
+        for (uint32_t w = lane; w < res_words; w += 64)
+            slot[kCoefWordsCap + w] = out_words[w];
+    }
     const uint32_t all_flags = wave_or(flags);
     if (lane == 0) {
         BlockMeta bm;
@@ -937,7 +1505,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         bm.flags = (uint8_t)all_flags;
         bm.coef_words = (uint16_t)coef_words;
         bm.res_words = (uint16_t)res_words;
-        meta[block_id] = bm;
+        if (kFused)
+            store_through(reinterpret_cast<uint64_t*>(meta + block_id), __builtin_bit_cast(uint64_t, bm));
+        else
+            meta[block_id] = bm;
         if (kTrace) {
             sela_hip_trace* tr = trace + block_id;
             tr->coef_k = coef_k;
@@ -948,53 +1519,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
     }
     SELA_STAMP(12);
+    // ---- host pipeline: count this block into its group; the group's last block places and writes the group's frames
+    if (kFused) {
+        const uint32_t g = frame / kGroupFrames;
+        const uint32_t blocks_in_group = min((uint32_t)kGroupFrames, n_frames - g * kGroupFrames) * n_sig;
+        stores_done(); // the slot and the BlockMeta of every lane, before the count
+        uint32_t last = 0;
+        if (lane == 0)
+            last = group_arrive(fa.group_count + (size_t)g * kGroupCountStride, fa.tag, blocks_in_group) ? 1u : 0u;
+        if (__builtin_amdgcn_readfirstlane((int)last)) {
+            drop_stale_lines(); // (the other blocks' slots and metas are in memory: nothing older may come from this CU's cache)
+            finish_group(fa, g, lane);
+        }
+    }
+    SELA_STAMP(13);
     if (kMode == 2 && lane == 0)
-        for (int i = 0; i < 12; i++)
+        for (int i = 0; i < 13; i++)
             phase_cycles[(size_t)block_id * 16 + i] = (uint64_t)(stamp[i + 1] - stamp[i]);
 }
 
-// ---- plan: stereo decision + frame sizes + exclusive scan (one workgroup of 1024) -------------------
+// ---- the device-pointer path's two small kernels behind k_encode_blocks -------------------------------------------
+// (batches that are resident in HBM: a kernel boundary costs a few microseconds there, less than the groups' last blocks
+// take to do the same work inside the launch -- the one-launch form is the host pipeline's, see finish_group.)
+// plan: stereo decision + frame sizes + exclusive scan (one workgroup of 1024)
 // choice[f] = 1 when the second channel of an exactly-stereo frame is stored as the difference
 // signal (src/frame/frame_encoder.cpp:64-72).
 constexpr int kPlanThreads = 1024;
 constexpr int kPlanLdsFrames = 12288; // frame sizes staged in LDS up to this batch size (48 KB)
-// The host pipeline's chunks (<= 1024 frames) get a plan of one wave and 4.5 KB of LDS: while the next chunk's blocks
-// fill the device (145 of a CU's 160 KB of LDS, 504 of a SIMD's 512 VGPRs) nothing larger finds a place -- the
-// 1024-thread, 57 KB plan waited 80-95 us for one (traced), the copy-out of the chunk behind it.
-constexpr int kSmallPlanThreads = 64;
-constexpr int kSmallPlanFrames = 1024;
 
-__device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t channels, uint32_t n_sig, uint32_t& choice,
-    uint32_t& flags)
-{
-    uint32_t words = 0;
-    choice = 0;
-    for (uint32_t c = 0; c < channels; c++) {
-        BlockMeta b = m[c];
-        if (c == 1 && channels == 2) { // exactly-stereo only, src/frame/frame_encoder.cpp:18
-            const BlockMeta d = m[2];
-            const uint32_t dsz = (uint32_t)d.coef_words + d.res_words, asz = (uint32_t)b.coef_words + b.res_words;
-            flags |= d.flags;
-            if (dsz < asz) {
-                choice = 1;
-                b = d;
-            }
-        }
-        flags |= b.flags;
-        words += (uint32_t)b.coef_words + b.res_words;
-    }
-    return words;
-}
-
-template <int kThreads, int kTileFrames>
-__global__ __launch_bounds__(kThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
+__global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* __restrict__ frame_offsets,
     uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status, uint64_t* __restrict__ mirror)
 {
     // mirror (optional, page-locked HOST memory): a copy of frame_offsets[0 .. n_frames] followed by one word
     // status[0] | status[1] << 32, so that the host pipeline reads a chunk's sizes without a copy of its own
-    __shared__ uint64_t part[kThreads];
-    __shared__ uint32_t frame_size[kTileFrames]; // bytes of the frames of one tile
+    __shared__ uint64_t part[kPlanThreads];
+    __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of the frames of one tile
     __shared__ uint32_t acc[2];                      // flags, frames that do not fit frames_cap
     const uint32_t tid = threadIdx.x;
     if (tid < 2)
@@ -1004,25 +1564,25 @@ __global__ __launch_bounds__(kThreads) void k_plan_frames(const BlockMeta* __res
     // Tiles of kPlanLdsFrames frames.  Within a tile, frame f is sized by thread f mod 1024: the metadata loads of
     // one pass are independent and coalesced, and the passes do not depend on each other (a thread that walks
     // consecutive frames waits for memory once per frame: 0.45 ms for 61 k frames, against 10 us per tile).
-    for (uint32_t tile0 = 0; tile0 < n_frames; tile0 += kTileFrames) {
-        const uint32_t tile_n = min((uint32_t)kTileFrames, n_frames - tile0);
+    for (uint32_t tile0 = 0; tile0 < n_frames; tile0 += kPlanLdsFrames) {
+        const uint32_t tile_n = min((uint32_t)kPlanLdsFrames, n_frames - tile0);
         __syncthreads(); // the previous tile's sizes have been read
 #pragma unroll 4
-        for (uint32_t i = tid; i < tile_n; i += kThreads) {
+        for (uint32_t i = tid; i < tile_n; i += kPlanThreads) {
             uint32_t choice;
-            const uint32_t words = frame_words(meta + (size_t)(tile0 + i) * n_sig, channels, n_sig, choice, flags);
+            const uint32_t words = frame_words(meta + (size_t)(tile0 + i) * n_sig, channels, choice, flags);
             choice_out[tile0 + i] = (uint8_t)choice;
             frame_size[i] = (uint32_t)sela_frame_bytes(channels, words);
         }
         __syncthreads();
-        const uint32_t per = (tile_n + kThreads - 1) / kThreads;
+        const uint32_t per = (tile_n + kPlanThreads - 1) / kPlanThreads;
         const uint32_t begin = min(tid * per, tile_n), end = min(begin + per, tile_n);
         uint64_t bytes = 0;
         for (uint32_t i = begin; i < end; i++)
             bytes += frame_size[i];
         part[tid] = bytes;
         __syncthreads();
-        for (uint32_t d = 1; d < (uint32_t)kThreads; d <<= 1) { // Hillis-Steele inclusive scan
+        for (uint32_t d = 1; d < (uint32_t)kPlanThreads; d <<= 1) { // Hillis-Steele inclusive scan
             const uint64_t v = tid >= d ? part[tid - d] : 0;
             __syncthreads();
             part[tid] += v;
@@ -1037,7 +1597,7 @@ __global__ __launch_bounds__(kThreads) void k_plan_frames(const BlockMeta* __res
             if (off > frames_cap)
                 overflow++;
         }
-        base += part[kThreads - 1];
+        base += part[kPlanThreads - 1];
     }
     if (tid == 0) {
         frame_offsets[n_frames] = base;
@@ -1064,8 +1624,7 @@ __global__ __launch_bounds__(kThreads) void k_plan_frames(const BlockMeta* __res
 // alignment (funnel shift below); the 5 bytes of the residue header realign the residue words.
 constexpr int kAsmThreads = 256;
 
-template <int kThreads>
-__global__ __launch_bounds__(kThreads) void k_assemble_frames(const BlockMeta* __restrict__ meta,
+__global__ __launch_bounds__(kAsmThreads) void k_assemble_frames(const BlockMeta* __restrict__ meta,
     const uint32_t* __restrict__ slots, const uint8_t* __restrict__ choice, const uint64_t* __restrict__ frame_offsets,
     uint32_t n_frames, uint32_t channels, uint32_t n_sig, size_t frames_cap, uint8_t* __restrict__ frames)
 {
@@ -1093,7 +1652,7 @@ __global__ __launch_bounds__(kThreads) void k_assemble_frames(const BlockMeta* _
         if (tid == 0)
             out[p] = c | (type << 8) | (parent << 16) | ((uint32_t)b.coef_k << 24);
         // words p+1 .. p+1+cw: [cw:16 | order:8] then the coefficient words shifted by 3 bytes, then res_k
-        for (uint32_t i = tid; i <= cw; i += kThreads) {
+        for (uint32_t i = tid; i <= cw; i += kAsmThreads) {
             const uint32_t low = i == 0 ? (cw | ((uint32_t)b.order << 16)) : (slot[i - 1] >> 8);
             const uint32_t top = i < cw ? slot[i] : (uint32_t)b.res_k;
             out[p + 1 + i] = (low & 0x00FFFFFFu) | (top << 24);
@@ -1102,7 +1661,7 @@ __global__ __launch_bounds__(kThreads) void k_assemble_frames(const BlockMeta* _
             out[p + 2 + cw] = rw | ((uint32_t)kBlock << 16);
         const uint32_t* rs = slot + kCoefWordsCap;
         uint32_t* ro = out + p + 3 + cw;
-        for (uint32_t i = tid; i < rw; i += kThreads)
+        for (uint32_t i = tid; i < rw; i += kAsmThreads)
             ro[i] = rs[i];
         p += 3 + cw + rw;
     }
@@ -1120,11 +1679,12 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
     size_t bytes = 0;
     bytes += (blocks * sizeof(BlockMeta) + 255) & ~(size_t)255;
     bytes += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
-    bytes += ((size_t)n_frames + 255) & ~(size_t)255; // choice
+    const size_t n_groups = ((size_t)n_frames + kGroupFrames - 1) / kGroupFrames;
+    bytes += ((n_groups * kGroupCountStride * sizeof(uint64_t) + 255) & ~(size_t)255) + ((n_groups * sizeof(GroupState) + 255) & ~(size_t)255); // finish_group
     bytes += (size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 256; // scalar-operand rings (L2-resident) ...
     bytes += (size_t)kXcds * kRingsPerXcd * 4 + 256;                          // ... and their owner words
-    const size_t padded = (((size_t)n_frames + 7) / 8) * 8 * n_sig;           // encode indices (frames rounded up to 8)
-    bytes += ((padded * sizeof(double) + 255) & ~(size_t)255) + ((padded * 4 + 255) & ~(size_t)255); // worker means + ready words
+    const size_t padded = (((size_t)n_frames + 63) / 64) * 64 * n_sig;        // encode indices (frames rounded up to a span of 64)
+    bytes += 2 * ((padded * sizeof(double) + 255) & ~(size_t)255); // worker means + ready words (64-bit launch tags)
     return bytes + 256;
 }
 
@@ -1146,43 +1706,50 @@ static uint32_t resident_encode_blocks()
     return v;
 }
 
+
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames,
     size_t frames_cap, uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace,
-    hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles, uint64_t* d_mirror /* host-mapped or nullptr */,
+    hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles,
+    const EncodeHostLink* link /* the host pipeline's one-launch form; nullptr: three kernels */,
     int force_plain_fir, int self_blocks_override)
 {
     const uint32_t n_sig = sela_hip_signals_per_frame(channels);
     const size_t blocks = (size_t)n_frames * n_sig;
+    const size_t n_groups = ((size_t)n_frames + kGroupFrames - 1) / kGroupFrames;
     unsigned char* ws = static_cast<unsigned char*>(d_workspace);
     ws = reinterpret_cast<unsigned char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     BlockMeta* meta = reinterpret_cast<BlockMeta*>(ws);
     ws += (blocks * sizeof(BlockMeta) + 255) & ~(size_t)255;
     uint32_t* slots = reinterpret_cast<uint32_t*>(ws);
     ws += (blocks * kSlotWords * 4 + 255) & ~(size_t)255;
-    uint8_t* choice = ws;
-    ws += ((size_t)n_frames + 255) & ~(size_t)255;
+    uint64_t* group_count = reinterpret_cast<uint64_t*>(ws);
+    ws += (n_groups * kGroupCountStride * sizeof(uint64_t) + 255) & ~(size_t)255;
+    GroupState* group_state = reinterpret_cast<GroupState*>(ws);
+    ws += (n_groups * sizeof(GroupState) + 255) & ~(size_t)255;
     double* rings = reinterpret_cast<double*>(ws);
     ws += ((size_t)kXcds * kRingsPerXcd * kRingLen * sizeof(double) + 255) & ~(size_t)255;
     uint32_t* ring_owner = reinterpret_cast<uint32_t*>(ws);
     ws += ((size_t)kXcds * kRingsPerXcd * 4 + 255) & ~(size_t)255;
-    const size_t padded = (((size_t)n_frames + 7) / 8) * 8 * n_sig;
+    const size_t padded = (((size_t)n_frames + 63) / 64) * 64 * n_sig;
     double* mean_out = reinterpret_cast<double*>(ws);
     ws += (padded * sizeof(double) + 255) & ~(size_t)255;
-    uint32_t* mean_ready = reinterpret_cast<uint32_t*>(ws);
+    uint64_t* mean_ready = reinterpret_cast<uint64_t*>(ws);
 
-    if (n_frames == 0) {
+    if (link && (d_trace || d_phase_cycles))
+        return hipErrorInvalidValue; // (the analysis trace and the phase counts are the device-pointer path's)
+    if (n_frames == 0) { // (nothing to launch; a job's stream position stays where it is)
         hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
-        if (err == hipSuccess && d_mirror)
-            err = hipMemsetAsync(d_mirror, 0, 2 * sizeof(uint64_t), stream);
-        return err != hipSuccess ? err : hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), stream);
+        if (err == hipSuccess && d_frame_offsets)
+            err = hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), stream);
+        return err;
     }
-    const uint32_t groups = (n_frames + 7) / 8;
-    const uint32_t total_e = groups * 8 * n_sig;
+    const uint32_t total_e = (n_frames + 63) / 64 * 64 * n_sig; // (whole spans of 64 frames: block_of)
     // mean workers (see mean_worker): blocks that cannot start before the first ones retire get their mean from
     // a worker.  self_blocks = what the device holds at once (12 workgroups per CU) less the workers themselves.
+    const bool staged = link && link->host_pcm && channels == 2;
     uint32_t self_blocks = self_blocks_override >= 0 ? (uint32_t)self_blocks_override : resident_encode_blocks();
     uint32_t n_workers = 0;
-    if (total_e > self_blocks) {
+    if (total_e > self_blocks && !staged) { // (with stagers the link sets the pace, and a worker has no await_frame)
         n_workers = (total_e - self_blocks + 63) / 64;
         if (self_blocks_override < 0) { // the workers take slots of the first fill too
             const uint32_t resident = self_blocks;
@@ -1191,45 +1758,70 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         }
         n_workers = (n_workers + 7) & ~7u; // keeps encode index == workgroup index mod 8 (XCD placement)
     }
+    if (n_workers == 0)
+        self_blocks = total_e; // (nobody to wait for)
     const dim3 grid(n_workers + total_e), wg(64);
-    // launch ticket: unique per launch in this process, never 0 (ring owner words and the mean workers' ready words carry
-    // it, so the workspace is never cleared).  The count starts at a random number: device memory keeps its contents from
-    // one process to the next, and with a fixed start another process's ready words -- and its means -- would carry the
-    // very tickets of this one.
-    static std::atomic<uint32_t> next_ticket{ [] {
+    // launch ticket: unique per launch in this process, never 0.  Everything a launch leaves in the workspace for its
+    // own workgroups (ring owners, worker means, group counters, look-back cells) carries it, so nothing is cleared
+    // between launches; the cells whose stale contents could be mistaken for this launch's carry a 64-bit tag, the
+    // ticket under a nonce drawn once per process (another process's launches count from the same start).
+    static std::atomic<uint32_t> next_ticket{ 0x5E1A0001u };
+    static const uint32_t nonce = [] {
         std::random_device rd;
-        return ((uint32_t)rd() ^ ((uint32_t)rd() << 16)) | 1u;
-    }() };
+        return (uint32_t)rd() ^ ((uint32_t)rd() << 16);
+    }();
     uint32_t ticket = next_ticket.fetch_add(1, std::memory_order_relaxed);
     if (ticket == 0)
         ticket = next_ticket.fetch_add(1, std::memory_order_relaxed);
+    FuseArgs fa;
+    fa.meta = meta;
+    fa.slots = slots;
+    fa.group_count = link ? group_count : nullptr; // (null: the blocks leave placing and writing to the two kernels behind them)
+    fa.group_state = group_state;
+    fa.frames = d_frames;
+    fa.frames_cap = frames_cap;
+    fa.frame_offsets = d_frame_offsets;
+    fa.mirror = link ? link->mirror : nullptr;
+    fa.status = d_status;
+    fa.pos_in = link ? link->pos_in : nullptr;
+    fa.pos_out = link ? link->pos_out : nullptr;
+    fa.pcm_ready = staged ? link->pcm_ready : nullptr;
+    if (staged) { // the stagers first, on their own stream
+        // (above the default dynamic-LDS limit; the attribute is per device, so every time)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage_in), hipFuncAttributeMaxDynamicSharedMemorySize, kStageLdsBytes);
+        (void)hipMemsetAsync(link->stage_started + 1, 0, 8, link->stage_stream); // the stagers' frame counter
+        hipLaunchKernelGGL(k_stage_in, dim3(link->stage_workgroups), dim3(kStageThreads), kStageLdsBytes, link->stage_stream, link->host_pcm,
+            const_cast<int16_t*>(d_pcm), n_frames, link->pcm_ready, ticket, link->stage_started);
+        hipLaunchKernelGGL(k_stage_gate, dim3(1), dim3(64), 0, stream, link->stage_started, ticket, link->stage_workgroups);
+    }
+    fa.n_frames = n_frames;
+    fa.channels = channels;
+    fa.n_sig = n_sig;
+    fa.ticket = ticket;
+    fa.tag = ((uint64_t)nonce << 32) | ticket;
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
-        hipLaunchKernelGGL(k_encode_blocks<2>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
+        hipLaunchKernelGGL((k_encode_blocks<2, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     else if (d_trace)
-        hipLaunchKernelGGL(k_encode_blocks<1>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
+        hipLaunchKernelGGL((k_encode_blocks<1, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
+    else if (link)
+        hipLaunchKernelGGL((k_encode_blocks<0, true>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     else
-        hipLaunchKernelGGL(k_encode_blocks<0>, grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e);
+        hipLaunchKernelGGL((k_encode_blocks<0, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
-    // (chunks of the host pipeline: a plan small enough to start beside the next chunk's blocks, see kSmallPlanThreads.
-    // Tried on top of it: plan + assemble on a stream of higher priority -- they then start 19 us after the blocks end and
-    // take 33 us together, but the copy-outs need a stream of their own as well, and a fifth stream shares a hardware
-    // queue with one of the others; one-wave assemble workgroups -- 100 us instead of 50 beside the next chunk's blocks.)
-    const bool small = d_mirror != nullptr && n_frames <= (uint32_t)kSmallPlanFrames;
-    if (small)
-        hipLaunchKernelGGL((k_plan_frames<kSmallPlanThreads, kSmallPlanFrames>), dim3(1), dim3(kSmallPlanThreads), 0, stream, meta, n_frames, channels,
-            n_sig, frames_cap, d_frame_offsets, choice, d_status, d_mirror);
-    else
-        hipLaunchKernelGGL((k_plan_frames<kPlanThreads, kPlanLdsFrames>), dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig,
-            frames_cap, d_frame_offsets, choice, d_status, d_mirror);
-    if (ev)
-        (void)hipEventRecord(ev[2], stream);
-    hipLaunchKernelGGL(k_assemble_frames<kAsmThreads>, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets,
-        n_frames, channels, n_sig, frames_cap, d_frames);
-    if (ev)
-        (void)hipEventRecord(ev[3], stream);
+    if (!link) {
+        uint8_t* const choice = reinterpret_cast<uint8_t*>(group_state); // (the look-back cells' space: five bytes per frame, unused on this path)
+        hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap, d_frame_offsets,
+            choice, d_status, static_cast<uint64_t*>(nullptr));
+        if (ev)
+            (void)hipEventRecord(ev[2], stream);
+        hipLaunchKernelGGL(k_assemble_frames, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets, n_frames, channels,
+            n_sig, frames_cap, d_frames);
+        if (ev)
+            (void)hipEventRecord(ev[3], stream);
+    }
     return hipGetLastError();
 }
 

@@ -33,8 +33,13 @@ def main():
     try:
         wav = os.path.join(tmp, "track.wav")
         write_track(wav)
-        out = subprocess.run([exe, wav, tmp, "15", "e2e"], capture_output=True, text=True, timeout=120)
-        print("untraced:", out.stdout.strip() or out.stderr.strip())
+        try:
+            out = subprocess.run([exe, wav, tmp, os.environ.get("E2E_REPS", "15"), "e2e"], capture_output=True, text=True,
+                                 timeout=float(os.environ.get("E2E_TIMEOUT", "120")))
+            print("untraced:", out.stdout.strip(), out.stderr.strip()[-400:])
+        except subprocess.TimeoutExpired as t:
+            print("untraced: TIMEOUT", (t.stdout or b"")[-400:], (t.stderr or b"")[-400:])
+            return
         if "--no-trace" in sys.argv:
             return
         prof = os.path.join(tmp, "prof")
@@ -43,14 +48,14 @@ def main():
                         exe, wav, tmp, "2", "e2e"], capture_output=True, text=True, timeout=300, cwd="/tmp", env=env)
         kern = glob.glob(prof + "/**/*kernel_trace.csv", recursive=True)
         copy = glob.glob(prof + "/**/*memory_copy_trace.csv", recursive=True)
-        if not kern or not copy:
+        if not kern:
             print("no trace files", os.listdir(prof) if os.path.isdir(prof) else "")
             return
         ev = []
         for r in csv.DictReader(open(kern[0])):
             name = r["Kernel_Name"].split("(")[0].replace("void sela::", "")[:28]
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, ""))
-        for r in csv.DictReader(open(copy[0])):
+        for r in (csv.DictReader(open(copy[0])) if copy else []):  # (no copy trace: the call made no copies)
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", "?").replace("MEMORY_COPY_", ""),
                        r.get("Bytes", r.get("Size", "?"))))
         ev.sort()
