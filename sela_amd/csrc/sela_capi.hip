@@ -164,7 +164,7 @@ struct HostBuffer {
     }
 };
 
-// Host-pointer calls run as a chunked pipeline: the copy-in of every chunk is queued, in order
+// Host-pointer decodes run as a chunked pipeline (encodes: see job_feed_encode_launch): the copy-in of every chunk is queued, in order
 // on one stream, as soon as the chunk is fed (kSets chunks deep); the kernels of consecutive chunks alternate
 // between streams (a chunk of this size leaves the device in its launch tail for a good part of its run time, so
 // neighbours overlap); a chunk is copied out as soon as its kernels have finished.  Nothing in the issue path
@@ -303,13 +303,12 @@ uint32_t run_streams()
     static const uint32_t v = env_u32("SELA_HOST_RUN_STREAMS", 1, kRunStreams, 2);
     return v;
 }
-// Size of chunk number `index` of a job that has `available` frames at hand.  A decode job opens with two shorter
+// Size of chunk number `index` of a decode job that has `available` frames at hand.  It opens with two shorter
 // chunks: its copy-outs run back to back from the moment the first chunk is done, so the job is as long as the way
 // to that moment plus the bare copy of the PCM -- provided every later chunk is decoded by the time the copy-out
-// before it ends, which is what keeps the first chunks from being shorter still.  (For encode jobs short first / last chunks and sizes halving towards
-// the end were tried: more chunks cost more in kernel efficiency than the shorter fill and drain save.)
+// before it ends, which is what keeps the first chunks from being shorter still.
 // SELA_HOST_CHUNK_PLAN="a,b,c" sets the sizes of the first chunks of every job (experiments).
-uint32_t next_chunk_frames(bool encode, uint32_t index, uint32_t available)
+uint32_t next_chunk_frames(uint32_t index, uint32_t available)
 {
     static const std::vector<uint32_t> plan = [] {
         std::vector<uint32_t> v;
@@ -327,7 +326,7 @@ uint32_t next_chunk_frames(bool encode, uint32_t index, uint32_t available)
     uint32_t want = chunk_frames();
     if (index < plan.size())
         want = plan[index];
-    else if (plan.empty() && !encode && index < 2)
+    else if (plan.empty() && index < 2)
         want = std::min<uint32_t>(want, index ? 640u : 384u);
     if (want < available && available - want < want / 4) // (no stub of a last chunk: split what is left in two)
         want = (available + 1) / 2;
@@ -422,14 +421,23 @@ void* device_view(const void* host)
 }
 
 // ---- encode jobs ---------------------------------------------------------------------------------------------------
-// One feed = one launch of k_encode_blocks, everything in it: the launch's first workgroups fetch the feed's PCM
-// from page-locked host memory frame by frame (stage_in), the blocks encode each frame as it lands, and the last
+// One feed = one launch of k_encode_blocks (and, beside it on the copy-in stream, of k_stage_in, whose workgroups fetch
+// the feed's PCM from page-locked host memory frame by frame): the blocks encode each frame as it lands, and the last
 // block of every group of frames (kGroupFrames) writes the group's finished bytes straight to their place in frames_out
 // and their offsets to page-locked memory (finish_group).  No copy engine, no hand-over: the host enqueues one kernel
 // per feed and an event behind it; a feed's bytes and offsets are final when its event has fired.  Feeds run one
 // after the other on one stream; the job's stream position passes from launch to launch in device memory
 // (enc_words).  Buffers that are not page-locked go through page-locked bounce buffers.
-constexpr uint32_t kStageWorkgroups = 8;         // of k_stage_in, 16 waves each: 128 waves copy in (55.9 GB/s from 128 waves up, tools/pcie_probe.hip)
+constexpr uint32_t kStageWorkgroups = 8;         // of k_stage_in, four waves each with eight 16-byte loads in flight per lane
+uint32_t stage_workgroups() // SELA_HOST_STAGE_WGS=n overrides (experiments)
+{
+    static const uint32_t n = [] {
+        const char* e = std::getenv("SELA_HOST_STAGE_WGS");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 1 && v <= 64 ? (uint32_t)v : kStageWorkgroups;
+    }();
+    return n;
+}
 constexpr uint32_t kEncodeLaunchFrames = 1u << 16; // a feed larger than this is cut (device buffers are sized for it)
 
 int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
@@ -472,7 +480,7 @@ int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
     link.pos_out = pos + ((job->feeds.size() + 1) & 1);
     link.host_pcm = static_cast<const int16_t*>(src);
     link.pcm_ready = static_cast<uint64_t*>(g_ctx.enc_ready.ptr);
-    link.stage_workgroups = kStageWorkgroups;
+    link.stage_workgroups = stage_workgroups();
     link.stage_stream = g_ctx.s_in;
     link.stage_started = pos + 4;
     // what fills the device's copy of the PCM waits for the launch before this one, which reads it (and for the
@@ -630,7 +638,7 @@ int job_feed_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* of
     std::memcpy(staged, offsets, ((size_t)n_frames + 1) * 8);
     job->offsets_used += (size_t)n_frames + 1;
     for (uint32_t done = 0; done < n_frames;) {
-        const uint32_t nf = next_chunk_frames(false, job->issued, n_frames - done);
+        const uint32_t nf = next_chunk_frames(job->issued, n_frames - done);
         const int rc = job_issue_decode(job, frames, offsets + done, mapped + done, nf);
         if (rc != SELA_HIP_OK)
             return rc;

@@ -242,9 +242,10 @@ def test_host_pointer_api(gpu):
 
 
 def test_host_pointer_api_chunked_pipeline(gpu):
-    """Batches of two chunks and more go through the copy-in / kernels / copy-out pipeline (sela_capi.hip:
-    chunks of <= 768 frames encoding, 384 / 640 / 1024 decoding): same bytes as the device-pointer call
-    on the whole batch, including a short last chunk, and a corrupt frame in a later chunk is still reported."""
+    """Host pointers (sela_capi.hip): an encode is one launch that fetches its PCM and writes its frames itself
+    (stereo; other channel counts are copied in first), a decode goes through the copy-in / kernel / copy-out
+    pipeline in chunks of 384 / 640 / 1024 frames: same bytes as the device-pointer call on the whole batch,
+    including a short last chunk, and a corrupt frame in a later chunk is still reported."""
     from sela_amd import capi, codec
 
     n = 2 * 1024 + 300
@@ -254,7 +255,7 @@ def test_host_pointer_api_chunked_pipeline(gpu):
     assert np.array_equal(offsets, dev_offsets) and np.array_equal(frames, dev_frames)
     assert np.array_equal(codec.index_frames(frames, n, 2), offsets)
     assert np.array_equal(codec.decode_host(frames, offsets, 2), _decode(gpu, frames, offsets, 2))
-    # mono, nine encode chunks / three decode chunks, the last of a single frame
+    # mono, nine decode chunks, the last of a single frame
     n1 = 2 * 4096 + 1
     pcm1 = np.tile(synth_frames(683, 1, 32), (13, 1, 1))[:n1]
     f1, o1 = codec.encode_host(pcm1)
