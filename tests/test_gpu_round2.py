@@ -178,6 +178,37 @@ def test_streaming_jobs_equal_one_shot(gpu):
     capi.check(lib.sela_hip_decode_end(job, None))
 
 
+def test_host_pointer_calls_from_two_threads(gpu):
+    """Two threads, each with its own context (streams, buffers, staging kernels), encode and decode different
+    tracks at the same time on the one GPU: every call returns the bytes the same call returns alone.  (The
+    one-launch host encoder's blocks wait for its staging kernel, and two of those pairs share the device here.)"""
+    import threading
+    from sela_amd import codec
+
+    tracks = [synth_frames(1500, 2, 91), synth_frames(1100, 2, 92)]
+    alone = [codec.encode_host(t) for t in tracks]
+    problems = []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                frames, offsets = codec.encode_host(tracks[i])
+                if not (np.array_equal(frames, alone[i][0]) and np.array_equal(offsets, alone[i][1])):
+                    problems.append("thread %d: encode differs" % i)
+                if not np.array_equal(codec.decode_host(frames, offsets, 2), tracks[i]):
+                    problems.append("thread %d: decode differs" % i)
+        except Exception as e:  # noqa: BLE001 -- reported below, from the test's thread
+            problems.append("thread %d: %r" % (i, e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not any(t.is_alive() for t in threads), "a thread is stuck"
+    assert not problems, problems
+
+
 @pytest.mark.parametrize("label", ["config0_mono_10s", "config1_stereo_3min", "stereo_48k_tail", "three_channel_96k", "shorter_than_a_frame"])
 def test_cli_files_match_reference_file_digests(tmp_path, file_digests, label):
     """`sela_mi355x -e` / `-d` (the streaming file-to-file path) write byte-identical files -- headers, dropped
