@@ -1,0 +1,131 @@
+"""The shipped gfx950 code object, disassembled: the instructions the cross-workgroup hand-overs of the one-launch
+host encoder rest on are really there (the note at store_through in sela_encode.hip).
+
+Two things went wrong in that code that no source review showed, both visible only in the ISA:
+  * a fence's `s_waitcnt vmcnt(0)` is dropped by the compiler when it believes nothing is outstanding
+    (MI355X_MICROARCH.md, "inter-workgroup visibility": write the wait out in asm) -- data published before it had
+    left the wave;
+  * the staging kernel's loop was re-structured so that lanes 1..63 went round again without a new frame number
+    (a loop around the copy that did not contain the fetch-and-add).
+No GPU needed: llvm-objdump on the .so that travels to the GPU box.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "sela_amd", "libsela_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+INSN = re.compile(r"^\t(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
+TARGET = re.compile(r"<([^>+]+)\+0x([0-9a-fA-F]+)>\s*$")
+HEAD = re.compile(r"^([0-9a-fA-F]+) <([^>]+)>:")
+
+
+@pytest.fixture(scope="module")
+def functions(tmp_path_factory):
+    """name -> list of (address, mnemonic, operands, branch target or None) for every function of the device code."""
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.exists(LIB) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("no built library or no LLVM tools")
+    d = tmp_path_factory.mktemp("isa")
+    fat, co = str(d / "fat.bin"), str(d / "dev.co")
+    subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, LIB])
+    subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    text = subprocess.check_output([tools[2], "-d", co], text=True)
+    out, cur, base = {}, None, {}
+    for line in text.splitlines():
+        h = HEAD.match(line)
+        if h:
+            cur = h.group(2)
+            base[cur] = int(h.group(1), 16)
+            out[cur] = []
+            continue
+        m = INSN.match(line)
+        if m and cur:
+            t = TARGET.search(line)
+            target = base.get(t.group(1), None) if t else None
+            if t and target is not None:
+                target += int(t.group(2), 16)
+            out[cur].append((int(m.group(3), 16), m.group(1), m.group(2), target))
+    return out
+
+
+def _one(functions, *parts):
+    names = [n for n in functions if all(p in n for p in parts)]
+    assert len(names) == 1, (parts, names)
+    return functions[names[0]]
+
+
+def _waits_for_stores(insn):
+    return insn[1] == "s_waitcnt" and "vmcnt(0)" in insn[2]
+
+
+def _is_store(insn):
+    return insn[1].startswith(("global_store", "flat_store", "buffer_store", "scratch_store"))
+
+
+def test_stager_publishes_a_frame_after_its_stores_and_draws_a_frame_every_round(functions):
+    f = _one(functions, "k_stage_in")
+    adds = [i for i, x in enumerate(f) if x[1] == "global_atomic_add_x2"]
+    loads = [i for i, x in enumerate(f) if x[1] == "global_load_dwordx4" and " nt" in x[2]]
+    stores = [i for i, x in enumerate(f) if x[1] == "global_store_dwordx2"]
+    assert len(adds) == 1 and len(loads) == 8 and len(stores) == 17, (len(adds), len(loads), len(stores))
+    assert all("sc1" in f[i][2] for i in stores), "a store that stays in the L2"
+    data, flag = stores[:-1], stores[-1]
+    assert adds[0] < loads[0] and loads[-1] < data[0] and data[-1] < flag
+    waits = [i for i in range(data[-1] + 1, flag) if _waits_for_stores(f[i])]
+    assert waits, "no s_waitcnt vmcnt(0) between the frame's stores and its ready word"
+    # no loop round the copy that does not also draw a frame: no backward branch lands behind the fetch-and-add
+    add_at, flag_at = f[adds[0]][0], f[flag][0]
+    for addr, op, _, target in f:
+        if op.startswith(("s_cbranch", "s_branch")) and target is not None and target < addr and addr > add_at:
+            assert target <= add_at, "a loop inside the stager's loop skips the fetch-and-add (branch at 0x%x to 0x%x)" % (addr, target)
+    # and the draw is handed to the whole wave from lane 0 with every lane awake: readfirstlane directly behind the wait
+    after = f[adds[0] + 1: adds[0] + 8]
+    assert any(_waits_for_stores(x) for x in after) and any(x[1] == "v_readfirstlane_b32" for x in after)
+    assert flag_at > add_at
+
+
+def test_fused_block_counts_itself_in_after_its_stores_and_the_last_block_acquires(functions):
+    f = _one(functions, "k_encode_blocksILi0ELb1E")
+    cas = [i for i, x in enumerate(f) if "atomic_cmpswap_x2" in x[1]]
+    assert cas, "no group counter update"
+    c = cas[-1]  # group_arrive (the ring allocation further up uses a 32-bit swap)
+    prev_store = max(i for i in range(c) if _is_store(f[i]) and not f[i][1].startswith("scratch"))
+    assert any(_waits_for_stores(f[i]) for i in range(prev_store + 1, c)), "slot / BlockMeta stores not waited for before the count"
+    # what the group's last block reads was stored through the L2
+    through = [x for x in f[:c] if x[1] in ("global_store_dwordx2", "flat_store_dwordx2") and "sc1" in x[2]]
+    assert len(through) >= 3, "slot and BlockMeta stores are not write-through"
+    # ... and it drops its CU's stale lines before it reads: buffer_inv sc1 between the count and the call of finish_group
+    call = next(i for i in range(c, len(f)) if f[i][1] == "s_swappc_b64")
+    assert any(f[i][1] == "buffer_inv" and "sc1" in f[i][2] for i in range(c, call)), "no agent-scope acquire before finish_group"
+    # the frame behind the stagers is read past the L2 (no acquire per block)
+    assert sum(1 for x in f if x[1] in ("global_load_dword", "flat_load_dword") and "sc1" in x[2]) >= 32
+
+
+def test_device_path_kernel_has_none_of_it(functions):
+    f = _one(functions, "k_encode_blocksILi0ELb0E")
+    assert not any("atomic_cmpswap_x2" in x[1] for x in f)
+    assert not any(x[1] == "buffer_inv" for x in f)
+    assert sum(1 for x in f if _is_store(x) and "sc1" in x[2]) == 0, "write-through stores on the device-pointer path"
+
+
+def test_mean_worker_publishes_mean_then_mark(functions):
+    f = _one(functions, "mean_worker")
+    st = [i for i, x in enumerate(f) if _is_store(x) and "sc1" in x[2]]
+    assert len(st) == 2, [f[i] for i in st]
+    assert any(_waits_for_stores(f[i]) for i in range(st[0] + 1, st[1])), "the mean is not waited for before its mark"
+
+
+def test_await_frame_and_look_back_read_past_the_l2(functions):
+    f = _one(functions, "await_frame")
+    loads = [x for x in f if x[1].startswith(("global_load", "flat_load"))]
+    assert loads and all("sc1" in x[2] for x in loads), [x for x in loads if "sc1" not in x[2]]
+    g = _one(functions, "finish_group")
+    cells = [x for x in g if x[1] in ("global_load_dwordx2", "flat_load_dwordx2") and "sc1" in x[2]]
+    assert len(cells) >= 5, "the look-back cells are not read past the L2"
+    marks = [x for x in g if x[1] in ("global_store_dwordx2", "flat_store_dwordx2") and "sc1" in x[2]]
+    assert len(marks) >= 5, "the look-back cells are not stored through the L2"
