@@ -182,7 +182,7 @@ struct HostContext {
     ChunkSet set[kSets];
     DeviceBuffer status;      // device-side status words (decode kernels of a job report through job_flags instead)
     // encode jobs: one launch per feed (see job_feed_encode)
-    DeviceBuffer enc_pcm, enc_workspace, enc_ready, enc_words; // enc_words: the job's stream position (two cells in turn), 4 status words, the stagers' roll call
+    DeviceBuffer enc_pcm, enc_workspace, enc_ready, enc_words; // enc_words: the job's stream position (two cells in turn), 4 status words, the stagers' four words (EncodeHostLink::stage_started)
     hipEvent_t enc_prev = nullptr; // behind the newest work on the encode stream
     HostBuffer enc_mirror;                                     // page-locked: offsets + status per feed
     uint64_t* enc_mirror_mapped = nullptr;
@@ -696,9 +696,9 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
     if (e == hipSuccess && encode) {
         // (offsets + status per feed, a feed has at least a frame)
         if ((e = g_ctx.enc_mirror.reserve((3 * (size_t)total_frames + 4) * 8)) == hipSuccess
-            && (e = g_ctx.enc_words.reserve(16 + 16 + 16)) == hipSuccess
+            && (e = g_ctx.enc_words.reserve(16 + 16 + 32)) == hipSuccess
             && (e = hipHostGetDevicePointer((void**)&g_ctx.enc_mirror_mapped, g_ctx.enc_mirror.ptr, 0)) == hipSuccess)
-            e = hipMemsetAsync(g_ctx.enc_words.ptr, 0, 16 + 16 + 16, g_ctx.s_run[0]); // the job's stream position: 0
+            e = hipMemsetAsync(g_ctx.enc_words.ptr, 0, 16 + 16 + 32, g_ctx.s_run[0]); // the job's stream position: 0
     }
     if (e == hipSuccess && !encode) {
         const size_t n_flags = (size_t)total_frames * sela::decode_waves(channels) + 1;

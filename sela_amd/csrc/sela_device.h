@@ -45,7 +45,7 @@ struct EncodeHostLink {
     uint64_t* pcm_ready;     // device: [n_frames] <- launch ticket | checksum, frame copied in
     uint32_t stage_workgroups; // of k_stage_in, each with a CU to itself
     hipStream_t stage_stream;  // where k_stage_in runs (not the encode launch's stream: the two may run side by side)
-    uint64_t* stage_started;   // device word: launch ticket | stager workgroups that have a CU
+    uint64_t* stage_started;   // four device words: launch ticket | stager workgroups that have a CU; the stagers' frame counter; the gate's mark; groups the launch has finished
 };
 
 // Order LDS traffic between the lanes of ONE wave (a wave executes in lockstep and the LDS serves a

@@ -421,6 +421,8 @@ __device__ __forceinline__ void drop_stale_lines() // (nothing older than now is
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
+// What marks a counter cell as this launch's (group_arrive): 40 bits of the hashed tag above a 24-bit count.
+__device__ __forceinline__ uint64_t count_mark(uint64_t tag) { return (tag * 0x9E3779B97F4A7C15ull) & ~(uint64_t)0xFFFFFF; }
 
 // ---- stagers: a second kernel fetches the PCM from page-locked host memory (host pipeline, stereo) ---------------
 // A kernel reads host memory at the link's rate (55.9 GB/s measured with >= 128 waves of 16-byte loads,
@@ -443,9 +445,13 @@ constexpr int kStageLdsBytes = 150 * 1024; // (with the 12.1 KB of a block that 
 
 __device__ __forceinline__ uint32_t frame_check_term(uint32_t word, uint32_t index) { return word * (2u * index + 1u); }
 
+constexpr uint32_t kStageLingerSpins = 8000; // x (s_sleep 64 + a trip to memory, ~2.5 us) = ~20 ms
+
 __global__ __launch_bounds__(kStageThreads) void k_stage_in(const int16_t* __restrict__ host_pcm, int16_t* __restrict__ pcm, uint32_t n_frames,
-    uint64_t* __restrict__ pcm_ready, uint32_t ticket, uint64_t* __restrict__ started)
+    uint64_t* __restrict__ pcm_ready, uint32_t ticket, uint64_t* __restrict__ started, uint64_t tag, uint32_t n_groups)
 {
+    // started[0]: roll call (launch ticket | workgroups that have a CU), [1]: the frame counter, [2]: k_stage_gate's mark,
+    // [3]: groups of frames the encode launch has finished (count_mark | count)
     extern __shared__ unsigned char stage_lds[]; // (never touched: it keeps other workgroups off this CU)
     if (threadIdx.x == 0) { // one more stager workgroup has its CU (k_stage_gate)
         uint64_t old = __hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -495,14 +501,32 @@ __global__ __launch_bounds__(kStageThreads) void k_stage_in(const int16_t* __res
         if (lane == 0) // (nothing comes back out of this one-lane region)
             store_through(pcm_ready + f, ((uint64_t)ticket << 32) | sum);
     }
+    // Do not END beside a running encode launch: when a kernel ends the device writes back its caches, and the blocks
+    // that were then still waiting for the last frames saw them 30-45 us late (stamped: the frames of the last 8 groups
+    // accepted 40 us after their publication instead of 8; the launch ended 50 us earlier with stagers that stayed).
+    // So the waves stay -- asleep, on CUs nobody else needs at the tail -- until the encode launch has finished its
+    // last group.  Only if that launch runs BESIDE this kernel, which k_stage_gate's mark says (the gate is on the
+    // encode launch's stream, directly in front of it): behind a stager kernel that has to end first there is nothing
+    // to wait for.  Bounded (~20 ms) like every wait here.
+    if (load_through(started + 2) == tag) {
+        const uint64_t mark = count_mark(tag);
+        for (uint32_t spins = 0; spins < kStageLingerSpins; spins++) {
+            const uint64_t c = load_through(started + 3);
+            if ((c & ~(uint64_t)0xFFFFFF) == mark && (uint32_t)(c & 0xFFFFFF) >= n_groups)
+                break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
 }
 
 // The stagers need whole CUs, and blocks that wait for their frames never leave theirs: an encode launch that got
 // onto the device before the stagers would keep them off it.  So this one wave goes first on the encode launch's
 // stream and ends when every stager workgroup has a CU (or, after ~20 ms, regardless: then the blocks' own waits
 // decide).  If the two streams share a hardware queue the stager kernel, launched first, has ended by now.
-__global__ __launch_bounds__(64) void k_stage_gate(const uint64_t* __restrict__ started, uint32_t ticket, uint32_t n_workgroups)
+__global__ __launch_bounds__(64) void k_stage_gate(uint64_t* __restrict__ started, uint32_t ticket, uint32_t n_workgroups, uint64_t tag)
 {
+    if (threadIdx.x == 0) // "the encode launch's stream runs beside the stagers" (see the end of k_stage_in)
+        store_through(started + 2, tag);
     for (uint32_t spins = 0; spins < 20000; spins++) {
         const uint64_t c = load_through(started);
         if ((uint32_t)(c >> 32) == ticket && (uint32_t)c >= n_workgroups)
@@ -639,6 +663,7 @@ struct FuseArgs {
     uint64_t* pos_out;       // ... and where the launch leaves the offset behind its last frame (null: nowhere).  Two cells: groups
                              // read the start long after the last group -- which only needs the others' sizes -- has written the end
     const uint64_t* pcm_ready; // [n_frames]: launch ticket | checksum of every frame k_stage_in has copied in; or null (the PCM is there)
+    uint64_t* groups_done;   // count_mark | groups finished, for the stagers (see the end of k_stage_in); or null
     uint32_t n_frames, channels, n_sig, ticket;
     uint64_t tag;            // process nonce << 32 | ticket (see launch_encode): what marks a cell as written by THIS launch
 };
@@ -858,7 +883,7 @@ __device__ __forceinline__ bool group_arrive(uint64_t* cell, uint64_t tag, uint3
 {
     // (agent scope: where the group's blocks run is not ours to rely on.  One counter per 128-byte line -- sixteen to
     // a line, the 11,625 updates of a 3,875-frame launch added 77 us to it.)
-    const uint64_t mark = (tag * 0x9E3779B97F4A7C15ull) & ~(uint64_t)0xFFFFFF; // (blocks_in_group <= 8 * 256 < 2^24)
+    const uint64_t mark = count_mark(tag); // (blocks_in_group <= 8 * 256 < 2^24)
     uint64_t old = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         const uint64_t neu = (old & ~(uint64_t)0xFFFFFF) == mark ? old + 1 : (mark | 1u);
@@ -984,6 +1009,8 @@ __device__ __attribute__((noinline)) void finish_group(const FuseArgs& fa, uint3
         if (ok && !timed_out)
             assemble_frame(fa, f0 + i, ch, reinterpret_cast<uint32_t*>(fa.frames + (((uint64_t)hi << 32) | lo)), lane);
     }
+    if (fa.groups_done && lane == 0)
+        (void)group_arrive(fa.groups_done, fa.tag, n_groups);
 }
 
 // kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts
@@ -1786,13 +1813,14 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     fa.pos_in = link ? link->pos_in : nullptr;
     fa.pos_out = link ? link->pos_out : nullptr;
     fa.pcm_ready = staged ? link->pcm_ready : nullptr;
+    fa.groups_done = staged ? link->stage_started + 3 : nullptr;
     if (staged) { // the stagers first, on their own stream
         // (above the default dynamic-LDS limit; the attribute is per device, so every time)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage_in), hipFuncAttributeMaxDynamicSharedMemorySize, kStageLdsBytes);
         (void)hipMemsetAsync(link->stage_started + 1, 0, 8, link->stage_stream); // the stagers' frame counter
         hipLaunchKernelGGL(k_stage_in, dim3(link->stage_workgroups), dim3(kStageThreads), kStageLdsBytes, link->stage_stream, link->host_pcm,
-            const_cast<int16_t*>(d_pcm), n_frames, link->pcm_ready, ticket, link->stage_started);
-        hipLaunchKernelGGL(k_stage_gate, dim3(1), dim3(64), 0, stream, link->stage_started, ticket, link->stage_workgroups);
+            const_cast<int16_t*>(d_pcm), n_frames, link->pcm_ready, ticket, link->stage_started, ((uint64_t)nonce << 32) | ticket, (uint32_t)n_groups);
+        hipLaunchKernelGGL(k_stage_gate, dim3(1), dim3(64), 0, stream, link->stage_started, ticket, link->stage_workgroups, ((uint64_t)nonce << 32) | ticket);
     }
     fa.n_frames = n_frames;
     fa.channels = channels;

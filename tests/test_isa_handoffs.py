@@ -78,11 +78,12 @@ def test_stager_publishes_a_frame_after_its_stores_and_draws_a_frame_every_round
     assert adds[0] < loads[0] and loads[-1] < data[0] and data[-1] < flag
     waits = [i for i in range(data[-1] + 1, flag) if _waits_for_stores(f[i])]
     assert waits, "no s_waitcnt vmcnt(0) between the frame's stores and its ready word"
-    # no loop round the copy that does not also draw a frame: no backward branch lands behind the fetch-and-add
+    # no loop round the copy that does not also draw a frame: no backward branch lands between the fetch-and-add and
+    # the ready word (the wait for the encode launch behind the loop is a loop of its own, further down)
     add_at, flag_at = f[adds[0]][0], f[flag][0]
     for addr, op, _, target in f:
-        if op.startswith(("s_cbranch", "s_branch")) and target is not None and target < addr and addr > add_at:
-            assert target <= add_at, "a loop inside the stager's loop skips the fetch-and-add (branch at 0x%x to 0x%x)" % (addr, target)
+        if op.startswith(("s_cbranch", "s_branch")) and target is not None and target < addr:
+            assert not add_at < target <= flag_at, "a loop inside the stager's loop skips the fetch-and-add (branch at 0x%x to 0x%x)" % (addr, target)
     # and the draw is handed to the whole wave from lane 0 with every lane awake: readfirstlane directly behind the wait
     after = f[adds[0] + 1: adds[0] + 8]
     assert any(_waits_for_stores(x) for x in after) and any(x[1] == "v_readfirstlane_b32" for x in after)
