@@ -1576,10 +1576,8 @@ constexpr int kPlanLdsFrames = 12288; // frame sizes staged in LDS up to this ba
 
 __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* __restrict__ frame_offsets,
-    uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status, uint64_t* __restrict__ mirror)
+    uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status)
 {
-    // mirror (optional, page-locked HOST memory): a copy of frame_offsets[0 .. n_frames] followed by one word
-    // status[0] | status[1] << 32, so that the host pipeline reads a chunk's sizes without a copy of its own
     __shared__ uint64_t part[kPlanThreads];
     __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of the frames of one tile
     __shared__ uint32_t acc[2];                      // flags, frames that do not fit frames_cap
@@ -1618,19 +1616,14 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
         uint64_t off = base + part[tid] - bytes;
         for (uint32_t i = begin; i < end; i++) {
             frame_offsets[tile0 + i] = off;
-            if (mirror)
-                mirror[tile0 + i] = off;
             off += frame_size[i];
             if (off > frames_cap)
                 overflow++;
         }
         base += part[kPlanThreads - 1];
     }
-    if (tid == 0) {
+    if (tid == 0)
         frame_offsets[n_frames] = base;
-        if (mirror)
-            mirror[n_frames] = base;
-    }
     if (flags)
         atomicOr(&acc[0], flags);
     if (overflow)
@@ -1640,8 +1633,6 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
         status[0] = acc[0];
         status[1] = acc[1];
         status[2] = status[3] = 0;
-        if (mirror)
-            mirror[(size_t)n_frames + 1] = (uint64_t)acc[0] | ((uint64_t)acc[1] << 32);
     }
 }
 
@@ -1842,7 +1833,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     if (!link) {
         uint8_t* const choice = reinterpret_cast<uint8_t*>(group_state); // (the look-back cells' space: five bytes per frame, unused on this path)
         hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap, d_frame_offsets,
-            choice, d_status, static_cast<uint64_t*>(nullptr));
+            choice, d_status);
         if (ev)
             (void)hipEventRecord(ev[2], stream);
         hipLaunchKernelGGL(k_assemble_frames, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets, n_frames, channels,
