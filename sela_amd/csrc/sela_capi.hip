@@ -298,11 +298,6 @@ uint32_t chunk_frames()
     static const uint32_t v = env_u32("SELA_HOST_CHUNK_FRAMES", 8, kHostChunkFrames, kHostChunkFrames);
     return v;
 }
-uint32_t run_streams()
-{
-    static const uint32_t v = env_u32("SELA_HOST_RUN_STREAMS", 1, kRunStreams, 2);
-    return v;
-}
 // Size of chunk number `index` of a decode job that has `available` frames at hand.  It opens with two shorter
 // chunks: its copy-outs run back to back from the moment the first chunk is done, so the job is as long as the way
 // to that moment plus the bare copy of the PCM -- provided every later chunk is decoded by the time the copy-out
