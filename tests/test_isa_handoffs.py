@@ -130,3 +130,19 @@ def test_await_frame_and_look_back_read_past_the_l2(functions):
     assert len(cells) >= 5, "the look-back cells are not read past the L2"
     marks = [x for x in g if x[1] in ("global_store_dwordx2", "flat_store_dwordx2") and "sc1" in x[2]]
     assert len(marks) >= 5, "the look-back cells are not stored through the L2"
+
+
+def test_stamp_tool_still_fits_the_sources(tmp_path):
+    """tools/group_stamps.py patches a COPY of the kernels' sources at anchored lines (the stamped build DESIGN.md 5.4's
+    per-group times come from): every anchor is still there."""
+    import importlib.util
+    import shutil
+
+    spec = importlib.util.spec_from_file_location("group_stamps", os.path.join(ROOT, "tools", "group_stamps.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    for name, patches, tail in (("sela_encode.hip", tool.ENCODE_PATCHES, tool.DUMP), ("sela_capi.hip", tool.CAPI_PATCHES, None)):
+        copy = tmp_path / name
+        shutil.copy(os.path.join(ROOT, "sela_amd", "csrc", name), copy)
+        tool.patch(str(copy), patches, tail)
+        assert "g_stamps" in copy.read_text() or "dump_stamps" in copy.read_text()
