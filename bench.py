@@ -5,28 +5,48 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over synthetic PCM that is already resident in HBM: encode to the
-.sela frame stream, decode the stream back to PCM.
+(`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the second form itself and
+prints the same ONE JSON line last on stdout.)
 
-  N = 1   BASELINE.json configs[1]: one 3-minute 16-bit stereo 44.1 kHz track = 3875 frames of 2048 samples.
-  N > 1   BASELINE.json configs[3]: the 100-track album (34/33/33 tracks at 44.1/48/96 kHz, 549,365 frames),
-          STRONG scaling: the (track, frame) space is cut into N contiguous balanced ranges
-          (sela_amd.sharding.partition -- the reference's static partition, src/sela/encoder.cpp:58-73), every
-          rank encodes and decodes its range in batches of <= 65,536 frames, and the ranks all-gather the
-          compressed frame sizes over RCCL -- the only exchange the path has -- inside the
-          timed region, beside the decode of the last batch.  The gathered layout is checked against the
-          digest of the one-GPU (reference) layout.  `--workload album` runs the same job on one GPU.
+One "step" = one pass of the hot path over synthetic PCM that is already resident in HBM: encode to the
+.sela frame stream, decode the stream back to PCM.  The HEADLINE (`value`) is the same job at every N, so that
+lines of different N divide into an efficiency:
+
+  track (default)   BASELINE.json configs[1], WEAK scaling: every rank encodes and decodes one 3-minute 16-bit
+                    stereo 44.1 kHz track = 3875 frames of 2048 samples (rank r: album track 3 r, the album's
+                    44.1 kHz tracks; N = 1: track 0).  For N > 1 the ranks all-gather the compressed frame sizes
+                    over RCCL every step -- the only exchange the path has -- inside the timed
+                    region.  value = N x 3875 x 2048 samples / step time.
+
+Two more workloads ride along as extra blocks of the same line (and can be made the headline with --workload):
+
+  album             BASELINE.json configs[3], STRONG scaling: the 100-track album (34/33/33 tracks at 44.1/48/96
+                    kHz, 549,365 frames); the (track, frame) space is cut into N contiguous balanced ranges
+                    (sela_amd.sharding.partition -- the reference's static partition, src/sela/encoder.cpp:58-73),
+                    every rank encodes and decodes its range in batches of <= 65,536 frames, one all-gather of
+                    the sizes per step; the gathered layout is checked against the reference's digest.  The
+                    `album` block of the --gpus 1 line is the one-GPU anchor of the N > 1 lines' `album` blocks.
+  decode10k         BASELINE.json configs[4], STRONG scaling, decode only: 10,000 frames encoded OUTSIDE the
+                    timed region, every rank decodes its contiguous 1/N; no collective (output offsets are
+                    frame x 2048 x channels x 2).
 
 K steps are timed, bracketed by barrier + torch.cuda.synchronize(), MAX over ranks; that measurement is
 repeated until at least ~0.5 s has been timed and `value` is the median repetition (min / max reported; the
 first repetition, which runs while the clocks still settle, is reported separately).
 
+WHAT IS TIMED IS WHAT IS CHECKED: the timed steps run as two independent encode->decode chains in flight on two
+HIP streams (`lanes`).  Every timed call leaves its status words in a slot of its own, all of them are OR-ed
+after the timed region; the outputs each lane's LAST timed step left in its buffers (frame bytes, offsets, decoded
+PCM) are compared on the device with those of a serial, synchronised step, and that step's with the CPU reference
+(`timed_outputs`).
+
 Rank 0 prints ONE JSON line: metric/value as BASELINE.json names them (Msamples/s, a sample = one stereo pair
 that went through encode AND decode), plus
   "roofline"      the dominant kernel (k_encode_blocks): algorithmic bytes per launch / its average duration
-                  measured with HIP events on the launch stream, against the 8 TB/s HBM peak
+                  measured with HIP events on the launch stream, against the 8 TB/s HBM peak; the resource that
+                  actually binds the kernel (vector-ALU issue) is beside it as "binding"
   "cpu_baseline"  the reference (oracle/_ref, kind "reference") or the CPU restatement (kind "port") timed on
-                  this box's host cores on a bounded sample of the same workload
+                  this box's host cores (rank 0) on a bounded sample of the same workload
   "e2e"           host-pointer API (H2D + kernels + D2H, steady_clock) and "file_to_file" (file read .. file
                   write, the reference's `sela -e` / `-d`), measured by host/sela_filebench (N = 1 only).
 """
@@ -36,6 +56,7 @@ import argparse
 import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -45,59 +66,87 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_QUARTER_RATE_GIPS = 256 * 4 * 2.4 / 4  # wave-instructions/ns the 1024 SIMDs can retire at 4 cycles each, 2.4 GHz peak clock
-FP64_UNFUSED_PEAK_TOPS = 39.3  # vector FP64: 78.6 TFLOP/s counts an FMA as 2; mul and add issue separately here
+PEAK_CLOCK_GHZ = 2.4   # the ONE clock every issue-rate figure here and in DESIGN.md is priced against (MI355X peak engine clock)
+VALU_ISSUE_PEAK_GIPS = 256 * 4 * PEAK_CLOCK_GHZ / 4  # wave-instructions/ns: 1024 SIMDs, one wave64 instruction per 4 cycles each
+FP64_UNFUSED_PEAK_TOPS = 256 * 4 * 16 * PEAK_CLOCK_GHZ / 1e3  # vector FP64, one operation per lane and cycle: 39.3 (78.6 TFLOP/s counts an FMA as 2)
 # unfused FP64 operations the reference's analysis needs per 2048-sample block:
 # 101 lags x (2048 - lag) x (mul + add) for the autocorrelation + 4950 Schur column updates x 4
 FP64_OPS_PER_BLOCK = 2 * sum(2048 - i for i in range(101)) + 4 * 4950
 TRACK_SECONDS, SAMPLE_RATE, CHANNELS = 180, 44100, 2
 ALBUM_BATCH_FRAMES = 65536
+DECODE10K_FRAMES, DECODE10K_TRACK = 10000, 2
 ENCODE_TARGET_MSPS = 1000.0  # BASELINE.json north_star: >= 1 G stereo samples/s encode on one MI355X
+METRIC = "Msamples/s encode+decode, 16-bit stereo 44.1kHz, 1/2/4/8 GPU; bit-exact vs CPU"  # BASELINE.json "metric"
 
 
-def cpu_baseline(pcm, repeats_target_s=12.0, gpu_frames=None, gpu_offsets=None, gpu_decoded=None):
-    """Time the CPU path (encode + decode of the same frames) on the host cores.
+# ---- N > 1 without a launcher: start one ----------------------------------------------------------------------
+def relaunch_under_torchrun(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE): run the same command under torch.distributed.run, one rank
+    per GPU, and print rank 0's JSON line LAST on stdout (anything else the ranks wrote to stdout goes to stderr)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for text in proc.stdout.splitlines():
+        try:
+            if text.startswith("{") and "metric" in json.loads(text):
+                if line is not None:
+                    print(line, file=sys.stderr)
+                line = text
+                continue
+        except ValueError:
+            pass
+        print(text, file=sys.stderr)
+    sys.stderr.flush()
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if proc.returncode else (0 if line is not None else 1)
 
-    Uses the unmodified reference when oracle/_ref/libsela_ref.so travelled with the repo, else the
-    CPU restatement.  Thread fan-out = the reference's static contiguous partition over
-    hardware_concurrency() threads (src/sela/encoder.cpp:58-73).  Bounded sample: the whole
-    3875-frame track, repeated until ~12 s of wall time or 3 repeats, whichever comes first.
-    """
+
+# ---- the CPU leg ---------------------------------------------------------------------------------------------------
+def cpu_reference():
+    """(library, kind): the unmodified reference when oracle/_ref/libsela_ref.so travelled with the repo, else the CPU
+    restatement.  Checker and CPU baseline only -- nothing of the product path goes through it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import oracle, reference
 
     impl = reference()
-    kind = "reference"
-    if impl is None:
-        impl, kind = oracle(), "port"
+    return (impl, "reference") if impl is not None else (oracle(), "port")
+
+
+def cpu_baseline(pcm, budget_s=12.0, max_reps=3):
+    """Time the CPU path (encode + decode of the same frames) on the host cores: thread fan-out = the reference's
+    static contiguous partition over hardware_concurrency() threads (src/sela/encoder.cpp:58-73).  Bounded sample:
+    the whole track, repeated until ~budget_s of wall time or max_reps.  Returns (record, blob, offsets, decoded)."""
+    impl, kind = cpu_reference()
     cores = os.cpu_count() or 1
     n_frames, n, ch = pcm.shape
     enc_s = dec_s = 0.0
     reps = 0
     t_start = time.time()
-    while reps < 3 and (reps == 0 or time.time() - t_start < repeats_target_s):
+    while reps < max_reps and (reps == 0 or time.time() - t_start < budget_s):
         blob, offs, es = impl.encode_frames(pcm, threads=cores)
         dec, ds = impl.decode_frames(blob, offs, ch, threads=cores)
         enc_s += es
         dec_s += ds
         reps += 1
     samples = reps * n_frames * n
-    bit_exact = None
-    if gpu_frames is not None:  # the CPU output doubles as the checker of what the GPU just produced
-        import numpy as np
-
-        bit_exact = bool(np.array_equal(blob, gpu_frames) and np.array_equal(offs, gpu_offsets) and np.array_equal(dec, gpu_decoded))
-    return {
-        "bit_exact_vs_gpu": bit_exact,
+    rec = {
         "value": samples / (enc_s + dec_s) / 1e6,
         "unit": "Msamples/s",
         "cores": cores,
         "kind": kind,
         "encode_msps": samples / enc_s / 1e6,
         "decode_msps": samples / dec_s / 1e6,
-        "sample": f"{reps} x the full {n_frames}-frame stereo track, encode+decode, {cores} threads "
+        "sample": f"{reps} x the full {n_frames}-frame stereo track (rank 0's), encode+decode, {cores} threads "
                   f"(static contiguous frame partition as src/sela/encoder.cpp:58-73)",
     }
+    return rec, blob, offs, dec
 
 
 def _flush_c_stdio():
@@ -175,187 +224,433 @@ def host_legs(pcm_host, repeats=9):
     return res
 
 
-def timed_repetitions(step, barrier, steps, dist, min_total_s=0.5, max_reps=40):
-    """Seconds per K-step measurement, each bracketed by barrier + synchronize, MAX over ranks."""
-    import torch
+# ---- the timed machinery ---------------------------------------------------------------------------------------------
+class Bench:
+    """One process = one rank = one GPU.  Holds what every workload shares: torch, the process group, the barrier."""
 
-    out = []
-    total = 0.0
-    while len(out) < max_reps and (not out or total < min_total_s):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            result = step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed, total + elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the same numbers -- and the same loop exit -- on every rank
-            elapsed, agreed_total = float(t[0].item()), float(t[1].item())
-        else:
-            agreed_total = total + elapsed
-        out.append(elapsed)
-        total = agreed_total
-    return out, result
+    def __init__(self, args):
+        import numpy as np
+        import torch
+
+        from sela_amd import capi, codec, sharding, synth
+
+        self.np, self.torch, self.capi, self.codec, self.sharding, self.synth = np, torch, capi, codec, sharding, synth
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        if self.world > 1 or os.environ.get("SELA_BENCH_FORCE_EXCHANGE") == "1":  # (the override runs the N>1 code path on one GPU)
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", str(self.rank))
+            os.environ.setdefault("WORLD_SIZE", str(self.world))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))  # nccl == RCCL on ROCm
+            self.dist = dist
+        self.lib = capi.lib()  # raises if the HIP library is missing: there is no CPU fallback
+        self.exchange = torch.cuda.Stream() if self.dist is not None else None
+        self.n_lanes = max(1, args.lanes)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed_repetitions(self, step, steps, after=None, min_total_s=0.5, max_reps=40):
+        """Seconds per K-step measurement, each bracketed by barrier + synchronize, MAX over ranks.  `after` runs
+        between two measurements (outside the timed region)."""
+        torch, dist = self.torch, self.dist
+        out = []
+        total = 0.0
+        while len(out) < max_reps and (not out or total < min_total_s):
+            self.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            self.barrier()
+            elapsed = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([elapsed, total + elapsed], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the same numbers -- and the same loop exit -- on every rank
+                elapsed, agreed_total = float(t[0].item()), float(t[1].item())
+            else:
+                agreed_total = total + elapsed
+            out.append(elapsed)
+            total = agreed_total
+            if after is not None:
+                after()
+        return out
+
+    @staticmethod
+    def summarise(reps, steps):
+        """The first K-step measurement runs a few % slow while the clocks settle behind the W warm-up steps: with four
+        measurements or more it is reported (ms_per_step_first) but kept out of median / min / max."""
+        settled = reps[1:] if len(reps) >= 4 else reps
+        per_step = sorted(r / steps for r in settled)
+        median_s = per_step[len(per_step) // 2]
+        return median_s, {
+            "count": len(reps), "timed_s": sum(reps), "ms_per_step_first": reps[0] / steps * 1e3, "ms_per_step_min": per_step[0] * 1e3,
+            "ms_per_step_median": median_s * 1e3, "ms_per_step_max": per_step[-1] * 1e3, "spread_frac": (per_step[-1] - per_step[0]) / median_s,
+            "spread_frac_p10_p90": (per_step[(9 * len(per_step)) // 10 - (1 if len(per_step) >= 10 else 0)] - per_step[len(per_step) // 10]) / median_s,
+        }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["track", "album"], default=None, help="default: track for --gpus 1, album otherwise")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-legs", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2, help="batches in flight: independent encode->decode chains on their own HIP streams")
-    args = ap.parse_args()
+class ChainJob:
+    """A list of HBM-resident batches; a step = every batch through encode -> decode (or decode only), consecutive
+    batches (N = 1 track: consecutive steps) on alternating lanes.
 
-    import numpy as np
-    import torch
+    Lanes: consecutive batches are independent chains, so they run on alternating HIP streams with their own buffers:
+    the decode of one batch fills the launch tail of the next batch's encode and the other way round.  Everything issued
+    inside the timed region completes inside it (device-wide synchronize on both sides); one lane is the strictly serial
+    form, reported beside it."""
 
-    from sela_amd import capi, codec, sharding
-    from sela_amd.synth import album_tracks, frames_for_seconds, synth_frames, synth_frames_torch
+    def __init__(self, bench: Bench, batches, n_total: int, exchange: bool, pre_encoded=None):
+        torch, codec = bench.torch, bench.codec
+        self.b, self.batches, self.n_total = bench, batches, n_total
+        self.pre = pre_encoded  # decode-only: [(frames, offsets)] per batch, produced outside the timed region
+        self.max_batch = max([int(x.shape[0]) for x in batches] + [1])
+        self.lanes = []
+        for _ in range(bench.n_lanes):
+            lane = {"dec": codec.Decoder(self.max_batch, CHANNELS), "stream": torch.cuda.Stream(), "calls": 0, "last": None}
+            if self.pre is None:
+                lane["enc"] = codec.Encoder(self.max_batch, CHANNELS)
+            self.lanes.append(lane)
+        self.next_lane = 0
+        self.steps_done = 0
+        self.exchange = exchange and bench.dist is not None
+        if self.exchange:
+            ranges = bench.sharding.partition(n_total, bench.world)
+            self.max_local = max(e - b for b, e in ranges)
+            # two sets in turn: a step's all-gather may still read its set while the next step fills the other
+            self.sets = [{"local": torch.zeros(self.max_local, dtype=torch.int64, device="cuda"),
+                          "all": torch.zeros(bench.world * self.max_local, dtype=torch.int64, device="cuda"),
+                          "done": None} for _ in range(2)]
+            self.last_set = None
+        self.ring = 0
+        self.flag_acc = torch.zeros(8, dtype=torch.int32, device="cuda")  # OR of enc status[0], dec status[0]; max of enc [1], dec [1]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    workload = args.workload or ("track" if world == 1 else "album")
-    assert workload == "album" or world == 1, "the single track is the one-GPU workload"
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("SELA_BENCH_FORCE_EXCHANGE") == "1":  # (the override runs the N>1 code path on one GPU)
-        import torch.distributed as dist
+    # -- status words: one slot per call, so that nothing a timed call reports is overwritten by the next -------------
+    def size_rings(self, steps: int):
+        torch = self.b.torch
+        self.ring = -(-steps * max(1, len(self.batches)) // len(self.lanes)) + 2
+        for lane in self.lanes:
+            lane["st_enc"] = torch.zeros((self.ring, 4), dtype=torch.int32, device="cuda")
+            lane["st_dec"] = torch.zeros((self.ring, 4), dtype=torch.int32, device="cuda")
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", str(rank))
-        os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+    def fold_status(self):
+        """OR every slot into the accumulator (between two measurements: outside the timed region) and clear them."""
+        torch = self.b.torch
+        sh = torch.arange(8, dtype=torch.int32, device="cuda")
+        for lane in self.lanes:
+            for j, key in enumerate(("st_enc", "st_dec")):
+                ring = lane[key]
+                bits = ((ring[:, 0:1] >> sh) & 1).amax(dim=0)  # flag bits 0..7, OR over the slots
+                self.flag_acc[j] |= (bits << sh).sum().to(torch.int32)
+                self.flag_acc[2 + j] = torch.maximum(self.flag_acc[2 + j], ring[:, 1].max())
+                ring.zero_()
 
-    lib = capi.lib()  # raises if the HIP library is missing: there is no CPU fallback
-    exchange = torch.cuda.Stream() if dist is not None else None
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- the workload, resident in HBM ---------------------------------------------------------------------
-    if workload == "track":
-        n_total = frames_for_seconds(TRACK_SECONDS, SAMPLE_RATE)  # 3875
-        pcm_host = synth_frames(n_total, CHANNELS, track=0)
-        batches = [torch.from_numpy(pcm_host).cuda()]
-        my_begin, my_end = 0, n_total
-        tracks = [(0, SAMPLE_RATE, n_total)]
-    else:
-        tracks = album_tracks()
-        starts = np.concatenate([[0], np.cumsum([f for _, _, f in tracks])]).astype(np.int64)
-        n_total = int(starts[-1])  # 549,365
-        my_begin, my_end = sharding.my_range(n_total, rank, world)
-        parts = []  # this rank's contiguous range of the album's (track, frame) space, generated on the GPU
-        for track, _, frames in tracks:
-            b, e = max(my_begin, int(starts[track])), min(my_end, int(starts[track + 1]))
-            if b < e:
-                parts.append(synth_frames_torch(e - b, CHANNELS, track, first_frame=b - int(starts[track]), device="cuda"))
-        local = torch.cat(parts) if parts else torch.zeros((0, 2048, CHANNELS), dtype=torch.int16, device="cuda")
-        del parts
-        n_batches = max(1, -(-int(local.shape[0]) // ALBUM_BATCH_FRAMES))  # equal batches of <= 65,536 frames
-        per_batch = max(1, -(-int(local.shape[0]) // n_batches))
-        batches = [local[i: i + per_batch] for i in range(0, local.shape[0], per_batch)] or [local]
-        pcm_host = None
-    n_local = my_end - my_begin
-    max_batch = max(int(b.shape[0]) for b in batches)
-    # Lanes: consecutive batches (N = 1: consecutive steps) are independent encode -> decode chains, so they run on
-    # alternating HIP streams with their own buffers: the decode of one batch fills the launch tail of the next
-    # batch's encode and the other way round.  Everything issued inside the timed region completes inside it
-    # (device-wide synchronize on both sides); `--lanes 1` is the strictly serial form, reported beside it.
-    n_lanes = max(1, args.lanes)
-    lanes = [{"enc": codec.Encoder(max(max_batch, 1), CHANNELS), "dec": codec.Decoder(max(max_batch, 1), CHANNELS),
-              "stream": torch.cuda.Stream()} for _ in range(n_lanes)]
-    enc, dec = lanes[0]["enc"], lanes[0]["dec"]
-    slot = {"next": 0}
-    max_local = max(e - b for b, e in sharding.partition(n_total, world))
-    local_sizes = torch.zeros(max_local, dtype=torch.int64, device="cuda")
-    all_sizes = torch.zeros(world * max_local, dtype=torch.int64, device="cuda")
-    state = {"lossy": 0, "bytes": 0}
-
-    def step(check=False, serial=False):
+    def step(self, serial=False, check=None):
+        b, torch = self.b, self.b.torch
+        ex = self.sets[self.steps_done % 2] if self.exchange else None
+        waited = set()
         at = 0
-        for i, pcm in enumerate(batches):
+        result = None
+        for i, pcm in enumerate(self.batches):
             nb = int(pcm.shape[0])
-            lane = lanes[0 if serial else slot["next"] % n_lanes]
-            slot["next"] += 1
+            li = 0 if serial else self.next_lane % len(self.lanes)
+            lane = self.lanes[li]
+            self.next_lane += 1
+            slot = lane["calls"] % self.ring
+            lane["calls"] += 1
             with torch.cuda.stream(lane["stream"]):
-                out = lane["enc"].encode(pcm)
-                if dist is not None:
-                    local_sizes[at: at + nb] = out.offsets[1:] - out.offsets[:-1]
-                    if i == len(batches) - 1:
-                        # the path's only exchange (SURVEY.md 8(e)): every rank learns the size of every frame of the
-                        # job, i.e. where its bytes land in every output file (8 bytes x frames, latency bound -- RCCL
-                        # over xGMI).  Decoding does not need the layout, so the collective runs beside the last
-                        # decode on its own stream and is joined at the end of the step, inside the timed region.
-                        for other in lanes:  # (the sizes of the earlier batches were written on the other lanes' streams)
-                            exchange.wait_stream(other["stream"])
-                        with torch.cuda.stream(exchange):
-                            dist.all_gather_into_tensor(all_sizes, local_sizes)
-                back = lane["dec"].decode(out.frames, out.offsets, nb)
-                if dist is not None and i == len(batches) - 1:
-                    lane["stream"].wait_stream(exchange)
-            if check:  # (outside the timed region) status words + round trip of every batch
+                if self.pre is None:
+                    out = lane["enc"].encode(pcm, status=lane["st_enc"][slot])
+                    frames, offsets = out.frames, out.offsets
+                    if ex is not None:
+                        if li not in waited and ex["done"] is not None:
+                            lane["stream"].wait_event(ex["done"])  # the all-gather of two steps ago has read this set
+                        waited.add(li)
+                        ex["local"][at: at + nb] = offsets[1:] - offsets[:-1]
+                        if i == len(self.batches) - 1:
+                            # the path's only exchange (SURVEY.md 8(e)): every rank learns the size of every frame of the
+                            # job, i.e. where its bytes land in every output file (8 bytes x frames, latency bound -- RCCL
+                            # over xGMI).  Decoding does not need the layout, so the collective runs beside the decode on its
+                            # own stream; it is complete inside the timed region (device-wide synchronize at its end).
+                            for lj in waited:  # (the sizes of the earlier batches were written on the other lanes' streams)
+                                b.exchange.wait_stream(self.lanes[lj]["stream"])
+                            with torch.cuda.stream(b.exchange):
+                                b.dist.all_gather_into_tensor(ex["all"], ex["local"])
+                                ex["done"] = torch.cuda.Event()
+                                ex["done"].record(b.exchange)
+                            self.last_set = ex
+                else:
+                    frames, offsets = self.pre[i]
+                back = lane["dec"].decode(frames, offsets, nb, status=lane["st_dec"][slot])
+            lane["last"] = (i, nb)
+            if check is not None:  # (outside the timed region) status words + round trip + the timed outputs of this batch
                 torch.cuda.synchronize()
-                out.check()
-                lane["dec"].check()
-                state["lossy"] += int((back != pcm).reshape(nb, -1).any(dim=1).sum().item()) if nb else 0
-                state["bytes"] += out.total_bytes()
+                check(i, nb, pcm, frames, offsets, back, lane, slot)
             at += nb
-        return out, back
+            result = (frames, offsets, back)
+        self.steps_done += 1
+        return result
 
-    for _ in range(args.warmup):
-        step()
-    reps, (out, back) = timed_repetitions(step, barrier, args.steps, dist)
-    serial_reps, _ = timed_repetitions(lambda: step(serial=True), barrier, args.steps, dist, min_total_s=0.15) if n_lanes > 1 else (reps, None)
-    # the first K-step measurement runs a few % slow while the clocks settle behind the W warm-up steps: with four
-    # measurements or more it is reported (ms_per_step_first) but kept out of median / min / max
-    settled = reps[1:] if len(reps) >= 4 else reps
-    per_step = sorted(r / args.steps for r in settled)
-    median_s = per_step[len(per_step) // 2]
+    def snapshot_lanes(self):
+        """What each lane's last (timed) call left in its buffers, cloned: batch index, frame bytes, offsets, PCM."""
+        torch = self.b.torch
+        torch.cuda.synchronize()
+        snaps = []
+        for lane in self.lanes:
+            if lane["last"] is None:
+                continue
+            i, nb = lane["last"]
+            rec = {"batch": i, "pcm": lane["dec"].pcm[:nb].clone()}
+            if self.pre is None:
+                offs = lane["enc"].offsets[: nb + 1].clone()
+                rec["offsets"] = offs
+                rec["frames"] = lane["enc"].frames[: int(offs[-1].item())].clone()
+            snaps.append(rec)
+        return snaps
 
-    # ---- correctness of what was timed ------------------------------------------------------------------------
-    # status words + round trip.  The reference codec is not lossless on every frame (its encoder rounds the
-    # prediction half-up, its decoder half-down: a frame whose Q35 sum hits 2^34 mod 2^35 comes back off by one;
-    # DESIGN.md section 2), and parity means reproducing that -- so the round trip may differ from the input in a
-    # handful of frames, never in many.
-    out, back = step(check=True)
+
+def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=0.5):
+    """Warm up, time (all lanes, then one lane), then verify what was timed.  Returns the measurement record."""
+    torch, np = bench.torch, bench.np
+    job.size_rings(max(steps, warmup, 1))
+    for _ in range(warmup):
+        job.step()
     torch.cuda.synchronize()
-    lossy_frames, payload_bytes = state["lossy"], state["bytes"]
-    assert lossy_frames <= max(1, n_local // 500), f"decode(encode(x)) differs from x in {lossy_frames} frames"
-    layout_ok = None
-    if dist is not None:
-        # the gathered layout must be the one-GPU layout: its digest was computed with the unmodified reference
-        ranges = sharding.partition(n_total, world)
-        g = all_sizes.cpu().numpy().reshape(world, max_local)
-        sizes = np.concatenate([g[r, : e - b] for r, (b, e) in enumerate(ranges)]).astype("<u8")
-        if workload == "album":
-            with open(os.path.join(ROOT, "tests", "golden", "album_digests.json")) as f:
-                golden = json.load(f)
-            offs = np.concatenate([[0], np.cumsum(sizes.astype(np.uint64))])
-            for t, (track, _, frames) in enumerate(tracks):
-                b, e = int(starts[t]), int(starts[t + 1])
-                assert 15 + int(offs[e] - offs[b]) == golden["tracks"][t]["sela_bytes"], f"track {track}: file size differs from the reference's"
-            layout_ok = golden.get("frame_sizes_sha256") in (None, hashlib.sha256(sizes.tobytes()).hexdigest())
-            assert layout_ok, "the gathered frame-size layout differs from the one-GPU (reference) layout"
-        t = torch.tensor([lossy_frames, payload_bytes], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t)
-        lossy_frames, payload_bytes = int(t[0].item()), int(t[1].item())
+    job.fold_status()
+    reps = bench.timed_repetitions(job.step, steps, after=job.fold_status, min_total_s=min_total_s)
+    snaps = job.snapshot_lanes()
+    timed_sizes = None
+    if job.exchange and job.last_set is not None:  # the layout the LAST TIMED step gathered
+        timed_sizes = job.last_set["all"].clone()
+    serial = bench.timed_repetitions(lambda: job.step(serial=True), steps, after=job.fold_status, min_total_s=0.15) if len(job.lanes) > 1 else reps
+    median_s, rep_stats = Bench.summarise(reps, steps)
+    serial_s, _ = Bench.summarise(serial, steps)
 
-    # ---- per-kernel timing leg (separate from the timed region: events add launch gaps) --------------
+    # ---- correctness of what was timed -------------------------------------------------------------------------------
+    # One more step, serial and synchronised after every batch: its status words, its round trip, and -- batch by batch --
+    # equality with what the lanes' last timed calls left behind.  The reference codec is not lossless on every frame
+    # (its encoder rounds the prediction half-up, its decoder half-down: a frame whose Q35 sum hits 2^34 mod 2^35 comes
+    # back off by one; DESIGN.md section 2), and parity means reproducing that -- so the round trip may differ from the
+    # input in a handful of frames, never in many.
+    state = {"lossy": 0, "bytes": 0, "same": True, "compared": 0}
+
+    def check(i, nb, pcm, frames, offsets, back, lane, slot):
+        dec_st = lane["st_dec"][slot].cpu().numpy().view(np.uint32)
+        if int(dec_st[0]) & (bench.capi.FLAG_BAD_FRAME | bench.capi.FLAG_RICE_OVERRUN):
+            raise bench.capi.SelaHipError(-5, f"decoder status 0x{int(dec_st[0]):x}")
+        state["lossy"] += int((back != pcm).reshape(nb, -1).any(dim=1).sum().item()) if nb else 0
+        total = int(offsets[-1].item())
+        state["bytes"] += total
+        for s in snaps:
+            if s["batch"] != i:
+                continue
+            same = torch.equal(s["pcm"], back)
+            if "frames" in s:
+                same = same and torch.equal(s["offsets"], offsets) and torch.equal(s["frames"], frames[:total])
+            state["same"] = state["same"] and bool(same)
+            state["compared"] += 1
+
+    last = job.step(serial=True, check=check)
+    torch.cuda.synchronize()
+    job.fold_status()
+    acc = job.flag_acc.cpu().numpy().view(np.uint32)
+    enc_bad = int(acc[0]) & (bench.capi.FLAG_WORDS_CAP | bench.capi.FLAG_RICE_RANGE | bench.capi.FLAG_COEF_OVERFLOW)
+    dec_bad = int(acc[1]) & (bench.capi.FLAG_BAD_FRAME | bench.capi.FLAG_RICE_OVERRUN)
+    n_local = sum(int(x.shape[0]) for x in job.batches)
+    assert enc_bad == 0 and int(acc[2]) == 0, f"an encode inside the timed region raised flags 0x{int(acc[0]):x} / {int(acc[2])} frames over capacity"
+    assert dec_bad == 0 and int(acc[3]) == 0, f"a decode inside the timed region raised flags 0x{int(acc[1]):x} / {int(acc[3])} bad frames"
+    assert state["same"] and state["compared"] == len(snaps), "the outputs of the timed (two-lane) steps differ from a serial step's"
+    assert state["lossy"] <= max(1, n_local // 500), f"decode(encode(x)) differs from x in {state['lossy']} frames"
+    return {
+        "median_s": median_s, "serial_s": serial_s, "rep_stats": rep_stats, "reps": reps, "last": last, "lossy": state["lossy"], "bytes": state["bytes"],
+        "timed_sizes": timed_sizes,
+        "timed_outputs": {"status_or_encode": int(acc[0]), "status_or_decode": int(acc[1]), "lanes_compared_with_serial_step": state["compared"],
+                          "equal_to_serial_step": bool(state["same"]),
+                          "what": "every timed call reports into a status slot of its own, all OR-ed; each lane's last timed outputs (frame bytes, offsets, "
+                                  "decoded PCM) compared on the device with a serial synchronised step's"},
+    }
+
+
+def lanes_block(job: ChainJob, m, samples, steps):
+    return {"in_flight": len(job.lanes), "ms_per_step_one_lane": m["serial_s"] * 1e3, "value_one_lane": samples / m["serial_s"] / 1e6,
+            "what": "consecutive batches are independent encode->decode chains on alternating HIP streams; one lane = strictly serial"}
+
+
+# ---- workloads -------------------------------------------------------------------------------------------------------
+def album_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "album_digests.json")) as f:
+        return json.load(f)
+
+
+def gathered_sizes(bench: Bench, all_sizes, n_total: int, max_local: int):
+    np = bench.np
+    ranges = bench.sharding.partition(n_total, bench.world)
+    g = all_sizes.cpu().numpy().reshape(bench.world, max_local)
+    return np.concatenate([g[r, : e - b] for r, (b, e) in enumerate(ranges)]).astype("<u8")
+
+
+def workload_track(bench: Bench, steps: int, warmup: int):
+    """configs[1] x N, weak scaling: rank r's track, + the all-gather of the sizes for N > 1."""
+    torch, np = bench.torch, bench.np
+    frames = bench.synth.frames_for_seconds(TRACK_SECONDS, SAMPLE_RATE)  # 3875
+    track = 3 * bench.rank  # the album's 44.1 kHz tracks (tests/golden/album_digests.json holds the reference's digest of each)
+    pcm = bench.synth.synth_frames_torch(frames, CHANNELS, track, device="cuda")
+    n_total = frames * bench.world
+    job = ChainJob(bench, [pcm], n_total, exchange=True)
+    m = run_chain(bench, job, steps, warmup)
+    out_frames, out_offsets, back = m["last"]
+    total = int(out_offsets[-1].item())
+    golden = album_golden()["tracks"][track] if track < 100 else None
+    # this rank's .sela file and decoded PCM against the reference's digests of the same track
+    header = bench.sharding.sela_header(SAMPLE_RATE, 16, CHANNELS, frames)
+    blob = out_frames[:total].cpu().numpy()
+    digest_ok = None
+    if golden is not None and golden["n_frames"] == frames:
+        digest_ok = (hashlib.sha256(header + blob.tobytes()).hexdigest() == golden["sela_sha256"]
+                     and hashlib.sha256(back.cpu().numpy().tobytes()).hexdigest() == golden["decoded_sha256"])
+        assert digest_ok, f"track {track}: .sela / decoded digests differ from the reference's"
+    layout_ok = None
+    if job.exchange:
+        sizes = gathered_sizes(bench, m["timed_sizes"], n_total, job.max_local)
+        offs = np.concatenate([[0], np.cumsum(sizes.astype(np.uint64))])
+        g = album_golden()["tracks"]
+        layout_ok = all(15 + int(offs[(r + 1) * frames] - offs[r * frames]) == g[3 * r]["sela_bytes"] for r in range(bench.world))
+        mine = sizes[bench.rank * frames: (bench.rank + 1) * frames]
+        layout_ok = layout_ok and bool(np.array_equal(mine, np.diff(out_offsets.cpu().numpy().view(np.uint64)).astype("<u8")))
+        assert layout_ok, "the gathered frame sizes differ from the reference's file sizes / this rank's own offsets"
+    t = torch.tensor([m["lossy"], m["bytes"]], dtype=torch.int64, device="cuda")
+    if bench.dist is not None:
+        bench.dist.all_reduce(t)
+    samples = n_total * 2048
+    rec = {
+        "value": samples / m["median_s"] / 1e6, "ms_per_step": m["median_s"] * 1e3, "scaling": "weak",
+        "config": {
+            "workload": ("BASELINE.json configs[1]: one 3-min 16-bit stereo 44.1 kHz track (3875 frames x 2048 stereo samples) PER GPU, "
+                         "encode to .sela frames then decode, bit-exact" + ("; RCCL all-gather of the frame sizes every step" if job.exchange else "")),
+            "frames_total": n_total, "frames_rank0": frames, "channels": CHANNELS,
+            "sharding": "single track" if bench.world == 1 else f"one track per GPU x{bench.world} (album tracks 0, 3, 6, ...)",
+            "batch_frames": frames, "sela_bytes_total": int(t[1].item()), "pcm_bytes_total": n_total * 2048 * CHANNELS * 2,
+        },
+        "lanes": lanes_block(job, m, samples, steps), "repetitions": m["rep_stats"], "roundtrip_lossy_frames": int(t[0].item()),
+        "layout_matches_reference": layout_ok, "digests_match_reference": digest_ok, "timed_outputs": m["timed_outputs"],
+    }
+    return rec, job, pcm, (blob, out_offsets.cpu().numpy().view(np.uint64), back.cpu().numpy())
+
+
+def workload_album(bench: Bench, steps: int, warmup: int):
+    """configs[3], strong scaling: this rank's contiguous range of the album's (track, frame) space."""
+    torch, np = bench.torch, bench.np
+    tracks = bench.synth.album_tracks()
+    starts = np.concatenate([[0], np.cumsum([f for _, _, f in tracks])]).astype(np.int64)
+    n_total = int(starts[-1])  # 549,365
+    my_begin, my_end = bench.sharding.my_range(n_total, bench.rank, bench.world)
+    parts = []  # generated on the GPU
+    for track, _, frames in tracks:
+        b, e = max(my_begin, int(starts[track])), min(my_end, int(starts[track + 1]))
+        if b < e:
+            parts.append(bench.synth.synth_frames_torch(e - b, CHANNELS, track, first_frame=b - int(starts[track]), device="cuda"))
+    local = torch.cat(parts) if parts else torch.zeros((0, 2048, CHANNELS), dtype=torch.int16, device="cuda")
+    del parts
+    n_batches = max(1, -(-int(local.shape[0]) // ALBUM_BATCH_FRAMES))  # equal batches of <= 65,536 frames
+    per_batch = max(1, -(-int(local.shape[0]) // n_batches))
+    batches = [local[i: i + per_batch] for i in range(0, local.shape[0], per_batch)] or [local]
+    job = ChainJob(bench, batches, n_total, exchange=True)
+    m = run_chain(bench, job, steps, warmup, min_total_s=0.3)
+    layout_ok = None
+    if job.exchange:
+        # the layout gathered by the last TIMED step must be the one-GPU layout: its digest was computed with the unmodified reference
+        golden = album_golden()
+        sizes = gathered_sizes(bench, m["timed_sizes"], n_total, job.max_local)
+        offs = np.concatenate([[0], np.cumsum(sizes.astype(np.uint64))])
+        for t, (track, _, frames) in enumerate(tracks):
+            b, e = int(starts[t]), int(starts[t + 1])
+            assert 15 + int(offs[e] - offs[b]) == golden["tracks"][t]["sela_bytes"], f"track {track}: file size differs from the reference's"
+        layout_ok = golden.get("frame_sizes_sha256") in (None, hashlib.sha256(sizes.tobytes()).hexdigest())
+        assert layout_ok, "the gathered frame-size layout differs from the one-GPU (reference) layout"
+    t = torch.tensor([m["lossy"], m["bytes"]], dtype=torch.int64, device="cuda")
+    if bench.dist is not None:
+        bench.dist.all_reduce(t)
+    samples = n_total * 2048
+    rec = {
+        "value": samples / m["median_s"] / 1e6, "ms_per_step": m["median_s"] * 1e3, "scaling": "strong", "steps": steps, "warmup": warmup,
+        "config": {
+            "workload": ("BASELINE.json configs[3]: 100-track synthetic album (34/33/33 tracks at 44.1/48/96 kHz, 549,365 frames x 2048 "
+                         f"stereo samples) sharded over {bench.world} GPU(s) in contiguous frame ranges, encode + "
+                         + ("RCCL all-gather of the frame sizes + " if job.exchange else "") + "decode"
+                         + (", layout checked against the reference's" if job.exchange else "")),
+            "frames_total": n_total, "frames_rank0": my_end - my_begin, "channels": CHANNELS, "sharding": f"contiguous frame ranges x{bench.world}",
+            "batch_frames": job.max_batch, "sela_bytes_total": int(t[1].item()), "pcm_bytes_total": n_total * 2048 * CHANNELS * 2,
+        },
+        "lanes": lanes_block(job, m, samples, steps), "repetitions": m["rep_stats"], "roundtrip_lossy_frames": int(t[0].item()),
+        "layout_matches_reference": layout_ok, "timed_outputs": m["timed_outputs"],
+        "one_gpu_anchor": "the `album` block (or, with --workload album, the headline) of the --gpus 1 line: same job, one GPU",
+    }
+    return rec, job, batches[0], None
+
+
+def workload_decode10k(bench: Bench, steps: int, warmup: int):
+    """configs[4], strong scaling, decode only: this rank's contiguous 1/N of 10,000 frames encoded outside the timed region."""
+    torch, np = bench.torch, bench.np
+    n_total = DECODE10K_FRAMES
+    b0, e0 = bench.sharding.my_range(n_total, bench.rank, bench.world)
+    pcm = bench.synth.synth_frames_torch(e0 - b0, CHANNELS, DECODE10K_TRACK, first_frame=b0, device="cuda")
+    enc = bench.codec.Encoder(max(e0 - b0, 1), CHANNELS)
+    out = enc.encode(pcm)
+    torch.cuda.synchronize()
+    out.check()
+    frames, offsets = out.frames, out.offsets
+    job = ChainJob(bench, [pcm], n_total, exchange=False, pre_encoded=[(frames, offsets)])
+    m = run_chain(bench, job, steps, warmup, min_total_s=0.3)
+    exact = None
+    if bench.rank == 0 and not bench.args.no_cpu_baseline:  # the decode of rank 0's share against the CPU decoder
+        impl, kind = cpu_reference()
+        f_host, o_host = out.to_host()
+        ref_back, _ = impl.decode_frames(f_host, o_host, CHANNELS, threads=os.cpu_count() or 1)
+        exact = bool(np.array_equal(ref_back, m["last"][2].cpu().numpy()))
+        assert exact, "decode10k: GPU decode differs from the CPU decoder's"
+    t = torch.tensor([m["lossy"]], dtype=torch.int64, device="cuda")
+    if bench.dist is not None:
+        bench.dist.all_reduce(t)
+    samples = n_total * 2048
+    rec = {
+        "value": samples / m["median_s"] / 1e6, "unit": "Msamples/s decode only", "ms_per_step": m["median_s"] * 1e3, "scaling": "strong",
+        "steps": steps, "warmup": warmup,
+        "config": {
+            "workload": (f"BASELINE.json configs[4]: decode-only, {n_total} pre-encoded stereo frames (encoded outside the timed region), "
+                         f"every rank decodes its contiguous 1/{bench.world}; no collective"),
+            "frames_total": n_total, "frames_rank0": e0 - b0, "channels": CHANNELS, "sharding": f"contiguous frame ranges x{bench.world}",
+        },
+        "lanes": lanes_block(job, m, samples, steps), "repetitions": m["rep_stats"], "roundtrip_lossy_frames": int(t[0].item()),
+        "bit_exact_vs_cpu_decode": exact, "timed_outputs": m["timed_outputs"],
+    }
+    return rec, job, pcm, None
+
+
+def release(bench: Bench):
+    """Give a finished workload's device buffers back (the caller has dropped its references)."""
+    import gc
+
+    gc.collect()
+    bench.torch.cuda.empty_cache()
+
+
+# ---- per-kernel timing leg (separate from the timed region: events add launch gaps) ---------------------------------
+def kernel_leg(bench: Bench, job: ChainJob, pcm0, steps: int):
+    np, capi, lib = bench.np, bench.capi, bench.lib
     lib.sela_hip_enable_kernel_timing(1)
+    enc, dec = job.lanes[0]["enc"], job.lanes[0]["dec"]
     k_enc, k_dec = [], []
-    pcm0 = batches[0]
     n0 = int(pcm0.shape[0])
     o2 = enc.encode(pcm0) if n0 else None
-    for _ in range(max(5, min(args.steps, 20)) if n0 else 0):
+    for _ in range(max(5, min(steps, 20)) if n0 else 0):
         # The timed kernel runs where it runs in a step: the encoder behind a decode, the decoder behind an encode, two
         # steps queued so that it starts on a busy, clocked-up device (a launch onto an idle device runs ~10 % slower;
         # an encoder behind an encoder 6 % slower than behind a decoder -- the device's clock follows the power the last
@@ -369,105 +664,134 @@ def main():
             dec.decode(o2.frames, o2.offsets, n0)
         k_dec.append(capi.kernel_times(1))
     lib.sela_hip_enable_kernel_timing(0)
-    torch.cuda.synchronize()
+    bench.torch.cuda.synchronize()
+    return np.array(k_enc), np.array(k_dec), n0, (o2.total_bytes() if o2 is not None else 0)
 
-    if rank == 0:
-        k_enc = np.array(k_enc)  # [reps, 3] ms: blocks, plan, assemble
-        k_dec = np.array(k_dec)  # [reps, 1] ms: the fused decode kernel
-        enc_blocks_ms = float(k_enc[:, 0].mean())
-        pcm_bytes0 = n0 * 2048 * CHANNELS * 2
-        algo_bytes = pcm_bytes0 + o2.total_bytes()  # PCM16 read + .sela frame bytes written, one launch
-        achieved = algo_bytes / (enc_blocks_ms * 1e-3) / 1e9
-        traffic, traffic_src = committed_traffic("k_encode_blocks")
-        valu_instr, valu_src = committed_valu_instructions("k_encode_blocks")
-        if workload != "track":
-            valu_instr = traffic = None  # the committed counter passes are of the single-track launch
-        samples = n_total * 2048
-        samples0 = n0 * 2048
-        enc_ms = float(k_enc.sum(axis=1).mean())
-        dec_ms = float(k_dec.sum(axis=1).mean())
-        fp64 = FP64_OPS_PER_BLOCK * n0 * 3 / (enc_blocks_ms * 1e-3) / 1e12
+
+def kernel_blocks(bench: Bench, k_enc, k_dec, n0: int, sela_bytes0: int, counters_apply: bool):
+    """roofline / fp64_valu / valu_issue / kernel_ms of the first batch's launch (rank 0)."""
+    enc_blocks_ms = float(k_enc[:, 0].mean())
+    pcm_bytes0 = n0 * 2048 * CHANNELS * 2
+    algo_bytes = pcm_bytes0 + sela_bytes0  # SURVEY.md 8(d): PCM16 read + .sela frame bytes written, one launch
+    achieved = algo_bytes / (enc_blocks_ms * 1e-3) / 1e9
+    traffic, traffic_src = committed_traffic("k_encode_blocks")
+    valu_instr, valu_src = committed_valu_instructions("k_encode_blocks")
+    if not counters_apply:
+        valu_instr = traffic = None  # the committed counter passes are of the single-track launch
+    samples0 = n0 * 2048
+    enc_ms = float(k_enc.sum(axis=1).mean())
+    dec_ms = float(k_dec.sum(axis=1).mean())
+    fp64 = FP64_OPS_PER_BLOCK * n0 * 3 / (enc_blocks_ms * 1e-3) / 1e12
+    valu = None if valu_instr is None else {
+        "achieved": valu_instr / (enc_blocks_ms * 1e-3) / 1e9, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instructions/s",
+        "frac": valu_instr / (enc_blocks_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GIPS,
+        "instructions_per_launch_from_profiles": valu_instr, "profiles_source": valu_src,
+        "note": f"SQ_INSTS_VALU from the committed counter pass named in profiles_source / live kernel time; peak = 1024 SIMDs x {PEAK_CLOCK_GHZ} GHz / 4 cycles per wave64 instruction",
+    }
+    return {
+        "encode_msps": samples0 / (enc_ms * 1e-3) / 1e6,   # kernels of the first batch, HBM resident
+        "decode_msps": samples0 / (dec_ms * 1e-3) / 1e6,
+        "encode_target": {"msps": ENCODE_TARGET_MSPS, "met": bool(samples0 / (enc_ms * 1e-3) / 1e6 >= ENCODE_TARGET_MSPS),
+                          "ratio": samples0 / (enc_ms * 1e-3) / 1e6 / ENCODE_TARGET_MSPS},
+        "kernel_ms": {"encode_blocks": enc_blocks_ms, "encode_plan": float(k_enc[:, 1].mean()),
+                      "encode_assemble": float(k_enc[:, 2].mean()), "decode_frames": dec_ms, "frames_in_launch": n0},
+        "fp64_valu": {  # the arithmetic the bit-exact analysis cannot avoid, against the vector FP64 rate
+            "achieved": fp64, "peak": FP64_UNFUSED_PEAK_TOPS, "unit": "T unfused FP64 op/s", "frac": fp64 / FP64_UNFUSED_PEAK_TOPS,
+        },
+        # what binds the kernel in practice: issue slots of the vector ALU (a wave64 instruction takes 4 cycles of a SIMD)
+        "valu_issue": valu,
+        "roofline": {
+            "kernel": "k_encode_blocks", "bound": "valu_issue",
+            # the HBM figures the contract asks for: algorithmic bytes per launch / live kernel time against the HBM peak
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_from_profiles": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
+            # ... and the resource that binds it
+            "binding": None if valu is None else {"resource": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]},
+            "note": "achieved/peak/frac are the HBM numbers (7 B per stereo sample: the path cannot be HBM bound, SURVEY.md 8(d)); the kernel is bound by "
+                    "vector-ALU issue (`binding`, DESIGN.md 5.1); traffic is the committed PMC pass, not this run",
+        },
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["track", "album", "decode10k"], default=None,
+                    help="the headline workload (default: track = one 3-min track per GPU, weak scaling; album and decode10k then ride along as extra blocks)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--extra-steps", type=int, default=3, help="steps per measurement of the album block")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-legs", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2, help="batches in flight: independent encode->decode chains on their own HIP streams")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
+
+    bench = Bench(args)
+    np, torch = bench.np, bench.torch
+    headline = args.workload or "track"
+    runners = {"track": workload_track, "album": workload_album, "decode10k": workload_decode10k}
+
+    rec, job, pcm0, host_out = runners[headline](bench, args.steps, args.warmup)
+    kern = None
+    if headline != "decode10k":
+        k_enc, k_dec, n0, sela0 = kernel_leg(bench, job, pcm0, args.steps)
+        if bench.rank == 0:
+            kern = kernel_blocks(bench, k_enc, k_dec, n0, sela0, counters_apply=headline == "track")
+    result = None
+    if bench.rank == 0:
         result = {
-            "metric": "Msamples/s encode+decode, 16-bit stereo 44.1kHz" if workload == "track"
-                      else "Msamples/s encode+decode, 16-bit stereo 44.1/48/96kHz album",
-            "value": samples / median_s / 1e6,
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": median_s * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak" if workload == "track" else "strong",
-            "vs_baseline": None,
-            "dtype": "f64+int64",
-            "data": "synthetic",
-            "config": {
-                "workload": ("BASELINE.json configs[1]: one 3-min 16-bit stereo 44.1 kHz track (3875 frames x 2048 stereo samples), "
-                             "encode to .sela frames then decode, bit-exact") if workload == "track" else
-                            ("BASELINE.json configs[3]: 100-track synthetic album (34/33/33 tracks at 44.1/48/96 kHz, 549,365 frames x 2048 "
-                             f"stereo samples) sharded over {world} GPU(s) in contiguous frame ranges, encode + RCCL all-gather of the "
-                             "frame sizes + decode, layout checked against the reference's"),
-                "frames_total": n_total, "frames_rank0": n_local, "channels": CHANNELS,
-                "sharding": f"contiguous frame ranges x{world}" if workload == "album" else "single track",
-                "batch_frames": max_batch, "sela_bytes_total": payload_bytes, "pcm_bytes_total": n_total * 2048 * CHANNELS * 2,
-            },
-            "lanes": {"in_flight": n_lanes, "ms_per_step_one_lane": sorted(serial_reps)[len(serial_reps) // 2] / args.steps * 1e3,
-                      "value_one_lane": samples / (sorted(serial_reps)[len(serial_reps) // 2] / args.steps) / 1e6,
-                      "what": "consecutive batches are independent encode->decode chains on alternating HIP streams; one lane = strictly serial"},
-            "repetitions": {"count": len(reps), "timed_s": sum(reps), "ms_per_step_first": reps[0] / args.steps * 1e3,
-                            "ms_per_step_min": per_step[0] * 1e3,
-                            "ms_per_step_median": median_s * 1e3, "ms_per_step_max": per_step[-1] * 1e3,
-                            "spread_frac": (per_step[-1] - per_step[0]) / median_s,
-                            "spread_frac_p10_p90": (per_step[(9 * len(per_step)) // 10 - (1 if len(per_step) >= 10 else 0)] - per_step[len(per_step) // 10]) / median_s},
-            "encode_msps": samples0 / (enc_ms * 1e-3) / 1e6,   # kernels of the first batch, HBM resident
-            "decode_msps": samples0 / (dec_ms * 1e-3) / 1e6,
-            "encode_target": {"msps": ENCODE_TARGET_MSPS, "met": bool(samples0 / (enc_ms * 1e-3) / 1e6 >= ENCODE_TARGET_MSPS),
-                              "ratio": samples0 / (enc_ms * 1e-3) / 1e6 / ENCODE_TARGET_MSPS},
-            "kernel_ms": {"encode_blocks": enc_blocks_ms, "encode_plan": float(k_enc[:, 1].mean()),
-                          "encode_assemble": float(k_enc[:, 2].mean()), "decode_frames": dec_ms, "frames_in_launch": n0},
-            "roundtrip_lossy_frames": lossy_frames,
-            "layout_matches_reference": layout_ok,
-            "fp64_valu": {  # the resource that actually binds k_encode_blocks
-                "achieved": fp64, "peak": FP64_UNFUSED_PEAK_TOPS, "unit": "T unfused FP64 op/s", "frac": fp64 / FP64_UNFUSED_PEAK_TOPS,
-            },
-            # what binds the kernel in practice: issue slots of the vector ALU.  Quarter-rate instructions
-            # (FP64, 64-bit integer multiply-add: most of this kernel) take 4 cycles of a SIMD each.
-            "valu_issue": None if valu_instr is None else {
-                "achieved": valu_instr / (enc_blocks_ms * 1e-3) / 1e9, "peak": VALU_QUARTER_RATE_GIPS, "unit": "G wave-instructions/s",
-                "frac": valu_instr / (enc_blocks_ms * 1e-3) / 1e9 / VALU_QUARTER_RATE_GIPS,
-                "instructions_per_launch_from_profiles": valu_instr, "profiles_source": valu_src,
-                "note": "SQ_INSTS_VALU from the committed counter pass named in profiles_source / live kernel time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles",
-            },
-            "roofline": {
-                "kernel": "k_encode_blocks", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from_profiles": traffic_src,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "the path is FP64-issue/latency bound, not HBM bound (DESIGN.md): 7 B per stereo sample; traffic is the committed PMC pass, not this run",
-            },
+            "metric": METRIC, "value": rec["value"], "unit": rec.get("unit", "Msamples/s"), "n_gpus": bench.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"], "vs_baseline": None,
+            "dtype": "f64+int64", "data": "synthetic",
         }
-        if workload == "track" and world == 1:
-            if not args.no_host_legs:
-                legs = host_legs(pcm_host.reshape(-1, CHANNELS))
-                if legs is not None and "error" not in legs:
-                    result["e2e"] = {"encode_ms": legs["e2e_encode_ms"], "decode_ms": legs["e2e_decode_ms"],
-                                     "encode_msps": legs["e2e_encode_msps"], "decode_msps": legs["e2e_decode_msps"],
-                                     "what": "sela_hip_encode / sela_hip_decode on page-locked host buffers: H2D + kernels + D2H, steady_clock, median of %d" % legs["repeats"]}
-                    result["file_to_file"] = {"encode_ms": legs["file_encode_ms"], "decode_ms": legs["file_decode_ms"],
-                                              "encode_msps": legs["file_encode_msps"], "decode_msps": legs["file_decode_msps"],
-                                              "equals_e2e_bytes": legs["file_equals_e2e"], "files_on": legs["files_on"],
-                                              "what": "sela::encodeFile / decodeFile (the reference's `sela -e` / `-d`, src/main.cpp:29-41): file read, "
-                                                      "H2D, kernels, D2H, file write overlapped; in-process, HIP initialised"}
-                else:
-                    result["e2e"] = result["file_to_file"] = legs
-            if not args.no_cpu_baseline:
-                g_frames, g_offsets = out.to_host()
-                result["cpu_baseline"] = cpu_baseline(pcm_host, gpu_frames=g_frames, gpu_offsets=g_offsets, gpu_decoded=back.cpu().numpy())
-                assert result["cpu_baseline"]["bit_exact_vs_gpu"], "GPU output differs from the CPU reference"
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        result.update({k: v for k, v in rec.items() if k not in ("value", "unit", "ms_per_step", "scaling", "steps", "warmup")})
+        if kern is not None:
+            result.update(kern)
+    pcm_host = None
+    if headline == "track" and bench.rank == 0:
+        pcm_host = pcm0.cpu().numpy()
+    del job, pcm0
+    release(bench)
+
+    # ---- the other workloads as extra blocks -------------------------------------------------------------------------
+    if args.workload is None and not args.no_extra_legs:
+        for name, steps, warmup in (("album", args.extra_steps, 1), ("decode10k", args.steps, args.warmup)):
+            extra, j, p, _ = runners[name](bench, steps, warmup)
+            if bench.rank == 0:
+                result[name] = extra
+            del j, p
+            release(bench)
+
+    if bench.rank == 0 and headline == "track":
+        if bench.world == 1 and not args.no_host_legs:
+            legs = host_legs(pcm_host.reshape(-1, CHANNELS))
+            if legs is not None and "error" not in legs:
+                result["e2e"] = {"encode_ms": legs["e2e_encode_ms"], "decode_ms": legs["e2e_decode_ms"],
+                                 "encode_msps": legs["e2e_encode_msps"], "decode_msps": legs["e2e_decode_msps"],
+                                 "what": "sela_hip_encode / sela_hip_decode on page-locked host buffers: H2D + kernels + D2H, steady_clock, median of %d" % legs["repeats"]}
+                result["file_to_file"] = {"encode_ms": legs["file_encode_ms"], "decode_ms": legs["file_decode_ms"],
+                                          "encode_msps": legs["file_encode_msps"], "decode_msps": legs["file_decode_msps"],
+                                          "equals_e2e_bytes": legs["file_equals_e2e"], "files_on": legs["files_on"],
+                                          "what": "sela::encodeFile / decodeFile on paths (the reference's `sela -e` / `-d`, src/main.cpp:29-41): reader threads, "
+                                                  "H2D, kernels, D2H, writer threads overlapped; in-process, HIP initialised"}
+            else:
+                result["e2e"] = result["file_to_file"] = legs
+        if not args.no_cpu_baseline:
+            # rank 0 times the reference on ITS track (bounded: ~12 s at N = 1, ~5 s beside waiting ranks); the CPU output
+            # doubles as the checker of what the GPU produced in the serial step the timed outputs were compared with
+            base, blob, offs, dec = cpu_baseline(pcm_host, budget_s=12.0 if bench.world == 1 else 5.0, max_reps=3 if bench.world == 1 else 2)
+            g_frames, g_offsets, g_back = host_out
+            base["bit_exact_vs_gpu"] = bool(np.array_equal(blob, g_frames) and np.array_equal(offs, g_offsets) and np.array_equal(dec, g_back))
+            result["cpu_baseline"] = base
+            assert base["bit_exact_vs_gpu"], "GPU output differs from the CPU reference"
+    if bench.dist is not None:
+        bench.dist.barrier()
+        bench.dist.destroy_process_group()
     _flush_c_stdio()  # RCCL prints its version banner through C stdio; keep the JSON line the LAST line of stdout
-    if rank == 0:
+    if bench.rank == 0:
         print(json.dumps(result), flush=True)
 
 

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <fstream>
+#include <string>
 #include <vector>
 
 #include "sela_host/files.hpp"
@@ -42,6 +43,14 @@ public:
 // Return the number of frames coded.
 size_t encodeFile(std::ifstream& in, std::ofstream& out);
 size_t decodeFile(std::ifstream& in, std::ofstream& out);
+// The same by path -- what the CLI's -e / -d use: the file is read with several pread()s in flight on a small pool of I/O
+// threads (sela_host/fileio.hpp) while earlier pieces are on the device, and finished ranges are written with several
+// pwrite()s in flight while later pieces are still being coded.  One thread reads or writes a page-cache file at a
+// few GB/s; the device codes 10 G samples/s.
+size_t encodeFile(const std::string& inPath, const std::string& outPath);
+size_t decodeFile(const std::string& inPath, const std::string& outPath);
+// Threads of that pool (before its first use; 0 = default: min(16, hardware threads / 2)).
+void setIoThreads(unsigned n);
 
 // ---- many files, all GPUs of the node ------------------------------------------------------------------
 // BASELINE.json configs[3]: an album's tracks are one index space of frames, cut into contiguous balanced
@@ -56,5 +65,12 @@ void setDevices(const std::vector<int>& devices);
 std::vector<int> devices();
 std::vector<file::SelaFile> encodeBatch(const std::vector<file::WavFile>& wavs);
 std::vector<file::WavFile> decodeBatch(const std::vector<file::SelaFile>& selas);
+// The same jobs by path (CLI -E / -D): nothing is read or written up front -- every GPU worker reads ITS pieces of the
+// input files (read-ahead on the I/O pool), codes them, and writes the results at their place in the output files
+// while its next piece is on the device.  Small tracks that follow each other are read into one buffer and coded as
+// one job.  A track cut between two workers: the later piece is placed when the earlier one's size is known; no
+// worker waits for another one before its own work is done.
+void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::string>& outputs);
+void decodeFiles(const std::vector<std::string>& inputs, const std::vector<std::string>& outputs);
 
 } // namespace sela

@@ -1,0 +1,122 @@
+// fileio.hpp -- positioned file I/O on a small pool of threads, for the path-based verbs of codec.hpp.
+//
+// What it replaces in the reference: `ifstream::read` of the whole file before the first frame is coded and
+// field-by-field `ofstream::write` after the last (src/file/wav_file.cpp:39-45, src/file/sela_file.cpp:105-137).
+// At GPU speed the file system is the slow side: one thread moves a page-cache file at a few GB/s (a fresh file
+// also pays a page allocation per 4 KB written), the device codes the same bytes ten times faster.  So a file is
+// read with several pread()s in flight into page-locked memory while earlier pieces are already on the device, and
+// finished ranges are written with several pwrite()s in flight while later pieces are still being coded.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace sela_host {
+
+// A file descriptor with exact positioned reads and writes.  Throws data::Exception.
+class PosixFile {
+    int fd = -1;
+    std::string name;
+
+public:
+    PosixFile() {}
+    PosixFile(const PosixFile&) = delete;
+    PosixFile& operator=(const PosixFile&) = delete;
+    PosixFile(PosixFile&& o) noexcept : fd(o.fd), name(std::move(o.name)) { o.fd = -1; }
+    PosixFile& operator=(PosixFile&& o) noexcept;
+    ~PosixFile() { close(); }
+
+    static PosixFile openForRead(const std::string& path);
+    static PosixFile create(const std::string& path); // truncates
+    static PosixFile openForWrite(const std::string& path); // an existing file, contents kept
+    bool isOpen() const { return fd >= 0; }
+    const std::string& path() const { return name; }
+    size_t size() const;
+    // false when the file ends before n bytes at `offset`
+    bool readAt(void* dst, size_t n, size_t offset) const;
+    void writeAt(const void* src, size_t n, size_t offset) const;
+    void truncate(size_t n) const;
+    void close();
+};
+
+// The process-wide pool of I/O threads (started on first use).  Tasks run in the order they were submitted.
+class IoPool {
+public:
+    static IoPool& instance();
+    void submit(std::function<void()> task);
+    unsigned threads() const { return count; }
+    // Threads the pool starts with (before its first use; later calls are ignored).  0 = the default:
+    // min(16, hardware threads / 2), at least 2.
+    static void configure(unsigned n);
+
+private:
+    IoPool();
+    ~IoPool();
+    void run();
+    struct Impl;
+    Impl* impl;
+    unsigned count;
+};
+
+// A set of tasks submitted to the pool whose completion is awaited together; remembers the first failure
+// (a data::Exception's message) and rethrows it from wait().
+class IoGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t pending = 0;
+    std::string error;
+    bool failed = false;
+
+public:
+    IoGroup() {}
+    IoGroup(const IoGroup&) = delete;
+    ~IoGroup() { waitNoThrow(); }
+    void run(std::function<void()> task);
+    void wait(); // throws data::Exception if a task failed
+    void waitNoThrow();
+    bool hasFailed();
+};
+
+// A byte range of a file being read into memory by pool tasks, consumed front to back: need(n) returns once
+// bytes [0, n) have arrived (or throws if the file turned out shorter / a read failed).
+class ReadAhead {
+    const PosixFile& file;
+    uint8_t* dst;
+    size_t fileOffset, total, piece;
+    std::vector<std::atomic<uint32_t>> left; // sub-reads still out per piece
+    std::mutex mu;
+    std::condition_variable cv;
+    bool shortFile = false;
+    std::string error;
+    IoGroup group;
+
+public:
+    // Reads file[fileOffset, fileOffset + total) into dst in pieces of `pieceBytes`, each cut into sub-reads of
+    // `subBytes`; every sub-read is a pool task, submitted now, in order.
+    ReadAhead(const PosixFile& f, void* dst, size_t fileOffset, size_t total, size_t pieceBytes, size_t subBytes);
+    void need(size_t upTo);
+    void finish() { group.wait(); }
+};
+
+// Ranges of a memory buffer that have become final, written to a file by pool tasks: [done so far, upTo) is cut
+// into sub-writes; finish() waits for them all.
+class WriteBehind {
+    const PosixFile& file;
+    size_t fileOffset, written = 0, subBytes;
+    IoGroup group;
+
+public:
+    WriteBehind(const PosixFile& f, size_t fileOffset, size_t subBytes) : file(f), fileOffset(fileOffset), subBytes(subBytes) {}
+    // base[0, upTo) is final: queue what has not been queued yet
+    void drain(const void* base, size_t upTo);
+    size_t queued() const { return written; }
+    void finish() { group.wait(); }
+};
+
+} // namespace sela_host

@@ -3,11 +3,14 @@
 #include "sela_host/codec.hpp"
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 
 #include "sela_hip.h"
+#include "sela_host/fileio.hpp"
 
 namespace {
 
@@ -35,31 +38,29 @@ size_t optimisticBytes(size_t frames, uint32_t channels)
     return std::min(sela_hip_encode_bound_bytes((uint32_t)frames, channels), pcm + pcm / 8 + 64 * frames + 4096);
 }
 
-// Encode `frames` frames that are (or, with `in`, are being read piece by piece) at pcm.  drain(bytes, n) is
-// told whenever more of the output is final.
-template <typename Drain>
-void streamEncode(std::ifstream* in, int16_t* pcm, size_t frames, uint32_t channels, sela_host::PinnedBuffer<uint8_t>& bytes,
+// Encode `frames` frames at pcm that are arriving in memory front to back: need(n) returns once the first n frames are
+// there (an ifstream read, or a wait for read-ahead tasks; a no-op for samples that are in memory already).  Every
+// `piece` frames are one feed = one kernel launch.  drain(bytes, n) is told whenever more of the output is final.
+template <typename Need, typename Drain>
+void streamEncode(Need need, size_t piece, int16_t* pcm, size_t frames, uint32_t channels, sela_host::PinnedBuffer<uint8_t>& bytes,
     std::vector<uint64_t>& offsets, Drain drain)
 {
     const size_t frameSamples = kBlock * channels;
     offsets.assign(frames + 1, 0);
-    size_t readFrames = in ? 0 : frames; // frames of pcm that are in memory
+    piece = std::max<size_t>(piece, 1);
     for (int attempt = 0; attempt < 2; attempt++) {
         bytes.resize(attempt == 0 ? optimisticBytes(frames, channels) : sela_hip_encode_bound_bytes((uint32_t)frames, channels));
         sela_hip_job* job = nullptr;
         if (sela_hip_encode_begin(&job, channels, (uint32_t)frames, bytes.data(), bytes.size(), offsets.data()) != SELA_HIP_OK)
             gpuFailure("Encoder");
         int rc = SELA_HIP_OK;
-        // (a feed is one kernel launch: samples that are in memory already go in one piece)
-        const size_t piece = in ? kPieceFrames : std::max<size_t>(frames, 1);
         for (size_t f0 = 0; f0 < frames && rc == SELA_HIP_OK; f0 += piece) {
             const size_t nf = std::min<size_t>(piece, frames - f0);
-            if (in && f0 + nf > readFrames) { // the device works on the earlier pieces while this one is read
-                if (!readExact(*in, pcm + f0 * frameSamples, nf * frameSamples * 2)) {
-                    (void)sela_hip_encode_end(job, nullptr, nullptr);
-                    throw data::Exception("data subChunk is shorter than its header says");
-                }
-                readFrames = f0 + nf;
+            try {
+                need(f0 + nf); // the device works on the earlier pieces while this one arrives
+            } catch (...) {
+                (void)sela_hip_encode_end(job, nullptr, nullptr);
+                throw;
             }
             uint64_t done = 0;
             rc = sela_hip_encode_feed(job, pcm + f0 * frameSamples, (uint32_t)nf, nullptr, &done);
@@ -82,10 +83,29 @@ void streamEncode(std::ifstream* in, int16_t* pcm, size_t frames, uint32_t chann
     }
 }
 
-// Decode the frame stream that is being read from `in` (payload bytes behind the 15-byte header) into pcm;
-// drain(samples, n) is told whenever more samples are final.  Fills sela.frameBytes / frameOffsets.
-template <typename Drain>
-void streamDecode(std::ifstream& in, file::SelaFile& sela, size_t payload, sela_host::PinnedBuffer<int16_t>& pcm, Drain drain)
+// need() of a file that is read with the calling thread's own ifstream reads
+struct StreamReader {
+    std::ifstream& in;
+    int16_t* pcm;
+    size_t frameSamples, readFrames = 0;
+    void operator()(size_t upTo)
+    {
+        if (upTo > readFrames) {
+            if (!readExact(in, pcm + readFrames * frameSamples, (upTo - readFrames) * frameSamples * 2))
+                throw data::Exception("data subChunk is shorter than its header says");
+            readFrames = upTo;
+        }
+    }
+};
+
+// Decode the frame stream that is arriving in sela.frameBytes front to back (payload bytes behind the 15-byte header;
+// fetch(have, payload) brings more of it in and returns the new number of bytes there) into pcm; drain(samples, n) is
+// told whenever more samples are final.  Fills sela.frameOffsets.  Only frames [firstFrame, firstFrame + maxFrames) are
+// decoded (the batch dispatcher cuts a file between workers; frames before the range are only indexed); pcm holds
+// those frames from its start.
+template <typename Fetch, typename Drain>
+void streamDecode(Fetch fetch, file::SelaFile& sela, size_t payload, sela_host::PinnedBuffer<int16_t>& pcm, Drain drain, size_t firstFrame = 0,
+    size_t maxFrames = (size_t)-1)
 {
     const uint32_t channels = sela.selaHeader.channels;
     if (channels == 0)
@@ -93,28 +113,32 @@ void streamDecode(std::ifstream& in, file::SelaFile& sela, size_t payload, sela_
     const size_t frameSamples = kBlock * channels;
     // the header's frame count is not trusted for sizing: a frame has at least 4 + 12 bytes per channel
     const size_t plausible = std::min<size_t>(sela.selaHeader.numFrames, payload / (4 + 12 * (size_t)channels));
-    sela.frameBytes.resize(payload);
-    sela.frameOffsets.assign(plausible + 1, 0);
-    pcm.resize(plausible * frameSamples);
+    const size_t stop = std::min(plausible, maxFrames == (size_t)-1 ? plausible : firstFrame + maxFrames); // frames indexed at most
+    const size_t mine = stop > firstFrame ? stop - firstFrame : 0;
+    if (sela.frameBytes.size() < payload)
+        sela.frameBytes.resize(payload);
+    sela.frameOffsets.assign(stop + 1, 0);
+    pcm.resize(mine * frameSamples);
     sela_hip_job* job = nullptr;
-    if (sela_hip_decode_begin(&job, channels, (uint32_t)plausible, pcm.data()) != SELA_HIP_OK)
+    if (sela_hip_decode_begin(&job, channels, (uint32_t)mine, pcm.data()) != SELA_HIP_OK)
         gpuFailure("Decoder");
-    size_t have = 0, indexed = 0, fed = 0;
+    size_t have = 0, indexed = 0, fed = std::min(firstFrame, stop);
+    bool ended = false; // a frame without a sync word: the stream stops there for good
     int rc = SELA_HIP_OK;
     std::vector<uint64_t> local(kPieceFrames + 1);
-    while (rc == SELA_HIP_OK && (have < payload || fed < indexed)) {
-        if (have < payload) {
-            const size_t n = std::min(kPieceBytes, payload - have);
-            if (!readExact(in, sela.frameBytes.data() + have, n)) {
+    while (rc == SELA_HIP_OK && ((have < payload && indexed < stop && !ended) || fed < indexed)) {
+        if (have < payload && indexed < stop && !ended) {
+            try {
+                have = fetch(have, payload);
+            } catch (...) {
                 (void)sela_hip_decode_end(job, nullptr);
-                throw data::Exception("File is too small, probably not a sela file.");
+                throw;
             }
-            have += n;
         }
         // index the frames that are complete in what has been read; like the reference, stop for good at the
         // first one without a sync word (which this cannot tell from "not yet read" until the file is in)
         for (;;) {
-            const size_t want = std::min<size_t>(kPieceFrames, plausible - indexed);
+            const size_t want = std::min<size_t>(kPieceFrames, stop - indexed);
             if (want == 0)
                 break;
             const uint64_t base = sela.frameOffsets[indexed];
@@ -122,17 +146,21 @@ void streamDecode(std::ifstream& in, file::SelaFile& sela, size_t payload, sela_
             for (uint32_t f = 1; f <= found; f++)
                 sela.frameOffsets[indexed + f] = base + local[f];
             indexed += found;
-            if (found < want)
+            if (found < want) {
+                ended = have == payload;
                 break;
+            }
         }
-        const bool last = have == payload;
-        if (indexed - fed >= kPieceFrames || (last && indexed > fed)) {
+        const bool last = have == payload || indexed == stop || ended;
+        if (indexed > fed && (indexed - fed >= kPieceFrames || last)) {
             uint32_t done = 0;
             rc = sela_hip_decode_feed(job, sela.frameBytes.data(), sela.frameOffsets.data() + fed, (uint32_t)(indexed - fed), &done);
             fed = indexed;
             if (rc == SELA_HIP_OK)
                 drain(pcm.data(), (size_t)done * frameSamples);
         }
+        if (have == payload && fed >= indexed)
+            break;
     }
     const std::string feedError = rc != SELA_HIP_OK ? sela_hip_last_error() : "";
     uint32_t done = 0;
@@ -142,10 +170,25 @@ void streamDecode(std::ifstream& in, file::SelaFile& sela, size_t payload, sela_
     if (rc != SELA_HIP_OK)
         throw data::Exception("Decoder: " + (feedError.empty() ? std::string(sela_hip_last_error()) : feedError));
     sela.frameOffsets.resize(indexed + 1);
-    sela.frameBytes.resize((size_t)sela.frameOffsets.back());
-    pcm.resize(indexed * frameSamples);
+    if (firstFrame == 0 && maxFrames == (size_t)-1)
+        sela.frameBytes.resize((size_t)sela.frameOffsets.back());
+    const size_t decoded = indexed > firstFrame ? indexed - firstFrame : 0;
+    pcm.resize(decoded * frameSamples);
     drain(pcm.data(), pcm.size());
 }
+
+// fetch() of a file that is read with the calling thread's own ifstream reads, kPieceBytes at a time
+struct StreamFetcher {
+    std::ifstream& in;
+    file::SelaFile& sela;
+    size_t operator()(size_t have, size_t payload)
+    {
+        const size_t n = std::min(kPieceBytes, payload - have);
+        if (!readExact(in, sela.frameBytes.data() + have, n))
+            throw data::Exception("File is too small, probably not a sela file.");
+        return have + n;
+    }
+};
 
 // ---- multi-GPU dispatcher ---------------------------------------------------------------------------------------
 std::mutex g_devicesMutex;
@@ -231,7 +274,8 @@ file::SelaFile Encoder::process()
     const size_t frames = wavFile.frameCount(); // tail samples beyond the last whole frame are dropped
     sela_host::PinnedBuffer<uint8_t> bytes;
     std::vector<uint64_t> offsets;
-    streamEncode(&ifStream, wavFile.pcm.data(), frames, channels, bytes, offsets, [](const uint8_t*, size_t) {});
+    streamEncode(StreamReader{ ifStream, wavFile.pcm.data(), kBlock * channels }, kPieceFrames, wavFile.pcm.data(), frames, channels, bytes, offsets,
+        [](const uint8_t*, size_t) {});
     const size_t coded = frames * kBlock * channels;
     if (wavFile.pcm.size() > coded && !readExact(ifStream, wavFile.pcm.data() + coded, (wavFile.pcm.size() - coded) * 2))
         throw data::Exception("data subChunk is shorter than its header says");
@@ -245,7 +289,7 @@ file::WavFile Decoder::process()
 {
     const size_t payload = selaFile.readHeader(ifStream);
     sela_host::PinnedBuffer<int16_t> pcm;
-    streamDecode(ifStream, selaFile, payload, pcm, [](const int16_t*, size_t) {});
+    streamDecode(StreamFetcher{ ifStream, selaFile }, selaFile, payload, pcm, [](const int16_t*, size_t) {});
     file::WavFile out(selaFile.selaHeader.sampleRate, (uint16_t)selaFile.selaHeader.channels, std::move(pcm));
     if (demuxFrames)
         out.demuxSamples();
@@ -270,7 +314,7 @@ size_t encodeFile(std::ifstream& in, std::ofstream& out)
     sela_host::PinnedBuffer<uint8_t> bytes;
     std::vector<uint64_t> offsets;
     size_t written = 0;
-    streamEncode(&in, wav.pcm.data(), frames, channels, bytes, offsets, [&](const uint8_t* p, size_t done) {
+    streamEncode(StreamReader{ in, wav.pcm.data(), kBlock * channels }, kPieceFrames, wav.pcm.data(), frames, channels, bytes, offsets, [&](const uint8_t* p, size_t done) {
         if (done > written) { // finished frames go to disk while later pieces are on the device
             out.write(reinterpret_cast<const char*>(p + written), (std::streamsize)(done - written));
             written = done;
@@ -290,7 +334,7 @@ size_t decodeFile(std::ifstream& in, std::ofstream& out)
     file::WavFile::writeHeader(out, sela.selaHeader.sampleRate, (uint16_t)channels, 16, (uint32_t)(announced * kBlock * channels * 2));
     sela_host::PinnedBuffer<int16_t> pcm;
     size_t written = 0;
-    streamDecode(in, sela, payload, pcm, [&](const int16_t* p, size_t done) {
+    streamDecode(StreamFetcher{ in, sela }, sela, payload, pcm, [&](const int16_t* p, size_t done) {
         if (done > written) {
             out.write(reinterpret_cast<const char*>(p + written), (std::streamsize)((done - written) * 2));
             written = done;
@@ -355,7 +399,8 @@ std::vector<file::SelaFile> encodeBatch(const std::vector<file::WavFile>& wavs)
             for (size_t p = 0; p < mine.size(); p++) {
                 const file::WavFile& wav = wavs[members[mine[p].track]];
                 int16_t* pcm = const_cast<int16_t*>(wav.pcm.data()) + mine[p].first * kBlock * channels;
-                streamEncode(nullptr, pcm, mine[p].n, channels, coded[w][p].bytes, coded[w][p].offsets, [](const uint8_t*, size_t) {});
+                // (a feed is one kernel launch: samples that are in memory already go in one piece)
+                streamEncode([](size_t) {}, mine[p].n, pcm, mine[p].n, channels, coded[w][p].bytes, coded[w][p].offsets, [](const uint8_t*, size_t) {});
             }
         });
         // the pieces' sizes meet here: every track's stream is its pieces back to back
@@ -433,6 +478,412 @@ std::vector<file::WavFile> decodeBatch(const std::vector<file::SelaFile>& selas)
         }
     }
     return out;
+}
+
+// ---- path-based verbs: positioned I/O on the pool's threads beside the feeding thread ------------------------------
+namespace {
+
+constexpr size_t kIoSubBytes = (size_t)1 << 20;  // one pread / pwrite task
+constexpr size_t kFeedFrames = 512;              // frames per encode feed while a file is being read (one launch each)
+
+void put16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v, p[1] = (uint8_t)(v >> 8); }
+void put32(uint8_t* p, uint32_t v) { put16(p, v), put16(p + 2, v >> 16); }
+
+// the 15 bytes of src/file/sela_file.cpp:108-112
+void selaHeaderBytes(uint8_t (&h)[15], uint32_t rate, uint16_t bps, uint8_t channels, uint32_t frames)
+{
+    std::memcpy(h, "SeLa", 4);
+    put32(h + 4, rate);
+    put16(h + 8, bps);
+    h[10] = channels;
+    put32(h + 11, frames);
+}
+
+// the canonical 44 bytes of src/file/wav_file.cpp:227-243
+void wavHeaderBytes(uint8_t (&h)[44], uint32_t rate, uint16_t channels, uint16_t bps, uint32_t dataBytes)
+{
+    std::memcpy(h, "RIFF", 4);
+    put32(h + 4, 36 + dataBytes);
+    std::memcpy(h + 8, "WAVEfmt ", 8);
+    put32(h + 16, 16);
+    put16(h + 20, 1);
+    put16(h + 22, channels);
+    put32(h + 24, rate);
+    put32(h + 28, rate * channels * bps / 8);
+    put16(h + 32, (uint16_t)(channels * bps / 8));
+    put16(h + 34, bps);
+    std::memcpy(h + 36, "data", 4);
+    put32(h + 40, dataBytes);
+}
+
+struct WavInfo {
+    uint32_t rate = 0;
+    uint16_t channels = 0, bps = 16;
+    size_t dataOffset = 0, dataBytes = 0, frames = 0;
+};
+
+// The header walk of file::WavFile::readHeader (same acceptance, same messages), for a file that is then read by offset.
+WavInfo probeWav(const std::string& path)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in)
+        throw data::Exception("cannot open " + path);
+    file::WavFile wav;
+    WavInfo info;
+    info.dataBytes = wav.readHeader(in);
+    info.dataOffset = (size_t)in.tellg();
+    info.rate = wav.sampleRate;
+    info.channels = wav.numChannels;
+    info.bps = wav.bitsPerSample;
+    if (info.channels == 0 || info.channels > 255)
+        throw data::Exception("Encoder: unsupported channel count");
+    info.frames = info.dataBytes / 2 / info.channels / kBlock; // tail samples beyond the last whole frame are dropped
+    return info;
+}
+
+struct SelaInfo {
+    data::SelaHeader header;
+    size_t payload = 0, announced = 0; // bytes behind the header; frames the header promises (as far as the file can hold them)
+};
+
+SelaInfo probeSela(const std::string& path)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in)
+        throw data::Exception("cannot open " + path);
+    file::SelaFile sela;
+    SelaInfo info;
+    info.payload = sela.readHeader(in);
+    info.header = sela.selaHeader;
+    if (info.header.channels == 0)
+        throw data::Exception("Decoder: unsupported channel count");
+    info.announced = std::min<size_t>(info.header.numFrames, info.payload / (4 + 12 * (size_t)info.header.channels));
+    return info;
+}
+
+// Frames [first, first + n) of a probed WAV -> .sela frame bytes, streamed: reads ahead on the pool, one feed per
+// kFeedFrames, sink(bytes, final) is told whenever more of the output is final.  Returns the total.
+template <typename Sink>
+size_t encodeRange(const sela_host::PosixFile& in, const WavInfo& info, size_t first, size_t n, sela_host::PinnedBuffer<int16_t>& pcm,
+    sela_host::PinnedBuffer<uint8_t>& bytes, std::vector<uint64_t>& offsets, Sink sink)
+{
+    const size_t frameBytes = kBlock * info.channels * 2;
+    pcm.resize(n * kBlock * info.channels);
+    sela_host::ReadAhead ahead(in, pcm.data(), info.dataOffset + first * frameBytes, n * frameBytes, kFeedFrames * frameBytes, kIoSubBytes);
+    streamEncode([&](size_t upTo) { ahead.need(upTo * frameBytes); }, kFeedFrames, pcm.data(), n, info.channels, bytes, offsets, sink);
+    ahead.finish();
+    return bytes.size();
+}
+
+} // namespace
+
+void setIoThreads(unsigned n) { sela_host::IoPool::configure(n); }
+
+size_t encodeFile(const std::string& inPath, const std::string& outPath)
+{
+    const WavInfo info = probeWav(inPath);
+    const sela_host::PosixFile in = sela_host::PosixFile::openForRead(inPath);
+    const sela_host::PosixFile out = sela_host::PosixFile::create(outPath);
+    uint8_t header[15];
+    selaHeaderBytes(header, info.rate, info.bps, (uint8_t)info.channels, (uint32_t)info.frames);
+    out.writeAt(header, 15, 0);
+    sela_host::PinnedBuffer<int16_t> pcm;
+    sela_host::PinnedBuffer<uint8_t> bytes;
+    std::vector<uint64_t> offsets;
+    sela_host::WriteBehind behind(out, 15, kIoSubBytes);
+    encodeRange(in, info, 0, info.frames, pcm, bytes, offsets, [&](const uint8_t* p, size_t done) { behind.drain(p, done); });
+    behind.finish();
+    return info.frames;
+}
+
+size_t decodeFile(const std::string& inPath, const std::string& outPath)
+{
+    const SelaInfo info = probeSela(inPath);
+    const uint32_t channels = info.header.channels;
+    const size_t frameBytes = kBlock * channels * 2;
+    const sela_host::PosixFile in = sela_host::PosixFile::openForRead(inPath);
+    const sela_host::PosixFile out = sela_host::PosixFile::create(outPath);
+    uint8_t header[44];
+    wavHeaderBytes(header, info.header.sampleRate, (uint16_t)channels, 16, (uint32_t)(info.announced * frameBytes));
+    out.writeAt(header, 44, 0);
+    file::SelaFile sela;
+    sela.selaHeader = info.header;
+    sela.frameBytes.resize(info.payload);
+    sela_host::PinnedBuffer<int16_t> pcm;
+    sela_host::ReadAhead ahead(in, sela.frameBytes.data(), 15, info.payload, kIoSubBytes, kIoSubBytes);
+    sela_host::WriteBehind behind(out, 44, kIoSubBytes);
+    streamDecode(
+        [&](size_t have, size_t payload) {
+            const size_t upTo = std::min(payload, have + kIoSubBytes);
+            ahead.need(upTo);
+            return upTo;
+        },
+        sela, info.payload, pcm, [&](const int16_t* p, size_t done) { behind.drain(p, done * 2); });
+    ahead.finish();
+    behind.finish();
+    const size_t frames = sela.frameCount();
+    if (frames != info.announced) { // the stream ended early (bad sync word): the header sizes follow what was decoded
+        wavHeaderBytes(header, info.header.sampleRate, (uint16_t)channels, 16, (uint32_t)(frames * frameBytes));
+        out.writeAt(header, 44, 0);
+        out.truncate(44 + frames * frameBytes);
+    }
+    return frames;
+}
+
+// ---- many files by path: every GPU worker reads, codes and writes its own pieces ----------------------------------
+namespace {
+
+// What workers that share a track tell each other: the byte count of every piece of the track, in frame order
+// (piece k of a track goes behind the header and the k pieces before it).
+struct SharedTracks {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool aborted = false;
+    std::vector<std::vector<int64_t>> pieceBytes; // [track][piece of the track] or -1
+    void publish(size_t track, size_t piece, size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            pieceBytes[track][piece] = (int64_t)bytes;
+        }
+        cv.notify_all();
+    }
+    // bytes of the pieces before `piece`; blocks until they are all known
+    size_t before(size_t track, size_t piece)
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        size_t sum = 0;
+        for (size_t k = 0; k < piece; k++) {
+            cv.wait(lock, [&] { return aborted || pieceBytes[track][k] >= 0; });
+            if (aborted)
+                throw data::Exception("another worker failed");
+            sum += (size_t)pieceBytes[track][k];
+        }
+        return sum;
+    }
+    void abort()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            aborted = true;
+        }
+        cv.notify_all();
+    }
+};
+
+// the index of every piece within its track, in (worker, piece) order
+std::vector<std::vector<size_t>> pieceIndexInTrack(const std::vector<std::vector<Piece>>& pieces, size_t tracks, std::vector<size_t>& piecesOfTrack)
+{
+    piecesOfTrack.assign(tracks, 0);
+    std::vector<std::vector<size_t>> index(pieces.size());
+    for (size_t w = 0; w < pieces.size(); w++)
+        for (const Piece& p : pieces[w])
+            index[w].push_back(piecesOfTrack[p.track]++);
+    return index;
+}
+
+} // namespace
+
+void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::string>& outputs)
+{
+    if (inputs.size() != outputs.size())
+        throw data::Exception("encodeFiles: one output path per input");
+    const std::vector<int> devs = workerDevices();
+    std::vector<WavInfo> info(inputs.size());
+    for (size_t i = 0; i < inputs.size(); i++) {
+        info[i] = probeWav(inputs[i]);
+        // every output exists with its header before the first worker starts: a track shorter than a frame has no piece
+        const sela_host::PosixFile out = sela_host::PosixFile::create(outputs[i]);
+        uint8_t header[15];
+        selaHeaderBytes(header, info[i].rate, info[i].bps, (uint8_t)info[i].channels, (uint32_t)info[i].frames);
+        out.writeAt(header, 15, 0);
+    }
+    std::vector<bool> done(inputs.size(), false);
+    for (size_t first = 0; first < inputs.size(); first++) {
+        if (done[first])
+            continue;
+        // every file with this channel count joins the job (the frames of one job have one layout)
+        const uint16_t channels = info[first].channels;
+        std::vector<size_t> members, trackFrames;
+        for (size_t i = first; i < inputs.size(); i++) {
+            if (done[i] || info[i].channels != channels)
+                continue;
+            members.push_back(i);
+            trackFrames.push_back(info[i].frames);
+            done[i] = true;
+        }
+        const std::vector<std::vector<Piece>> pieces = partitionPieces(trackFrames, devs.size());
+        SharedTracks shared;
+        std::vector<size_t> piecesOfTrack;
+        const std::vector<std::vector<size_t>> indexInTrack = pieceIndexInTrack(pieces, members.size(), piecesOfTrack);
+        for (size_t t = 0; t < members.size(); t++)
+            shared.pieceBytes.emplace_back(piecesOfTrack[t], -1);
+        const size_t frameBytes = kBlock * channels * 2;
+        try {
+            runOnDevices(pieces, devs, [&](size_t w, const std::vector<Piece>& mine) {
+                try {
+                    // A RUN = consecutive pieces read into one page-locked buffer back to back and coded as ONE job, so that many
+                    // small tracks cost one set of launches instead of one each (a feed may span tracks); a piece larger than
+                    // the run size is a run of its own and is written while it is still being coded.
+                    constexpr size_t kRunFrames = 4096;
+                    struct Deferred { // a piece that starts inside a track: its place is known when the pieces before it are
+                        size_t track, piece;
+                        sela_host::PinnedBuffer<uint8_t> bytes;
+                    };
+                    std::vector<Deferred> deferred;
+                    sela_host::PinnedBuffer<int16_t> pcm;
+                    for (size_t p0 = 0; p0 < mine.size();) {
+                        size_t p1 = p0 + 1, runFrames = mine[p0].n;
+                        while (p1 < mine.size() && runFrames + mine[p1].n <= kRunFrames)
+                            runFrames += mine[p1++].n;
+                        sela_host::PinnedBuffer<uint8_t> bytes;
+                        std::vector<uint64_t> offsets;
+                        if (p1 == p0 + 1) { // one piece: streamed in and -- if it starts its track -- streamed out
+                            const Piece& pc = mine[p0];
+                            const size_t member = members[pc.track];
+                            const sela_host::PosixFile in = sela_host::PosixFile::openForRead(inputs[member]);
+                            if (pc.first == 0) {
+                                const sela_host::PosixFile out = sela_host::PosixFile::openForWrite(outputs[member]);
+                                sela_host::WriteBehind behind(out, 15, kIoSubBytes);
+                                encodeRange(in, info[member], 0, pc.n, pcm, bytes, offsets, [&](const uint8_t* b, size_t n) { behind.drain(b, n); });
+                                behind.finish();
+                                shared.publish(pc.track, indexInTrack[w][p0], bytes.size());
+                            } else {
+                                encodeRange(in, info[member], pc.first, pc.n, pcm, bytes, offsets, [](const uint8_t*, size_t) {});
+                                shared.publish(pc.track, indexInTrack[w][p0], bytes.size());
+                                deferred.push_back({ pc.track, indexInTrack[w][p0], std::move(bytes) });
+                            }
+                        } else { // several small pieces: one buffer, one job
+                            pcm.resize(runFrames * kBlock * channels);
+                            std::vector<sela_host::PosixFile> files;
+                            std::vector<std::unique_ptr<sela_host::ReadAhead>> reads;
+                            std::vector<size_t> startFrame; // of every piece in the run
+                            size_t at = 0;
+                            for (size_t p = p0; p < p1; p++) {
+                                const size_t member = members[mine[p].track];
+                                files.push_back(sela_host::PosixFile::openForRead(inputs[member]));
+                                startFrame.push_back(at);
+                                at += mine[p].n;
+                            }
+                            startFrame.push_back(at);
+                            for (size_t p = p0; p < p1; p++) {
+                                const size_t member = members[mine[p].track], k = p - p0;
+                                reads.emplace_back(new sela_host::ReadAhead(files[k], pcm.data() + startFrame[k] * kBlock * channels,
+                                    info[member].dataOffset + mine[p].first * frameBytes, mine[p].n * frameBytes, kFeedFrames * frameBytes, kIoSubBytes));
+                            }
+                            streamEncode(
+                                [&](size_t upTo) {
+                                    for (size_t k = 0; k < reads.size() && startFrame[k] < upTo; k++)
+                                        reads[k]->need((std::min(upTo, startFrame[k + 1]) - startFrame[k]) * frameBytes);
+                                },
+                                kFeedFrames * 2, pcm.data(), runFrames, channels, bytes, offsets, [](const uint8_t*, size_t) {});
+                            for (auto& r : reads)
+                                r->finish();
+                            for (size_t p = p0; p < p1; p++) {
+                                const size_t k = p - p0;
+                                const size_t b0 = (size_t)offsets[startFrame[k]], b1 = (size_t)offsets[startFrame[k + 1]];
+                                shared.publish(mine[p].track, indexInTrack[w][p], b1 - b0);
+                                if (mine[p].first == 0) {
+                                    const sela_host::PosixFile out = sela_host::PosixFile::openForWrite(outputs[members[mine[p].track]]);
+                                    out.writeAt(bytes.data() + b0, b1 - b0, 15);
+                                } else {
+                                    sela_host::PinnedBuffer<uint8_t> part;
+                                    part.assign(bytes.data() + b0, b1 - b0);
+                                    deferred.push_back({ mine[p].track, indexInTrack[w][p], std::move(part) });
+                                }
+                            }
+                        }
+                        p0 = p1;
+                    }
+                    for (Deferred& d : deferred) { // (the pieces before these belong to workers that do not wait for anybody)
+                        const size_t at = shared.before(d.track, d.piece);
+                        const sela_host::PosixFile out = sela_host::PosixFile::openForWrite(outputs[members[d.track]]);
+                        sela_host::WriteBehind behind(out, 15 + at, kIoSubBytes);
+                        behind.drain(d.bytes.data(), d.bytes.size());
+                        behind.finish();
+                    }
+                } catch (...) {
+                    shared.abort();
+                    throw;
+                }
+            });
+        } catch (...) {
+            shared.abort();
+            throw;
+        }
+    }
+}
+
+void decodeFiles(const std::vector<std::string>& inputs, const std::vector<std::string>& outputs)
+{
+    if (inputs.size() != outputs.size())
+        throw data::Exception("decodeFiles: one output path per input");
+    const std::vector<int> devs = workerDevices();
+    std::vector<SelaInfo> info(inputs.size());
+    for (size_t i = 0; i < inputs.size(); i++) {
+        info[i] = probeSela(inputs[i]);
+        const sela_host::PosixFile out = sela_host::PosixFile::create(outputs[i]);
+        uint8_t header[44];
+        wavHeaderBytes(header, info[i].header.sampleRate, info[i].header.channels, 16,
+            (uint32_t)(info[i].announced * kBlock * info[i].header.channels * 2));
+        out.writeAt(header, 44, 0);
+    }
+    std::vector<bool> done(inputs.size(), false);
+    for (size_t first = 0; first < inputs.size(); first++) {
+        if (done[first])
+            continue;
+        const uint32_t channels = info[first].header.channels;
+        std::vector<size_t> members, trackFrames;
+        for (size_t i = first; i < inputs.size(); i++) {
+            if (done[i] || info[i].header.channels != channels)
+                continue;
+            members.push_back(i);
+            trackFrames.push_back(info[i].announced);
+            done[i] = true;
+        }
+        const std::vector<std::vector<Piece>> pieces = partitionPieces(trackFrames, devs.size());
+        const size_t frameBytes = kBlock * channels * 2;
+        std::mutex foundMutex;
+        std::vector<size_t> found(members.size(), (size_t)-1); // frames a track really holds, where a worker saw its stream end early
+        runOnDevices(pieces, devs, [&](size_t, const std::vector<Piece>& mine) {
+            sela_host::PinnedBuffer<int16_t> pcm;
+            for (const Piece& pc : mine) {
+                // output offsets are frame x 2048 x channels x 2: nothing to agree on with the other workers.  A piece that
+                // starts inside a file walks the frame headers before it (the bytes in front are read, not decoded).
+                const size_t member = members[pc.track];
+                const sela_host::PosixFile in = sela_host::PosixFile::openForRead(inputs[member]);
+                const sela_host::PosixFile out = sela_host::PosixFile::openForWrite(outputs[member]);
+                file::SelaFile sela;
+                sela.selaHeader = info[member].header;
+                sela.frameBytes.resize(info[member].payload);
+                sela_host::ReadAhead ahead(in, sela.frameBytes.data(), 15, info[member].payload, kIoSubBytes, kIoSubBytes);
+                sela_host::WriteBehind behind(out, 44 + pc.first * frameBytes, kIoSubBytes);
+                streamDecode(
+                    [&](size_t have, size_t payload) {
+                        const size_t upTo = std::min(payload, have + kIoSubBytes);
+                        ahead.need(upTo);
+                        return upTo;
+                    },
+                    sela, info[member].payload, pcm, [&](const int16_t* p, size_t n) { behind.drain(p, n * 2); }, pc.first, pc.n);
+                ahead.finish();
+                behind.finish();
+                if (sela.frameCount() < pc.first + pc.n) {
+                    std::lock_guard<std::mutex> lock(foundMutex);
+                    found[pc.track] = std::min(found[pc.track], sela.frameCount());
+                }
+            }
+        });
+        for (size_t t = 0; t < members.size(); t++) {
+            if (found[t] == (size_t)-1)
+                continue; // every announced frame was there
+            const size_t member = members[t];
+            const sela_host::PosixFile out = sela_host::PosixFile::openForWrite(outputs[member]);
+            uint8_t header[44];
+            wavHeaderBytes(header, info[member].header.sampleRate, (uint16_t)channels, 16, (uint32_t)(found[t] * frameBytes));
+            out.writeAt(header, 44, 0);
+            out.truncate(44 + found[t] * frameBytes);
+        }
+    }
 }
 
 bool Encoder::materializeFrames = true;

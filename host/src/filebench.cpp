@@ -4,7 +4,7 @@
 //
 // Measures, with steady_clock, after one untimed warm-up of each (HIP initialisation, buffer pinning):
 //   e2e         sela_hip_encode / sela_hip_decode on page-locked host buffers: H2D + kernels + D2H
-//   file        sela::encodeFile / sela::decodeFile: file read, H2D, kernels, D2H and file write overlapped
+//   file        sela::encodeFile / sela::decodeFile (by path): file read, H2D, kernels, D2H and file write overlapped
 //               (what the reference's `sela -e` / `sela -d` do, src/main.cpp:29-41)
 // and prints one JSON object: medians in ms and stereo Msamples/s.  Results are checked against each other
 // (file-to-file .sela == header + e2e frames; decoded .wav == e2e decode) -- parity against the reference is
@@ -43,12 +43,14 @@ std::vector<uint8_t> slurp(const std::string& path)
 int main(int argc, char** argv)
 {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s in.wav scratch_dir [repeats] [e2e]   (e2e: only the host-pointer leg, for traces)\n", argv[0]);
+        std::fprintf(stderr, "usage: %s in.wav scratch_dir [repeats] [e2e|all] [io threads]   (e2e: only the host-pointer leg, for traces)\n", argv[0]);
         return 2;
     }
     const std::string wavPath = argv[1], dir = argv[2];
     const int repeats = argc > 3 ? std::max(1, std::atoi(argv[3])) : 9;
     const bool onlyE2e = argc > 4 && std::string(argv[4]) == "e2e";
+    if (argc > 5)
+        sela::setIoThreads((unsigned)std::max(0, std::atoi(argv[5]))); // (experiments: sela_filebench in.wav dir repeats all N)
     const std::string selaPath = dir + "/filebench.sela", backPath = dir + "/filebench.wav";
     using clock = std::chrono::steady_clock;
     auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -115,17 +117,9 @@ int main(int argc, char** argv)
         std::vector<double> fenc, fdec;
         for (int r = 0; r <= repeats; r++) {
             const auto t0 = clock::now();
-            {
-                std::ifstream in(wavPath, std::ios::binary);
-                std::ofstream out(selaPath, std::ios::binary);
-                sela::encodeFile(in, out);
-            }
+            sela::encodeFile(wavPath, selaPath);
             const auto t1 = clock::now();
-            {
-                std::ifstream in(selaPath, std::ios::binary);
-                std::ofstream out(backPath, std::ios::binary);
-                sela::decodeFile(in, out);
-            }
+            sela::decodeFile(selaPath, backPath);
             const auto t2 = clock::now();
             if (r) {
                 fenc.push_back(ms(t0, t1));

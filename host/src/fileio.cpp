@@ -1,0 +1,295 @@
+// fileio.cpp -- see fileio.hpp.
+#include "sela_host/fileio.hpp"
+
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+#include <deque>
+#include <thread>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "sela_host/data.hpp"
+
+namespace sela_host {
+
+namespace {
+
+[[noreturn]] void ioFailure(const std::string& what, const std::string& path)
+{
+    throw data::Exception(what + " " + path + ": " + std::strerror(errno));
+}
+
+std::atomic<unsigned> g_configured{ 0 };
+
+} // namespace
+
+PosixFile& PosixFile::operator=(PosixFile&& o) noexcept
+{
+    if (this != &o) {
+        close();
+        fd = o.fd;
+        name = std::move(o.name);
+        o.fd = -1;
+    }
+    return *this;
+}
+
+PosixFile PosixFile::openForRead(const std::string& path)
+{
+    PosixFile f;
+    f.fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (f.fd < 0)
+        throw data::Exception("cannot open " + path);
+    f.name = path;
+    return f;
+}
+
+PosixFile PosixFile::create(const std::string& path)
+{
+    PosixFile f;
+    f.fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (f.fd < 0)
+        throw data::Exception("cannot open " + path + " for writing");
+    f.name = path;
+    return f;
+}
+
+PosixFile PosixFile::openForWrite(const std::string& path)
+{
+    PosixFile f;
+    f.fd = ::open(path.c_str(), O_WRONLY | O_CLOEXEC);
+    if (f.fd < 0)
+        throw data::Exception("cannot open " + path + " for writing");
+    f.name = path;
+    return f;
+}
+
+size_t PosixFile::size() const
+{
+    struct stat st;
+    if (::fstat(fd, &st) != 0)
+        ioFailure("cannot stat", name);
+    return st.st_size > 0 ? (size_t)st.st_size : 0;
+}
+
+bool PosixFile::readAt(void* dst, size_t n, size_t offset) const
+{
+    char* p = static_cast<char*>(dst);
+    while (n) {
+        const ssize_t got = ::pread(fd, p, n, (off_t)offset);
+        if (got < 0) {
+            if (errno == EINTR)
+                continue;
+            ioFailure("reading", name);
+        }
+        if (got == 0)
+            return false;
+        p += got, offset += (size_t)got, n -= (size_t)got;
+    }
+    return true;
+}
+
+void PosixFile::writeAt(const void* src, size_t n, size_t offset) const
+{
+    const char* p = static_cast<const char*>(src);
+    while (n) {
+        const ssize_t put = ::pwrite(fd, p, n, (off_t)offset);
+        if (put < 0) {
+            if (errno == EINTR)
+                continue;
+            ioFailure("writing", name);
+        }
+        p += put, offset += (size_t)put, n -= (size_t)put;
+    }
+}
+
+void PosixFile::truncate(size_t n) const
+{
+    if (::ftruncate(fd, (off_t)n) != 0)
+        ioFailure("truncating", name);
+}
+
+void PosixFile::close()
+{
+    if (fd >= 0)
+        (void)::close(fd);
+    fd = -1;
+}
+
+// ---- the pool ------------------------------------------------------------------------------------------------------
+struct IoPool::Impl {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> queue;
+    std::vector<std::thread> workers;
+    bool stopping = false;
+};
+
+void IoPool::configure(unsigned n) { g_configured.store(n, std::memory_order_relaxed); }
+
+IoPool::IoPool() : impl(new Impl)
+{
+    unsigned n = g_configured.load(std::memory_order_relaxed);
+    if (n == 0) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        n = std::min(16u, std::max(2u, hw / 2));
+    }
+    count = std::min(n, 256u);
+    for (unsigned i = 0; i < count; i++)
+        impl->workers.emplace_back([this] { run(); });
+}
+
+IoPool::~IoPool()
+{
+    {
+        std::lock_guard<std::mutex> lock(impl->mu);
+        impl->stopping = true;
+    }
+    impl->cv.notify_all();
+    for (std::thread& t : impl->workers)
+        t.join();
+    delete impl;
+}
+
+IoPool& IoPool::instance()
+{
+    static IoPool pool;
+    return pool;
+}
+
+void IoPool::submit(std::function<void()> task)
+{
+    {
+        std::lock_guard<std::mutex> lock(impl->mu);
+        impl->queue.push_back(std::move(task));
+    }
+    impl->cv.notify_one();
+}
+
+void IoPool::run()
+{
+    for (;;) {
+        std::function<void()> task;
+        {
+            std::unique_lock<std::mutex> lock(impl->mu);
+            impl->cv.wait(lock, [this] { return impl->stopping || !impl->queue.empty(); });
+            if (impl->queue.empty())
+                return; // stopping
+            task = std::move(impl->queue.front());
+            impl->queue.pop_front();
+        }
+        task(); // (IoGroup::run wraps every task: nothing escapes)
+    }
+}
+
+// ---- groups --------------------------------------------------------------------------------------------------------
+void IoGroup::run(std::function<void()> task)
+{
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        pending++;
+    }
+    IoPool::instance().submit([this, task = std::move(task)] {
+        std::string what;
+        bool bad = false;
+        try {
+            task();
+        } catch (const data::Exception& e) {
+            bad = true, what = e.exceptionMessage;
+        } catch (const std::exception& e) {
+            bad = true, what = e.what();
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        if (bad && !failed)
+            failed = true, error = what;
+        if (--pending == 0)
+            cv.notify_all();
+    });
+}
+
+void IoGroup::waitNoThrow()
+{
+    std::unique_lock<std::mutex> lock(mu);
+    cv.wait(lock, [this] { return pending == 0; });
+}
+
+void IoGroup::wait()
+{
+    waitNoThrow();
+    std::lock_guard<std::mutex> lock(mu);
+    if (failed) {
+        failed = false;
+        throw data::Exception(error);
+    }
+}
+
+bool IoGroup::hasFailed()
+{
+    std::lock_guard<std::mutex> lock(mu);
+    return failed;
+}
+
+// ---- read ahead ----------------------------------------------------------------------------------------------------
+ReadAhead::ReadAhead(const PosixFile& f, void* dstBase, size_t fileOffset, size_t total, size_t pieceBytes, size_t subBytes)
+    : file(f), dst(static_cast<uint8_t*>(dstBase)), fileOffset(fileOffset), total(total), piece(std::max<size_t>(pieceBytes, 1)),
+      left((total + std::max<size_t>(pieceBytes, 1) - 1) / std::max<size_t>(pieceBytes, 1))
+{
+    subBytes = std::max<size_t>(subBytes, 4096);
+    for (size_t p = 0; p < left.size(); p++) {
+        const size_t begin = p * piece, end = std::min(total, begin + piece);
+        left[p].store((uint32_t)((end - begin + subBytes - 1) / subBytes), std::memory_order_relaxed);
+    }
+    for (size_t p = 0; p < left.size(); p++) {
+        const size_t begin = p * piece, end = std::min(total, begin + piece);
+        for (size_t at = begin; at < end; at += subBytes) {
+            const size_t n = std::min(subBytes, end - at);
+            group.run([this, p, at, n] {
+                bool ok = false;
+                std::string what;
+                try {
+                    ok = file.readAt(dst + at, n, this->fileOffset + at);
+                } catch (const data::Exception& e) {
+                    what = e.exceptionMessage;
+                }
+                {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (!what.empty() && error.empty())
+                        error = what;
+                    else if (!ok && what.empty())
+                        shortFile = true;
+                    left[p].fetch_sub(1, std::memory_order_release);
+                }
+                cv.notify_all();
+            });
+        }
+    }
+}
+
+void ReadAhead::need(size_t upTo)
+{
+    upTo = std::min(upTo, total);
+    const size_t lastPiece = upTo ? (upTo - 1) / piece : 0;
+    std::unique_lock<std::mutex> lock(mu);
+    for (size_t p = 0; upTo && p <= lastPiece; p++)
+        cv.wait(lock, [this, p] { return left[p].load(std::memory_order_acquire) == 0; });
+    if (!error.empty())
+        throw data::Exception(error);
+    if (shortFile)
+        throw data::Exception("file " + file.path() + " is shorter than its header says");
+}
+
+// ---- write behind --------------------------------------------------------------------------------------------------
+void WriteBehind::drain(const void* base, size_t upTo)
+{
+    const uint8_t* p = static_cast<const uint8_t*>(base);
+    while (written < upTo) {
+        const size_t n = std::min(subBytes, upTo - written), at = written;
+        group.run([this, p, at, n] { file.writeAt(p + at, n, fileOffset + at); });
+        written += n;
+    }
+}
+
+} // namespace sela_host

@@ -83,10 +83,14 @@ size_t WavFile::readHeader(std::ifstream& in)
     if (std::memcmp(riff + 8, "WAVE", 4) != 0)
         throw data::Exception("format is not WAVE, probably not a wav file.");
 
-    bool haveFmt = false;
-    size_t pos = 12;
+    // Every chunk header of the file is walked, as the reference does (src/file/wav_file.cpp:80-162): a 'fmt ' chunk
+    // counts wherever it stands, and when there are several 'data' chunks the LAST one is the audio.  Only the
+    // headers are touched here; the payload is read later, piece by piece.
+    bool haveFmt = false, haveData = false;
+    size_t pos = 12, dataAt = 0, dataBytes = 0;
     while (pos + 8 <= size) {
         uint8_t head[8];
+        in.seekg((std::streamoff)pos, std::ios::beg);
         if (!readExact(in, head, 8))
             break;
         size_t chunk = le32(head + 4);
@@ -105,14 +109,19 @@ size_t WavFile::readHeader(std::ifstream& in)
         } else if (std::memcmp(head, "data", 4) == 0) {
             if (!haveFmt)
                 throw data::Exception("Probably corrupt wav, data subChunk present without fmt subChunk.");
-            return chunk; // the stream stands at the first PCM byte
+            haveData = true;
+            dataAt = pos + 8;
+            dataBytes = chunk;
         }
         pos += 8 + chunk;
-        in.seekg((std::streamoff)pos, std::ios::beg);
     }
+    in.clear();
     if (!haveFmt)
         throw data::Exception("fmt subChunk is missing from file");
-    throw data::Exception("data subChunk is missing from file");
+    if (!haveData)
+        throw data::Exception("data subChunk is missing from file");
+    in.seekg((std::streamoff)dataAt, std::ios::beg); // the stream stands at the first PCM byte
+    return dataBytes;
 }
 
 void WavFile::readFromFile(std::ifstream& in)

@@ -3,8 +3,10 @@
 //   sela_mi355x -d in.sela out.wav     decode
 //   sela_mi355x -E out_dir [--gpus N | --devices a,b,..] a.wav b.wav ...    encode many files as one job -> out_dir/<name>.sela
 //   sela_mi355x -D out_dir [--gpus N | --devices a,b,..] a.sela b.sela ...  decode many files as one job -> out_dir/<name>.wav
+//   (-E / -D also take --io-threads N: threads that read and write files beside the GPU workers)
 // Same verbs as the reference CLI (src/main.cpp:16-27); playback (-p) is not part of this build.  The batch
 // verbs spread the files' frames over the GPUs of the node (default: all of them), one host thread each.
+#include <algorithm>
 #include <cstdlib>
 #include <exception>
 #include <fstream>
@@ -36,28 +38,15 @@ std::string sibling(const std::string& out_dir, const std::string& in, const cha
     return out_dir + "/" + name + extension;
 }
 
-std::ofstream openOutput(const std::string& path)
-{
-    std::ofstream out(path, std::ios::binary);
-    if (!out)
-        throw data::Exception("cannot open " + path + " for writing");
-    return out;
-}
-
-void finish(std::ofstream& out, const std::string& path)
-{
-    out.flush();
-    if (!out)
-        throw data::Exception("writing " + path + " failed");
-}
-
 int batch(const std::string& verb, int argc, char** argv)
 {
     const std::string out_dir = argv[2];
     std::vector<std::string> inputs;
     for (int i = 3; i < argc; i++) {
         const std::string a = argv[i];
-        if ((a == "--gpus" || a == "--devices") && i + 1 < argc) {
+        if (a == "--io-threads" && i + 1 < argc) {
+            sela::setIoThreads((unsigned)std::max(0, std::atoi(argv[++i])));
+        } else if ((a == "--gpus" || a == "--devices") && i + 1 < argc) {
             std::vector<int> devs;
             const std::string v = argv[++i];
             if (a == "--gpus") {
@@ -79,39 +68,14 @@ int batch(const std::string& verb, int argc, char** argv)
     }
     if (inputs.empty())
         return 2;
-    if (verb == "-E") {
-        std::vector<file::WavFile> wavs(inputs.size());
-        for (size_t i = 0; i < inputs.size(); i++) {
-            std::ifstream in(inputs[i], std::ios::binary);
-            if (!in)
-                throw data::Exception("cannot open " + inputs[i]);
-            wavs[i].readFromFile(in);
-        }
-        sela::Encoder::materializeFrames = false;
-        std::vector<file::SelaFile> selas = sela::encodeBatch(wavs);
-        for (size_t i = 0; i < inputs.size(); i++) {
-            const std::string path = sibling(out_dir, inputs[i], ".sela");
-            std::ofstream out = openOutput(path);
-            selas[i].writeToFile(out);
-            finish(out, path);
-        }
-    } else {
-        std::vector<file::SelaFile> selas(inputs.size());
-        for (size_t i = 0; i < inputs.size(); i++) {
-            std::ifstream in(inputs[i], std::ios::binary);
-            if (!in)
-                throw data::Exception("cannot open " + inputs[i]);
-            selas[i].readFromFile(in);
-        }
-        sela::Decoder::demuxFrames = false;
-        std::vector<file::WavFile> wavs = sela::decodeBatch(selas);
-        for (size_t i = 0; i < inputs.size(); i++) {
-            const std::string path = sibling(out_dir, inputs[i], ".wav");
-            std::ofstream out = openOutput(path);
-            wavs[i].writeToFile(out);
-            finish(out, path);
-        }
-    }
+    // nothing is read or written here: every GPU worker reads, codes and writes its own pieces of the files
+    std::vector<std::string> outputs;
+    for (const std::string& in : inputs)
+        outputs.push_back(sibling(out_dir, in, verb == "-E" ? ".sela" : ".wav"));
+    if (verb == "-E")
+        sela::encodeFiles(inputs, outputs);
+    else
+        sela::decodeFiles(inputs, outputs);
     return 0;
 }
 
@@ -125,18 +89,13 @@ int run(int argc, char** argv)
     }
     if (argc != 4 || (verb != "-e" && verb != "-d"))
         return usage(program);
-    std::ifstream in(argv[2], std::ios::binary);
-    if (!in)
-        throw data::Exception(std::string("cannot open ") + argv[2]);
-    std::ofstream out = openOutput(argv[3]);
     if (verb == "-e") {
         std::cout << "Encoding: " << argv[2] << std::endl;
-        sela::encodeFile(in, out); // read, GPU and write overlap; only the byte stream is produced
+        sela::encodeFile(std::string(argv[2]), std::string(argv[3])); // read, GPU and write overlap; only the byte stream is produced
     } else {
         std::cout << "Decoding: " << argv[2] << std::endl;
-        sela::decodeFile(in, out);
+        sela::decodeFile(std::string(argv[2]), std::string(argv[3]));
     }
-    finish(out, argv[3]);
     return 0;
 }
 

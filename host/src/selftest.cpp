@@ -9,6 +9,7 @@
 #include <string>
 
 #include "sela_hip.h"
+#include "sela_host/fileio.hpp"
 #include "sela_host/files.hpp"
 #include "sela_host/frame.hpp"
 
@@ -89,6 +90,70 @@ int main(int argc, char** argv)
         w24[34] = 24; // 24 bits per sample
         writeBytes(dir + "/w24.wav", w24);
         CHECK(expectError(dir + "/w24.wav", true) == "Only 16bits per sample wav is supported.");
+    }
+    // ---- several 'data' chunks: the last one is the audio, a 'fmt ' chunk counts wherever it stands (the reference walks
+    // every chunk, src/file/wav_file.cpp:80-162) ------------------------------------------------------------------------
+    {
+        auto u32 = [](uint32_t v) { return std::string({ (char)v, (char)(v >> 8), (char)(v >> 16), (char)(v >> 24) }); };
+        auto u16 = [](uint32_t v) { return std::string({ (char)v, (char)(v >> 8) }); };
+        const std::string fmt = std::string("fmt ") + u32(16) + u16(1) + u16(1) + u32(8000) + u32(16000) + u16(2) + u16(16);
+        const std::string first = std::string("data") + u32(8) + std::string("\x01\x00\x02\x00\x03\x00\x04\x00", 8);
+        const std::string junk = std::string("LIST") + u32(4) + "abcd";
+        const std::string second = std::string("data") + u32(6) + std::string("\x11\x00\x12\x00\x13\x00", 6);
+        const std::string body = std::string("WAVE") + fmt + first + junk + second;
+        writeBytes(dir + "/two.wav", std::string("RIFF") + u32((uint32_t)body.size()) + body);
+        std::ifstream in(dir + "/two.wav", std::ios::binary);
+        file::WavFile w;
+        w.readFromFile(in);
+        CHECK(w.numChannels == 1 && w.sampleRate == 8000);
+        CHECK(w.pcm.size() == 3 && w.pcm[0] == 0x11 && w.pcm[2] == 0x13);
+    }
+    // ---- positioned I/O on the pool: a file read ahead in pieces, written behind in pieces -----------------------------
+    {
+        std::string blob(5 * 1000 * 1000 + 123, '\0');
+        uint32_t x = 99;
+        for (char& c : blob)
+            c = (char)((x = x * 1664525u + 1013904223u) >> 24);
+        writeBytes(dir + "/blob.bin", blob);
+        try {
+            const sela_host::PosixFile in = sela_host::PosixFile::openForRead(dir + "/blob.bin");
+            CHECK(in.size() == blob.size());
+            std::vector<char> got(blob.size() - 100);
+            {
+                sela_host::ReadAhead ahead(in, got.data(), 100, got.size(), 1 << 20, 1 << 18);
+                ahead.need(10);
+                CHECK(std::memcmp(got.data(), blob.data() + 100, 10) == 0);
+                ahead.need(got.size());
+                ahead.finish();
+            }
+            CHECK(std::memcmp(got.data(), blob.data() + 100, got.size()) == 0);
+            {
+                const sela_host::PosixFile out = sela_host::PosixFile::create(dir + "/copy.bin");
+                out.writeAt("0123456", 7, 0);
+                sela_host::WriteBehind behind(out, 7, 1 << 18);
+                behind.drain(got.data(), 1000);
+                behind.drain(got.data(), 3000000);
+                behind.drain(got.data(), got.size());
+                behind.finish();
+                CHECK(out.size() == 7 + got.size());
+            }
+            std::ifstream back(dir + "/copy.bin", std::ios::binary);
+            std::string copy((std::istreambuf_iterator<char>(back)), std::istreambuf_iterator<char>());
+            CHECK(copy.size() == 7 + got.size() && copy.compare(0, 7, "0123456") == 0 && std::memcmp(copy.data() + 7, got.data(), got.size()) == 0);
+            // a file that ends before the range does
+            bool threw = false;
+            try {
+                std::vector<char> more(blob.size() + 4096);
+                sela_host::ReadAhead ahead(in, more.data(), 0, more.size(), 1 << 20, 1 << 18);
+                ahead.need(more.size());
+            } catch (const data::Exception&) {
+                threw = true;
+            }
+            CHECK(threw);
+        } catch (const data::Exception& e) {
+            std::fprintf(stderr, "FAIL exception: %s\n", e.exceptionMessage.c_str());
+            failures++;
+        }
     }
     // ---- .sela container: objects -> bytes -> objects ---------------------------------------------------
     {

@@ -97,11 +97,11 @@ uint32_t sela_hip_signals_per_frame(uint32_t channels);
 /* Bytes of device workspace the *_device calls need for a batch of n_frames.  The workspace needs no
  * initialisation and may be reused by later calls; one call at a time may use it. */
 size_t sela_hip_encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
-/* (The decoder keeps positions and samples on chip; the workspace is only written for frames that take the
- * kernel's generic mode -- Rice streams beyond what 16-bit audio produces, more than 8 channels.) */
+/* (The decoder keeps positions and samples on chip; the workspace is only written for subframes that take the
+ * kernels' generic mode -- Rice streams beyond what 16-bit audio produces.) */
 size_t sela_hip_decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
-/* Most channels the decoder takes (28: every channel of a frame has to be in LDS for the parent - difference
- * pass, src/frame/frame_decoder.cpp:40-69).  The .sela header allows 255; more than this is SELA_HIP_EINVAL. */
+/* Most channels the decoder takes: 255, what the 8-bit channel field of the .sela header can say (up to eight channels
+ * take one wave per subframe, more take the same waves in rounds; src/frame/frame_decoder.cpp:11-72). */
 uint32_t sela_hip_decode_max_channels(void);
 /* Upper bound of the frame byte stream produced by encoding n_frames (what `frames_cap` must be
  * to be certain never to get SELA_HIP_ECAPACITY). */
@@ -132,9 +132,10 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
 
 /* ---- host-pointer API (synchronous) -------------------------------------------------------------- */
 /* frames_out must hold sela_hip_encode_bound_bytes() or the call may return SELA_HIP_ECAPACITY.
- * Batches run as a pipeline of 1024-frame chunks on library-owned streams (copy in / kernels / copy out
- * overlapped, the kernels of consecutive chunks overlapped too); results are identical to one call on the
- * whole batch.  These are begin + feed(everything) + end of the streaming jobs below. */
+ * These are begin + feed(everything) + end of the streaming jobs below, on library-owned streams: an encode is ONE
+ * kernel launch per feed (it fetches the PCM from page-locked memory itself and stores the finished frames into
+ * frames_out), a decode a pipeline of 1024-frame chunks (copy in / kernel / copy out overlapped).  Results are
+ * identical to one device-pointer call on the whole batch. */
 int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel,
     uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out /* [n_frames+1] */);
 int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels,
@@ -145,8 +146,13 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
  * returns at once -- from page-locked buffers nothing in it waits for the device (an encode feed is one kernel
  * launch; a decode feed waits when one of its eight chunk buffer sets comes round again) -- so the caller's next
  * read runs beside the device work.  A piece's buffer must stay valid and unchanged until the job reports its
- * frames final (or ends); pieces in ordinary memory are copied to page-locked memory first.  One open job per
- * calling thread; a job is used from the thread that began it.
+ * frames final (or ends).  Encode pieces in ordinary (pageable) memory are copied to page-locked memory first; decode
+ * pieces and pcm_out in ordinary memory go through the runtime's own staging (the copies then block the caller: slower,
+ * same results).  One open job per calling thread; a job is used from the thread that began it.
+ * An encode feed normally has its PCM fetched by a staging kernel beside the encode launch.  If the device is so busy
+ * with other work that the two cannot run side by side within the launch's bounded wait (or another thread's job on
+ * this device is using that path), the feed -- and any queued behind it -- is issued again with the copy engine in
+ * place of the staging kernel: a busy device costs time, never the result.
  *
  * encode: the job appends to frames_out (capacity frames_cap) and fills frame_offsets_out[0 .. total_frames];
  * *frames_final / *bytes_final (optional) report how much of both is complete in host memory, so a writer can
@@ -175,21 +181,6 @@ uint32_t sela_hip_index_frames(const uint8_t* frames, size_t frames_bytes, uint3
  * in milliseconds; it returns the number of kernels reported (0 if timing was off). */
 void sela_hip_enable_kernel_timing(int enable);
 int sela_hip_kernel_times(float* ms_out, int capacity);
-
-/* Debug hook: while a non-NULL device buffer is set, the *_device calls of the calling thread run an
- * instrumented build of the kernels that stores s_memtime deltas per phase: 16 uint64 per
- * (frame, signal) for the encoder and per (frame, subframe) for the decoder.  Slower; never set
- * in the timed path. */
-void sela_hip_debug_phase_buffer(uint64_t* d_cycles);
-/* Debug hook: while set, every block of the calling thread's encodes computes its residues with the plain
- * 64-bit loop that predictors beyond the fast FIR's coefficient range take (never reached by 16-bit audio);
- * results are identical by construction, which is what the tests check. */
-void sela_hip_debug_force_plain_fir(int enable);
-/* Debug hook: the encoder hands the sequential mean of every block beyond the first `self_blocks` of a launch
- * to "mean worker" workgroups (normally self_blocks = what the device holds at once, so small batches never use
- * workers).  Setting a small value makes small test batches take the worker path; -1 restores the default.
- * Results are identical by construction, which is what the tests check. */
-void sela_hip_debug_mean_workers(int self_blocks);
 
 /* ---- flag bits reported through d_status[0] / sela_hip_trace.flags --------------------------------- */
 #define SELA_HIP_FLAG_Q_RANGE 1u       /* quantised reflection coefficient outside [-64,63] (clamped) */

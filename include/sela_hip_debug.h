@@ -1,0 +1,39 @@
+/*
+ * sela_hip_debug.h -- TEST HOOKS of libsela_hip.so.  NOT part of the drop-in boundary (include/sela_hip.h) and not
+ * stable: tests/ and tools/ use them to send the PRODUCT kernels down branches real audio never takes and to read
+ * instrumentation; nothing of host/ or of an integration calls them.  All are per calling thread.
+ */
+#ifndef SELA_HIP_DEBUG_H_
+#define SELA_HIP_DEBUG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Debug hook: while a non-NULL device buffer is set, the *_device calls of the calling thread run an
+ * instrumented build of the kernels that stores s_memtime deltas per phase: 16 uint64 per
+ * (frame, signal) for the encoder and per (frame, subframe) for the decoder.  Slower; never set
+ * in the timed path. */
+void sela_hip_debug_phase_buffer(uint64_t* d_cycles);
+/* Debug hook: while set, every block of the calling thread's encodes computes its residues with the plain
+ * 64-bit loop that predictors beyond the fast FIR's coefficient range take (never reached by 16-bit audio);
+ * results are identical by construction, which is what the tests check. */
+void sela_hip_debug_force_plain_fir(int enable);
+/* Debug hook: the encoder hands the sequential mean of every block beyond the first `self_blocks` of a launch
+ * to "mean worker" workgroups (normally self_blocks = what the device holds at once, so small batches never use
+ * workers).  Setting a small value makes small test batches take the worker path; -1 restores the default.
+ * Results are identical by construction, which is what the tests check. */
+void sela_hip_debug_mean_workers(int self_blocks);
+/* Debug hook: bound of an encode block's wait for its frame from the staging kernel, in naps of 2048 cycles (0: a
+ * block whose frame is not there when it first looks gives up at once, which flags the launch and sends the feed
+ * through the copy-engine path again); -1 restores the default (~0.5 s). */
+void sela_hip_debug_stage_wait(int naps);
+/* Debug hook: how many encode feeds of the calling thread were issued again through the copy-engine path so far. */
+int sela_hip_debug_reissued_feeds(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELA_HIP_DEBUG_H_ */

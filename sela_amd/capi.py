@@ -15,7 +15,7 @@ OK = 0
 ERRORS = {-1: "ENODEV", -2: "EINVAL", -3: "ENOMEM", -4: "ECAPACITY", -5: "EFORMAT", -6: "ERANGE"}
 SAMPLES_PER_FRAME = 2048
 
-FLAG_Q_RANGE, FLAG_COEF_OVERFLOW, FLAG_RICE_RANGE, FLAG_RICE_OVERRUN, FLAG_WORDS_CAP, FLAG_BAD_FRAME = 1, 2, 4, 8, 16, 32
+FLAG_Q_RANGE, FLAG_COEF_OVERFLOW, FLAG_RICE_RANGE, FLAG_RICE_OVERRUN, FLAG_WORDS_CAP, FLAG_BAD_FRAME, FLAG_INTERNAL = 1, 2, 4, 8, 16, 32, 64
 
 # every symbol include/sela_hip.h declares
 EXPORTS = [
@@ -23,10 +23,17 @@ EXPORTS = [
     "sela_hip_signals_per_frame", "sela_hip_encode_workspace_bytes", "sela_hip_decode_workspace_bytes",
     "sela_hip_encode_bound_bytes", "sela_hip_encode_device", "sela_hip_decode_device",
     "sela_hip_encode", "sela_hip_decode", "sela_hip_index_frames",
-    "sela_hip_enable_kernel_timing", "sela_hip_kernel_times", "sela_hip_debug_phase_buffer",
-    "sela_hip_host_alloc", "sela_hip_host_free", "sela_hip_decode_max_channels", "sela_hip_debug_force_plain_fir", "sela_hip_debug_mean_workers",
+    "sela_hip_enable_kernel_timing", "sela_hip_kernel_times",
+    "sela_hip_host_alloc", "sela_hip_host_free", "sela_hip_decode_max_channels",
     "sela_hip_encode_begin", "sela_hip_encode_feed", "sela_hip_encode_end",
     "sela_hip_decode_begin", "sela_hip_decode_feed", "sela_hip_decode_end",
+]
+
+
+# the test hooks include/sela_hip_debug.h declares (not part of the boundary)
+DEBUG_EXPORTS = [
+    "sela_hip_debug_phase_buffer", "sela_hip_debug_force_plain_fir", "sela_hip_debug_mean_workers", "sela_hip_debug_stage_wait",
+    "sela_hip_debug_reissued_feeds",
 ]
 
 
@@ -100,6 +107,10 @@ def lib() -> C.CDLL:
     L.sela_hip_debug_force_plain_fir.restype = None
     L.sela_hip_debug_mean_workers.argtypes = [C.c_int]
     L.sela_hip_debug_mean_workers.restype = None
+    L.sela_hip_debug_stage_wait.argtypes = [C.c_int]
+    L.sela_hip_debug_stage_wait.restype = None
+    L.sela_hip_debug_reissued_feeds.argtypes = []
+    L.sela_hip_debug_reissued_feeds.restype = C.c_int
     L.sela_hip_host_alloc.argtypes = [sz]
     L.sela_hip_host_alloc.restype = C.c_void_p
     L.sela_hip_host_free.argtypes = [C.c_void_p]

@@ -60,18 +60,21 @@ class Encoder:
             self.trace = (torch.zeros(max_frames * self.n_sig * C.sizeof(capi.Trace), dtype=torch.uint8, device=self.device)
                           if with_trace else None)
 
-    def encode(self, pcm) -> EncodedFrames:
-        """pcm: int16 cuda tensor [n_frames, 2048, channels] (contiguous).  Asynchronous on the current stream."""
+    def encode(self, pcm, status=None) -> EncodedFrames:
+        """pcm: int16 cuda tensor [n_frames, 2048, channels] (contiguous).  Asynchronous on the current stream.
+        status: where this call leaves its four status words (int32 cuda tensor [4]); default: the encoder's own."""
         torch = self.torch
+        status = self.status if status is None else status
+        assert status.dtype == torch.int32 and status.numel() == 4 and status.is_cuda and status.is_contiguous()
         assert pcm.dtype == torch.int16 and pcm.is_cuda and pcm.is_contiguous()
         n_frames = pcm.shape[0]
         assert pcm.shape[1] == BLOCK and pcm.shape[2] == self.channels and n_frames <= self.max_frames
         stream = torch.cuda.current_stream(self.device).cuda_stream
         capi.check(self.lib.sela_hip_encode_device(
             pcm.data_ptr(), n_frames, self.channels, self.frames.data_ptr(), self.capacity, self.offsets.data_ptr(),
-            self.status.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            status.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
             self.trace.data_ptr() if self.trace is not None else None, stream))
-        return EncodedFrames(self.frames, self.offsets[: n_frames + 1], self.status, n_frames, self.channels)
+        return EncodedFrames(self.frames, self.offsets[: n_frames + 1], status, n_frames, self.channels)
 
     def traces(self, n_frames: int):
         raw = self.trace[: n_frames * self.n_sig * C.sizeof(capi.Trace)].cpu().numpy().tobytes()
@@ -92,13 +95,16 @@ class Decoder:
             ws = int(self.lib.sela_hip_decode_workspace_bytes(max_frames, channels))
             self.workspace = torch.empty(ws, dtype=torch.uint8, device=self.device)
 
-    def decode(self, frames, offsets, n_frames: int):
-        """frames: uint8 cuda tensor, offsets: int64 cuda tensor [n_frames+1].  Asynchronous."""
+    def decode(self, frames, offsets, n_frames: int, status=None):
+        """frames: uint8 cuda tensor, offsets: int64 cuda tensor [n_frames+1].  Asynchronous.
+        status: where this call leaves its status words (int32 cuda tensor [4]); default: the decoder's own."""
         torch = self.torch
+        status = self.status if status is None else status
+        assert status.dtype == torch.int32 and status.numel() == 4 and status.is_cuda and status.is_contiguous()
         assert frames.is_cuda and offsets.is_cuda and offsets.dtype == torch.int64 and n_frames <= self.max_frames
         stream = torch.cuda.current_stream(self.device).cuda_stream
         capi.check(self.lib.sela_hip_decode_device(
-            frames.data_ptr(), offsets.data_ptr(), n_frames, self.channels, self.pcm.data_ptr(), self.status.data_ptr(),
+            frames.data_ptr(), offsets.data_ptr(), n_frames, self.channels, self.pcm.data_ptr(), status.data_ptr(),
             self.workspace.data_ptr(), self.workspace.numel(), stream))
         return self.pcm[:n_frames]
 

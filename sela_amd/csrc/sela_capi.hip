@@ -169,7 +169,7 @@ struct HostBuffer {
 // between streams (a chunk of this size leaves the device in its launch tail for a good part of its run time, so
 // neighbours overlap); a chunk is copied out as soon as its kernels have finished.  Nothing in the issue path
 // waits for the device until a buffer set comes round again.
-constexpr uint32_t kHostChunkFrames = 1024; // (buffers are sized for this; chunk_frames() may cut chunks shorter)
+constexpr uint32_t kHostChunkFrames = 1024; // (for up to eight channels, see chunk_frames())
 constexpr uint32_t kSets = 8;
 constexpr uint32_t kRunStreams = 2;
 
@@ -285,44 +285,49 @@ thread_local KernelTiming g_timing;
 thread_local uint64_t* g_phase_cycles = nullptr; // debug: per-block phase cycle counts (sela_hip_debug_phase_buffer)
 thread_local int g_force_plain_fir = 0;          // debug: sela_hip_debug_force_plain_fir
 thread_local int g_self_blocks = -1;             // debug: sela_hip_debug_mean_workers
+thread_local int g_stage_wait_naps = -1;         // debug: sela_hip_debug_stage_wait
+thread_local int g_reissued_feeds = 0;           // debug: sela_hip_debug_reissued_feeds
 
-uint32_t env_u32(const char* name, uint32_t lo, uint32_t hi, uint32_t fallback)
+// The staging kernel asks for whole CUs and the blocks that wait for it never leave theirs: two jobs staging on one
+// device at once (two host threads on one GPU) can keep each other's stagers off the device until the bounded waits run
+// out.  So one job per device stages at a time; a job that finds the path taken uses the copy engine instead.
+std::mutex g_staged_mu;
+bool g_staged_busy[64] = {};
+bool staged_path_acquire(int device)
 {
-    const char* e = std::getenv(name);
-    const long n = e ? std::atol(e) : -1;
-    return (n >= (long)lo && n <= (long)hi) ? (uint32_t)n : fallback;
+    if (device < 0 || device >= 64)
+        return false;
+    std::lock_guard<std::mutex> lock(g_staged_mu);
+    if (g_staged_busy[device])
+        return false;
+    g_staged_busy[device] = true;
+    return true;
 }
-// Pipeline shape; the environment variables are for experiments.
-uint32_t chunk_frames()
+void staged_path_release(int device)
 {
-    static const uint32_t v = env_u32("SELA_HOST_CHUNK_FRAMES", 8, kHostChunkFrames, kHostChunkFrames);
-    return v;
+    if (device < 0 || device >= 64)
+        return;
+    std::lock_guard<std::mutex> lock(g_staged_mu);
+    g_staged_busy[device] = false;
+}
+
+// Frames per decode chunk: kHostChunkFrames for up to eight channels; beyond that a chunk keeps about the bytes of
+// 1024 eight-channel frames (a 255-channel frame is 1 MB of PCM: chunks are sized by what they move, and the chunk
+// buffers -- PCM and the generic-mode workspace of every set -- by the chunk).
+uint32_t chunk_frames(uint32_t channels)
+{
+    return channels <= 8 ? kHostChunkFrames : std::max(16u, kHostChunkFrames * 8 / channels);
 }
 // Size of chunk number `index` of a decode job that has `available` frames at hand.  It opens with two shorter
 // chunks: its copy-outs run back to back from the moment the first chunk is done, so the job is as long as the way
 // to that moment plus the bare copy of the PCM -- provided every later chunk is decoded by the time the copy-out
 // before it ends, which is what keeps the first chunks from being shorter still.
-// SELA_HOST_CHUNK_PLAN="a,b,c" sets the sizes of the first chunks of every job (experiments).
-uint32_t next_chunk_frames(uint32_t index, uint32_t available)
+uint32_t next_chunk_frames(uint32_t index, uint32_t available, uint32_t channels)
 {
-    static const std::vector<uint32_t> plan = [] {
-        std::vector<uint32_t> v;
-        if (const char* e = std::getenv("SELA_HOST_CHUNK_PLAN"))
-            for (const char* p = e; *p;) {
-                char* end = nullptr;
-                const long n = std::strtol(p, &end, 10);
-                if (end == p)
-                    break;
-                v.push_back((uint32_t)std::min<long>(std::max<long>(n, 8), kHostChunkFrames));
-                p = *end ? end + 1 : end;
-            }
-        return v;
-    }();
-    uint32_t want = chunk_frames();
-    if (index < plan.size())
-        want = plan[index];
-    else if (plan.empty() && index < 2)
-        want = std::min<uint32_t>(want, index ? 640u : 384u);
+    const uint32_t full = chunk_frames(channels);
+    uint32_t want = full;
+    if (index < 2)
+        want = std::min<uint32_t>(want, std::max(8u, (index ? 640u : 384u) * full / kHostChunkFrames));
     if (want < available && available - want < want / 4) // (no stub of a last chunk: split what is left in two)
         want = (available + 1) / 2;
     return want < available ? want : available;
@@ -341,6 +346,9 @@ struct EncodeFeed {      // one feed of an encode job = one launch
     size_t mirror_at = 0;        // where the launch reports (offsets, status) in g_ctx.enc_mirror
     hipEvent_t done = nullptr;   // recorded behind the launch
     void* bounce_in = nullptr;   // page-locked copy of a feed that came from ordinary memory
+    const int16_t* host_src = nullptr;   // the feed's PCM in page-locked host memory, as the host sees it ...
+    const int16_t* mapped_src = nullptr; // ... and as the device sees it
+    bool reissued = false;       // went through the copy-engine path a second time (see job_reissue_encode)
 };
 
 struct sela_hip_job {
@@ -363,6 +371,8 @@ struct sela_hip_job {
     bool out_bounce = false;
     std::vector<EncodeFeed> feeds;
     size_t mirror_used = 0;
+    bool staged = false;      // this job's feeds have their PCM fetched by the staging kernel (one such job per device at a time)
+    bool holds_staged_path = false; // (taken at begin, given back at end -- also by a job that fell back to the copy engine on the way)
     uint32_t feeds_final = 0; // feeds whose launch has finished: their bytes and offsets are complete in host memory
     uint32_t frames_final = 0;
     uint64_t bytes_final = 0, bytes_copied = 0; // (bytes_copied: bounce buffer -> frames_out)
@@ -394,10 +404,11 @@ int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
 hipError_t reserve_chunk_buffers(uint32_t channels)
 {
     const size_t frame_pcm = (size_t)sela::kBlock * channels * sizeof(int16_t);
+    const uint32_t frames = chunk_frames(channels);
     for (ChunkSet& c : g_ctx.set) {
         hipError_t e;
-        if ((e = c.pcm.reserve(kHostChunkFrames * frame_pcm + 16)) != hipSuccess
-            || (e = c.workspace.reserve(sela::decode_workspace_bytes(kHostChunkFrames, channels))) != hipSuccess)
+        if ((e = c.pcm.reserve(frames * frame_pcm + 16)) != hipSuccess
+            || (e = c.workspace.reserve(sela::decode_workspace_bytes(frames, channels))) != hipSuccess)
             return e;
     }
     return hipSuccess;
@@ -423,17 +434,48 @@ void* device_view(const void* host)
 // per feed and an event behind it; a feed's bytes and offsets are final when its event has fired.  Feeds run one
 // after the other on one stream; the job's stream position passes from launch to launch in device memory
 // (enc_words).  Buffers that are not page-locked go through page-locked bounce buffers.
-constexpr uint32_t kStageWorkgroups = 8;         // of k_stage_in, four waves each with eight 16-byte loads in flight per lane
-uint32_t stage_workgroups() // SELA_HOST_STAGE_WGS=n overrides (experiments)
-{
-    static const uint32_t n = [] {
-        const char* e = std::getenv("SELA_HOST_STAGE_WGS");
-        const int v = e ? std::atoi(e) : 0;
-        return v >= 1 && v <= 64 ? (uint32_t)v : kStageWorkgroups;
-    }();
-    return n;
-}
+constexpr uint32_t kStageWorkgroups = 8;         // of k_stage_in, four waves each with eight 16-byte loads in flight per lane (6: 0.95 ms, 16: 0.90, 24: 0.99)
 constexpr uint32_t kEncodeLaunchFrames = 1u << 16; // a feed larger than this is cut (device buffers are sized for it)
+
+// Enqueue the launch of feed number `index` (its PCM in page-locked memory, its place in the mirror and its event are
+// in `feed`).  staged: the PCM is fetched by the staging kernel beside the launch; otherwise by the copy engine in
+// front of it.
+hipError_t issue_encode_feed(sela_hip_job* job, EncodeFeed& feed, size_t index, bool staged)
+{
+    const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
+    const hipStream_t s = g_ctx.s_run[0];
+    hipError_t e;
+    sela::EncodeHostLink link;
+    link.mirror = g_ctx.enc_mirror_mapped + feed.mirror_at;
+    // (two cells in turn: a launch reads where the one before left the stream and leaves its own end in the other)
+    uint64_t* const pos = static_cast<uint64_t*>(g_ctx.enc_words.ptr);
+    link.pos_in = pos + (index & 1);
+    link.pos_out = pos + ((index + 1) & 1);
+    link.host_pcm = feed.mapped_src;
+    link.pcm_ready = static_cast<uint64_t*>(g_ctx.enc_ready.ptr);
+    link.stage_workgroups = kStageWorkgroups;
+    link.stage_stream = g_ctx.s_in;
+    link.stage_started = pos + 4;
+    link.wait_naps = g_stage_wait_naps;
+    // what fills the device's copy of the PCM waits for the launch before this one, which reads it (and for the
+    // allocation that may just have cleared the marks)
+    if ((e = hipEventRecord(g_ctx.enc_prev, s)) != hipSuccess || (e = hipStreamWaitEvent(g_ctx.s_in, g_ctx.enc_prev, 0)) != hipSuccess)
+        return e;
+    if (!staged) { // (the stagers copy stereo frames; anything else goes in by the copy engine, ahead of the launch)
+        if ((e = hipMemcpyAsync(g_ctx.enc_pcm.ptr, feed.host_src, feed.n_frames * frame_pcm, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
+            || (e = hipEventRecord(g_ctx.enc_prev, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s, g_ctx.enc_prev, 0)) != hipSuccess)
+            return e;
+        link.host_pcm = nullptr;
+    }
+    uint32_t* d_status = reinterpret_cast<uint32_t*>(pos + 2);
+    e = sela::launch_encode(static_cast<const int16_t*>(g_ctx.enc_pcm.ptr), feed.n_frames, job->channels, job->out_mapped, job->frames_cap, nullptr, d_status,
+        g_ctx.enc_workspace.ptr, nullptr, s, nullptr, nullptr, &link, g_force_plain_fir, g_self_blocks);
+    if (e == hipSuccess && !feed.done)
+        e = hipEventCreateWithFlags(&feed.done, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipEventRecord(feed.done, s);
+    return e;
+}
 
 int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
 {
@@ -444,13 +486,15 @@ int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
     feed.first = job->fed;
     feed.n_frames = nf;
     feed.mirror_at = job->mirror_used;
-    const void* src = device_view(pcm);
-    if (!src) { // ordinary memory: through a page-locked copy (kept until the job ends)
+    feed.host_src = pcm;
+    feed.mapped_src = static_cast<const int16_t*>(device_view(pcm));
+    if (!feed.mapped_src) { // ordinary memory: through a page-locked copy (kept until the job ends)
         feed.bounce_in = pool().take(nf * frame_pcm);
         if (!feed.bounce_in)
             return job_fail(job, fail(SELA_HIP_ENOMEM, "page-locked bounce buffer"));
         std::memcpy(feed.bounce_in, pcm, nf * frame_pcm);
-        if (!(src = device_view(feed.bounce_in))) {
+        feed.host_src = static_cast<const int16_t*>(feed.bounce_in);
+        if (!(feed.mapped_src = static_cast<const int16_t*>(device_view(feed.bounce_in)))) {
             pool().give(feed.bounce_in);
             return job_fail(job, fail(SELA_HIP_ENODEV, "page-locked memory is not visible to the device"));
         }
@@ -467,38 +511,7 @@ int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
             return job_fail(job, fail_hip(e, "hipMalloc"));
         }
     }
-    sela::EncodeHostLink link;
-    link.mirror = g_ctx.enc_mirror_mapped + feed.mirror_at;
-    // (two cells in turn: a launch reads where the one before left the stream and leaves its own end in the other)
-    uint64_t* const pos = static_cast<uint64_t*>(g_ctx.enc_words.ptr);
-    link.pos_in = pos + (job->feeds.size() & 1);
-    link.pos_out = pos + ((job->feeds.size() + 1) & 1);
-    link.host_pcm = static_cast<const int16_t*>(src);
-    link.pcm_ready = static_cast<uint64_t*>(g_ctx.enc_ready.ptr);
-    link.stage_workgroups = stage_workgroups();
-    link.stage_stream = g_ctx.s_in;
-    link.stage_started = pos + 4;
-    // what fills the device's copy of the PCM waits for the launch before this one, which reads it (and for the
-    // allocation that may just have cleared the marks)
-    if ((e = hipEventRecord(g_ctx.enc_prev, s)) != hipSuccess || (e = hipStreamWaitEvent(g_ctx.s_in, g_ctx.enc_prev, 0)) != hipSuccess) {
-        if (feed.bounce_in)
-            pool().give(feed.bounce_in);
-        return job_fail(job, fail_hip(e, "hipStreamWaitEvent"));
-    }
-    if (job->channels != 2) { // (the stagers copy stereo frames; anything else goes in by the copy engine, ahead of the launch)
-        if ((e = hipMemcpyAsync(g_ctx.enc_pcm.ptr, feed.bounce_in ? feed.bounce_in : pcm, nf * frame_pcm, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
-            || (e = hipEventRecord(g_ctx.enc_prev, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s, g_ctx.enc_prev, 0)) != hipSuccess) {
-            if (feed.bounce_in)
-                pool().give(feed.bounce_in);
-            return job_fail(job, fail_hip(e, "H2D pcm"));
-        }
-        link.host_pcm = nullptr;
-    }
-    uint32_t* d_status = reinterpret_cast<uint32_t*>(pos + 2);
-    e = sela::launch_encode(static_cast<const int16_t*>(g_ctx.enc_pcm.ptr), nf, job->channels, job->out_mapped, job->frames_cap, nullptr, d_status,
-        g_ctx.enc_workspace.ptr, nullptr, s, nullptr, nullptr, &link, g_force_plain_fir, g_self_blocks);
-    if (e == hipSuccess && (e = hipEventCreateWithFlags(&feed.done, hipEventDisableTiming)) == hipSuccess)
-        e = hipEventRecord(feed.done, s);
+    e = issue_encode_feed(job, feed, job->feeds.size(), job->staged && job->channels == 2);
     if (e != hipSuccess) {
         if (feed.bounce_in)
             pool().give(feed.bounce_in);
@@ -509,6 +522,30 @@ int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
     job->mirror_used += (size_t)nf + 2;
     job->fed += nf;
     job->feeds.push_back(feed);
+    return SELA_HIP_OK;
+}
+
+// A launch whose bounded wait for the staging kernel ran out (SELA_HIP_FLAG_INTERNAL: the device was kept so busy by
+// other work that the stagers got no compute units in time) has coded frames that were not there: its bytes, its
+// sizes -- and with them the stream position every later feed started from -- are void.  Feed `from` and everything
+// queued behind it are issued again, PCM by the copy engine this time (nothing waits for a kernel beside it there).
+// A busy device costs time, never the result; only a feed that fails this way too is an error.
+int job_reissue_encode(sela_hip_job* job, size_t from)
+{
+    hipError_t e;
+    g_ctx.sync_all(); // (nothing of the void launches is left running)
+    job->staged = false;
+    uint64_t* const pos = static_cast<uint64_t*>(g_ctx.enc_words.ptr);
+    const uint64_t start = job->bytes_final; // the stream behind the last good feed
+    if ((e = hipMemcpyAsync(pos + (from & 1), &start, 8, hipMemcpyHostToDevice, g_ctx.s_run[0])) != hipSuccess
+        || (e = hipStreamSynchronize(g_ctx.s_run[0])) != hipSuccess) // (`start` is a local)
+        return job_fail(job, fail_hip(e, "encode re-issue"));
+    for (size_t k = from; k < job->feeds.size(); k++) {
+        job->feeds[k].reissued = true;
+        g_reissued_feeds++;
+        if ((e = issue_encode_feed(job, job->feeds[k], k, false)) != hipSuccess)
+            return job_fail(job, fail_hip(e, "encode re-issue"));
+    }
     return SELA_HIP_OK;
 }
 
@@ -544,8 +581,14 @@ int job_encode_progress(sela_hip_job* job, bool wait)
         const uint64_t* m = mirror + f.mirror_at;
         const uint64_t st = m[f.n_frames + 1];
         const uint32_t flags = (uint32_t)st, overflow = (uint32_t)(st >> 32);
-        if (flags & SELA_HIP_FLAG_INTERNAL)
-            return job_fail(job, fail(SELA_HIP_ENODEV, "a wait inside the encode kernel ran out (internal error)"));
+        if (flags & SELA_HIP_FLAG_INTERNAL) {
+            if (f.reissued)
+                return job_fail(job, fail(SELA_HIP_ENODEV, "a wait inside the encode kernel ran out (internal error)"));
+            const int rc = job_reissue_encode(job, job->feeds_final);
+            if (rc != SELA_HIP_OK)
+                return rc;
+            continue; // (this feed again, now behind its new event)
+        }
         if (flags_to_error(flags)) {
             char msg[160];
             std::snprintf(msg, sizeof msg, "a block left the range the .sela format can carry (flags 0x%x)", flags);
@@ -633,7 +676,7 @@ int job_feed_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* of
     std::memcpy(staged, offsets, ((size_t)n_frames + 1) * 8);
     job->offsets_used += (size_t)n_frames + 1;
     for (uint32_t done = 0; done < n_frames;) {
-        const uint32_t nf = next_chunk_frames(job->issued, n_frames - done);
+        const uint32_t nf = next_chunk_frames(job->issued, n_frames - done, job->channels);
         const int rc = job_issue_decode(job, frames, offsets + done, mapped + done, nf);
         if (rc != SELA_HIP_OK)
             return rc;
@@ -710,6 +753,7 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
     job->encode = encode;
     job->channels = channels;
     job->total_frames = total_frames;
+    job->staged = job->holds_staged_path = encode && channels == 2 && staged_path_acquire(g_ctx.device);
     g_ctx.job_open = true;
     *out = job;
     return SELA_HIP_OK;
@@ -750,6 +794,8 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
     }
     job_progress(job, frames_final, bytes_final);
     g_ctx.job_open = false;
+    if (job->holds_staged_path)
+        staged_path_release(g_ctx.device);
     delete job;
     if (rc != SELA_HIP_OK)
         return rc;
@@ -811,6 +857,10 @@ void sela_hip_debug_phase_buffer(uint64_t* d_cycles) { g_phase_cycles = d_cycles
 void sela_hip_debug_force_plain_fir(int enable) { g_force_plain_fir = enable != 0; }
 
 void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks; }
+
+void sela_hip_debug_stage_wait(int naps) { g_stage_wait_naps = naps; }
+
+int sela_hip_debug_reissued_feeds(void) { return g_reissued_feeds; }
 
 void sela_hip_enable_kernel_timing(int enable) { g_timing.enabled = enable != 0; }
 

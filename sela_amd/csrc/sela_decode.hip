@@ -45,16 +45,16 @@
 // both streams are zones of ONE bit space, the subframe's aligned words.  tools/parse_model.py is an
 // executable model of this algorithm; tests/test_host_logic.py runs it against the CPU oracle.
 //
-// A frame whose subframes do not fit the LDS plan (a Rice stream longer than any 16-bit audio produces,
-// or more than 8 channels) takes the GENERIC mode of the same kernel: a plain serial parse into the
-// workspace, then the same synthesis.  Slow, complete, and never needed by files the encoder writes
-// for 1..8 channels.
+// A frame with a subframe that does not fit the LDS plan (a Rice stream longer than any 16-bit audio produces)
+// takes the GENERIC mode of the same kernel: a plain serial parse into the workspace, then the same synthesis.
+// Slow, complete, and never needed by files the encoder writes.  Frames of more than 8 channels (up to the 255 the
+// header's field carries) are decoded by k_decode_frames_wide, eight subframes at a time.
 #include "sela_device.h"
 
 namespace sela {
 
-constexpr int kDecMaxWaves = 8;     // waves per workgroup; frames with more channels loop (generic mode)
-constexpr int kDecMaxChannels = 28; // one DecSubframeLds per channel + eight wave scratch records within 160 KB
+constexpr int kDecMaxWaves = 8;     // waves per workgroup; frames with more channels take k_decode_frames_wide
+constexpr int kDecMaxChannels = 255; // what the 8-bit channel field of the .sela header can say (src/file/sela_file.cpp:40)
 constexpr int kCoefLanes = 4;       // lanes of a wave that parse the coefficient stream
 constexpr int kResLanes = kWave - kCoefLanes;
 // Aligned words of one subframe the segment-parallel parser takes: coefficient words + 2 + residue words
@@ -916,6 +916,178 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
     }
 }
 
+
+// ---- more than eight channels: k_decode_frames_wide ---------------------------------------------------------------
+// frame::FrameDecoder::process takes any channel count the header's 8-bit field carries (src/frame/frame_decoder.cpp:
+// 11-72).  k_decode_frames keeps every channel of a frame in LDS until the parent - difference pass, which bounds it
+// (one wave and one 4.5 KB record per channel).  Here the eight waves of a workgroup take the frame's subframes in
+// rounds, each wave with a record of its own: a subframe goes from the frame bytes to finished samples exactly as above
+// (the segment-parallel parse when it fits the plan, the serial parse into the workspace otherwise -- decided per
+// SUBFRAME: no other wave depends on this one's record) and leaves its raw samples in the output, strided.  The second
+// pass (src/frame/frame_decoder.cpp:40-69) then runs over the output: a difference-coded channel becomes parent -
+// difference, where the parent's samples are the raw ones an independent subframe left there.  The reference's encoder
+// writes difference subframes for exactly-stereo input only (src/frame/frame_encoder.cpp:18), so for these frames the
+// pass has nothing to do -- but files are input, not promises.
+struct HeaderCursor {
+    uint32_t index; // subframe the cursor stands in front of
+    uint64_t p;     // its byte offset in the frame
+    bool ok;
+};
+
+__device__ inline SubHeader walk_on(const uint8_t* fb, uint64_t fbytes, HeaderCursor& cur, uint32_t c, uint32_t channels)
+{
+    SubHeader h;
+    h.ok = cur.ok;
+    h.channel = h.type = h.parent = h.ck = h.cw = h.order = h.rk = h.rw = 0;
+    uint32_t n = 0;
+    uint64_t p = cur.p;
+    while (h.ok && cur.index <= c) { // over the headers up to and including subframe c
+        p = cur.p;
+        if (p + 12 > fbytes) {
+            h.ok = false;
+            break;
+        }
+        const uint32_t h0 = *reinterpret_cast<const uint32_t*>(fb + p);
+        const uint32_t h1 = *reinterpret_cast<const uint32_t*>(fb + p + 4);
+        h.channel = h0 & 0xFF, h.type = (h0 >> 8) & 0xFF, h.parent = (h0 >> 16) & 0xFF, h.ck = h0 >> 24;
+        h.cw = h1 & 0xFFFF, h.order = (h1 >> 16) & 0xFF;
+        const uint64_t p2 = p + 4 + 4 * (uint64_t)h.cw;
+        if (p2 + 8 > fbytes) {
+            h.ok = false;
+            break;
+        }
+        const uint32_t h2 = *reinterpret_cast<const uint32_t*>(fb + p2);
+        const uint32_t h3 = *reinterpret_cast<const uint32_t*>(fb + p2 + 4);
+        h.rk = h2 >> 24, h.rw = h3 & 0xFFFF, n = h3 >> 16;
+        const uint64_t next = p + 12 + 4 * ((uint64_t)h.cw + h.rw);
+        if (next > fbytes) {
+            h.ok = false;
+            break;
+        }
+        cur.p = next;
+        cur.index++;
+    }
+    cur.ok = h.ok; // (a frame is walked front to back: behind a broken header there is nothing to find)
+    h.ok = h.ok && h.channel < channels && h.order <= (uint32_t)kMaxOrder && n == (uint32_t)kBlock && h.ck < 32 && h.rk < 32 && h.type <= 1
+        && (h.type == 0 || h.parent < channels);
+    h.p = (uint32_t)p;
+    return h;
+}
+
+constexpr uint32_t kNoSubframe = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames_wide(const uint8_t* __restrict__ frames,
+    const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* __restrict__ pcm_out,
+    uint32_t* __restrict__ status, int32_t* __restrict__ ws_residues, uint8_t* __restrict__ frame_flags)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
+    DecSubframeLds* const sl = reinterpret_cast<DecSubframeLds*>(dyn) + wave;
+    DecWaveScratch* const scratch = reinterpret_cast<DecWaveScratch*>(dyn + (size_t)kDecMaxWaves * sizeof(DecSubframeLds)) + wave;
+    uint32_t* const sub_info = reinterpret_cast<uint32_t*>(dyn + (size_t)kDecMaxWaves * (sizeof(DecSubframeLds) + sizeof(DecWaveScratch)));
+    const uint32_t f = blockIdx.x;
+    if (f >= n_frames)
+        return;
+    const uint8_t* const fb = frames + frame_offsets[f];
+    const uint64_t fbytes = frame_offsets[f + 1] - frame_offsets[f];
+    uint32_t flags = 0;
+    for (uint32_t c = threadIdx.x; c < channels; c += blockDim.x)
+        sub_info[c] = kNoSubframe; // "no subframe delivered this channel"
+    __syncthreads();
+    HeaderCursor cur;
+    cur.index = 0;
+    cur.p = 4;
+    cur.ok = fbytes >= 4 && fbytes < 0x7FFFFFFFull && (fbytes & 3) == 0 && reinterpret_cast<const uint32_t*>(fb)[0] == SELA_SYNC_WORD;
+    int16_t* const out_frame = pcm_out + (size_t)f * kBlock * channels;
+    for (uint32_t c = wave; c < channels; c += kDecMaxWaves) {
+        const SubHeader hd = walk_on(fb, fbytes, cur, c, channels);
+        if (!hd.ok) {
+            flags |= SELA_HIP_FLAG_BAD_FRAME;
+            continue;
+        }
+        const uint32_t nw = hd.cw + 2 + hd.rw;
+        const uint32_t* const gw = reinterpret_cast<const uint32_t*>(fb + hd.p + 4); // the subframe's aligned words
+        const int32_t* ws_c = nullptr;
+        ParseProfile pp;
+        if (nw <= (uint32_t)kStreamCap) { // (hd.order <= 100 <= 2 waves' worth: checked by walk_on)
+            for (uint32_t w = lane; w < nw + kStreamMargin; w += kWave) // the start bitmap
+                sl->marks[w] = 0;
+            wave_sync();
+            const StreamWords sw = { gw, nw };
+            flags |= parse_subframe<false>(sw, sl->marks, sl->pos, reinterpret_cast<uint16_t*>(&scratch->t), coef_values(scratch), hd.cw, hd.rw, hd.ck, hd.rk,
+                hd.order, lane, pp);
+        } else {
+            int32_t* const wres = ws_residues + ((size_t)f * channels + c) * kBlock;
+            const uint32_t n_frame_words = (uint32_t)((fbytes - hd.p - 4) / 4);
+            flags |= parse_stream_serial(gw, 24, 24 + 32 * hd.cw, n_frame_words, hd.ck, hd.order, coef_values(scratch), lane);
+            flags |= parse_stream_serial(gw, 32 * (hd.cw + 2), 32 * (hd.cw + 2 + hd.rw), n_frame_words, hd.rk, (uint32_t)kBlock, wres, lane);
+            __threadfence(); // lane 0's stores to the workspace are read back by every lane
+            ws_c = wres;
+        }
+        SynthTables* const tables = &scratch->t;
+        const uint32_t order = hd.order;
+        const int32_t q_lo = (uint32_t)lane < order ? coef_values(scratch)[lane] : 0, q_hi = (uint32_t)lane + 64 < order ? coef_values(scratch)[lane + 64] : 0;
+        wave_sync();
+        if ((uint32_t)lane < order)
+            tables->k[lane] = order <= 1 ? 0.0 : dequant(lane, q_lo, flags);
+        if ((uint32_t)lane + 64 < order)
+            tables->k[lane + 64] = dequant(lane + 64, q_hi, flags);
+        wave_sync();
+        step_up(tables->k, tables->a, (int)order, lane, flags);
+        const bool fits24 = build_synth_table(tables->a, tables->tab, (int)order, lane);
+        if (order <= 48)
+            synthesize<1, 16>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
+        else if (order <= 60)
+            synthesize<1, 4>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
+        else
+            synthesize<2, 16>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
+        // the raw samples of this subframe, where its channel lies in the output (mod 2^16: src/file/wav_file.cpp:248-251)
+        for (int i = lane; i < kBlock; i += kWave)
+            out_frame[(size_t)i * channels + hd.channel] = sl->smp[i];
+        wave_sync(); // (the record is reused by this wave's next subframe)
+        if (lane == 0)
+            sub_info[hd.channel] = hd.type | (hd.parent << 8);
+    }
+    // ---- second pass of frame::FrameDecoder, over the output -----------------------------------------------------------
+    // Writers and readers are waves of ONE workgroup, i.e. of one CU behind one L2: the stores only have to have left the
+    // CU (the wait is written out -- a fence's own wait is dropped when the compiler believes nothing is outstanding,
+    // MI355X_MICROARCH.md "inter-workgroup visibility"), and nothing older may be served from its vector cache.  (A release
+    // fence at agent scope would write back the whole L2 for nothing.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (uint32_t c = 0; c < channels; c++) {
+        const uint32_t info = sub_info[c]; // (wave-uniform)
+        if (info == kNoSubframe) { // a channel that no valid subframe delivered decodes to silence
+            for (uint32_t i = threadIdx.x; i < (uint32_t)kBlock; i += blockDim.x)
+                out_frame[(size_t)i * channels + c] = 0;
+            if (threadIdx.x == 0)
+                flags |= SELA_HIP_FLAG_BAD_FRAME;
+        } else if ((info & 0xFF) == 1) {
+            const uint32_t parent = (info >> 8) & 0xFF;
+            const uint32_t pinfo = sub_info[parent];
+            // (a parent that is itself difference-coded is outside what the reference defines: flagged, and its raw samples taken)
+            if (threadIdx.x == 0 && (pinfo == kNoSubframe || (pinfo & 0xFF) != 0))
+                flags |= SELA_HIP_FLAG_BAD_FRAME;
+            for (uint32_t i = threadIdx.x; i < (uint32_t)kBlock; i += blockDim.x) {
+                const uint32_t pv = pinfo == kNoSubframe ? 0u : (uint32_t)(uint16_t)out_frame[(size_t)i * channels + parent];
+                const uint32_t dv = (uint32_t)(uint16_t)out_frame[(size_t)i * channels + c];
+                out_frame[(size_t)i * channels + c] = (int16_t)(uint16_t)(pv - dv);
+            }
+        }
+    }
+    flags = wave_or(flags);
+    if (lane == 0 && flags) {
+        if (frame_flags)
+            frame_flags[(size_t)f * kDecMaxWaves + wave] = (uint8_t)flags;
+        else {
+            atomicOr(&status[0], flags);
+            if (wave == 0 && (flags & SELA_HIP_FLAG_BAD_FRAME))
+                atomicAdd(&status[1], 1u);
+        }
+    }
+}
+
 int decode_waves(uint32_t channels)
 {
     return channels < (uint32_t)kDecMaxWaves ? (int)channels : kDecMaxWaves;
@@ -939,9 +1111,22 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
     if (err != hipSuccess || n_frames == 0)
         return err;
     const int n_waves = decode_waves(channels);
-    const size_t need = decode_lds_bytes(channels);
-    if (channels > (uint32_t)kDecMaxChannels || need > 160 * 1024)
+    if (channels > (uint32_t)kDecMaxChannels)
         return hipErrorInvalidValue;
+    int32_t* ws = reinterpret_cast<int32_t*>(((uintptr_t)d_workspace + 255) & ~(uintptr_t)255);
+    if (channels > (uint32_t)kDecMaxWaves) { // more channels than a workgroup has waves: rounds (k_decode_frames_wide)
+        if (d_phase_cycles)
+            return hipErrorInvalidValue; // (the phase counts are the one-wave-per-subframe kernel's)
+        const size_t lds = (size_t)kDecMaxWaves * (sizeof(DecSubframeLds) + sizeof(DecWaveScratch)) + (size_t)channels * 4;
+        if (ev)
+            (void)hipEventRecord(ev[0], stream);
+        hipLaunchKernelGGL(k_decode_frames_wide, dim3(n_frames), dim3(kDecMaxWaves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
+            d_pcm_out, d_status, ws, frame_flags);
+        if (ev)
+            (void)hipEventRecord(ev[1], stream);
+        return hipGetLastError();
+    }
+    const size_t need = decode_lds_bytes(channels);
     // (Capping the occupancy so that a batch fills whole rounds of resident workgroups was tried -- extra dynamic
     // LDS -- and lost at every batch size: the recurrence is latency-bound per wave, more waves always overlap more.)
     const size_t lds = need;
@@ -952,7 +1137,6 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
         if (err != hipSuccess)
             return err;
     }
-    int32_t* ws = reinterpret_cast<int32_t*>(((uintptr_t)d_workspace + 255) & ~(uintptr_t)255);
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)

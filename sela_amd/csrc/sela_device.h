@@ -12,6 +12,7 @@
 #define SELA_TABLE_QUAL static __device__ const
 #include "sela_format.h"
 #include "sela_hip.h"
+#include "sela_hip_debug.h"
 
 namespace sela {
 
@@ -46,6 +47,7 @@ struct EncodeHostLink {
     uint32_t stage_workgroups; // of k_stage_in, each with a CU to itself
     hipStream_t stage_stream;  // where k_stage_in runs (not the encode launch's stream: the two may run side by side)
     uint64_t* stage_started;   // four device words: launch ticket | stager workgroups that have a CU; the stagers' frame counter; the gate's mark; groups the launch has finished
+    int wait_naps;             // bound of a block's wait for its frame, in naps of 2048 cycles; -1: the default (~0.5 s).  Tests set 0.
 };
 
 // Order LDS traffic between the lanes of ONE wave (a wave executes in lockstep and the LDS serves a

@@ -370,7 +370,7 @@ __device__ __attribute__((noinline)) void fir_plain(int order, int lane, const i
 // walk their own chain as before; so does any block whose ready word has not turned up after a bounded wait, so
 // no block ever depends on another workgroup making progress.
 constexpr uint32_t kFuseSpinLimit = 1u << 18; // bounded waits on other groups: x (s_sleep 64 + a trip to memory, ~4 us) = ~1 s, then the launch flags an error instead of hanging
-constexpr uint32_t kFuseNapLimit = 600000;  // waits for the stagers: x 2048 cycles = ~0.5 s
+constexpr uint32_t kFuseNapLimit = 600000;  // waits for the stagers: x 2048 cycles = ~0.5 s (EncodeHostLink::wait_naps overrides: tests)
 constexpr uint32_t kMeanWaitSpins = 24;   // x s_sleep 16 (~1000 cycles each): ~10 us, then the block computes its own mean
 
 __device__ __forceinline__ void block_of(uint32_t e, uint32_t n_sig, uint32_t& frame, uint32_t& sig)
@@ -547,7 +547,7 @@ __device__ __forceinline__ const int16_t* pcm_after_wait(const int16_t* p)
 // Wait until stereo frame `f` has been copied in and can be read from here (no-op without stagers): its word in
 // pcm_ready carries this launch's ticket, and the frame, read past this XCD's L2, has the checksum that word gives.
 // Bounded: a wait that runs out flags the launch.
-__device__ __attribute__((noinline)) bool await_frame(const uint64_t* pcm_ready, const int16_t* pcm, uint32_t f, uint32_t ticket)
+__device__ __attribute__((noinline)) bool await_frame(const uint64_t* pcm_ready, const int16_t* pcm, uint32_t f, uint32_t ticket, uint32_t nap_limit)
 {
     // Most of a launch's resident blocks wait here for most of the copy, and these loads go to memory: polled every
     // quarter microsecond by 3,000 waves, the ready words took the link's bandwidth from the stagers (4.7 ms for a
@@ -566,7 +566,7 @@ __device__ __attribute__((noinline)) bool await_frame(const uint64_t* pcm_ready,
                 return true;
             }
         }
-        if (slept > kFuseNapLimit)
+        if (slept > nap_limit)
             return false;
         for (uint32_t i = 0; i < naps; i++)
             __builtin_amdgcn_s_sleep(32); // 2048 cycles
@@ -665,6 +665,7 @@ struct FuseArgs {
     const uint64_t* pcm_ready; // [n_frames]: launch ticket | checksum of every frame k_stage_in has copied in; or null (the PCM is there)
     uint64_t* groups_done;   // count_mark | groups finished, for the stagers (see the end of k_stage_in); or null
     uint32_t n_frames, channels, n_sig, ticket;
+    uint32_t nap_limit;      // bound of a block's wait for its frame (await_frame)
     uint64_t tag;            // process nonce << 32 | ticket (see launch_encode): what marks a cell as written by THIS launch
 };
 
@@ -1048,7 +1049,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         return;
     const uint32_t block_id = frame * n_sig + sig;
     uint32_t flags = 0;
-    if (kFused && fa.pcm_ready && !await_frame(fa.pcm_ready, pcm, frame, ticket))
+    if (kFused && fa.pcm_ready && !await_frame(fa.pcm_ready, pcm, frame, ticket, fa.nap_limit))
         flags |= SELA_HIP_FLAG_INTERNAL;
 
     double* const E = reinterpret_cast<double*>(big) + kPadC;              // first half: E[-64 .. 575]
@@ -1813,6 +1814,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
             const_cast<int16_t*>(d_pcm), n_frames, link->pcm_ready, ticket, link->stage_started, ((uint64_t)nonce << 32) | ticket, (uint32_t)n_groups);
         hipLaunchKernelGGL(k_stage_gate, dim3(1), dim3(64), 0, stream, link->stage_started, ticket, link->stage_workgroups, ((uint64_t)nonce << 32) | ticket);
     }
+    fa.nap_limit = link && link->wait_naps >= 0 ? (uint32_t)link->wait_naps : kFuseNapLimit;
     fa.n_frames = n_frames;
     fa.channels = channels;
     fa.n_sig = n_sig;

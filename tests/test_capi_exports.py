@@ -9,14 +9,16 @@ from sela_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "sela_hip.h")).read()
+def _declared(header="sela_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(sela_hip_[a-z_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
     assert _declared() == sorted(capi.EXPORTS)
+    assert _declared("sela_hip_debug.h") == sorted(capi.DEBUG_EXPORTS)
+    assert not [n for n in _declared() if "debug" in n], "test hooks belong in sela_hip_debug.h, not in the boundary"
 
 
 def test_library_exports_every_declared_symbol():
@@ -25,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
         g.build_hip_library()
     lib = capi.lib()
-    for name in _declared():
+    for name in _declared() + _declared("sela_hip_debug.h"):
         assert hasattr(lib, name), name
 
 
