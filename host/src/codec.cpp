@@ -3,6 +3,7 @@
 #include "sela_host/codec.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -63,9 +64,25 @@ void streamEncode(Need need, size_t piece, int16_t* pcm, size_t frames, uint32_t
                 throw;
             }
             uint64_t done = 0;
+            const long long t0 = sela_host::ioTrace ? sela_host::ioNow() : 0;
             rc = sela_hip_encode_feed(job, pcm + f0 * frameSamples, (uint32_t)nf, nullptr, &done);
+            if (sela_host::ioTrace)
+                sela_host::ioTrace("encode feed", t0, sela_host::ioNow(), nf * frameSamples * 2);
             if (rc == SELA_HIP_OK)
                 drain(bytes.data(), (size_t)done);
+        }
+        // everything is queued: hand finished bytes on while the last launches run (a feed of zero frames only reports)
+        uint64_t reported = 0;
+        const long long tPoll = sela_host::ioTrace ? sela_host::ioNow() : 0;
+        for (uint32_t finalFrames = 0; rc == SELA_HIP_OK && frames && finalFrames < frames;) {
+            uint64_t done = 0;
+            rc = sela_hip_encode_feed(job, pcm, 0, &finalFrames, &done);
+            if (sela_host::ioTrace && done > reported)
+                sela_host::ioTrace("encoded bytes final", tPoll, sela_host::ioNow(), (size_t)done), reported = done;
+            if (rc == SELA_HIP_OK)
+                drain(bytes.data(), (size_t)done);
+            if (finalFrames < frames)
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
         const std::string feedError = rc != SELA_HIP_OK ? sela_hip_last_error() : "";
         uint64_t total = 0;
@@ -154,13 +171,28 @@ void streamDecode(Fetch fetch, file::SelaFile& sela, size_t payload, sela_host::
         const bool last = have == payload || indexed == stop || ended;
         if (indexed > fed && (indexed - fed >= kPieceFrames || last)) {
             uint32_t done = 0;
+            const long long t0 = sela_host::ioTrace ? sela_host::ioNow() : 0;
             rc = sela_hip_decode_feed(job, sela.frameBytes.data(), sela.frameOffsets.data() + fed, (uint32_t)(indexed - fed), &done);
+            if (sela_host::ioTrace)
+                sela_host::ioTrace("decode feed", t0, sela_host::ioNow(), indexed - fed);
             fed = indexed;
             if (rc == SELA_HIP_OK)
                 drain(pcm.data(), (size_t)done * frameSamples);
         }
         if (have == payload && fed >= indexed)
             break;
+    }
+    // everything is queued: hand finished samples on while the last chunks are decoded and copied out
+    uint32_t reportedFrames = 0;
+    const long long tPoll = sela_host::ioTrace ? sela_host::ioNow() : 0;
+    for (uint32_t finalFrames = 0; rc == SELA_HIP_OK && fed > firstFrame && finalFrames < fed - std::min(firstFrame, stop);) {
+        rc = sela_hip_decode_feed(job, sela.frameBytes.data(), sela.frameOffsets.data(), 0, &finalFrames);
+        if (sela_host::ioTrace && finalFrames > reportedFrames)
+            sela_host::ioTrace("decoded frames final", tPoll, sela_host::ioNow(), finalFrames), reportedFrames = finalFrames;
+        if (rc == SELA_HIP_OK)
+            drain(pcm.data(), (size_t)finalFrames * frameSamples);
+        if (finalFrames < fed - std::min(firstFrame, stop))
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
     const std::string feedError = rc != SELA_HIP_OK ? sela_hip_last_error() : "";
     uint32_t done = 0;
@@ -484,7 +516,7 @@ std::vector<file::WavFile> decodeBatch(const std::vector<file::SelaFile>& selas)
 namespace {
 
 constexpr size_t kIoSubBytes = (size_t)1 << 20;  // one pread / pwrite task
-constexpr size_t kFeedFrames = 512;              // frames per encode feed while a file is being read (one launch each)
+constexpr size_t kFeedFrames = 2048;             // frames per encode feed while a file is being read (one launch each; a 3-minute track is two)
 
 void put16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v, p[1] = (uint8_t)(v >> 8); }
 void put32(uint8_t* p, uint32_t v) { put16(p, v), put16(p + 2, v >> 16); }
@@ -575,6 +607,8 @@ size_t encodeRange(const sela_host::PosixFile& in, const WavInfo& info, size_t f
     return bytes.size();
 }
 
+size_t expectedSelaBytes(const WavInfo& info) { return info.frames * kBlock * info.channels * 2 / 4 * 3; }
+
 } // namespace
 
 void setIoThreads(unsigned n) { sela_host::IoPool::configure(n); }
@@ -590,9 +624,10 @@ size_t encodeFile(const std::string& inPath, const std::string& outPath)
     sela_host::PinnedBuffer<int16_t> pcm;
     sela_host::PinnedBuffer<uint8_t> bytes;
     std::vector<uint64_t> offsets;
-    sela_host::WriteBehind behind(out, 15, kIoSubBytes);
-    encodeRange(in, info, 0, info.frames, pcm, bytes, offsets, [&](const uint8_t* p, size_t done) { behind.drain(p, done); });
-    behind.finish();
+    // (the pages of the output are allocated in one go while the input is read and coded: audio codes to about 3/4)
+    sela_host::WriteBehind behind(out, 15, kIoSubBytes, expectedSelaBytes(info));
+    const size_t total = encodeRange(in, info, 0, info.frames, pcm, bytes, offsets, [&](const uint8_t* p, size_t done) { behind.drain(p, done); });
+    behind.finish(&total);
     return info.frames;
 }
 
@@ -611,7 +646,7 @@ size_t decodeFile(const std::string& inPath, const std::string& outPath)
     sela.frameBytes.resize(info.payload);
     sela_host::PinnedBuffer<int16_t> pcm;
     sela_host::ReadAhead ahead(in, sela.frameBytes.data(), 15, info.payload, kIoSubBytes, kIoSubBytes);
-    sela_host::WriteBehind behind(out, 44, kIoSubBytes);
+    sela_host::WriteBehind behind(out, 44, kIoSubBytes, info.announced * frameBytes);
     streamDecode(
         [&](size_t have, size_t payload) {
             const size_t upTo = std::min(payload, have + kIoSubBytes);
@@ -620,12 +655,12 @@ size_t decodeFile(const std::string& inPath, const std::string& outPath)
         },
         sela, info.payload, pcm, [&](const int16_t* p, size_t done) { behind.drain(p, done * 2); });
     ahead.finish();
-    behind.finish();
-    const size_t frames = sela.frameCount();
+    const size_t frames = sela.frameCount(), decodedBytes = frames * frameBytes;
+    behind.finish(&decodedBytes);
     if (frames != info.announced) { // the stream ended early (bad sync word): the header sizes follow what was decoded
-        wavHeaderBytes(header, info.header.sampleRate, (uint16_t)channels, 16, (uint32_t)(frames * frameBytes));
+        wavHeaderBytes(header, info.header.sampleRate, (uint16_t)channels, 16, (uint32_t)decodedBytes);
         out.writeAt(header, 44, 0);
-        out.truncate(44 + frames * frameBytes);
+        out.truncate(44 + decodedBytes);
     }
     return frames;
 }
@@ -744,9 +779,13 @@ void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
                             const sela_host::PosixFile in = sela_host::PosixFile::openForRead(inputs[member]);
                             if (pc.first == 0) {
                                 const sela_host::PosixFile out = sela_host::PosixFile::openForWrite(outputs[member]);
-                                sela_host::WriteBehind behind(out, 15, kIoSubBytes);
+                                sela_host::WriteBehind behind(out, 15, kIoSubBytes, expectedSelaBytes(info[member]));
                                 encodeRange(in, info[member], 0, pc.n, pcm, bytes, offsets, [&](const uint8_t* b, size_t n) { behind.drain(b, n); });
-                                behind.finish();
+                                if (pc.n == info[member].frames) {
+                                    const size_t total = bytes.size();
+                                    behind.finish(&total); // (the whole track: the file ends here)
+                                } else
+                                    behind.finish();
                                 shared.publish(pc.track, indexInTrack[w][p0], bytes.size());
                             } else {
                                 encodeRange(in, info[member], pc.first, pc.n, pcm, bytes, offsets, [](const uint8_t*, size_t) {});
@@ -801,6 +840,8 @@ void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
                         sela_host::WriteBehind behind(out, 15 + at, kIoSubBytes);
                         behind.drain(d.bytes.data(), d.bytes.size());
                         behind.finish();
+                        if (d.piece + 1 == piecesOfTrack[d.track]) // (the track's first piece allocated the file's pages from an estimate)
+                            out.truncate(15 + at + d.bytes.size());
                     }
                 } catch (...) {
                     shared.abort();

@@ -24,7 +24,33 @@
 #include "sela_hip.h"
 #include "sela_host/codec.hpp"
 
+#include <mutex>
+
+#include "sela_host/fileio.hpp"
+
 namespace {
+
+// `trace` mode: the pool's tasks and the feeding thread's waits of ONE file-to-file encode and decode on one time axis
+struct TraceRow {
+    std::string what;
+    long long t0, t1;
+    size_t bytes;
+};
+std::mutex g_traceMutex;
+std::vector<TraceRow> g_trace;
+void traceHook(const char* what, long long t0, long long t1, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_traceMutex);
+    g_trace.push_back({ what, t0, t1, bytes });
+}
+void printTrace(const char* title, long long origin)
+{
+    std::sort(g_trace.begin(), g_trace.end(), [](const TraceRow& a, const TraceRow& b) { return a.t0 < b.t0; });
+    std::printf("---- %s (us from the call; what, start, end, bytes or frames)\n", title);
+    for (const TraceRow& r : g_trace)
+        std::printf("%-22s %9.1f %9.1f %10zu\n", r.what.c_str(), (r.t0 - origin) / 1e3, (r.t1 - origin) / 1e3, r.bytes);
+    g_trace.clear();
+}
 
 double median(std::vector<double> v)
 {
@@ -113,9 +139,31 @@ int main(int argc, char** argv)
                 // (back and bytes were overwritten with the same contents they held)
             }
         }
+        if (argc > 4 && std::string(argv[4]) == "trace") { // (after the warm-up above: buffers pinned, pool started)
+            for (int r = 0; r < 2; r++) {
+                std::remove(selaPath.c_str());
+                std::remove(backPath.c_str());
+                sela_host::ioTrace = r ? traceHook : nullptr;
+                const long long a = sela_host::ioNow();
+                sela::encodeFile(wavPath, selaPath);
+                const long long b = sela_host::ioNow();
+                if (r)
+                    printTrace("sela::encodeFile", a), std::printf("encodeFile: %.1f us\n", (b - a) / 1e3);
+                const long long c = sela_host::ioNow();
+                sela::decodeFile(selaPath, backPath);
+                const long long d = sela_host::ioNow();
+                if (r)
+                    printTrace("sela::decodeFile", c), std::printf("decodeFile: %.1f us\n", (d - c) / 1e3);
+            }
+            return 0;
+        }
         // ---- file to file -------------------------------------------------------------------------------------
         std::vector<double> fenc, fdec;
         for (int r = 0; r <= repeats; r++) {
+            // Into NEW files: opening an existing 32 MB file with O_TRUNC takes the kernel 4 ms to free its pages
+            // (tools/io_probe.cpp), which is not the codec's time -- the outputs of the last round are removed first.
+            std::remove(selaPath.c_str());
+            std::remove(backPath.c_str());
             const auto t0 = clock::now();
             sela::encodeFile(wavPath, selaPath);
             const auto t1 = clock::now();

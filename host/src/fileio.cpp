@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <thread>
@@ -15,7 +16,22 @@
 
 namespace sela_host {
 
+void (*ioTrace)(const char*, long long, long long, size_t) = nullptr;
+long long ioNow() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 namespace {
+
+struct Traced { // reports its lifetime when the hook is set
+    const char* what;
+    size_t bytes;
+    long long t0;
+    Traced(const char* w, size_t b) : what(w), bytes(b), t0(ioTrace ? ioNow() : 0) {}
+    ~Traced()
+    {
+        if (ioTrace)
+            ioTrace(what, t0, ioNow(), bytes);
+    }
+};
 
 [[noreturn]] void ioFailure(const std::string& what, const std::string& path)
 {
@@ -106,6 +122,18 @@ void PosixFile::writeAt(const void* src, size_t n, size_t offset) const
     }
 }
 
+void PosixFile::allocate(size_t from, size_t n) const
+{
+    if (n == 0)
+        return;
+    int rc;
+    do // (the Linux call, not posix_fallocate: where the file system cannot do it, that one writes zeros instead)
+        rc = ::fallocate(fd, 0, (off_t)from, (off_t)n);
+    while (rc != 0 && errno == EINTR);
+    if (rc != 0)
+        ioFailure("allocating", name);
+}
+
 void PosixFile::truncate(size_t n) const
 {
     if (::ftruncate(fd, (off_t)n) != 0)
@@ -135,7 +163,7 @@ IoPool::IoPool() : impl(new Impl)
     unsigned n = g_configured.load(std::memory_order_relaxed);
     if (n == 0) {
         const unsigned hw = std::thread::hardware_concurrency();
-        n = std::min(16u, std::max(2u, hw / 2));
+        n = std::min(8u, std::max(2u, hw / 2));
     }
     count = std::min(n, 256u);
     for (unsigned i = 0; i < count; i++)
@@ -160,11 +188,14 @@ IoPool& IoPool::instance()
     return pool;
 }
 
-void IoPool::submit(std::function<void()> task)
+void IoPool::submit(std::function<void()> task, bool first)
 {
     {
         std::lock_guard<std::mutex> lock(impl->mu);
-        impl->queue.push_back(std::move(task));
+        if (first)
+            impl->queue.push_front(std::move(task));
+        else
+            impl->queue.push_back(std::move(task));
     }
     impl->cv.notify_one();
 }
@@ -250,6 +281,7 @@ ReadAhead::ReadAhead(const PosixFile& f, void* dstBase, size_t fileOffset, size_
                 bool ok = false;
                 std::string what;
                 try {
+                    Traced t("pread", n);
                     ok = file.readAt(dst + at, n, this->fileOffset + at);
                 } catch (const data::Exception& e) {
                     what = e.exceptionMessage;
@@ -270,6 +302,7 @@ ReadAhead::ReadAhead(const PosixFile& f, void* dstBase, size_t fileOffset, size_
 
 void ReadAhead::need(size_t upTo)
 {
+    Traced t("wait for reads", upTo);
     upTo = std::min(upTo, total);
     const size_t lastPiece = upTo ? (upTo - 1) / piece : 0;
     std::unique_lock<std::mutex> lock(mu);
@@ -282,14 +315,88 @@ void ReadAhead::need(size_t upTo)
 }
 
 // ---- write behind --------------------------------------------------------------------------------------------------
-void WriteBehind::drain(const void* base, size_t upTo)
+WriteBehind::WriteBehind(const PosixFile& f, size_t fileOffset, size_t subBytes, size_t expectBytes)
+    : file(f), fileOffset(fileOffset), subBytes(std::max<size_t>(subBytes, 4096)), expect(expectBytes)
 {
-    const uint8_t* p = static_cast<const uint8_t*>(base);
-    while (written < upTo) {
-        const size_t n = std::min(subBytes, upTo - written), at = written;
-        group.run([this, p, at, n] { file.writeAt(p + at, n, fileOffset + at); });
-        written += n;
+    if (expect) { // the pages of a fresh file, in one go, while the data is still on its way
+        std::lock_guard<std::mutex> lock(mu);
+        active = true;
+        IoPool::instance().submit([this] { strand(); }, true); // (ahead of the reads that are queued already: it has 1-2 ms of work that needs no data)
+    } else
+        allocated = true;
+}
+
+WriteBehind::~WriteBehind()
+{
+    std::unique_lock<std::mutex> lock(mu);
+    cv.wait(lock, [this] { return !active; });
+}
+
+void WriteBehind::strand()
+{
+    std::unique_lock<std::mutex> lock(mu);
+    for (;;) {
+        std::string what;
+        if (!allocated) {
+            // the file's pages, in ONE call (4 MB at a time between the writes took twice as long per byte), before the
+            // first byte is there: this runs while the input is being read and coded
+            lock.unlock();
+            try {
+                Traced t("fallocate", expect);
+                file.allocate(fileOffset, expect);
+            } catch (const data::Exception&) {
+                // (a file system without fallocate: the writes allocate as they go)
+            }
+            lock.lock();
+            allocated = true;
+            continue;
+        }
+        if (failed || written >= target)
+            break;
+        const size_t at = written, n = std::min(subBytes, target - written);
+        const uint8_t* from = base;
+        lock.unlock();
+        try {
+            Traced t("pwrite", n);
+            file.writeAt(from + at, n, fileOffset + at);
+        } catch (const data::Exception& e) {
+            what = e.exceptionMessage;
+        }
+        lock.lock();
+        if (!what.empty()) {
+            failed = true;
+            error = what;
+            break;
+        }
+        written = at + n;
     }
+    active = false;
+    cv.notify_all();
+}
+
+void WriteBehind::drain(const void* from, size_t upTo)
+{
+    std::lock_guard<std::mutex> lock(mu);
+    base = static_cast<const uint8_t*>(from);
+    if (upTo > target)
+        target = upTo;
+    if (!active && written < target && !failed) {
+        active = true;
+        IoPool::instance().submit([this] { strand(); }, true);
+    }
+}
+
+void WriteBehind::finish(const size_t* truncateTo)
+{
+    Traced t("wait for writes", 0);
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [this] { return !active; });
+        if (failed)
+            throw data::Exception(error);
+    }
+    if (truncateTo && expect && *truncateTo != expect)
+        file.truncate(fileOffset + *truncateTo);
 }
 
 } // namespace sela_host

@@ -146,9 +146,9 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
  * returns at once -- from page-locked buffers nothing in it waits for the device (an encode feed is one kernel
  * launch; a decode feed waits when one of its eight chunk buffer sets comes round again) -- so the caller's next
  * read runs beside the device work.  A piece's buffer must stay valid and unchanged until the job reports its
- * frames final (or ends).  Encode pieces in ordinary (pageable) memory are copied to page-locked memory first; decode
- * pieces and pcm_out in ordinary memory go through the runtime's own staging (the copies then block the caller: slower,
- * same results).  One open job per calling thread; a job is used from the thread that began it.
+ * frames final (or ends).  Pieces -- and a decode job's pcm_out -- in ordinary (pageable) memory go through page-locked
+ * bounce buffers of the library (one more host copy: slower, same results).  One open job per calling thread; a job is
+ * used from the thread that began it.
  * An encode feed normally has its PCM fetched by a staging kernel beside the encode launch.  If the device is so busy
  * with other work that the two cannot run side by side within the launch's bounded wait (or another thread's job on
  * this device is using that path), the feed -- and any queued behind it -- is issued again with the copy engine in

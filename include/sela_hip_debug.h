@@ -26,9 +26,9 @@ void sela_hip_debug_force_plain_fir(int enable);
  * workers).  Setting a small value makes small test batches take the worker path; -1 restores the default.
  * Results are identical by construction, which is what the tests check. */
 void sela_hip_debug_mean_workers(int self_blocks);
-/* Debug hook: bound of an encode block's wait for its frame from the staging kernel, in naps of 2048 cycles (0: a
- * block whose frame is not there when it first looks gives up at once, which flags the launch and sends the feed
- * through the copy-engine path again); -1 restores the default (~0.5 s). */
+/* Debug hook: bound of an encode block's wait for its frame from the staging kernel, in naps of 2048 cycles; 0: every
+ * block gives up without looking ("the stagers never showed up"), which flags the launch and sends the feed through
+ * the copy-engine path again; -1 restores the default (~0.5 s). */
 void sela_hip_debug_stage_wait(int naps);
 /* Debug hook: how many encode feeds of the calling thread were issued again through the copy-engine path so far. */
 int sela_hip_debug_reissued_feeds(void);

@@ -360,7 +360,11 @@ struct sela_hip_job {
     uint32_t issued = 0;       // chunks whose copies and kernel are enqueued
     uint32_t final_chunks = 0; // chunks whose results are complete in host memory
     std::vector<uint32_t> chunk_first, chunk_frames; // per issued chunk
-    int16_t* pcm_out = nullptr;
+    int16_t* pcm_out = nullptr;   // where the copy-outs land: the caller's buffer if it is page-locked, else a page-locked bounce buffer
+    int16_t* pcm_caller = nullptr; // the caller's buffer
+    bool pcm_bounce = false;
+    uint32_t frames_moved = 0;     // frames copied from the bounce buffer to the caller's so far
+    std::vector<void*> bounce_frames; // page-locked copies of feeds that came from ordinary memory
     size_t offsets_used = 0; // entries of g_ctx.job_offsets_host taken by the feeds so far
     // ---- encode: feeds
     uint8_t* frames_out = nullptr; // the caller's buffer
@@ -387,6 +391,21 @@ int job_fail(sela_hip_job* job, int code)
     return code;
 }
 
+// Decode into ordinary memory: the chunks that have arrived in the page-locked bounce buffer go on to the caller's.
+void job_move_decoded(sela_hip_job* job)
+{
+    if (!job->pcm_bounce || job->final_chunks == 0)
+        return;
+    const uint32_t n = job->final_chunks;
+    const uint32_t frames = job->chunk_first[n - 1] + job->chunk_frames[n - 1];
+    if (frames > job->frames_moved) {
+        const size_t frame_samples = (size_t)sela::kBlock * job->channels;
+        std::memcpy(job->pcm_caller + job->frames_moved * frame_samples, job->pcm_out + job->frames_moved * frame_samples,
+            (size_t)(frames - job->frames_moved) * frame_samples * sizeof(int16_t));
+        job->frames_moved = frames;
+    }
+}
+
 // Results of decode chunk `i` are in host memory once its copy-out has finished.
 int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
 {
@@ -398,6 +417,7 @@ int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
             return job_fail(job, fail_hip(e, "copy-out"));
         job->final_chunks++;
     }
+    job_move_decoded(job);
     return SELA_HIP_OK;
 }
 
@@ -675,6 +695,18 @@ int job_feed_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* of
     const uint64_t* mapped = g_ctx.job_offsets_mapped + job->offsets_used;
     std::memcpy(staged, offsets, ((size_t)n_frames + 1) * 8);
     job->offsets_used += (size_t)n_frames + 1;
+    if (!device_view(frames + offsets[0])) {
+        // ordinary memory: through a page-locked copy (kept until the job ends).  Copies from pageable memory go through
+        // the runtime's own staging, and with several host threads decoding at once their results were seen to arrive
+        // behind the event that should cover them (tests/test_gpu_round3.py::test_four_threads_encode_on_one_gpu).
+        const size_t bytes = (size_t)(offsets[n_frames] - offsets[0]);
+        void* copy = pool().take(bytes ? bytes : 1);
+        if (!copy)
+            return job_fail(job, fail(SELA_HIP_ENOMEM, "page-locked bounce buffer"));
+        std::memcpy(copy, frames + offsets[0], bytes);
+        job->bounce_frames.push_back(copy);
+        frames = static_cast<const uint8_t*>(copy) - offsets[0];
+    }
     for (uint32_t done = 0; done < n_frames;) {
         const uint32_t nf = next_chunk_frames(job->issued, n_frames - done, job->channels);
         const int rc = job_issue_decode(job, frames, offsets + done, mapped + done, nf);
@@ -693,6 +725,7 @@ int job_drain_ready(sela_hip_job* job)
     while (job->final_chunks < job->issued && hipEventQuery(g_ctx.set[job->final_chunks % kSets].copied_out) == hipSuccess)
         job->final_chunks++;
     (void)hipGetLastError(); // (hipErrorNotReady from the query is not an error)
+    job_move_decoded(job);
     return SELA_HIP_OK;
 }
 
@@ -777,8 +810,16 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
         }
         if (job->out_bounce && job->out_host)
             pool().give(job->out_host);
-    } else if (rc == SELA_HIP_OK)
-        rc = job_finalize(job, job->issued);
+    } else {
+        if (rc == SELA_HIP_OK)
+            rc = job_finalize(job, job->issued);
+        if (rc != SELA_HIP_OK)
+            g_ctx.sync_all(); // (nothing may still be reading or writing the bounce buffers)
+        for (void* b : job->bounce_frames)
+            pool().give(b);
+        if (job->pcm_bounce && job->pcm_out)
+            pool().give(job->pcm_out);
+    }
     uint32_t seen_flags = 0;
     if (rc == SELA_HIP_OK && !job->encode && job->issued) {
         // every frame is decoded (bad ones to silence) before the verdict; the kernels left their flags in host memory
@@ -991,7 +1032,18 @@ int sela_hip_decode_begin(sela_hip_job** job, uint32_t channels, uint32_t total_
     int rc = job_begin(job, false, channels, total_frames);
     if (rc != SELA_HIP_OK)
         return rc;
-    (*job)->pcm_out = pcm_out;
+    sela_hip_job* j = *job;
+    j->pcm_out = j->pcm_caller = pcm_out;
+    if (total_frames && !device_view(pcm_out)) { // ordinary memory: the copy-outs land in a page-locked buffer first
+        const size_t bytes = (size_t)total_frames * sela::kBlock * channels * sizeof(int16_t);
+        j->pcm_out = static_cast<int16_t*>(pool().take(bytes));
+        j->pcm_bounce = true;
+        if (!j->pcm_out) {
+            (void)job_end(j, nullptr, nullptr);
+            *job = nullptr;
+            return fail(SELA_HIP_ENOMEM, "page-locked bounce buffer");
+        }
+    }
     return SELA_HIP_OK;
 }
 

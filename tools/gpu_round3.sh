@@ -21,29 +21,6 @@ echo "bench rc=$?" | tee -a "$OUT/summary.txt"
 tail -1 "$OUT/bench.log" > "$OUT/bench_line.json"
 tail -c 6000 "$OUT/bench.log"
 tail -5 "$OUT/bench.err"
-# file-to-file against the I/O pool's size (host/sela_filebench <wav> <dir> <repeats> all <threads>)
-python - "$OUT" <<'PY'
-import os, struct, subprocess, sys, json
-sys.path.insert(0, os.getcwd())
-from sela_amd.synth import synth_frames
-out = sys.argv[1]
-pcm = synth_frames(3875, 2, 0).reshape(-1, 2)
-d = "/dev/shm/sela_io"
-os.makedirs(d, exist_ok=True)
-data = pcm.astype("<i2").tobytes()
-with open(d + "/track.wav", "wb") as f:
-    f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IhHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16) + b"data" + struct.pack("<I", len(data)) + data)
-rows = []
-for threads in (1, 2, 4, 6, 8, 12, 16, 24, 32):
-    r = subprocess.run(["host/sela_filebench", d + "/track.wav", d, "9", "all", str(threads)], capture_output=True, text=True, timeout=300)
-    try:
-        j = json.loads(r.stdout.strip().splitlines()[-1])
-        rows.append((threads, j["file_encode_ms"], j["file_decode_ms"], j["e2e_encode_ms"], j["e2e_decode_ms"], j["file_equals_e2e"]))
-    except Exception as e:
-        rows.append((threads, "error", r.stderr[-200:], str(e), "", ""))
-with open(out + "/io_threads.txt", "w") as f:
-    f.write("io threads | file encode ms | file decode ms | e2e encode ms | e2e decode ms | equal\n")
-    for row in rows:
-        f.write(" | ".join(str(x) for x in row) + "\n")
-print(open(out + "/io_threads.txt").read())
-PY
+# file-to-file against the I/O pool's size
+timeout 600 python tools/io_sweep.py > "$OUT/io_threads.txt" 2>&1
+cat "$OUT/io_threads.txt"
