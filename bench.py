@@ -421,6 +421,11 @@ def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=
     """Warm up, time (all lanes, then one lane), then verify what was timed.  Returns the measurement record."""
     torch, np = bench.torch, bench.np
     job.size_rings(max(steps, warmup, 1))
+    # The batches, the codecs' buffers and the status slots were allocated and filled on torch's default stream; the
+    # lanes are streams of their own that do not wait for it.  Without this, a lane's first kernels ran while the default
+    # stream was still generating the album -- and wrote into memory the allocator had handed out a second time in
+    # default-stream order (the sizes of a batch of not-yet-written PCM ended up copied into the album's first frames).
+    torch.cuda.synchronize()
     for _ in range(warmup):
         job.step()
     torch.cuda.synchronize()
@@ -440,7 +445,7 @@ def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=
     # (its encoder rounds the prediction half-up, its decoder half-down: a frame whose Q35 sum hits 2^34 mod 2^35 comes
     # back off by one), and parity means reproducing that -- so the round trip may differ from the
     # input in a handful of frames, never in many.
-    state = {"lossy": 0, "bytes": 0, "same": True, "compared": 0}
+    state = {"lossy": 0, "bytes": 0, "same": True, "compared": 0, "sizes": []}
 
     def check(i, nb, pcm, frames, offsets, back, lane, slot):
         dec_st = lane["st_dec"][slot].cpu().numpy().view(np.uint32)
@@ -449,6 +454,7 @@ def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=
         state["lossy"] += int((back != pcm).reshape(nb, -1).any(dim=1).sum().item()) if nb else 0
         total = int(offsets[-1].item())
         state["bytes"] += total
+        state["sizes"].append((offsets[1:] - offsets[:-1]).clone())
         for s in snaps:
             if s["batch"] != i:
                 continue
@@ -460,6 +466,11 @@ def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=
 
     last = job.step(serial=True, check=check)
     torch.cuda.synchronize()
+    if timed_sizes is not None and bench.world == 1:  # (one rank: the gathered layout of the last timed step IS this rank's sizes)
+        serial_sizes = torch.cat(state["sizes"])
+        diff = torch.nonzero(timed_sizes[: serial_sizes.numel()] != serial_sizes).flatten()
+        assert diff.numel() == 0, (f"the sizes gathered in the last timed step differ from a serial step's at {diff.numel()} frames: first {diff[:8].tolist()}, "
+                                   f"timed {timed_sizes[diff[:8]].tolist()} serial {serial_sizes[diff[:8]].tolist()}")
     job.fold_status()
     acc = job.flag_acc.cpu().numpy().view(np.uint32)
     enc_bad = int(acc[0]) & (bench.capi.FLAG_WORDS_CAP | bench.capi.FLAG_RICE_RANGE | bench.capi.FLAG_COEF_OVERFLOW)
@@ -570,9 +581,9 @@ def workload_album(bench: Bench, steps: int, warmup: int):
         golden = album_golden()
         sizes = gathered_sizes(bench, m["timed_sizes"], n_total, job.max_local)
         offs = np.concatenate([[0], np.cumsum(sizes.astype(np.uint64))])
-        for t, (track, _, frames) in enumerate(tracks):
-            b, e = int(starts[t]), int(starts[t + 1])
-            assert 15 + int(offs[e] - offs[b]) == golden["tracks"][t]["sela_bytes"], f"track {track}: file size differs from the reference's"
+        wrong = [t for t in range(len(tracks)) if 15 + int(offs[int(starts[t + 1])] - offs[int(starts[t])]) != golden["tracks"][t]["sela_bytes"]]
+        assert not wrong, (f"{len(wrong)} tracks' file sizes differ from the reference's (first: track {wrong[0]}); "
+                           f"{int((sizes == 0).sum())} of {len(sizes)} gathered sizes are zero; steps done {job.steps_done}")
         layout_ok = golden.get("frame_sizes_sha256") in (None, hashlib.sha256(sizes.tobytes()).hexdigest())
         assert layout_ok, "the gathered frame-size layout differs from the one-GPU (reference) layout"
     t = torch.tensor([m["lossy"], m["bytes"]], dtype=torch.int64, device="cuda")
