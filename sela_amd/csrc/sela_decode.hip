@@ -469,12 +469,13 @@ __device__ inline uint32_t parse_stream_serial(const uint32_t* __restrict__ word
 // lane = a ring of 128).  Once sample s_i is known, the lane that owns sample i + d adds a[d] * s_i; its
 // coefficient a[(lane - i) mod ring] comes out of a doubled table in LDS at a compile-time offset (the 64
 // steps of a block are unrolled), so nothing is shifted between lanes.  The recurrence itself (sum -> s_i)
-// runs on the scalar unit: v_readlane of the finished sum, two SALU ops, and s_i feeds the multiply-adds
-// as a scalar operand.
+// runs on the scalar unit: v_readlane of the finished sum, one SALU op (two in the exact form), and the result
+// feeds the multiply-adds as a scalar operand.
 //
-// What is accumulated is N = 2^34 - sum(a_j s_(i-j)): the coefficients are negated once and every sum
-// starts at the rounding constant 2^34, so the prediction (int32)((2^34 - P) >> 35) is the arithmetic
-// shift (int32)N_hi >> 3 of the HIGH word alone (the reference's cast keeps exactly those 29 bits).
+// What is accumulated is N = 2^34 - sum(a_j s_(i-j)) = 2^34 + sum(a_j (-s_(i-j))): every sum starts at the
+// rounding constant 2^34 and the multiplier of a step is MINUS its sample, so the prediction
+// (int32)((2^34 - P) >> 35) is the arithmetic shift (int32)N_hi >> 3 of the HIGH word alone (the reference's cast
+// keeps exactly those 29 bits).
 //
 // A finished sum is not touched again until its lane is recycled: the coefficients of lags
 // ring - G + 1 .. ring - 1 are zero (order <= ring - G), so lanes are recycled in aligned groups of G
@@ -483,7 +484,7 @@ __device__ inline uint32_t parse_stream_serial(const uint32_t* __restrict__ word
 // 3 + 3/G VALU instructions (5 + 3/G on the ring of 128) and one (two) ds_read_b64.
 //
 // 64x32-bit products: a' = ah*2^32 + al with al = (int32)a', so
-//     z + a'*s mod 2^64 = (z + al*s)  [v_mad_i64_i32, exact]  +  ((ah*s mod 2^32) << 32)
+//     z + a*m mod 2^64 = (z + al*m)  [v_mad_i64_i32, exact]  +  ((ah*m mod 2^32) << 32)
 //
 // kFold: the residue is folded into its sum at the start of its block of 64,
 //     N' = N - r * 2^35  (one subtract on the high word per 64 samples)   ==>   s = -(N' >> 35),
@@ -520,17 +521,19 @@ template <int R, bool kFold, int G, int M>
 __device__ __forceinline__ void synth_steps(uint32_t& cl, uint32_t& ch, uint32_t& ol, uint32_t& oh, uint32_t& kept,
     LdsTable tab_lane, int32_t r_block, uint32_t four, uint32_t zero, uint64_t (&pf_c)[kAhead], uint64_t (&pf_o)[kAhead])
 {
-    // scalar side: the sum of this sample sits in lane M
+    // scalar side: the sum of this sample sits in lane M.  What goes back into the sums is -a_d * s_i; the table holds
+    // +a_d, so the multiplier is -s_i: in the folded form that IS the shifted sum (s_i = -pred: one scalar operation
+    // between the readlane and the multiply-adds instead of two), in the exact form pred - r_i.
     const int32_t pred = __builtin_amdgcn_readlane((int)ch, M) >> 3;
-    int32_t s_i;
+    int32_t m_i;
     if (kFold)
-        s_i = (int32_t)(0u - (uint32_t)pred);
+        m_i = pred;
     else
-        s_i = (int32_t)((uint32_t)__builtin_amdgcn_readlane(r_block, M) - (uint32_t)pred);
-    // vector side: lane L adds a'[(L - M) mod ring] * s_i  (a'[0] = 0: the finished sum stays)
-    synth_mac<kFold>(cl, ch, pf_c[M % kAhead], s_i);
+        m_i = (int32_t)((uint32_t)pred - (uint32_t)__builtin_amdgcn_readlane(r_block, M));
+    // vector side: lane L adds a[(L - M) mod ring] * (-s_i)  (a[0] = 0: the finished sum stays)
+    synth_mac<kFold>(cl, ch, pf_c[M % kAhead], m_i);
     if (R == 2)
-        synth_mac<kFold>(ol, oh, pf_o[M % kAhead], s_i);
+        synth_mac<kFold>(ol, oh, pf_o[M % kAhead], m_i);
     if constexpr (M + kAhead < 64) {
         pf_c[M % kAhead] = tab_lane[64 * R - (M + kAhead)];
         if (R == 2)
@@ -567,7 +570,8 @@ __device__ __forceinline__ bool synth_block(int32_t r_block, int32_t& s, uint32_
     __builtin_amdgcn_sched_barrier(0);
     synth_steps<R, kFold, G, 0>(cl, ch, ol, oh, kept, tab_lane, r_block, four, zero, pf_c, pf_o);
     s = (int32_t)((kFold ? 0u : (uint32_t)r_block) - (uint32_t)((int32_t)kept >> 3));
-    return !kFold || !__any((uint32_t)(s + (1 << 23)) >= (1u << 24));
+    // (the multiplier of a folded step is -s: both s and -s must fit the 24-bit operand)
+    return !kFold || !__any((uint32_t)(s + (1 << 23) - 1) >= (1u << 24) - 1u);
 }
 
 // All 2048 samples of a subframe.  R = ring / 64 (1: order <= 64 - G, 2: order <= 128 - G); G = recycling
@@ -653,8 +657,9 @@ __device__ inline void synthesize(const uint32_t* words, uint32_t n_words, uint3
     wave_sync();
 }
 
-// Negated coefficients a'[d] = -a[d] (0 for d = 0 and beyond `order`), packed {al, ah}, ring-periodic
-// and doubled, written over the wave's k[] / a[] arrays.  Returns whether every ah fits 24 bits.
+// The coefficients a[d] (0 for d = 0 and beyond `order`), packed {al, ah}, ring-periodic and doubled, written
+// over the wave's k[] / a[] arrays.  Returns whether every ah fits 24 bits.  (The sums accumulate
+// 2^34 - sum a_d s = 2^34 + sum a_d (-s): the multiplier carries the sign, see synth_steps.)
 __device__ inline bool build_synth_table(const int64_t* a, uint64_t* tab, int order, int lane)
 {
     uint64_t c[2];
@@ -662,7 +667,7 @@ __device__ inline bool build_synth_table(const int64_t* a, uint64_t* tab, int or
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int d = lane + 64 * h;
-        const uint64_t nv = 0 - (uint64_t)(d >= 1 && d <= order ? a[d] : 0);
+        const uint64_t nv = (uint64_t)(d >= 1 && d <= order ? a[d] : 0);
         const int32_t al = (int32_t)(uint32_t)nv;
         const int32_t ah = (int32_t)(uint32_t)((nv - (uint64_t)(int64_t)al) >> 32); // nv = ah 2^32 + al, al signed
         fits &= ah >= -(1 << 23) && ah < (1 << 23);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/collect_all.sh <round-tag>  (run ON THE GPU BOX through gpurun): everything profiles/<tag>/ holds.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"

@@ -14,7 +14,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-legs --lanes 1"   # one lane: kernels back to back, so a duration is the kernel's own
+CMD="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-legs --no-extra-legs --lanes 1"   # one lane: kernels back to back, so a duration is the kernel's own
 
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o stats -- $CMD > "$OUT/bench_under_rocprof.log" 2>&1
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;

@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_tl
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -o tl -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-legs --lanes ${LANES:-1} > /tmp/prof_tl.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -o tl -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-legs --no-extra-legs --lanes ${LANES:-1} > /tmp/prof_tl.log 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/prof_tl/**/*kernel_trace.csv", recursive=True)[0]

@@ -3,7 +3,7 @@
 # rocprofv3 --pmc pass (kernel trace only).  Prints per-kernel averages; quoted in DESIGN.md.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-legs --lanes 1"
+CMD="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-legs --no-extra-legs --lanes 1"
 for SET in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
   TAG=$(echo $SET | cut -d' ' -f1)
   rm -rf /tmp/pc_$TAG
