@@ -577,15 +577,28 @@ __device__ __attribute__((noinline)) bool await_frame(const uint64_t* pcm_ready,
     }
 }
 
-__device__ __attribute__((noinline)) void mean_worker(const int16_t* __restrict__ pcm, uint32_t n_frames, uint32_t channels, uint32_t n_sig,
-    uint32_t first_e, uint32_t total_e, double* __restrict__ mean_out, uint64_t* __restrict__ mean_ready, uint32_t ticket, uint64_t tag)
+// Which lane of which worker sums which block: lane -> (frame, signal) with the signals of a frame in NEIGHBOURING lanes
+// (64 / n_sig frames per wave).  The lanes of one frame then load the same addresses, which the memory pipeline serves with
+// one request: a frame is fetched once per worker instead of once per signal (lane = encode index, the first version,
+// fetched every stereo frame three times -- 26 MB of the launch's 58 MB of reads, PMC FETCH_SIZE).
+__device__ __forceinline__ uint32_t worker_frames_per_wave(uint32_t n_sig) { return n_sig < 64u ? 64u / n_sig : 1u; }
+__device__ __forceinline__ uint32_t worker_first_frame(uint32_t self_blocks, uint32_t n_sig) { return self_blocks / (64u * n_sig) * 64u; } // the span of 64 frames that holds encode index self_blocks
+__device__ __forceinline__ uint32_t encode_index_of(uint32_t frame, uint32_t sig, uint32_t n_sig) // (block_of, the other way round)
 {
-    const uint32_t e = first_e + threadIdx.x;
-    uint32_t frame, sig;
-    block_of(e < total_e ? e : 0u, n_sig, frame, sig);
-    const bool live = e < total_e && frame < n_frames;
+    const uint32_t span = frame / 64, within = frame % 64;
+    return span * 64 * n_sig + (sig * 8 + within % 8) * 8 + within / 8;
+}
+
+__device__ __attribute__((noinline)) void mean_worker(const int16_t* __restrict__ pcm, uint32_t n_frames, uint32_t channels, uint32_t n_sig,
+    uint32_t first_frame, double* __restrict__ mean_out, uint64_t* __restrict__ mean_ready, uint64_t tag)
+{
+    const uint32_t per_wave = worker_frames_per_wave(n_sig);
+    const uint32_t slot = n_sig <= 64u ? threadIdx.x / n_sig : 0u;
+    uint32_t frame = first_frame + slot, sig = n_sig <= 64u ? threadIdx.x % n_sig : threadIdx.x; // (more than 64 signals: one frame, lane = signal, the first 64)
+    const bool live = slot < per_wave && frame < n_frames && sig < n_sig;
     if (!live)
         frame = 0, sig = 0; // idle lanes shadow a valid block, never publish
+    const uint32_t e = encode_index_of(frame, sig, n_sig);
     const int16_t* fp = pcm + (size_t)frame * kBlock * channels;
     // the blocks that wait for these means hold CU slots: take the issue slots the co-resident block waves would
     // otherwise win (their phases are throughput-bound, this one is a chain)
@@ -1034,7 +1047,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 {
     constexpr bool kTrace = kMode == 1;
     if (blockIdx.x < n_workers) { // (the first workgroups of the launch: see mean_worker)
-        mean_worker(pcm, n_frames, channels, n_sig, self_blocks + 64 * blockIdx.x, total_e, mean_out, mean_ready, ticket, fa.tag);
+        mean_worker(pcm, n_frames, channels, n_sig, worker_first_frame(self_blocks, n_sig) + blockIdx.x * worker_frames_per_wave(n_sig), mean_out, mean_ready, fa.tag);
         return;
     }
     long long stamp[14];
@@ -1770,12 +1783,16 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     const bool staged = link && link->host_pcm && channels == 2;
     uint32_t self_blocks = self_blocks_override >= 0 ? (uint32_t)self_blocks_override : resident_encode_blocks();
     uint32_t n_workers = 0;
+    // a worker wave sums the blocks of 64 / n_sig frames (mean_worker); the workers cover the frames from the span of 64
+    // that holds encode index self_blocks to the end
+    const uint32_t frames_padded = (n_frames + 63) / 64 * 64, per_wave = n_sig < 64u ? 64u / n_sig : 1u;
+    auto workers_for = [&](uint32_t self) { return (frames_padded - std::min(frames_padded, self / (64u * n_sig) * 64u) + per_wave - 1) / per_wave; };
     if (total_e > self_blocks && !staged) { // (with stagers the link sets the pace, and a worker has no await_frame)
-        n_workers = (total_e - self_blocks + 63) / 64;
+        n_workers = workers_for(self_blocks);
         if (self_blocks_override < 0) { // the workers take slots of the first fill too
             const uint32_t resident = self_blocks;
             self_blocks = resident > n_workers + 64 ? resident - n_workers : 64;
-            n_workers = (total_e - self_blocks + 63) / 64;
+            n_workers = workers_for(self_blocks);
         }
         n_workers = (n_workers + 7) & ~7u; // keeps encode index == workgroup index mod 8 (XCD placement)
     }
