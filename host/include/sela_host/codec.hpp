@@ -49,7 +49,7 @@ size_t decodeFile(std::ifstream& in, std::ofstream& out);
 // few GB/s; the device codes 10 G samples/s.
 size_t encodeFile(const std::string& inPath, const std::string& outPath);
 size_t decodeFile(const std::string& inPath, const std::string& outPath);
-// Threads of that pool (before its first use; 0 = default: min(16, hardware threads / 2)).
+// Threads of that pool (before its first use; 0 = default: min(6, hardware threads / 2)).
 void setIoThreads(unsigned n);
 
 // ---- many files, all GPUs of the node ------------------------------------------------------------------

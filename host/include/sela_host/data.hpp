@@ -76,6 +76,46 @@ public:
     explicit SelaFrame(uint8_t bps) : bitsPerSample(bps) {}
 };
 
+// The RIFF view of a WAV file (reference: src/include/data/wav_chunk.hpp:7-16, wav_sub_chunk.hpp:9-33), kept so that
+// code written against file::WavFile::wavChunk compiles: the same classes and member names.  What differs is where
+// the audio lives: the data chunk's bytes are NOT copied into dataSubChunk.subChunkData (that copy is what the flat
+// design exists to avoid) -- they are file::WavFile::pcm, and dataSubChunk.samples / sampleCount point at them.
+class WavSubChunk {
+public:
+    std::string subChunkId;
+    uint32_t subChunkSize = 0;
+    std::vector<int8_t> subChunkData; // (other chunks: not kept; 'fmt ': its 16 bytes; 'data': empty, see samples)
+};
+
+class WavFormatSubChunk : public WavSubChunk {
+public:
+    int16_t audioFormat = 1;
+    uint16_t numChannels = 0;
+    uint32_t sampleRate = 0;
+    uint32_t byteRate = 0;
+    uint16_t blockAlign = 0;
+    uint16_t bitsPerSample = 16;
+};
+
+class WavDataSubChunk : public WavSubChunk {
+public:
+    uint8_t bitsPerSample = 16;
+    uint8_t channels = 0;
+    std::vector<WavFrame> wavFrames;   // filled by file::WavFile::demuxSamples()
+    const int16_t* samples = nullptr;  // the interleaved samples where they lie (file::WavFile::pcm)
+    size_t sampleCount = 0;
+};
+
+class WavChunk {
+public:
+    std::string chunkId = "RIFF";
+    uint32_t chunkSize = 0;
+    std::string format = "WAVE";
+    WavFormatSubChunk formatSubChunk;
+    WavDataSubChunk dataSubChunk;
+    std::vector<WavSubChunk> wavSubChunks;
+};
+
 class SelaHeader {
 public:
     uint8_t magicNumber[4] = { 'S', 'e', 'L', 'a' };

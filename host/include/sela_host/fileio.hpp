@@ -58,7 +58,7 @@ public:
     void submit(std::function<void()> task, bool first = false); // first: ahead of what is queued
     unsigned threads() const { return count; }
     // Threads the pool starts with (before its first use; later calls are ignored).  0 = the default:
-    // min(8, hardware threads / 2), at least 2 (reads of one file scale to about that many; writes to one file
+    // min(6, hardware threads / 2), at least 2 (reads of one file stop scaling at 4-8 threads; writes to one file
     // do not scale at all, see WriteBehind).
     static void configure(unsigned n);
 

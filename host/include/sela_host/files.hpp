@@ -28,8 +28,17 @@ public:
     uint16_t numChannels = 0;
     sela_host::PinnedBuffer<int16_t> pcm;   // interleaved, whole data chunk
     std::vector<data::WavFrame> wavFrames;  // filled by demuxSamples()
+    // The reference's view of the same file (src/include/file/wav_file.hpp:14): format fields, sizes, and the data
+    // chunk as a pointer into `pcm` (no copy).  Refreshed by the readers, the constructors and syncChunk().
+    data::WavChunk wavChunk;
+    void syncChunk();
 
     WavFile() {}
+    // (wavChunk points into pcm: copies and moves re-point it)
+    WavFile(const WavFile& o) { *this = o; }
+    WavFile(WavFile&& o) noexcept { *this = std::move(o); }
+    WavFile& operator=(const WavFile& o);
+    WavFile& operator=(WavFile&& o) noexcept;
     WavFile(uint32_t rate, uint16_t bps, uint16_t channels, std::vector<data::WavFrame>&& frames);
     WavFile(uint32_t rate, uint16_t channels, std::vector<int16_t>&& interleaved);
     WavFile(uint32_t rate, uint16_t channels, sela_host::PinnedBuffer<int16_t>&& interleaved);

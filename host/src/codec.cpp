@@ -311,6 +311,7 @@ file::SelaFile Encoder::process()
     const size_t coded = frames * kBlock * channels;
     if (wavFile.pcm.size() > coded && !readExact(ifStream, wavFile.pcm.data() + coded, (wavFile.pcm.size() - coded) * 2))
         throw data::Exception("data subChunk is shorter than its header says");
+    wavFile.syncChunk();
     file::SelaFile out(wavFile.sampleRate, wavFile.bitsPerSample, (uint8_t)channels, std::move(bytes), std::move(offsets));
     if (materializeFrames)
         out.materializeFrames();

@@ -163,7 +163,7 @@ IoPool::IoPool() : impl(new Impl)
     unsigned n = g_configured.load(std::memory_order_relaxed);
     if (n == 0) {
         const unsigned hw = std::thread::hardware_concurrency();
-        n = std::min(8u, std::max(2u, hw / 2));
+        n = std::min(6u, std::max(2u, hw / 2));
     }
     count = std::min(n, 256u);
     for (unsigned i = 0; i < count; i++)

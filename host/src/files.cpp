@@ -58,16 +58,73 @@ WavFile::WavFile(uint32_t rate, uint16_t bps, uint16_t channels, std::vector<dat
             for (size_t c = 0; c < f.samples.size(); c++)
                 pcm[at++] = (int16_t)(uint16_t)f.samples[c][i];
     }
+    syncChunk();
+    wavChunk.dataSubChunk.wavFrames = wavFrames;
 }
 
 WavFile::WavFile(uint32_t rate, uint16_t channels, std::vector<int16_t>&& interleaved)
     : sampleRate(rate), bitsPerSample(16), numChannels(channels), pcm(interleaved)
 {
+    syncChunk();
 }
 
 WavFile::WavFile(uint32_t rate, uint16_t channels, sela_host::PinnedBuffer<int16_t>&& interleaved)
     : sampleRate(rate), bitsPerSample(16), numChannels(channels), pcm(std::move(interleaved))
 {
+    syncChunk();
+}
+
+WavFile& WavFile::operator=(const WavFile& o)
+{
+    if (this != &o) {
+        samplesPerChannelPerFrame = o.samplesPerChannelPerFrame;
+        sampleRate = o.sampleRate, bitsPerSample = o.bitsPerSample, numChannels = o.numChannels;
+        pcm = o.pcm;
+        wavFrames = o.wavFrames;
+        wavChunk = o.wavChunk;
+        wavChunk.dataSubChunk.samples = pcm.data();
+    }
+    return *this;
+}
+
+WavFile& WavFile::operator=(WavFile&& o) noexcept
+{
+    if (this != &o) {
+        samplesPerChannelPerFrame = o.samplesPerChannelPerFrame;
+        sampleRate = o.sampleRate, bitsPerSample = o.bitsPerSample, numChannels = o.numChannels;
+        pcm = std::move(o.pcm);
+        wavFrames = std::move(o.wavFrames);
+        wavChunk = std::move(o.wavChunk);
+        wavChunk.dataSubChunk.samples = pcm.data();
+        o.wavChunk.dataSubChunk.samples = nullptr, o.wavChunk.dataSubChunk.sampleCount = 0;
+    }
+    return *this;
+}
+
+// wavChunk as the reference's constructor and readFromFile leave it (src/file/wav_file.cpp:9-36, 80-162), minus the
+// byte copy of the data chunk.
+void WavFile::syncChunk()
+{
+    const uint32_t dataBytes = (uint32_t)(pcm.size() * 2);
+    wavChunk.chunkId = "RIFF";
+    wavChunk.format = "WAVE";
+    wavChunk.chunkSize = 36 + dataBytes;
+    data::WavFormatSubChunk& f = wavChunk.formatSubChunk;
+    f.subChunkId = "fmt ";
+    f.subChunkSize = 16;
+    f.audioFormat = 1;
+    f.numChannels = numChannels;
+    f.sampleRate = sampleRate;
+    f.bitsPerSample = bitsPerSample;
+    f.blockAlign = (uint16_t)(numChannels * bitsPerSample / 8);
+    f.byteRate = sampleRate * f.blockAlign;
+    data::WavDataSubChunk& d = wavChunk.dataSubChunk;
+    d.subChunkId = "data";
+    d.subChunkSize = dataBytes;
+    d.bitsPerSample = (uint8_t)bitsPerSample;
+    d.channels = (uint8_t)numChannels;
+    d.samples = pcm.data();
+    d.sampleCount = pcm.size();
 }
 
 size_t WavFile::readHeader(std::ifstream& in)
@@ -121,6 +178,9 @@ size_t WavFile::readHeader(std::ifstream& in)
     if (!haveData)
         throw data::Exception("data subChunk is missing from file");
     in.seekg((std::streamoff)dataAt, std::ios::beg); // the stream stands at the first PCM byte
+    syncChunk();                                       // (format fields now; the data view when the samples are in)
+    wavChunk.chunkSize = le32(riff + 4);
+    wavChunk.dataSubChunk.subChunkSize = (uint32_t)dataBytes;
     return dataBytes;
 }
 
@@ -130,6 +190,9 @@ void WavFile::readFromFile(std::ifstream& in)
     pcm.resize(bytes / 2);
     if (!pcm.empty() && !readExact(in, pcm.data(), pcm.size() * 2)) // already interleaved little-endian int16
         throw data::Exception("data subChunk is shorter than its header says");
+    const uint32_t chunkSize = wavChunk.chunkSize;
+    syncChunk();
+    wavChunk.chunkSize = chunkSize; // (what the file's header says)
 }
 
 void WavFile::demuxSamples()
@@ -145,6 +208,8 @@ void WavFile::demuxSamples()
                 s[c][i] = src[i * numChannels + c];
         wavFrames.emplace_back((uint8_t)bitsPerSample, std::move(s));
     }
+    syncChunk();
+    wavChunk.dataSubChunk.wavFrames = wavFrames; // (where reference-side code looks for them)
 }
 
 void WavFile::writeHeader(std::ofstream& out, uint32_t rate, uint16_t channels, uint16_t bps, uint32_t dataBytes)

@@ -69,7 +69,14 @@ int main(int argc, char** argv)
         CHECK(r.numChannels == 2 && r.sampleRate == 44100 && r.bitsPerSample == 16);
         CHECK(r.pcm == pcm);
         CHECK(r.frameCount() == 2); // 100 tail samples per channel are dropped
+        // the reference's view of the file (src/include/file/wav_file.hpp:14): same member names, no copy of the samples
+        CHECK(r.wavChunk.chunkId == "RIFF" && r.wavChunk.format == "WAVE" && r.wavChunk.chunkSize == 36 + pcm.size() * 2);
+        CHECK(r.wavChunk.formatSubChunk.numChannels == 2 && r.wavChunk.formatSubChunk.sampleRate == 44100 && r.wavChunk.formatSubChunk.bitsPerSample == 16);
+        CHECK(r.wavChunk.formatSubChunk.blockAlign == 4 && r.wavChunk.formatSubChunk.byteRate == 44100 * 4 && r.wavChunk.formatSubChunk.audioFormat == 1);
+        CHECK(r.wavChunk.dataSubChunk.subChunkSize == pcm.size() * 2 && r.wavChunk.dataSubChunk.channels == 2);
+        CHECK(r.wavChunk.dataSubChunk.samples == r.pcm.data() && r.wavChunk.dataSubChunk.sampleCount == pcm.size());
         r.demuxSamples();
+        CHECK(r.wavChunk.dataSubChunk.wavFrames.size() == 2);
         CHECK(r.wavFrames.size() == 2 && r.wavFrames[1].samples[1][5] == pcm[(2048 + 5) * 2 + 1]);
     }
     // ---- WAV error paths (messages as the reference's src/file/wav_file.cpp) ---------------------------

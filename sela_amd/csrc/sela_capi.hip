@@ -57,6 +57,8 @@ struct PinnedPool {
     };
     std::mutex mu;
     std::vector<Block> live, idle;
+    size_t idle_bytes = 0;
+    static constexpr size_t kIdleCap = (size_t)1 << 30; // blocks kept for reuse beyond this are unpinned and freed, oldest first
 
     void* take(size_t bytes)
     {
@@ -69,10 +71,12 @@ struct PinnedPool {
         if (best != idle.size()) {
             b = idle[best];
             idle.erase(idle.begin() + (std::ptrdiff_t)best);
+            idle_bytes -= b.cap;
         } else {
             b.cap = (bytes + 4095) & ~(size_t)4095;
             b.ptr = nullptr;
-            b.pinned = hipHostMalloc(&b.ptr, b.cap, hipHostMallocDefault) == hipSuccess && b.ptr;
+            // (portable + mapped: one worker's kernels read and write these blocks from whichever device it is bound to)
+            b.pinned = hipHostMalloc(&b.ptr, b.cap, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && b.ptr;
             if (!b.pinned) { // no device (CPU-only container code still runs): ordinary memory
                 (void)hipGetLastError();
                 b.ptr = std::aligned_alloc(4096, b.cap);
@@ -89,7 +93,17 @@ struct PinnedPool {
         for (size_t i = 0; i < live.size(); i++)
             if (live[i].ptr == p) {
                 idle.push_back(live[i]);
+                idle_bytes += live[i].cap;
                 live.erase(live.begin() + (std::ptrdiff_t)i);
+                while (idle_bytes > kIdleCap && idle.size() > 1) { // (the block just returned stays: it is the likeliest to be asked for again)
+                    const Block old = idle.front();
+                    idle.erase(idle.begin());
+                    idle_bytes -= old.cap;
+                    if (old.pinned)
+                        (void)hipHostFree(old.ptr);
+                    else
+                        std::free(old.ptr);
+                }
                 return;
             }
     }
@@ -103,6 +117,7 @@ struct PinnedPool {
                 std::free(b.ptr);
         }
         idle.clear();
+        idle_bytes = 0;
     }
 };
 PinnedPool& pool()
@@ -147,7 +162,7 @@ struct HostBuffer {
             return hipSuccess;
         release();
         const size_t want = bytes + bytes / 4 + 4096;
-        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocPortable | hipHostMallocMapped);
         if (e == hipSuccess) {
             cap = want;
             std::memset(ptr, 0, want); // (tickets and flags the device leaves here are compared with what was there before)
@@ -455,7 +470,7 @@ void* device_view(const void* host)
 // after the other on one stream; the job's stream position passes from launch to launch in device memory
 // (enc_words).  Buffers that are not page-locked go through page-locked bounce buffers.
 constexpr uint32_t kStageWorkgroups = 8;         // of k_stage_in, four waves each with eight 16-byte loads in flight per lane (6: 0.95 ms, 16: 0.90, 24: 0.99)
-constexpr uint32_t kEncodeLaunchFrames = 1u << 16; // a feed larger than this is cut (device buffers are sized for it)
+constexpr uint32_t kEncodeLaunchFrames = 1u << 14; // a feed larger than this is cut (the device buffers -- 27 KB of workspace per stereo frame -- are sized for it)
 
 // Enqueue the launch of feed number `index` (its PCM in page-locked memory, its place in the mirror and its event are
 // in `feed`).  staged: the PCM is fetched by the staging kernel beside the launch; otherwise by the copy engine in
@@ -590,7 +605,7 @@ int job_encode_progress(sela_hip_job* job, bool wait)
 {
     const uint64_t* mirror = static_cast<const uint64_t*>(g_ctx.enc_mirror.ptr);
     while (job->feeds_final < job->feeds.size()) {
-        const EncodeFeed& f = job->feeds[job->feeds_final];
+        EncodeFeed& f = job->feeds[job->feeds_final];
         const hipError_t q = wait ? hipEventSynchronize(f.done) : hipEventQuery(f.done);
         if (q == hipErrorNotReady) {
             (void)hipGetLastError();
@@ -629,6 +644,11 @@ int job_encode_progress(sela_hip_job* job, bool wait)
         }
         if (overflow)
             return job_fail(job, fail(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes)"));
+        if (f.bounce_in) { // (a final feed is never issued again: its page-locked copy can go)
+            pool().give(f.bounce_in);
+            f.bounce_in = nullptr;
+            f.host_src = f.mapped_src = nullptr;
+        }
         job->feeds_final++;
     }
     return SELA_HIP_OK;
