@@ -196,6 +196,48 @@ int main(int argc, char** argv)
                 unlink((out + std::to_string(f)).c_str());
         }
     }
+    // ---- does the kind of page-locked memory matter to the CPU side?  fallocate + pwrite from / pread into each kind -----
+    {
+        char* pm = nullptr;
+        if (hipHostMalloc((void**)&pm, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess)
+            pm = nullptr;
+        if (pm)
+            memset(pm, 3, bytes);
+        const char* names[3] = { "ordinary", "hipHostMallocDefault", "hipHostMallocPortable|Mapped" };
+        char* mems[3] = { plain, pinned, pm };
+        for (int round = 0; round < 2; round++)
+            for (int k = 0; k < 3; k++) {
+                if (!mems[k])
+                    continue;
+                double fa = 0;
+                const double wr = med(9, [&] {
+                    unlink(out.c_str());
+                    int fd = open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+                    auto t0 = clk::now();
+                    if (fallocate(fd, 0, 0, bytes) != 0)
+                        abort();
+                    auto t1 = clk::now();
+                    for (size_t at = 0; at < bytes; at += 1 << 20)
+                        if (pwrite(fd, mems[k] + at, 1 << 20, at) != (ssize_t)(1 << 20))
+                            abort();
+                    auto t2 = clk::now();
+                    close(fd);
+                    fa = ms(t0, t1);
+                    return ms(t1, t2);
+                });
+                const double rd = med(9, [&] {
+                    int fd = open(path.c_str(), O_RDONLY);
+                    auto t0 = clk::now();
+                    par(4, bytes, 1 << 20, [&](size_t at, size_t n) { if (pread(fd, mems[k] + at, n, at) != (ssize_t)n) abort(); });
+                    auto t1 = clk::now();
+                    close(fd);
+                    return ms(t0, t1);
+                });
+                printf("%-30s pwrite over fallocated pages, 1 thread: %.2f ms (fallocate %.2f) | pread by 4 threads: %.2f ms\n", names[k], wr, fa, rd);
+            }
+        if (pm)
+            (void)hipHostFree(pm);
+    }
     // ---- pages first (fallocate), then copies through a shared mapping by several threads (minor faults only) -----------
     for (int populate = 0; populate < 2; populate++)
         for (int threads : { 1, 2, 4, 8, 16 }) {
