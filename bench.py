@@ -240,8 +240,12 @@ class Bench:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
-        torch.cuda.set_device(self.local_rank)
+        # SELA_BENCH_RANKS_SHARE_GPU=1 (tests): every rank of an N > 1 run uses GPU 0 and the ranks talk over gloo (RCCL
+        # refuses two ranks on one device) -- the whole multi-rank logic of this file on a one-GPU box; not a measurement.
+        self.share_gpu = os.environ.get("SELA_BENCH_RANKS_SHARE_GPU") == "1"
+        torch.cuda.set_device(0 if self.share_gpu else self.local_rank)
         self.dist = None
+        self.coll_device = "cuda"  # where the tensors of the collectives live
         if self.world > 1 or os.environ.get("SELA_BENCH_FORCE_EXCHANGE") == "1":  # (the override runs the N>1 code path on one GPU)
             import torch.distributed as dist
 
@@ -249,7 +253,11 @@ class Bench:
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", str(self.rank))
             os.environ.setdefault("WORLD_SIZE", str(self.world))
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))  # nccl == RCCL on ROCm
+            if self.share_gpu:
+                dist.init_process_group("gloo")
+                self.coll_device = "cpu"
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))  # nccl == RCCL on ROCm
             self.dist = dist
         self.lib = capi.lib()  # raises if the HIP library is missing: there is no CPU fallback
         self.exchange = torch.cuda.Stream() if self.dist is not None else None
@@ -274,7 +282,7 @@ class Bench:
             self.barrier()
             elapsed = time.perf_counter() - t0
             if dist is not None:
-                t = torch.tensor([elapsed, total + elapsed], dtype=torch.float64, device="cuda")
+                t = torch.tensor([elapsed, total + elapsed], dtype=torch.float64, device=self.coll_device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the same numbers -- and the same loop exit -- on every rank
                 elapsed, agreed_total = float(t[0].item()), float(t[1].item())
             else:
@@ -383,7 +391,12 @@ class ChainJob:
                             for lj in waited:  # (the sizes of the earlier batches were written on the other lanes' streams)
                                 b.exchange.wait_stream(self.lanes[lj]["stream"])
                             with torch.cuda.stream(b.exchange):
-                                b.dist.all_gather_into_tensor(ex["all"], ex["local"])
+                                if b.coll_device == "cuda":
+                                    b.dist.all_gather_into_tensor(ex["all"], ex["local"])
+                                else:  # (the test mode: ranks on one GPU, gloo -- through host memory, synchronously)
+                                    gathered = torch.empty(ex["all"].numel(), dtype=torch.int64)
+                                    b.dist.all_gather_into_tensor(gathered, ex["local"].cpu())
+                                    ex["all"].copy_(gathered)
                                 ex["done"] = torch.cuda.Event()
                                 ex["done"].record(b.exchange)
                             self.last_set = ex
@@ -537,7 +550,7 @@ def workload_track(bench: Bench, steps: int, warmup: int):
         mine = sizes[bench.rank * frames: (bench.rank + 1) * frames]
         layout_ok = layout_ok and bool(np.array_equal(mine, np.diff(out_offsets.cpu().numpy().view(np.uint64)).astype("<u8")))
         assert layout_ok, "the gathered frame sizes differ from the reference's file sizes / this rank's own offsets"
-    t = torch.tensor([m["lossy"], m["bytes"]], dtype=torch.int64, device="cuda")
+    t = torch.tensor([m["lossy"], m["bytes"]], dtype=torch.int64, device=bench.coll_device)
     if bench.dist is not None:
         bench.dist.all_reduce(t)
     samples = n_total * 2048
@@ -586,7 +599,7 @@ def workload_album(bench: Bench, steps: int, warmup: int):
                            f"{int((sizes == 0).sum())} of {len(sizes)} gathered sizes are zero; steps done {job.steps_done}")
         layout_ok = golden.get("frame_sizes_sha256") in (None, hashlib.sha256(sizes.tobytes()).hexdigest())
         assert layout_ok, "the gathered frame-size layout differs from the one-GPU (reference) layout"
-    t = torch.tensor([m["lossy"], m["bytes"]], dtype=torch.int64, device="cuda")
+    t = torch.tensor([m["lossy"], m["bytes"]], dtype=torch.int64, device=bench.coll_device)
     if bench.dist is not None:
         bench.dist.all_reduce(t)
     samples = n_total * 2048
@@ -627,7 +640,7 @@ def workload_decode10k(bench: Bench, steps: int, warmup: int):
         ref_back, _ = impl.decode_frames(f_host, o_host, CHANNELS, threads=os.cpu_count() or 1)
         exact = bool(np.array_equal(ref_back, m["last"][2].cpu().numpy()))
         assert exact, "decode10k: GPU decode differs from the CPU decoder's"
-    t = torch.tensor([m["lossy"]], dtype=torch.int64, device="cuda")
+    t = torch.tensor([m["lossy"]], dtype=torch.int64, device=bench.coll_device)
     if bench.dist is not None:
         bench.dist.all_reduce(t)
     samples = n_total * 2048

@@ -1026,7 +1026,10 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames_wide(const 
             const uint32_t n_frame_words = (uint32_t)((fbytes - hd.p - 4) / 4);
             flags |= parse_stream_serial(gw, 24, 24 + 32 * hd.cw, n_frame_words, hd.ck, hd.order, coef_values(scratch), lane);
             flags |= parse_stream_serial(gw, 32 * (hd.cw + 2), 32 * (hd.cw + 2 + hd.rw), n_frame_words, hd.rk, (uint32_t)kBlock, wres, lane);
-            __threadfence(); // lane 0's stores to the workspace are read back by every lane
+            // lane 0's stores to the workspace are read back by every lane of this wave: they have left the CU, and nothing
+            // older is served from its vector cache (not __threadfence(): its release half writes back the whole L2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             ws_c = wres;
         }
         SynthTables* const tables = &scratch->t;

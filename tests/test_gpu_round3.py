@@ -129,6 +129,32 @@ def test_bench_relaunches_itself_for_more_than_one_gpu():
         assert not r.stdout.strip().startswith("{")
 
 
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """The multi-rank logic of bench.py on a one-GPU box: two ranks under torch.distributed.run, both on GPU 0, talking
+    over gloo (SELA_BENCH_RANKS_SHARE_GPU=1; RCCL refuses two ranks on one device).  Rank r's track (album track 3 r)
+    against the reference's digests on every rank, the gathered layout of the two tracks, the album cut in two contiguous
+    ranges (inside track 43) with its layout against the reference's, 10,000 frames decoded in two halves, one JSON line
+    from rank 0 with n_gpus = 2.  Not a measurement: the two ranks share the device and the exchange goes through host
+    memory."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SELA_BENCH_RANKS_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-host-legs", "--extra-steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([t for t in r.stdout.strip().splitlines() if t.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["frames_total"] == 2 * 3875
+    assert line["layout_matches_reference"] is True and line["digests_match_reference"] is True
+    assert line["timed_outputs"]["equal_to_serial_step"] is True and line["cpu_baseline"]["bit_exact_vs_gpu"] is True
+    assert line["album"]["layout_matches_reference"] is True and line["album"]["config"]["frames_rank0"] in (274682, 274683)
+    assert line["album"]["roundtrip_lossy_frames"] == 39  # (the reference's own lossy frames on the album, summed over the ranks)
+    assert line["decode10k"]["config"]["frames_rank0"] == 5000 and line["decode10k"]["bit_exact_vs_cpu_decode"] is True
+
+
 @pytest.mark.parametrize("channels,n_frames", [(9, 6), (17, 3), (32, 5), (64, 3), (255, 2)])
 def test_wide_frames_encode_and_decode(gpu, channels, n_frames):
     """More than eight channels -- up to the 255 the .sela header's field carries -- through k_decode_frames_wide:

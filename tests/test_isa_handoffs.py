@@ -31,10 +31,21 @@ def functions(tmp_path_factory):
     if not os.path.exists(LIB) or not all(os.path.exists(t) for t in tools):
         pytest.skip("no built library or no LLVM tools")
     d = tmp_path_factory.mktemp("isa")
-    fat, co = str(d / "fat.bin"), str(d / "dev.co")
+    fat = str(d / "fat.bin")
     subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, LIB])
-    subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    text = subprocess.check_output([tools[2], "-d", co], text=True)
+    # one offload bundle per translation unit that has kernels (sela_encode.hip, sela_decode.hip), back to back
+    blob = open(fat, "rb").read()
+    magic, starts, at = b"__CLANG_OFFLOAD_BUNDLE__", [], 0
+    while (at := blob.find(magic, at)) >= 0:
+        starts.append(at)
+        at += 1
+    text = ""
+    for k, begin in enumerate(starts):
+        part, co = str(d / f"bundle{k}.bin"), str(d / f"dev{k}.co")
+        with open(part, "wb") as f:
+            f.write(blob[begin: starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + part, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        text += subprocess.check_output([tools[2], "-d", co], text=True)
     out, cur, base = {}, None, {}
     for line in text.splitlines():
         h = HEAD.match(line)
@@ -130,6 +141,23 @@ def test_await_frame_and_look_back_read_past_the_l2(functions):
     assert len(cells) >= 5, "the look-back cells are not read past the L2"
     marks = [x for x in g if x[1] in ("global_store_dwordx2", "flat_store_dwordx2") and "sc1" in x[2]]
     assert len(marks) >= 5, "the look-back cells are not stored through the L2"
+
+
+def test_wide_decoder_hands_its_samples_over_inside_the_cu(functions):
+    """k_decode_frames_wide: the raw samples a wave left in the output are read by the other waves of the workgroup in
+    the second pass.  Same CU, same L2: the stores are waited for (written-out s_waitcnt vmcnt(0)), then the barrier,
+    then the CU's vector cache is invalidated (buffer_inv sc1) -- and no release fence that would write back the L2."""
+    f = _one(functions, "k_decode_frames_wide")
+    barriers = [i for i, x in enumerate(f) if x[1] == "s_barrier"]
+    assert barriers
+    ok = False
+    for b in barriers:
+        before = f[max(0, b - 6): b]
+        after = f[b + 1: b + 8]
+        if any(_waits_for_stores(x) for x in before) and any(x[1] == "buffer_inv" and "sc1" in x[2] for x in after):
+            ok = True
+    assert ok, "no vmcnt(0) -> s_barrier -> buffer_inv sc1 sequence in the wide decoder"
+    assert not any(x[1] == "buffer_wbl2" for x in f), "an L2 write-back in the wide decoder"
 
 
 def test_stamp_tool_still_fits_the_sources(tmp_path):
