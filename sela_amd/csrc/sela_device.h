@@ -201,11 +201,16 @@ __device__ __forceinline__ int64_t q35_trunc(double v, uint32_t& flags)
 // Reflection coefficients kd[0..order) (LDS) -> Q35 predictor a[0..order] (LDS, int64).
 // src/lpc/linear_predictor.cpp:30-61.  Stage i turns every t[m], m < i, into t[m] + k_i * t[i-1-m]
 // (the reference's pairwise update and its odd-i middle element, written per element from the OLD
-// values) and appends t[i] = k_i.  The whole recursion stays in registers: lane m (+64 in a second
-// register) holds t[m] and, beside it, the mirrored element u[m] = t[i-1-m] it is about to meet.
-// The mirror of the NEW array is u'[m] = t'[i-m] = u[m-1] + k_i * t[m-1], i.e. the same
-// multiply-add with the roles swapped, moved up one lane, and u'[0] = k_i.  Elements beyond the
-// current length are kept at +0.0 (0 + k*0 = +0 under round-to-nearest), so no lane is masked.
+// values) and appends t[i] = k_i.  The whole recursion stays in registers, on the MONIC polynomial
+// A = [1, t[0], t[1], ...]: lane m (+64 in a second register) holds A[m] and, beside it, the mirrored
+// element R[m] = A[i+1-m] it is about to meet.  With the leading 1 in the arrays every element obeys ONE rule,
+//     A'[m] = A[m] + k_i * R[m]        (m = i+1:  0 + k_i * 1 = k_i, the appended coefficient;  m = 0:  1 + k_i * 0)
+//     R'[m] = R[m-1] + k_i * A[m-1]    (the same multiply-add with the roles swapped, moved up one lane; R'[0] = 0)
+// so a stage is one scalar read of k_i, four FP64 operations and one lane shift -- no lane is selected or masked
+// (round 2 kept t[] without its leading 1 and selected k_i into two lanes per stage: 15 instructions instead of 8).
+// Every A[m] sees the reference's operations on the reference's operands (t + k * t', the product rounded
+// first); 0 + k * 1 is k for every finite k (a -0 becomes +0: it can only ever meet other zeros, and
+// (int64)(2^35 * -t) is 0 for both).  Elements beyond the current degree are +0.0 (0 + k*0 = +0).
 __device__ __forceinline__ double read_lane(double v, int src_lane /* wave-uniform */)
 {
     const uint64_t x = __builtin_bit_cast(uint64_t, v);
@@ -221,38 +226,46 @@ __device__ __forceinline__ double wave_shr1_zero(double v)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), 0x138, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
+// lane l <- lane l-1 ; lane 0 receives `fill`
+__device__ __forceinline__ double wave_shr1(double fill, double v)
+{
+    const uint64_t f = __builtin_bit_cast(uint64_t, fill), x = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)f, (int)(uint32_t)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(f >> 32), (int)(uint32_t)(x >> 32), 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
 
 __device__ inline void step_up(const double* kd, int64_t* a, int order, int lane, uint32_t& flags)
 {
     const double k_lo = lane < order ? kd[lane] : 0.0;
     const double k_hi = lane + 64 < order ? kd[lane + 64] : 0.0;
-    double t_lo = 0.0, u_lo = 0.0, t_hi = 0.0, u_hi = 0.0;
-    const int n_lo = order < 64 ? order : 64;
-    for (int i = 0; i < n_lo; i++) { // everything still fits the first register
+    double t_lo = lane == 0 ? 1.0 : 0.0, r_lo = lane == 1 ? 1.0 : 0.0; // degree 0: A = [1], R[m] = A[1 - m]
+    double t_hi = 0.0, r_hi = 0.0;
+    // while the mirror of the new degree (i + 2 elements) fits lanes 0..63, the second register is all zeros
+    const int n_lo = order < 62 ? order : 62;
+    for (int i = 0; i < n_lo; i++) {
         const double ki = read_lane(k_lo, i);
-        const double tn = t_lo + ki * u_lo;
-        const double un = u_lo + ki * t_lo;
-        t_lo = lane == i ? ki : tn;
-        const double us = wave_shr1_zero(un);
-        u_lo = lane == 0 ? ki : us;
+        const double tn = t_lo + ki * r_lo;
+        const double rn = r_lo + ki * t_lo;
+        t_lo = tn;
+        r_lo = wave_shr1_zero(rn);
     }
-    for (int i = 64; i < order; i++) {
-        const double ki = read_lane(k_hi, i - 64);
-        const double tn_lo = t_lo + ki * u_lo, un_lo = u_lo + ki * t_lo;
-        const double tn_hi = t_hi + ki * u_hi, un_hi = u_hi + ki * t_hi;
+    for (int i = 62; i < order; i++) {
+        const double ki = i < 64 ? read_lane(k_lo, i) : read_lane(k_hi, i - 64);
+        const double tn_lo = t_lo + ki * r_lo, rn_lo = r_lo + ki * t_lo;
+        const double tn_hi = t_hi + ki * r_hi, rn_hi = r_hi + ki * t_hi;
         t_lo = tn_lo;
-        t_hi = lane + 64 == i ? ki : tn_hi;
-        const double carry = read_lane(un_lo, 63);
-        const double us_lo = wave_shr1_zero(un_lo), us_hi = wave_shr1_zero(un_hi);
-        u_lo = lane == 0 ? ki : us_lo;
-        u_hi = lane == 0 ? carry : us_hi;
+        t_hi = tn_hi;
+        const double carry = read_lane(rn_lo, 63); // crosses from the first register into the second
+        r_lo = wave_shr1_zero(rn_lo);
+        r_hi = wave_shr1(carry, rn_hi);
     }
     if (lane == 0)
         a[0] = 0;
-    if (lane < order)
-        a[lane + 1] = q35_trunc(-t_lo, flags);
-    if (lane + 64 < order)
-        a[lane + 65] = q35_trunc(-t_hi, flags);
+    else if (lane <= order)
+        a[lane] = q35_trunc(-t_lo, flags);
+    if (lane + 64 <= order)
+        a[lane + 64] = q35_trunc(-t_hi, flags);
     wave_sync();
 }
 
