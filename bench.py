@@ -259,6 +259,11 @@ class Bench:
             else:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))  # nccl == RCCL on ROCm
             self.dist = dist
+            # RCCL prints its version banner through C stdio when the communicator comes up; get it out NOW, on every rank,
+            # so that nothing but rank 0's JSON line is left to appear at the end of stdout
+            dist.barrier()
+            torch.cuda.synchronize()
+            _flush_c_stdio()
         self.lib = capi.lib()  # raises if the HIP library is missing: there is no CPU fallback
         self.exchange = torch.cuda.Stream() if self.dist is not None else None
         self.n_lanes = max(1, args.lanes)

@@ -57,6 +57,7 @@ public:
     static IoPool& instance();
     void submit(std::function<void()> task, bool first = false); // first: ahead of what is queued
     unsigned threads() const { return count; }
+    void grow(unsigned atLeast); // more threads (never fewer): the batch verbs ask for a few per GPU worker
     // Threads the pool starts with (before its first use; later calls are ignored).  0 = the default:
     // min(6, hardware threads / 2), at least 2 (reads of one file stop scaling at 4-8 threads; writes to one file
     // do not scale at all, see WriteBehind).

@@ -725,6 +725,7 @@ void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
     if (inputs.size() != outputs.size())
         throw data::Exception("encodeFiles: one output path per input");
     const std::vector<int> devs = workerDevices();
+    sela_host::IoPool::instance().grow((unsigned)(3 * devs.size())); // (a write strand and two reads per GPU worker)
     std::vector<WavInfo> info(inputs.size());
     for (size_t i = 0; i < inputs.size(); i++) {
         info[i] = probeWav(inputs[i]);
@@ -861,6 +862,7 @@ void decodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
     if (inputs.size() != outputs.size())
         throw data::Exception("decodeFiles: one output path per input");
     const std::vector<int> devs = workerDevices();
+    sela_host::IoPool::instance().grow((unsigned)(3 * devs.size()));
     std::vector<SelaInfo> info(inputs.size());
     for (size_t i = 0; i < inputs.size(); i++) {
         info[i] = probeSela(inputs[i]);

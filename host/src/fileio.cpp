@@ -182,6 +182,16 @@ IoPool::~IoPool()
     delete impl;
 }
 
+void IoPool::grow(unsigned atLeast)
+{
+    atLeast = std::min(atLeast, 256u);
+    std::lock_guard<std::mutex> lock(impl->mu);
+    while (count < atLeast) {
+        impl->workers.emplace_back([this] { run(); });
+        count++;
+    }
+}
+
 IoPool& IoPool::instance()
 {
     static IoPool pool;
