@@ -3,6 +3,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 from oracle_lib import oracle
 from sela_amd.synth import synth_frames, synth_pcm
@@ -232,3 +233,22 @@ def test_album_ranges_tile_the_album():
                 assert not covered[p.job_frame: p.job_frame + p.n_frames].any()
                 covered[p.job_frame: p.job_frame + p.n_frames] = True
         assert covered.all()
+
+
+def test_bench_with_more_than_one_gpu_and_no_launcher_starts_its_own():
+    """`python bench.py --gpus 2` without WORLD_SIZE used to die on an assertion before anything ran; now it starts
+    torch.distributed.run itself.  Without GPUs the ranks fail -- loudly, with a non-zero exit code and no JSON line --
+    but they ARE started (the failure is torch's, about the device, not bench.py's about WORLD_SIZE)."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extra-legs", "--no-host-legs",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs here: the GPU tests run the real thing")
+    assert r.returncode != 0
+    assert "AssertionError: --gpus" not in r.stderr
+    assert not [t for t in r.stdout.splitlines() if t.startswith("{")]
