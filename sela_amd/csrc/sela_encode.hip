@@ -1587,9 +1587,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 // plan: stereo decision + frame sizes + exclusive scan (one workgroup of 1024)
 // choice[f] = 1 when the second channel of an exactly-stereo frame is stored as the difference
 // signal (src/frame/frame_encoder.cpp:64-72).
-constexpr int kPlanThreads = 1024;
-constexpr int kPlanLdsFrames = 12288; // frame sizes staged in LDS up to this batch size (48 KB)
+constexpr int kPlanThreadsBig = 1024, kPlanFramesBig = 12288;  // large batches: 57 KB of LDS, 10 us per tile of 12,288 frames
+constexpr int kPlanThreadsSmall = 256, kPlanFramesSmall = 4096; // up to 4096 frames: four waves and 18 KB -- a workgroup that finds a
+                                                                // place between another stream's resident blocks at once (the big one
+                                                                // waited 80-160 us for sixteen waves and 57 KB on ONE CU, timeline_two_lanes.txt)
 
+template <int kPlanThreads, int kPlanLdsFrames>
 __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
     uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* __restrict__ frame_offsets,
     uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status)
@@ -1853,8 +1856,12 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         (void)hipEventRecord(ev[1], stream);
     if (!link) {
         uint8_t* const choice = reinterpret_cast<uint8_t*>(group_state); // (the look-back cells' space: five bytes per frame, unused on this path)
-        hipLaunchKernelGGL(k_plan_frames, dim3(1), dim3(kPlanThreads), 0, stream, meta, n_frames, channels, n_sig, frames_cap, d_frame_offsets,
-            choice, d_status);
+        if (n_frames <= (uint32_t)kPlanFramesSmall)
+            hipLaunchKernelGGL((k_plan_frames<kPlanThreadsSmall, kPlanFramesSmall>), dim3(1), dim3(kPlanThreadsSmall), 0, stream, meta, n_frames, channels, n_sig,
+                frames_cap, d_frame_offsets, choice, d_status);
+        else
+            hipLaunchKernelGGL((k_plan_frames<kPlanThreadsBig, kPlanFramesBig>), dim3(1), dim3(kPlanThreadsBig), 0, stream, meta, n_frames, channels, n_sig,
+                frames_cap, d_frame_offsets, choice, d_status);
         if (ev)
             (void)hipEventRecord(ev[2], stream);
         hipLaunchKernelGGL(k_assemble_frames, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets, n_frames, channels,
