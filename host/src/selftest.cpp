@@ -10,6 +10,7 @@
 
 #include "sela_hip.h"
 #include "sela_host/fileio.hpp"
+#include "sela_host/codec.hpp"
 #include "sela_host/files.hpp"
 #include "sela_host/frame.hpp"
 
@@ -227,6 +228,72 @@ int main(int argc, char** argv)
                 threw = true;
             }
             CHECK(threw);
+        } catch (const data::Exception& e) {
+            std::fprintf(stderr, "FAIL exception: %s\n", e.exceptionMessage.c_str());
+            failures++;
+        }
+        // ---- the reference's file-level classes (src/include/sela/encoder.hpp:9-22, decoder.hpp:9-22) and the three forms of
+        // the file verbs -- objects, streams, paths -- write the same bytes
+        try {
+            const uint32_t ch = 2;
+            std::vector<int16_t> pcm((size_t)ch * (2048 * 2300 + 777)); // two and a bit read pieces, a tail that is dropped
+            uint32_t x = 777u;
+            int v[2] = { 0, 0 };
+            for (size_t i = 0; i < pcm.size(); i++) {
+                x = x * 1664525u + 1013904223u;
+                int& smp = v[i & 1];
+                smp += (int)((x >> 21) & 511) - 256;
+                smp = smp > 30000 ? 30000 : (smp < -30000 ? -30000 : smp);
+                pcm[i] = (int16_t)smp;
+            }
+            const std::string wav = dir + "/forms.wav";
+            {
+                file::WavFile w(48000, (uint16_t)ch, std::vector<int16_t>(pcm));
+                std::ofstream out(wav, std::ios::binary);
+                w.writeToFile(out);
+            }
+            auto slurp = [](const std::string& path) {
+                std::ifstream in(path, std::ios::binary);
+                return std::string((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+            };
+            // objects: sela::Encoder(ifstream).process() + SelaFile::writeToFile, as src/main.cpp:29-41 does
+            {
+                std::ifstream in(wav, std::ios::binary);
+                sela::Encoder enc(in);
+                file::SelaFile sf = enc.process();
+                CHECK(sf.selaHeader.numFrames == 2300 && sf.selaFrames.size() == 2300 && sf.selaHeader.sampleRate == 48000);
+                std::ofstream out(dir + "/forms_obj.sela", std::ios::binary);
+                sf.writeToFile(out);
+            }
+            { // streams
+                std::ifstream in(wav, std::ios::binary);
+                std::ofstream out(dir + "/forms_stream.sela", std::ios::binary);
+                CHECK(sela::encodeFile(in, out) == 2300);
+            }
+            CHECK(sela::encodeFile(wav, dir + "/forms_path.sela") == 2300); // paths
+            const std::string a = slurp(dir + "/forms_obj.sela"), b = slurp(dir + "/forms_stream.sela"), c = slurp(dir + "/forms_path.sela");
+            CHECK(a.size() > 15 && a == b && a == c);
+            {
+                std::ifstream in(dir + "/forms_obj.sela", std::ios::binary);
+                sela::Decoder dec(in);
+                file::WavFile wf = dec.process();
+                CHECK(wf.numChannels == ch && wf.sampleRate == 48000 && wf.frameCount() == 2300 && wf.wavFrames.size() == 2300);
+                CHECK(wf.wavChunk.formatSubChunk.numChannels == ch && wf.wavChunk.dataSubChunk.samples == wf.pcm.data());
+                std::ofstream out(dir + "/forms_obj.wav", std::ios::binary);
+                wf.writeToFile(out);
+            }
+            {
+                std::ifstream in(dir + "/forms_obj.sela", std::ios::binary);
+                std::ofstream out(dir + "/forms_stream.wav", std::ios::binary);
+                CHECK(sela::decodeFile(in, out) == 2300);
+            }
+            CHECK(sela::decodeFile(dir + "/forms_obj.sela", dir + "/forms_path.wav") == 2300);
+            const std::string wa = slurp(dir + "/forms_obj.wav"), wb = slurp(dir + "/forms_stream.wav"), wc = slurp(dir + "/forms_path.wav");
+            CHECK(wa.size() == 44 + (size_t)2300 * 2048 * ch * 2 && wa == wb && wa == wc);
+            size_t differing = 0; // (the codec is the reference's: off by one in a handful of frames at most)
+            for (size_t i = 0; i < (size_t)2300 * 2048 * ch; i++)
+                differing += std::memcmp(&wa[44 + 2 * i], &pcm[i], 2) != 0;
+            CHECK(differing < 4096 * 4);
         } catch (const data::Exception& e) {
             std::fprintf(stderr, "FAIL exception: %s\n", e.exceptionMessage.c_str());
             failures++;

@@ -406,3 +406,70 @@ def test_batch_verbs_small_tracks_in_one_job_and_three_workers(tmp_path):
     assert r.returncode == 0, r.stderr
     assert (cutdir / "cut.wav").read_bytes() == (tmp_path / "cut1.wav").read_bytes()
     assert len((tmp_path / "cut1.wav").read_bytes()) == 44 + 120 * 2048 * 2 * 2
+
+
+@pytest.mark.parametrize("channels,pinned_io", [(2, True), (2, False), (1, True), (5, False)])
+def test_streaming_jobs_with_random_feeds(gpu, channels, pinned_io):
+    """Encode and decode jobs fed in pieces of random sizes (1 frame to 1500, sixteen jobs each), from page-locked and from
+    ordinary memory, progress polled with empty feeds in between: whatever is reported final is final and equal to the
+    oracle's, the totals are the oracle's."""
+    from sela_amd import capi
+
+    lib = capi.lib()
+    o = oracle()
+    rng = np.random.default_rng(100 + channels + 10 * pinned_io)
+    n_max = 2600 if channels <= 2 else 700
+    pool = synth_frames(n_max, channels, 200 + channels)
+    ref_frames, ref_offsets, _ = o.encode_frames(pool, threads=os.cpu_count() or 1)
+    ref_back, _ = o.decode_frames(ref_frames, ref_offsets, channels, threads=os.cpu_count() or 1)
+    frame_bytes = 2048 * channels * 2
+
+    def buffer(nbytes):
+        if pinned_io:
+            p = lib.sela_hip_host_alloc(max(nbytes, 1))
+            return p, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),))
+        a = np.zeros(max(nbytes, 1), np.uint8)
+        return a.ctypes.data, a
+
+    for _ in range(16):
+        n = int(rng.integers(1, n_max + 1))
+        start = int(rng.integers(0, n_max - n + 1))
+        want_offs = ref_offsets[start: start + n + 1] - ref_offsets[start]
+        want = ref_frames[int(ref_offsets[start]): int(ref_offsets[start + n])]
+        p_pcm, a_pcm = buffer(n * frame_bytes)
+        a_pcm[: n * frame_bytes] = pool[start: start + n].reshape(-1).view(np.uint8)
+        cap = int(lib.sela_hip_encode_bound_bytes(n, channels))
+        p_out, a_out = buffer(cap)
+        offs = np.zeros(n + 1, np.uint64)
+        job, ff, bf = C.c_void_p(), C.c_uint32(0), C.c_uint64(0)
+        capi.check(lib.sela_hip_encode_begin(C.byref(job), channels, n, p_out, cap, offs.ctypes.data))
+        fed = 0
+        while fed < n:
+            nf = min(int(rng.choice([1, 2, 7, 64, 300, 1024, 1500])), n - fed)
+            capi.check(lib.sela_hip_encode_feed(job, p_pcm + fed * frame_bytes, nf, C.byref(ff), C.byref(bf)))
+            fed += nf
+            if rng.random() < 0.5:
+                capi.check(lib.sela_hip_encode_feed(job, p_pcm, 0, C.byref(ff), C.byref(bf)))  # (only reports)
+            assert ff.value <= fed and bf.value == int(want_offs[ff.value])
+            assert np.array_equal(a_out[: bf.value], want[: bf.value])
+        capi.check(lib.sela_hip_encode_end(job, C.byref(ff), C.byref(bf)))
+        assert ff.value == n and bf.value == len(want)
+        assert np.array_equal(offs, want_offs) and np.array_equal(a_out[: bf.value], want)
+        # ... and back
+        p_back, a_back = buffer(n * frame_bytes)
+        want_pcm = ref_back[start: start + n].reshape(-1).view(np.uint8)
+        job = C.c_void_p()
+        capi.check(lib.sela_hip_decode_begin(C.byref(job), channels, n, p_back))
+        fed = 0
+        while fed < n:
+            nf = min(int(rng.choice([1, 3, 50, 700, 1024, 1500])), n - fed)
+            piece = np.ascontiguousarray(offs[fed: fed + nf + 1])
+            capi.check(lib.sela_hip_decode_feed(job, p_out, piece.ctypes.data, nf, C.byref(ff)))
+            fed += nf
+            assert ff.value <= fed
+            assert np.array_equal(a_back[: ff.value * frame_bytes], want_pcm[: ff.value * frame_bytes])
+        capi.check(lib.sela_hip_decode_end(job, C.byref(ff)))
+        assert ff.value == n and np.array_equal(a_back[: n * frame_bytes], want_pcm)
+        if pinned_io:
+            for p in (p_pcm, p_out, p_back):
+                lib.sela_hip_host_free(p)
