@@ -6,6 +6,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -707,6 +708,35 @@ struct SharedTracks {
     }
 };
 
+// An output file whose last ranges are still being written behind a worker's back while the worker reads and codes its next
+// piece: the file, the page-locked buffer the bytes come from, and the strand that writes them.  A worker keeps two of
+// these in flight (writes to DIFFERENT files run side by side, section 5.5 of DESIGN.md) and waits for the oldest.
+template <typename T>
+struct PendingOutput {
+    sela_host::PosixFile out;
+    sela_host::PinnedBuffer<T> data;
+    std::unique_ptr<sela_host::WriteBehind> behind;
+    bool cut = false;   // the file ends behind these bytes (allocated from an estimate)
+    size_t cutTo = 0;
+    void finish()
+    {
+        if (cut)
+            behind->finish(&cutTo);
+        else
+            behind->finish();
+    }
+};
+constexpr size_t kOutputsInFlight = 2;
+
+template <typename T>
+void settle(std::deque<std::unique_ptr<PendingOutput<T>>>& pending, size_t keep)
+{
+    while (pending.size() > keep) {
+        pending.front()->finish();
+        pending.pop_front();
+    }
+}
+
 // the index of every piece within its track, in (worker, piece) order
 std::vector<std::vector<size_t>> pieceIndexInTrack(const std::vector<std::vector<Piece>>& pieces, size_t tracks, std::vector<size_t>& piecesOfTrack)
 {
@@ -768,6 +798,7 @@ void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
                         sela_host::PinnedBuffer<uint8_t> bytes;
                     };
                     std::vector<Deferred> deferred;
+                    std::deque<std::unique_ptr<PendingOutput<uint8_t>>> pending;
                     sela_host::PinnedBuffer<int16_t> pcm;
                     for (size_t p0 = 0; p0 < mine.size();) {
                         size_t p1 = p0 + 1, runFrames = mine[p0].n;
@@ -780,15 +811,17 @@ void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
                             const size_t member = members[pc.track];
                             const sela_host::PosixFile in = sela_host::PosixFile::openForRead(inputs[member]);
                             if (pc.first == 0) {
-                                const sela_host::PosixFile out = sela_host::PosixFile::openForWrite(outputs[member]);
-                                sela_host::WriteBehind behind(out, 15, kIoSubBytes, expectedSelaBytes(info[member]));
-                                encodeRange(in, info[member], 0, pc.n, pcm, bytes, offsets, [&](const uint8_t* b, size_t n) { behind.drain(b, n); });
-                                if (pc.n == info[member].frames) {
-                                    const size_t total = bytes.size();
-                                    behind.finish(&total); // (the whole track: the file ends here)
-                                } else
-                                    behind.finish();
-                                shared.publish(pc.track, indexInTrack[w][p0], bytes.size());
+                                // (the last writes of this file go on while the next piece is read and coded)
+                                std::unique_ptr<PendingOutput<uint8_t>> po(new PendingOutput<uint8_t>);
+                                po->out = sela_host::PosixFile::openForWrite(outputs[member]);
+                                po->behind.reset(new sela_host::WriteBehind(po->out, 15, kIoSubBytes, expectedSelaBytes(info[member])));
+                                sela_host::WriteBehind* const behind = po->behind.get();
+                                encodeRange(in, info[member], 0, pc.n, pcm, po->data, offsets, [behind](const uint8_t* b, size_t n) { behind->drain(b, n); });
+                                po->cut = pc.n == info[member].frames; // (the whole track: the file ends here)
+                                po->cutTo = po->data.size();
+                                shared.publish(pc.track, indexInTrack[w][p0], po->data.size());
+                                pending.push_back(std::move(po));
+                                settle(pending, kOutputsInFlight);
                             } else {
                                 encodeRange(in, info[member], pc.first, pc.n, pcm, bytes, offsets, [](const uint8_t*, size_t) {});
                                 shared.publish(pc.track, indexInTrack[w][p0], bytes.size());
@@ -836,6 +869,7 @@ void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
                         }
                         p0 = p1;
                     }
+                    settle(pending, 0);
                     for (Deferred& d : deferred) { // (the pieces before these belong to workers that do not wait for anybody)
                         const size_t at = shared.before(d.track, d.piece);
                         const sela_host::PosixFile out = sela_host::PosixFile::openForWrite(outputs[members[d.track]]);
@@ -890,32 +924,38 @@ void decodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
         std::mutex foundMutex;
         std::vector<size_t> found(members.size(), (size_t)-1); // frames a track really holds, where a worker saw its stream end early
         runOnDevices(pieces, devs, [&](size_t, const std::vector<Piece>& mine) {
-            sela_host::PinnedBuffer<int16_t> pcm;
+            std::deque<std::unique_ptr<PendingOutput<int16_t>>> pending;
             for (const Piece& pc : mine) {
                 // output offsets are frame x 2048 x channels x 2: nothing to agree on with the other workers.  A piece that
                 // starts inside a file walks the frame headers before it (the bytes in front are read, not decoded).
                 const size_t member = members[pc.track];
                 const sela_host::PosixFile in = sela_host::PosixFile::openForRead(inputs[member]);
-                const sela_host::PosixFile out = sela_host::PosixFile::openForWrite(outputs[member]);
+                std::unique_ptr<PendingOutput<int16_t>> po(new PendingOutput<int16_t>);
+                po->out = sela_host::PosixFile::openForWrite(outputs[member]);
                 file::SelaFile sela;
                 sela.selaHeader = info[member].header;
                 sela.frameBytes.resize(info[member].payload);
                 sela_host::ReadAhead ahead(in, sela.frameBytes.data(), 15, info[member].payload, kIoSubBytes, kIoSubBytes);
-                sela_host::WriteBehind behind(out, 44 + pc.first * frameBytes, kIoSubBytes);
+                // (a piece that starts its file allocates the whole file's pages, for the pieces behind it too)
+                po->behind.reset(new sela_host::WriteBehind(po->out, 44 + pc.first * frameBytes, kIoSubBytes,
+                    pc.first == 0 ? info[member].announced * frameBytes : 0));
+                sela_host::WriteBehind* const behind = po->behind.get();
                 streamDecode(
                     [&](size_t have, size_t payload) {
                         const size_t upTo = std::min(payload, have + kIoSubBytes);
                         ahead.need(upTo);
                         return upTo;
                     },
-                    sela, info[member].payload, pcm, [&](const int16_t* p, size_t n) { behind.drain(p, n * 2); }, pc.first, pc.n);
+                    sela, info[member].payload, po->data, [behind](const int16_t* p, size_t n) { behind->drain(p, n * 2); }, pc.first, pc.n);
                 ahead.finish();
-                behind.finish();
+                pending.push_back(std::move(po)); // (its last samples are written while the next piece is read and decoded)
+                settle(pending, kOutputsInFlight);
                 if (sela.frameCount() < pc.first + pc.n) {
                     std::lock_guard<std::mutex> lock(foundMutex);
                     found[pc.track] = std::min(found[pc.track], sela.frameCount());
                 }
             }
+            settle(pending, 0);
         });
         for (size_t t = 0; t < members.size(); t++) {
             if (found[t] == (size_t)-1)

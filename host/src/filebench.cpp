@@ -72,6 +72,59 @@ int main(int argc, char** argv)
         std::fprintf(stderr, "usage: %s in.wav scratch_dir [repeats] [e2e|all] [io threads]   (e2e: only the host-pointer leg, for traces)\n", argv[0]);
         return 2;
     }
+    if (std::string(argv[1]) == "batch") {
+        // sela_filebench batch <scratch dir> <devices, e.g. 0 or 0,0> <repeats> a.wav b.wav ...: the batch verbs in-process (HIP
+        // initialised, buffers pinned by an untimed first pass), outputs removed before every timed pass
+        if (argc < 6) {
+            std::fprintf(stderr, "usage: %s batch scratch_dir devices repeats a.wav ...\n", argv[0]);
+            return 2;
+        }
+        using clock = std::chrono::steady_clock;
+        const std::string dir = argv[2], devs = argv[3];
+        const int repeats = std::max(1, std::atoi(argv[4]));
+        std::vector<int> devices;
+        for (size_t at = 0; at <= devs.size();) {
+            const size_t comma = std::min(devs.find(',', at), devs.size());
+            devices.push_back(std::atoi(devs.substr(at, comma - at).c_str()));
+            at = comma + 1;
+        }
+        sela::setDevices(devices);
+        std::vector<std::string> wavs, selas, backs;
+        for (int i = 5; i < argc; i++) {
+            wavs.push_back(argv[i]);
+            selas.push_back(dir + "/b" + std::to_string(i) + ".sela");
+            backs.push_back(dir + "/b" + std::to_string(i) + ".wav");
+        }
+        try {
+            std::vector<double> enc, dec;
+            size_t inBytes = 0, outBytes = 0;
+            for (int r = 0; r <= repeats; r++) {
+                for (const std::string& p : selas)
+                    std::remove(p.c_str());
+                for (const std::string& p : backs)
+                    std::remove(p.c_str());
+                const auto t0 = clock::now();
+                sela::encodeFiles(wavs, selas);
+                const auto t1 = clock::now();
+                sela::decodeFiles(selas, backs);
+                const auto t2 = clock::now();
+                if (r) {
+                    enc.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+                    dec.push_back(std::chrono::duration<double, std::milli>(t2 - t1).count());
+                }
+            }
+            for (size_t i = 0; i < wavs.size(); i++) {
+                inBytes += slurp(wavs[i]).size();
+                outBytes += slurp(selas[i]).size();
+            }
+            std::printf("{\"files\": %zu, \"workers\": %zu, \"wav_bytes\": %zu, \"sela_bytes\": %zu, \"encode_ms\": %.3f, \"decode_ms\": %.3f}\n", wavs.size(),
+                devices.size(), inBytes, outBytes, median(enc), median(dec));
+            return 0;
+        } catch (const data::Exception& e) {
+            std::fprintf(stderr, "%s\n", e.exceptionMessage.c_str());
+            return 1;
+        }
+    }
     const std::string wavPath = argv[1], dir = argv[2];
     const int repeats = argc > 3 ? std::max(1, std::atoi(argv[3])) : 9;
     const bool onlyE2e = argc > 4 && std::string(argv[4]) == "e2e";
