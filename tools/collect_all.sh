@@ -18,7 +18,9 @@ SELA_BENCH_FORCE_EXCHANGE=1 python bench.py --workload album --steps 3 --warmup 
 tail -1 "$OUT/bench_album.log" > "$OUT/bench_album_1gpu_line.json"
 # the file-to-file verbs: what the file system gives (tools/io_probe), one encodeFile / decodeFile on a time axis, and
 # the legs against the size of the I/O pool
-[ -x tools/io_probe ] && tools/io_probe /dev/shm 32 > "$OUT/io_probe.txt" 2>&1
+[ -x tools/io_probe ] || g++ -O2 -std=c++17 -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tools/io_probe.cpp -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -o tools/io_probe
+tools/io_probe /dev/shm 32 > "$OUT/io_probe.txt" 2>&1
+python tools/batch_rate.py 12 > "$OUT/batch_rate.txt" 2>&1
 python tools/io_sweep.py 1 2 4 8 16 > "$OUT/io_threads.txt" 2>&1
 host/sela_filebench /dev/shm/sela_io/track.wav /dev/shm/sela_io 3 trace > "$OUT/io_trace.txt" 2>&1
 python tools/e2e_trace.py > "$OUT/e2e_trace.txt" 2>&1
