@@ -59,7 +59,7 @@ constexpr int kCoefLanes = 4;       // lanes of a wave that parse the coefficien
 constexpr int kResLanes = kWave - kCoefLanes;
 // Aligned words of one subframe the segment-parallel parser takes: coefficient words + 2 + residue words
 // (start bitmap: one bit per stream bit; positions must fit 16 bits).
-constexpr int kStreamCap = 1144;
+constexpr int kStreamCap = 1072;
 constexpr int kStreamMargin = 4;    // a window may run this many words past the end (they read as zero)
 constexpr uint32_t kEndOfStream = 0xFFFFFFFFu;
 
@@ -69,20 +69,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // ---- per-wave LDS scratch --------------------------------------------------------------------------------
 struct SynthTables {
     union {
-        struct {
-            double k[104];  // dequantised reflection coefficients
-            int64_t a[104]; // Q35 predictor
-        };
-        uint64_t tab[256];  // synthesis coefficient table (build_synth_table), replaces k[] and a[]
+        int64_t a[104];     // Q35 predictor (the reflection coefficients never touch LDS here: dequantised into registers)
+        uint64_t tab[192];  // synthesis coefficient table (build_synth_table), replaces a[]: entries 1 .. 191 are read
     };
 };
 struct DecWaveScratch {
     SynthTables t;
     // (the parsed coefficient values q[0 .. order) live inside t, see coef_values(): between the parse, whose scratch lies
-    // in front of them, and the dequantisation, which reads them into registers before k[] and a[] are written)
+    // in front of them, and the dequantisation, which reads them into registers before a[] is written)
 };
-constexpr int kCoefValuesAt = 1152; // byte offset in SynthTables: behind the parse's positions, chain table and flags, inside a[]
-static_assert(kCoefValuesAt + 128 * 4 <= 104 * 8 * 2, "the coefficient values must lie inside k[] / a[]");
+constexpr int kCoefValuesAt = 896; // byte offset in SynthTables: behind the parse's positions (0..256), chain flags (512..577) and entries (640..896)
+static_assert(kCoefValuesAt + 104 * 4 <= (int)sizeof(SynthTables) && kCoefValuesAt >= 104 * 8, "the coefficient values lie behind a[] inside the table's space");
 __device__ __forceinline__ int32_t* coef_values(DecWaveScratch* s)
 {
     return reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(&s->t) + kCoefValuesAt);
@@ -680,8 +677,7 @@ __device__ inline bool build_synth_table(const int64_t* a, uint64_t* tab, int or
     } else {           // ring of 128
         tab[lane] = c[0];
         tab[lane + 64] = c[1];
-        tab[lane + 128] = c[0];
-        tab[lane + 192] = c[1];
+        tab[lane + 128] = c[0]; // (a step reads entries lane + 128 - M and lane + 64 - M, M = 0 .. 63: 1 .. 191)
     }
     wave_sync();
     return !__any(!fits);
@@ -741,7 +737,7 @@ __host__ __device__ inline size_t decode_lds_bytes_for(uint32_t channels, int n_
 
 // kProf: also write per-phase cycle counts (debug hook sela_hip_debug_phase_buffer; 16 uint64 per subframe).
 template <bool kProf>
-__global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8_t* __restrict__ frames,
+__global__ __launch_bounds__(kDecMaxWaves * 64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_decode_frames(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* __restrict__ pcm_out,
     uint32_t* __restrict__ status, int32_t* __restrict__ ws_residues, uint64_t* __restrict__ phase_cycles,
     uint8_t* __restrict__ frame_flags /* or null: one byte per (frame, wave), written only when not zero */)
@@ -821,12 +817,9 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames(const uint8
         const uint32_t order = hd.order;
         const int32_t q_lo = (uint32_t)lane < order ? coef_values(scratch)[lane] : 0, q_hi = (uint32_t)lane + 64 < order ? coef_values(scratch)[lane + 64] : 0;
         wave_sync();
-        if ((uint32_t)lane < order)
-            tables->k[lane] = order <= 1 ? 0.0 : dequant(lane, q_lo, flags);
-        if ((uint32_t)lane + 64 < order)
-            tables->k[lane + 64] = dequant(lane + 64, q_hi, flags);
-        wave_sync();
-        step_up(tables->k, tables->a, (int)order, lane, flags);
+        const double k_lo = (uint32_t)lane < order ? (order <= 1 ? 0.0 : dequant(lane, q_lo, flags)) : 0.0;
+        const double k_hi = (uint32_t)lane + 64 < order ? dequant(lane + 64, q_hi, flags) : 0.0;
+        step_up_regs(k_lo, k_hi, tables->a, (int)order, lane, flags);
         const bool fits24 = build_synth_table(tables->a, tables->tab, (int)order, lane);
         if (kProf)
             stamp[7] = clock64();
@@ -1036,12 +1029,9 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames_wide(const 
         const uint32_t order = hd.order;
         const int32_t q_lo = (uint32_t)lane < order ? coef_values(scratch)[lane] : 0, q_hi = (uint32_t)lane + 64 < order ? coef_values(scratch)[lane + 64] : 0;
         wave_sync();
-        if ((uint32_t)lane < order)
-            tables->k[lane] = order <= 1 ? 0.0 : dequant(lane, q_lo, flags);
-        if ((uint32_t)lane + 64 < order)
-            tables->k[lane + 64] = dequant(lane + 64, q_hi, flags);
-        wave_sync();
-        step_up(tables->k, tables->a, (int)order, lane, flags);
+        const double k_lo = (uint32_t)lane < order ? (order <= 1 ? 0.0 : dequant(lane, q_lo, flags)) : 0.0;
+        const double k_hi = (uint32_t)lane + 64 < order ? dequant(lane + 64, q_hi, flags) : 0.0;
+        step_up_regs(k_lo, k_hi, tables->a, (int)order, lane, flags);
         const bool fits24 = build_synth_table(tables->a, tables->tab, (int)order, lane);
         if (order <= 48)
             synthesize<1, 16>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);

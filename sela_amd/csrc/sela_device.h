@@ -235,10 +235,9 @@ __device__ __forceinline__ double wave_shr1(double fill, double v)
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
-__device__ inline void step_up(const double* kd, int64_t* a, int order, int lane, uint32_t& flags)
+// k_lo / k_hi: reflection coefficient `lane` / `lane + 64` (0 beyond the order)
+__device__ inline void step_up_regs(double k_lo, double k_hi, int64_t* a, int order, int lane, uint32_t& flags)
 {
-    const double k_lo = lane < order ? kd[lane] : 0.0;
-    const double k_hi = lane + 64 < order ? kd[lane + 64] : 0.0;
     double t_lo = lane == 0 ? 1.0 : 0.0, r_lo = lane == 1 ? 1.0 : 0.0; // degree 0: A = [1], R[m] = A[1 - m]
     double t_hi = 0.0, r_hi = 0.0;
     // while the mirror of the new degree (i + 2 elements) fits lanes 0..63, the second register is all zeros
@@ -267,6 +266,13 @@ __device__ inline void step_up(const double* kd, int64_t* a, int order, int lane
     if (lane + 64 <= order)
         a[lane + 64] = q35_trunc(-t_hi, flags);
     wave_sync();
+}
+
+__device__ inline void step_up(const double* kd, int64_t* a, int order, int lane, uint32_t& flags)
+{
+    const double k_lo = lane < order ? kd[lane] : 0.0;
+    const double k_hi = lane + 64 < order ? kd[lane + 64] : 0.0;
+    step_up_regs(k_lo, k_hi, a, order, lane, flags);
 }
 
 } // namespace sela

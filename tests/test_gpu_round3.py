@@ -194,7 +194,7 @@ def test_wide_frames_with_difference_subframes_and_long_streams(gpu):
     for _ in range(3):
         subs = [sub(c, *types.get(c, (0, c))) for c in order]
         frames.append(_build_frame(subs))
-    # one subframe with residues so wide that its stream exceeds the plan's 1144 words
+    # one subframe with residues so wide that its stream exceeds the plan's 1072 words
     subs = [sub(c, *types.get(c, (0, c)), scale=(1 << 20) if c == 6 else 300) for c in order]
     frames.append(_build_frame(subs))
     stream = np.frombuffer(b"".join(frames), np.uint8).copy()
