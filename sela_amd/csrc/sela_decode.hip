@@ -13,7 +13,7 @@
 // coalesced.
 //
 // The synthesis recurrence is a dependent chain of ~90 cycles per sample, so the kernel lives on occupancy:
-// what a subframe keeps in LDS is cut to 7.4 KB (22 waves per CU).  The Rice stream is NOT copied on chip --
+// what a subframe keeps in LDS is cut to 5.7 KB (28 waves per CU).  The Rice stream is NOT copied on chip --
 // it is read where it lies through a bounds-checked buffer resource (reads past the subframe's words
 // return zero) -- the parser leaves one 16-bit POSITION per codeword instead of a 32-bit value, the
 // residues of a block of 64 samples are decoded from those positions just in time (the loads are in
