@@ -806,6 +806,10 @@ def main():
                                           "equals_e2e_bytes": legs["file_equals_e2e"], "files_on": legs["files_on"],
                                           "what": "sela::encodeFile / decodeFile on paths (the reference's `sela -e` / `-d`, src/main.cpp:29-41): reader threads, "
                                                   "H2D, kernels, D2H, writer threads overlapped; in-process, HIP initialised"}
+                if "play_first_packet_ms" in legs:
+                    result["file_to_file"]["play"] = {"first_packet_ms": legs["play_first_packet_ms"], "all_packets_ms": legs["play_all_ms"],
+                                                      "what": "sela::Player::playFile (the reference's `sela -p`, src/sela/player.cpp:30-104) into a sink that "
+                                                              "compares the packets with the decoded file: call -> first packet, call -> last packet"}
             else:
                 result["e2e"] = result["file_to_file"] = legs
         if not args.no_cpu_baseline:

@@ -44,11 +44,22 @@ public:
 size_t encodeFile(std::ifstream& in, std::ofstream& out);
 size_t decodeFile(std::ifstream& in, std::ofstream& out);
 // The same by path -- what the CLI's -e / -d use: the file is read with several pread()s in flight on a small pool of I/O
-// threads (sela_host/fileio.hpp) while earlier pieces are on the device, and finished ranges are written with several
-// pwrite()s in flight while later pieces are still being coded.  One thread reads or writes a page-cache file at a
-// few GB/s; the device codes 10 G samples/s.
+// threads (sela_host/fileio.hpp) while earlier pieces are on the device, and finished ranges are written by a task of
+// that pool -- over pages allocated in one go while the input was still on its way -- while later pieces are being coded.
+// One thread reads or writes a page-cache file at a few GB/s; the device codes 10 G samples/s.
 size_t encodeFile(const std::string& inPath, const std::string& outPath);
 size_t decodeFile(const std::string& inPath, const std::string& outPath);
+// Decoding for a consumer that takes the samples in order (the player, sela_host/player.hpp): begin() once the header is
+// known, then ready(pcm, n) -- on the calling thread -- whenever the first n interleaved samples of pcm are final (n only
+// grows; pcm is the caller's buffer `into`, sized here before the first call, so the samples outlive the decoding: a player is
+// still handing them out long after the last frame was decoded).  Returns the frames decoded.
+class DecodedStream {
+public:
+    virtual ~DecodedStream() {}
+    virtual void begin(const data::SelaHeader& header, size_t announcedFrames) = 0;
+    virtual void ready(const int16_t* pcm, size_t samples) = 0;
+};
+size_t decodeFileTo(const std::string& inPath, DecodedStream& to, sela_host::PinnedBuffer<int16_t>& into);
 // Threads of that pool (before its first use; 0 = default: min(6, hardware threads / 2)).
 void setIoThreads(unsigned n);
 

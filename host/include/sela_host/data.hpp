@@ -7,6 +7,7 @@
 // objects are only materialised for callers that ask for them -- the bytes travel as flat buffers.
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 #include <string>
 #include <utility>
@@ -114,6 +115,16 @@ public:
     WavFormatSubChunk formatSubChunk;
     WavDataSubChunk dataSubChunk;
     std::vector<WavSubChunk> wavSubChunks;
+};
+
+// One frame's worth of interleaved int16 samples on its way to the audio device (reference:
+// src/include/data/audio_packet.hpp:6-12).  Here `audio` points INTO the decoded samples (file::WavFile::pcm or the
+// player's page-locked buffer): nothing is allocated per packet and nothing is to be freed.
+class AudioPacket {
+public:
+    char* audio;
+    const size_t bufferSize;
+    AudioPacket(char* audio, const size_t bufferSize) : audio(audio), bufferSize(bufferSize) {}
 };
 
 class SelaHeader {

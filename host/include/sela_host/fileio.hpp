@@ -5,7 +5,8 @@
 // At GPU speed the file system is the slow side: one thread moves a page-cache file at a few GB/s (a fresh file
 // also pays a page allocation per 4 KB written), the device codes the same bytes ten times faster.  So a file is
 // read with several pread()s in flight into page-locked memory while earlier pieces are already on the device, and
-// finished ranges are written with several pwrite()s in flight while later pieces are still being coded.
+// finished ranges are written behind the feeding thread's back while later pieces are still being coded -- by one
+// task per output file (writes to one file do not run side by side, see WriteBehind), over pages allocated up front.
 #pragma once
 
 #include <atomic>

@@ -123,7 +123,7 @@ struct StreamReader {
 // those frames from its start.
 template <typename Fetch, typename Drain>
 void streamDecode(Fetch fetch, file::SelaFile& sela, size_t payload, sela_host::PinnedBuffer<int16_t>& pcm, Drain drain, size_t firstFrame = 0,
-    size_t maxFrames = (size_t)-1)
+    size_t maxFrames = (size_t)-1, size_t firstFeedFrames = kPieceFrames /* the first feed does not wait for a whole piece (a player wants its first samples early) */)
 {
     const uint32_t channels = sela.selaHeader.channels;
     if (channels == 0)
@@ -170,13 +170,19 @@ void streamDecode(Fetch fetch, file::SelaFile& sela, size_t payload, sela_host::
             }
         }
         const bool last = have == payload || indexed == stop || ended;
-        if (indexed > fed && (indexed - fed >= kPieceFrames || last)) {
+        if (indexed > fed && (indexed - fed >= (fed == std::min(firstFrame, stop) ? std::min<size_t>(firstFeedFrames, kPieceFrames) : kPieceFrames) || last)) {
             uint32_t done = 0;
             const long long t0 = sela_host::ioTrace ? sela_host::ioNow() : 0;
             rc = sela_hip_decode_feed(job, sela.frameBytes.data(), sela.frameOffsets.data() + fed, (uint32_t)(indexed - fed), &done);
             if (sela_host::ioTrace)
                 sela_host::ioTrace("decode feed", t0, sela_host::ioNow(), indexed - fed);
             fed = indexed;
+            if (rc == SELA_HIP_OK)
+                drain(pcm.data(), (size_t)done * frameSamples);
+        } else if (firstFeedFrames < kPieceFrames && fed > std::min(firstFrame, stop)) {
+            // an eager consumer also hears of finished frames between the feeds (a feed of no frames only looks)
+            uint32_t done = 0;
+            rc = sela_hip_decode_feed(job, sela.frameBytes.data(), sela.frameOffsets.data(), 0, &done);
             if (rc == SELA_HIP_OK)
                 drain(pcm.data(), (size_t)done * frameSamples);
         }
@@ -665,6 +671,26 @@ size_t decodeFile(const std::string& inPath, const std::string& outPath)
         out.truncate(44 + decodedBytes);
     }
     return frames;
+}
+
+size_t decodeFileTo(const std::string& inPath, DecodedStream& to, sela_host::PinnedBuffer<int16_t>& pcm)
+{
+    const SelaInfo info = probeSela(inPath);
+    const sela_host::PosixFile in = sela_host::PosixFile::openForRead(inPath);
+    file::SelaFile sela;
+    sela.selaHeader = info.header;
+    sela.frameBytes.resize(info.payload);
+    to.begin(info.header, info.announced);
+    sela_host::ReadAhead ahead(in, sela.frameBytes.data(), 15, info.payload, kIoSubBytes, kIoSubBytes);
+    streamDecode(
+        [&](size_t have, size_t payload) {
+            const size_t upTo = std::min(payload, have + kIoSubBytes);
+            ahead.need(upTo);
+            return upTo;
+        },
+        sela, info.payload, pcm, [&](const int16_t* p, size_t done) { to.ready(p, done); }, 0, (size_t)-1, 64);
+    ahead.finish();
+    return sela.frameCount();
 }
 
 // ---- many files by path: every GPU worker reads, codes and writes its own pieces ----------------------------------

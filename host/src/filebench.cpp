@@ -23,6 +23,7 @@
 
 #include "sela_hip.h"
 #include "sela_host/codec.hpp"
+#include "sela_host/player.hpp"
 
 #include <mutex>
 
@@ -227,6 +228,33 @@ int main(int argc, char** argv)
                 fdec.push_back(ms(t1, t2));
             }
         }
+        // ---- the player's feed (sela::Player::playFile into a sink that only compares): time to the first packet ---
+        struct Comparing : sela::AudioSink {
+            const int16_t* expect;
+            size_t at = 0;
+            bool same = true;
+            void open(const data::WavFormatSubChunk&) override {}
+            void play(const data::AudioPacket& p) override
+            {
+                same = same && std::memcmp(p.audio, reinterpret_cast<const char*>(expect) + at, p.bufferSize) == 0;
+                at += p.bufferSize;
+            }
+        };
+        std::vector<double> pfirst, pall;
+        bool samePlayed = true;
+        for (int r = 0; r <= repeats; r++) {
+            Comparing sink;
+            sink.expect = back.data();
+            sela::Player player(sink);
+            const auto t0 = clock::now();
+            player.playFile(selaPath);
+            const auto t1 = clock::now();
+            samePlayed = samePlayed && sink.same && sink.at == back.size() * 2;
+            if (r) {
+                pfirst.push_back(player.firstPacketSeconds * 1e3);
+                pall.push_back(ms(t0, t1));
+            }
+        }
         // the two paths agree with each other
         const std::vector<uint8_t> selaFile = slurp(selaPath), backFile = slurp(backPath);
         const bool sameSela = selaFile.size() == 15 + (size_t)offs[frames] && std::memcmp(selaFile.data() + 15, bytes.data(), (size_t)offs[frames]) == 0;
@@ -235,11 +263,11 @@ int main(int argc, char** argv)
                     "\"e2e_encode_ms\": %.4f, \"e2e_decode_ms\": %.4f, \"e2e_encode_msps\": %.1f, \"e2e_decode_msps\": %.1f, "
                     "\"file_encode_ms\": %.4f, \"file_decode_ms\": %.4f, \"file_encode_msps\": %.1f, \"file_decode_msps\": %.1f, "
                     "\"pcie_h2d_pcm_ms\": %.4f, \"pcie_d2h_pcm_ms\": %.4f, \"pcie_h2d_sela_ms\": %.4f, \"pcie_d2h_sela_ms\": %.4f, "
-                    "\"file_equals_e2e\": %s}\n",
+                    "\"play_first_packet_ms\": %.4f, \"play_all_ms\": %.4f, \"file_equals_e2e\": %s}\n",
             frames, ch, repeats, (size_t)offs[frames], median(enc), median(dec), samples / median(enc) / 1e3, samples / median(dec) / 1e3,
             median(fenc), median(fdec), samples / median(fenc) / 1e3, samples / median(fdec) / 1e3, h2d_pcm, d2h_pcm, h2d_sela, d2h_sela,
-            (sameSela && sameWav) ? "true" : "false");
-        return (sameSela && sameWav) ? 0 : 1;
+            median(pfirst), median(pall), (sameSela && sameWav && samePlayed) ? "true" : "false");
+        return (sameSela && sameWav && samePlayed) ? 0 : 1;
     } catch (const data::Exception& e) {
         std::fprintf(stderr, "%s\n", e.exceptionMessage.c_str());
     } catch (const std::exception& e) {

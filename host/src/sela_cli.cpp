@@ -4,8 +4,11 @@
 //   sela_mi355x -E out_dir [--gpus N | --devices a,b,..] a.wav b.wav ...    encode many files as one job -> out_dir/<name>.sela
 //   sela_mi355x -D out_dir [--gpus N | --devices a,b,..] a.sela b.sela ...  decode many files as one job -> out_dir/<name>.wav
 //   (-E / -D also take --io-threads N: threads that read and write files beside the GPU workers)
-// Same verbs as the reference CLI (src/main.cpp:16-27); playback (-p) is not part of this build.  The batch
-// verbs spread the files' frames over the GPUs of the node (default: all of them), one host thread each.
+//   sela_mi355x -p in.sela [out.pcm]   play: the packets the reference's player would hand to libao (src/sela/player.cpp:30-62),
+//                                      handed out while the file is still being decoded -- to out.pcm, or to standard output
+//                                      (`sela_mi355x -p in.sela | aplay -f S16_LE -c 2 -r 44100`; this build has no audio device)
+// Same verbs as the reference CLI (src/main.cpp:16-27).  The batch verbs spread the files' frames over the GPUs of the
+// node (default: all of them), one host thread each.
 #include <algorithm>
 #include <cstdlib>
 #include <exception>
@@ -14,7 +17,11 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include "sela_host/codec.hpp"
+#include "sela_host/player.hpp"
 
 namespace {
 
@@ -23,6 +30,7 @@ int usage(const std::string& program)
     std::cout << "Usage:\n\n"
               << "Encoding a file:\n" << program << " -e path/to/input.wav path/to/output.sela\n\n"
               << "Decoding a file:\n" << program << " -d path/to/input.sela path/to/output.wav\n\n"
+              << "Playing a file (raw interleaved int16 to a file, or to standard output):\n" << program << " -p path/to/input.sela [path/to/output.pcm]\n\n"
               << "Many files, all GPUs:\n" << program << " -E|-D path/to/output_dir [--gpus N | --devices 0,1,..] inputs...\n";
     return 2;
 }
@@ -87,6 +95,33 @@ int run(int argc, char** argv)
         const int rc = batch(verb, argc, argv);
         return rc == 2 ? usage(program) : rc;
     }
+    if (verb == "-p" && (argc == 3 || argc == 4)) {
+        int fd = STDOUT_FILENO;
+        if (argc == 4) {
+            fd = ::open(argv[3], O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+            if (fd < 0)
+                throw data::Exception(std::string("cannot open ") + argv[3] + " for writing");
+        } else if (::isatty(STDOUT_FILENO)) {
+            std::cerr << "-p writes raw samples to standard output: redirect it, or name an output file" << std::endl;
+            return 2;
+        }
+        std::cerr << "Playing: " << argv[2] << std::endl;
+        sela::RawPcmSink sink(fd);
+        sela::Player player(sink);
+        player.showProgress = ::isatty(STDERR_FILENO) != 0;
+        size_t frames = 0;
+        try {
+            frames = player.playFile(argv[2]);
+        } catch (...) {
+            if (fd != STDOUT_FILENO)
+                (void)::close(fd);
+            throw;
+        }
+        if (fd != STDOUT_FILENO)
+            (void)::close(fd);
+        std::cerr << frames << " frames, first packet after " << player.firstPacketSeconds * 1e3 << " ms" << std::endl;
+        return 0;
+    }
     if (argc != 4 || (verb != "-e" && verb != "-d"))
         return usage(program);
     if (verb == "-e") {
@@ -103,7 +138,8 @@ int run(int argc, char** argv)
 
 int main(int argc, char** argv)
 {
-    std::cout << "SimplE Lossless Audio (.sela v2 bitstream) -- MI355X host" << std::endl;
+    // (-p may write the samples to standard output: everything else it says goes to standard error)
+    (argc > 1 && std::string(argv[1]) == "-p" ? std::cerr : std::cout) << "SimplE Lossless Audio (.sela v2 bitstream) -- MI355X host" << std::endl;
     try {
         return run(argc, argv);
     } catch (const data::Exception& e) {

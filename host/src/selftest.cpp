@@ -11,6 +11,7 @@
 #include "sela_hip.h"
 #include "sela_host/fileio.hpp"
 #include "sela_host/codec.hpp"
+#include "sela_host/player.hpp"
 #include "sela_host/files.hpp"
 #include "sela_host/frame.hpp"
 
@@ -200,6 +201,51 @@ int main(int argc, char** argv)
         CHECK(c.selaFrames.size() == 1 && c.selaHeader.numFrames == 3);
         writeBytes(dir + "/magic.sela", "NoPe00000000000000");
         CHECK(expectError(dir + "/magic.sela", false) == "Magic number is incorrect, probably not a sela file.");
+    }
+    // ---- the player's feed: one packet per whole frame, views of the interleaved samples (src/sela/player.cpp:30-62) ----
+    {
+        struct Counting : sela::AudioSink {
+            data::WavFormatSubChunk format;
+            std::vector<std::pair<const char*, size_t>> packets;
+            int opened = 0, closed = 0;
+            void open(const data::WavFormatSubChunk& f) override { format = f, opened++; }
+            void play(const data::AudioPacket& p) override { packets.emplace_back(p.audio, p.bufferSize); }
+            void close() override { closed++; }
+        } sink;
+        std::vector<int16_t> pcm(3 * (2048 * 3 + 77)); // three channels, three frames and a tail
+        for (size_t i = 0; i < pcm.size(); i++)
+            pcm[i] = (int16_t)(i * 31u + (i >> 5));
+        file::WavFile w(48000, 3, std::vector<int16_t>(pcm));
+        sela::Player player(sink);
+        player.play(w);
+        CHECK(sink.opened == 1 && sink.closed == 1 && player.packetsPlayed == 3 && sink.packets.size() == 3);
+        CHECK(sink.format.numChannels == 3 && sink.format.sampleRate == 48000 && sink.format.bitsPerSample == 16 && sink.format.blockAlign == 6
+            && sink.format.byteRate == 48000 * 6);
+        for (size_t f = 0; f < sink.packets.size(); f++) {
+            CHECK(sink.packets[f].second == 2048 * 3 * 2);
+            CHECK(sink.packets[f].first == reinterpret_cast<const char*>(w.pcm.data()) + f * 2048 * 3 * 2); // a view, in order
+        }
+        // the raw sink: the packets' bytes as they are
+        const std::string path = dir + "/played.pcm";
+        std::FILE* fp = std::fopen(path.c_str(), "wb");
+        CHECK(fp != nullptr);
+        if (fp) {
+            sela::RawPcmSink raw(fileno(fp));
+            sela::Player p2(raw);
+            p2.play(w);
+            std::fclose(fp);
+            std::ifstream in(path, std::ios::binary);
+            std::string got((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+            CHECK(got.size() == 3 * 2048 * 3 * 2 && std::memcmp(got.data(), pcm.data(), got.size()) == 0);
+        }
+        // a file that is not there: the reference's kind of exception, nothing opened
+        bool threw = false;
+        try {
+            player.playFile(dir + "/no_such_file.sela");
+        } catch (const data::Exception&) {
+            threw = true;
+        }
+        CHECK(threw && sink.opened == 1);
     }
     // ---- GPU mode: the reference's own frame tests (test/frametests.cpp:8-70) through the host classes --
     if (argc > 2 && std::string(argv[2]) == "gpu") {

@@ -78,8 +78,10 @@ typedef struct sela_hip_trace {
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* Select/initialise `device` (>= 0) for the calling thread, or -1 to keep the current device. */
 int sela_hip_init(int device);
-/* Free the calling thread's staging buffers and streams (host-pointer API); worker threads call this before
- * they exit.  sela_hip_shutdown() does the same and also returns the idle page-locked blocks to the system. */
+/* The host-pointer API keeps staging buffers, streams and events per calling thread; creating them costs the runtime
+ * about 10 ms.  sela_hip_thread_release() PARKS the calling thread's set for the next thread that uses the same device
+ * (a thread that simply ends parks it too), so short-lived worker threads start warm.  sela_hip_shutdown() frees the
+ * calling thread's set and every parked one, and returns the idle page-locked blocks to the system. */
 void sela_hip_thread_release(void);
 void sela_hip_shutdown(void);
 const char* sela_hip_last_error(void);

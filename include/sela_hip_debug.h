@@ -1,7 +1,7 @@
 /*
  * sela_hip_debug.h -- TEST HOOKS of libsela_hip.so.  NOT part of the drop-in boundary (include/sela_hip.h) and not
  * stable: tests/ and tools/ use them to send the PRODUCT kernels down branches real audio never takes and to read
- * instrumentation; nothing of host/ or of an integration calls them.  All are per calling thread.
+ * instrumentation; nothing of host/ or of an integration calls them.  All but the last are per calling thread.
  */
 #ifndef SELA_HIP_DEBUG_H_
 #define SELA_HIP_DEBUG_H_
@@ -32,6 +32,9 @@ void sela_hip_debug_mean_workers(int self_blocks);
 void sela_hip_debug_stage_wait(int naps);
 /* Debug hook: how many encode feeds of the calling thread were issued again through the copy-engine path so far. */
 int sela_hip_debug_reissued_feeds(void);
+/* Debug hook: how many per-thread contexts (streams, events, staging buffers) this process has CREATED so far -- threads
+ * that take over a parked one (sela_hip.h, sela_hip_thread_release) do not count. */
+int sela_hip_debug_contexts_created(void);
 
 #ifdef __cplusplus
 }

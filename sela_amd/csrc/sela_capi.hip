@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include <cstdio>
 #include <cstdlib>
@@ -279,7 +280,71 @@ struct HostContext {
         }
     }
 };
-thread_local HostContext g_ctx;
+// A thread's context is LEASED: creating one (four streams, 25 events, a dozen device and page-locked buffers) takes the
+// runtime about 10 ms -- three times what a 3-minute track takes file to file -- and host programs start threads per job
+// (one worker per GPU and batch, the player's decoder).  A thread that ends, or calls sela_hip_thread_release(), parks its
+// context; the next thread that needs one on that device takes it over warm.  sela_hip_shutdown() frees the parked ones.
+struct ContextPark {
+    std::mutex mu;
+    std::vector<HostContext*> idle;
+};
+ContextPark& park()
+{
+    static ContextPark* p = new ContextPark; // (never destroyed: threads may end after the statics have)
+    return *p;
+}
+std::atomic<int> g_contexts_created{ 0 }; // debug: sela_hip_debug_contexts_created
+constexpr size_t kParkedContexts = 16; // more than this many idle ones are freed instead (a context holds up to a few hundred MB of HBM)
+
+struct ContextLease {
+    HostContext* held = nullptr;
+    HostContext& get()
+    {
+        if (!held) {
+            int dev = -1;
+            (void)hipGetDevice(&dev);
+            ContextPark& p = park();
+            {
+                std::lock_guard<std::mutex> lock(p.mu);
+                for (size_t i = p.idle.size(); i-- > 0 && !held;)
+                    if (p.idle[i]->device == dev) {
+                        held = p.idle[i];
+                        p.idle.erase(p.idle.begin() + (long)i);
+                    }
+            }
+            if (!held) {
+                held = new HostContext;
+                g_contexts_created.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
+        return *held;
+    }
+    void give_back()
+    {
+        if (!held)
+            return;
+        HostContext* c = held;
+        held = nullptr;
+        if (c->job_open) { // a thread that ended in the middle of a job: nothing of it may be left in flight or marked
+            c->sync_all();
+            c->release();
+            c->job_open = false;
+        }
+        ContextPark& p = park();
+        {
+            std::lock_guard<std::mutex> lock(p.mu);
+            if (c->device >= 0 && p.idle.size() < kParkedContexts) {
+                p.idle.push_back(c);
+                return;
+            }
+        }
+        c->release();
+        delete c;
+    }
+    ~ContextLease() { give_back(); }
+};
+thread_local ContextLease g_lease;
+inline HostContext& ctx() { return g_lease.get(); }
 
 // Per-thread kernel timing (bench.py's roofline leg): events bracketing the kernels of the last call.
 struct KernelTiming {
@@ -358,7 +423,7 @@ uint32_t flags_to_error(uint32_t flags)
 // ---- streaming jobs ----------------------------------------------------------------------------------------
 struct EncodeFeed {      // one feed of an encode job = one launch
     uint32_t first = 0, n_frames = 0;
-    size_t mirror_at = 0;        // where the launch reports (offsets, status) in g_ctx.enc_mirror
+    size_t mirror_at = 0;        // where the launch reports (offsets, status) in ctx().enc_mirror
     hipEvent_t done = nullptr;   // recorded behind the launch
     void* bounce_in = nullptr;   // page-locked copy of a feed that came from ordinary memory
     const int16_t* host_src = nullptr;   // the feed's PCM in page-locked host memory, as the host sees it ...
@@ -380,7 +445,7 @@ struct sela_hip_job {
     bool pcm_bounce = false;
     uint32_t frames_moved = 0;     // frames copied from the bounce buffer to the caller's so far
     std::vector<void*> bounce_frames; // page-locked copies of feeds that came from ordinary memory
-    size_t offsets_used = 0; // entries of g_ctx.job_offsets_host taken by the feeds so far
+    size_t offsets_used = 0; // entries of ctx().job_offsets_host taken by the feeds so far
     // ---- encode: feeds
     uint8_t* frames_out = nullptr; // the caller's buffer
     size_t frames_cap = 0;
@@ -425,7 +490,7 @@ void job_move_decoded(sela_hip_job* job)
 int job_finalize(sela_hip_job* job, uint32_t upto /* chunks */)
 {
     while (job->final_chunks < upto) {
-        ChunkSet& c = g_ctx.set[job->final_chunks % kSets];
+        ChunkSet& c = ctx().set[job->final_chunks % kSets];
         // (chunk i and chunk i + kSets share the event; waiting for the later record covers the earlier one)
         hipError_t e = hipEventSynchronize(c.copied_out);
         if (e != hipSuccess)
@@ -440,7 +505,7 @@ hipError_t reserve_chunk_buffers(uint32_t channels)
 {
     const size_t frame_pcm = (size_t)sela::kBlock * channels * sizeof(int16_t);
     const uint32_t frames = chunk_frames(channels);
-    for (ChunkSet& c : g_ctx.set) {
+    for (ChunkSet& c : ctx().set) {
         hipError_t e;
         if ((e = c.pcm.reserve(frames * frame_pcm + 16)) != hipSuccess
             || (e = c.workspace.reserve(sela::decode_workspace_bytes(frames, channels))) != hipSuccess)
@@ -478,33 +543,33 @@ constexpr uint32_t kEncodeLaunchFrames = 1u << 14; // a feed larger than this is
 hipError_t issue_encode_feed(sela_hip_job* job, EncodeFeed& feed, size_t index, bool staged)
 {
     const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
-    const hipStream_t s = g_ctx.s_run[0];
+    const hipStream_t s = ctx().s_run[0];
     hipError_t e;
     sela::EncodeHostLink link;
-    link.mirror = g_ctx.enc_mirror_mapped + feed.mirror_at;
+    link.mirror = ctx().enc_mirror_mapped + feed.mirror_at;
     // (two cells in turn: a launch reads where the one before left the stream and leaves its own end in the other)
-    uint64_t* const pos = static_cast<uint64_t*>(g_ctx.enc_words.ptr);
+    uint64_t* const pos = static_cast<uint64_t*>(ctx().enc_words.ptr);
     link.pos_in = pos + (index & 1);
     link.pos_out = pos + ((index + 1) & 1);
     link.host_pcm = feed.mapped_src;
-    link.pcm_ready = static_cast<uint64_t*>(g_ctx.enc_ready.ptr);
+    link.pcm_ready = static_cast<uint64_t*>(ctx().enc_ready.ptr);
     link.stage_workgroups = kStageWorkgroups;
-    link.stage_stream = g_ctx.s_in;
+    link.stage_stream = ctx().s_in;
     link.stage_started = pos + 4;
     link.wait_naps = g_stage_wait_naps;
     // what fills the device's copy of the PCM waits for the launch before this one, which reads it (and for the
     // allocation that may just have cleared the marks)
-    if ((e = hipEventRecord(g_ctx.enc_prev, s)) != hipSuccess || (e = hipStreamWaitEvent(g_ctx.s_in, g_ctx.enc_prev, 0)) != hipSuccess)
+    if ((e = hipEventRecord(ctx().enc_prev, s)) != hipSuccess || (e = hipStreamWaitEvent(ctx().s_in, ctx().enc_prev, 0)) != hipSuccess)
         return e;
     if (!staged) { // (the stagers copy stereo frames; anything else goes in by the copy engine, ahead of the launch)
-        if ((e = hipMemcpyAsync(g_ctx.enc_pcm.ptr, feed.host_src, feed.n_frames * frame_pcm, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess
-            || (e = hipEventRecord(g_ctx.enc_prev, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s, g_ctx.enc_prev, 0)) != hipSuccess)
+        if ((e = hipMemcpyAsync(ctx().enc_pcm.ptr, feed.host_src, feed.n_frames * frame_pcm, hipMemcpyHostToDevice, ctx().s_in)) != hipSuccess
+            || (e = hipEventRecord(ctx().enc_prev, ctx().s_in)) != hipSuccess || (e = hipStreamWaitEvent(s, ctx().enc_prev, 0)) != hipSuccess)
             return e;
         link.host_pcm = nullptr;
     }
     uint32_t* d_status = reinterpret_cast<uint32_t*>(pos + 2);
-    e = sela::launch_encode(static_cast<const int16_t*>(g_ctx.enc_pcm.ptr), feed.n_frames, job->channels, job->out_mapped, job->frames_cap, nullptr, d_status,
-        g_ctx.enc_workspace.ptr, nullptr, s, nullptr, nullptr, &link, g_force_plain_fir, g_self_blocks);
+    e = sela::launch_encode(static_cast<const int16_t*>(ctx().enc_pcm.ptr), feed.n_frames, job->channels, job->out_mapped, job->frames_cap, nullptr, d_status,
+        ctx().enc_workspace.ptr, nullptr, s, nullptr, nullptr, &link, g_force_plain_fir, g_self_blocks);
     if (e == hipSuccess && !feed.done)
         e = hipEventCreateWithFlags(&feed.done, hipEventDisableTiming);
     if (e == hipSuccess)
@@ -515,7 +580,7 @@ hipError_t issue_encode_feed(sela_hip_job* job, EncodeFeed& feed, size_t index, 
 int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
 {
     const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
-    const hipStream_t s = g_ctx.s_run[0];
+    const hipStream_t s = ctx().s_run[0];
     hipError_t e;
     EncodeFeed feed;
     feed.first = job->fed;
@@ -536,11 +601,11 @@ int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
     }
     // (grow-only; the launches of a job run in order on one stream, so growing waits for the last one)
     const size_t need_pcm = nf * frame_pcm + 16, need_ws = sela::encode_workspace_bytes(nf, job->channels), need_ready = (size_t)nf * 8;
-    if (need_pcm > g_ctx.enc_pcm.cap || need_ws > g_ctx.enc_workspace.cap || need_ready > g_ctx.enc_ready.cap) {
-        if ((e = hipStreamSynchronize(s)) != hipSuccess || (e = g_ctx.enc_pcm.reserve(need_pcm)) != hipSuccess
-            || (e = g_ctx.enc_workspace.reserve(need_ws)) != hipSuccess || (e = g_ctx.enc_ready.reserve(need_ready)) != hipSuccess
+    if (need_pcm > ctx().enc_pcm.cap || need_ws > ctx().enc_workspace.cap || need_ready > ctx().enc_ready.cap) {
+        if ((e = hipStreamSynchronize(s)) != hipSuccess || (e = ctx().enc_pcm.reserve(need_pcm)) != hipSuccess
+            || (e = ctx().enc_workspace.reserve(need_ws)) != hipSuccess || (e = ctx().enc_ready.reserve(need_ready)) != hipSuccess
             // (the "frame copied in" words carry the bare ticket -- and a checksum -- and another process's tickets count from the same start)
-            || (e = hipMemsetAsync(g_ctx.enc_ready.ptr, 0, g_ctx.enc_ready.cap, s)) != hipSuccess) {
+            || (e = hipMemsetAsync(ctx().enc_ready.ptr, 0, ctx().enc_ready.cap, s)) != hipSuccess) {
             if (feed.bounce_in)
                 pool().give(feed.bounce_in);
             return job_fail(job, fail_hip(e, "hipMalloc"));
@@ -568,12 +633,12 @@ int job_feed_encode_launch(sela_hip_job* job, const int16_t* pcm, uint32_t nf)
 int job_reissue_encode(sela_hip_job* job, size_t from)
 {
     hipError_t e;
-    g_ctx.sync_all(); // (nothing of the void launches is left running)
+    ctx().sync_all(); // (nothing of the void launches is left running)
     job->staged = false;
-    uint64_t* const pos = static_cast<uint64_t*>(g_ctx.enc_words.ptr);
+    uint64_t* const pos = static_cast<uint64_t*>(ctx().enc_words.ptr);
     const uint64_t start = job->bytes_final; // the stream behind the last good feed
-    if ((e = hipMemcpyAsync(pos + (from & 1), &start, 8, hipMemcpyHostToDevice, g_ctx.s_run[0])) != hipSuccess
-        || (e = hipStreamSynchronize(g_ctx.s_run[0])) != hipSuccess) // (`start` is a local)
+    if ((e = hipMemcpyAsync(pos + (from & 1), &start, 8, hipMemcpyHostToDevice, ctx().s_run[0])) != hipSuccess
+        || (e = hipStreamSynchronize(ctx().s_run[0])) != hipSuccess) // (`start` is a local)
         return job_fail(job, fail_hip(e, "encode re-issue"));
     for (size_t k = from; k < job->feeds.size(); k++) {
         job->feeds[k].reissued = true;
@@ -603,7 +668,7 @@ int job_feed_encode(sela_hip_job* job, const int16_t* pcm, uint32_t n_frames)
 // L2 write-back per group.)
 int job_encode_progress(sela_hip_job* job, bool wait)
 {
-    const uint64_t* mirror = static_cast<const uint64_t*>(g_ctx.enc_mirror.ptr);
+    const uint64_t* mirror = static_cast<const uint64_t*>(ctx().enc_mirror.ptr);
     while (job->feeds_final < job->feeds.size()) {
         EncodeFeed& f = job->feeds[job->feeds_final];
         const hipError_t q = wait ? hipEventSynchronize(f.done) : hipEventQuery(f.done);
@@ -666,8 +731,8 @@ int job_encode_progress(sela_hip_job* job, bool wait)
 int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* offsets, const uint64_t* k_offsets, uint32_t nf)
 {
     const uint32_t i = job->issued;
-    ChunkSet& c = g_ctx.set[i % kSets];
-    const hipStream_t s = g_ctx.decode_stream(i);
+    ChunkSet& c = ctx().set[i % kSets];
+    const hipStream_t s = ctx().decode_stream(i);
     hipError_t e;
     if (i >= kSets) {
         // chunk i - kSets used this set.  The host goes no further ahead than that chunk's kernel (which also keeps
@@ -684,13 +749,13 @@ int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* o
         if ((e = c.frames.reserve((size_t)bytes + 16)) != hipSuccess)
             return job_fail(job, fail_hip(e, "hipMalloc"));
     }
-    if ((bytes && (e = hipMemcpyAsync(c.frames.ptr, frames + offsets[0], (size_t)bytes, hipMemcpyHostToDevice, g_ctx.s_in)) != hipSuccess)
-        || (e = hipEventRecord(c.copied_in, g_ctx.s_in)) != hipSuccess || (e = hipStreamWaitEvent(s, c.copied_in, 0)) != hipSuccess)
+    if ((bytes && (e = hipMemcpyAsync(c.frames.ptr, frames + offsets[0], (size_t)bytes, hipMemcpyHostToDevice, ctx().s_in)) != hipSuccess)
+        || (e = hipEventRecord(c.copied_in, ctx().s_in)) != hipSuccess || (e = hipStreamWaitEvent(s, c.copied_in, 0)) != hipSuccess)
         return job_fail(job, fail_hip(e, "H2D frames"));
     // the kernel adds the feed's absolute offsets to its base: bias the base so that offsets[0] lands on the chunk's copy
     const uint8_t* d_base = static_cast<const uint8_t*>(c.frames.ptr) - offsets[0];
-    uint8_t* flags = g_ctx.job_flags_mapped + (size_t)job->fed * sela::decode_waves(job->channels);
-    e = sela::launch_decode(d_base, k_offsets, nf, job->channels, static_cast<int16_t*>(c.pcm.ptr), static_cast<uint32_t*>(g_ctx.status.ptr),
+    uint8_t* flags = ctx().job_flags_mapped + (size_t)job->fed * sela::decode_waves(job->channels);
+    e = sela::launch_decode(d_base, k_offsets, nf, job->channels, static_cast<int16_t*>(c.pcm.ptr), static_cast<uint32_t*>(ctx().status.ptr),
         c.workspace.ptr, s, nullptr, nullptr, flags);
     if (e != hipSuccess || (e = hipEventRecord(c.ran, s)) != hipSuccess)
         return job_fail(job, fail_hip(e, "decode launch"));
@@ -711,8 +776,8 @@ int job_feed_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* of
     if (n_frames == 0)
         return SELA_HIP_OK;
     // (sized at begin for the whole job: total_frames entries + one more per feed, and a feed has at least a frame)
-    uint64_t* staged = static_cast<uint64_t*>(g_ctx.job_offsets_host.ptr) + job->offsets_used;
-    const uint64_t* mapped = g_ctx.job_offsets_mapped + job->offsets_used;
+    uint64_t* staged = static_cast<uint64_t*>(ctx().job_offsets_host.ptr) + job->offsets_used;
+    const uint64_t* mapped = ctx().job_offsets_mapped + job->offsets_used;
     std::memcpy(staged, offsets, ((size_t)n_frames + 1) * 8);
     job->offsets_used += (size_t)n_frames + 1;
     if (!device_view(frames + offsets[0])) {
@@ -742,7 +807,7 @@ int job_drain_ready(sela_hip_job* job)
 {
     if (job->encode)
         return job_encode_progress(job, false);
-    while (job->final_chunks < job->issued && hipEventQuery(g_ctx.set[job->final_chunks % kSets].copied_out) == hipSuccess)
+    while (job->final_chunks < job->issued && hipEventQuery(ctx().set[job->final_chunks % kSets].copied_out) == hipSuccess)
         job->final_chunks++;
     (void)hipGetLastError(); // (hipErrorNotReady from the query is not an error)
     job_move_decoded(job);
@@ -777,28 +842,28 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
     int rc = sela_hip_init(-1);
     if (rc != SELA_HIP_OK)
         return rc;
-    if (!g_ctx.bind_current_device())
+    if (!ctx().bind_current_device())
         return fail(SELA_HIP_ENODEV, "hipGetDevice failed");
-    if (g_ctx.job_open)
+    if (ctx().job_open)
         return fail(SELA_HIP_EINVAL, "this thread already has an open job");
-    hipError_t e = g_ctx.streams();
+    hipError_t e = ctx().streams();
     if (e == hipSuccess)
-        e = g_ctx.status.reserve(16);
+        e = ctx().status.reserve(16);
     if (e == hipSuccess && encode) {
         // (offsets + status per feed, a feed has at least a frame)
-        if ((e = g_ctx.enc_mirror.reserve((3 * (size_t)total_frames + 4) * 8)) == hipSuccess
-            && (e = g_ctx.enc_words.reserve(16 + 16 + 32)) == hipSuccess
-            && (e = hipHostGetDevicePointer((void**)&g_ctx.enc_mirror_mapped, g_ctx.enc_mirror.ptr, 0)) == hipSuccess)
-            e = hipMemsetAsync(g_ctx.enc_words.ptr, 0, 16 + 16 + 32, g_ctx.s_run[0]); // the job's stream position: 0
+        if ((e = ctx().enc_mirror.reserve((3 * (size_t)total_frames + 4) * 8)) == hipSuccess
+            && (e = ctx().enc_words.reserve(16 + 16 + 32)) == hipSuccess
+            && (e = hipHostGetDevicePointer((void**)&ctx().enc_mirror_mapped, ctx().enc_mirror.ptr, 0)) == hipSuccess)
+            e = hipMemsetAsync(ctx().enc_words.ptr, 0, 16 + 16 + 32, ctx().s_run[0]); // the job's stream position: 0
     }
     if (e == hipSuccess && !encode) {
         const size_t n_flags = (size_t)total_frames * sela::decode_waves(channels) + 1;
         if ((e = reserve_chunk_buffers(channels)) == hipSuccess
-            && (e = g_ctx.job_offsets_host.reserve((2 * (size_t)total_frames + 2) * 8)) == hipSuccess
-            && (e = g_ctx.job_flags.reserve(n_flags)) == hipSuccess
-            && (e = hipHostGetDevicePointer((void**)&g_ctx.job_offsets_mapped, g_ctx.job_offsets_host.ptr, 0)) == hipSuccess
-            && (e = hipHostGetDevicePointer((void**)&g_ctx.job_flags_mapped, g_ctx.job_flags.ptr, 0)) == hipSuccess)
-            std::memset(g_ctx.job_flags.ptr, 0, n_flags);
+            && (e = ctx().job_offsets_host.reserve((2 * (size_t)total_frames + 2) * 8)) == hipSuccess
+            && (e = ctx().job_flags.reserve(n_flags)) == hipSuccess
+            && (e = hipHostGetDevicePointer((void**)&ctx().job_offsets_mapped, ctx().job_offsets_host.ptr, 0)) == hipSuccess
+            && (e = hipHostGetDevicePointer((void**)&ctx().job_flags_mapped, ctx().job_flags.ptr, 0)) == hipSuccess)
+            std::memset(ctx().job_flags.ptr, 0, n_flags);
     }
     if (e != hipSuccess)
         return fail_hip(e, "hipMalloc");
@@ -806,8 +871,8 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
     job->encode = encode;
     job->channels = channels;
     job->total_frames = total_frames;
-    job->staged = job->holds_staged_path = encode && channels == 2 && staged_path_acquire(g_ctx.device);
-    g_ctx.job_open = true;
+    job->staged = job->holds_staged_path = encode && channels == 2 && staged_path_acquire(ctx().device);
+    ctx().job_open = true;
     *out = job;
     return SELA_HIP_OK;
 }
@@ -818,7 +883,7 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
     hipError_t e = hipSuccess;
     if (job->encode) {
         // (also after an error: nothing of the job may still be running when its buffers go back)
-        if ((e = hipStreamSynchronize(g_ctx.s_run[0])) != hipSuccess && rc == SELA_HIP_OK)
+        if ((e = hipStreamSynchronize(ctx().s_run[0])) != hipSuccess && rc == SELA_HIP_OK)
             rc = fail_hip(e, "encode kernels");
         if (rc == SELA_HIP_OK)
             rc = job_encode_progress(job, true);
@@ -834,7 +899,7 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
         if (rc == SELA_HIP_OK)
             rc = job_finalize(job, job->issued);
         if (rc != SELA_HIP_OK)
-            g_ctx.sync_all(); // (nothing may still be reading or writing the bounce buffers)
+            ctx().sync_all(); // (nothing may still be reading or writing the bounce buffers)
         for (void* b : job->bounce_frames)
             pool().give(b);
         if (job->pcm_bounce && job->pcm_out)
@@ -843,20 +908,20 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
     uint32_t seen_flags = 0;
     if (rc == SELA_HIP_OK && !job->encode && job->issued) {
         // every frame is decoded (bad ones to silence) before the verdict; the kernels left their flags in host memory
-        const uint8_t* flags = static_cast<const uint8_t*>(g_ctx.job_flags.ptr);
+        const uint8_t* flags = static_cast<const uint8_t*>(ctx().job_flags.ptr);
         const size_t n = (size_t)job->fed * sela::decode_waves(job->channels);
         for (size_t i = 0; i < n; i++)
             seen_flags |= flags[i];
     }
     if (rc != SELA_HIP_OK) { // leave nothing in flight behind an error
         const std::string msg = sela_hip_last_error();
-        g_ctx.sync_all();
+        ctx().sync_all();
         (void)fail(rc, msg);
     }
     job_progress(job, frames_final, bytes_final);
-    g_ctx.job_open = false;
+    ctx().job_open = false;
     if (job->holds_staged_path)
-        staged_path_release(g_ctx.device);
+        staged_path_release(ctx().device);
     delete job;
     if (rc != SELA_HIP_OK)
         return rc;
@@ -897,11 +962,26 @@ int sela_hip_init(int device)
     return SELA_HIP_OK;
 }
 
-void sela_hip_thread_release(void) { g_ctx.release(); }
+void sela_hip_thread_release(void) { g_lease.give_back(); }
 
 void sela_hip_shutdown(void)
 {
-    g_ctx.release();
+    g_lease.give_back();
+    std::vector<HostContext*> idle;
+    {
+        std::lock_guard<std::mutex> lock(park().mu);
+        idle.swap(park().idle);
+    }
+    int before = -1;
+    (void)hipGetDevice(&before);
+    for (HostContext* c : idle) { // (streams and buffers are freed on the device they belong to)
+        if (c->device >= 0)
+            (void)hipSetDevice(c->device);
+        c->release();
+        delete c;
+    }
+    if (before >= 0)
+        (void)hipSetDevice(before);
     pool().trim();
 }
 
@@ -922,6 +1002,7 @@ void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks;
 void sela_hip_debug_stage_wait(int naps) { g_stage_wait_naps = naps; }
 
 int sela_hip_debug_reissued_feeds(void) { return g_reissued_feeds; }
+int sela_hip_debug_contexts_created(void) { return g_contexts_created.load(std::memory_order_relaxed); }
 
 void sela_hip_enable_kernel_timing(int enable) { g_timing.enabled = enable != 0; }
 

@@ -309,6 +309,56 @@ def test_four_threads_encode_on_one_gpu(gpu):
     assert not problems, problems
 
 
+def test_threads_take_over_parked_contexts(gpu):
+    """A thread's streams, events and staging buffers are parked when it ends (or calls sela_hip_thread_release) and taken
+    over by the next thread on the device: ten threads one after the other create at most one context between them, three
+    at once at most three, and what they encode and decode -- different audio, different sizes, mono after stereo -- is what
+    the same calls give on the test's own thread."""
+    import threading
+    from sela_amd import capi, codec
+
+    lib = capi.lib()
+    jobs = [synth_frames(40 + 37 * i, 1 + (i % 3 != 2), 400 + i) for i in range(10)]
+    expect = []
+    for pcm in jobs:
+        frames, offsets = codec.encode_host(pcm)
+        expect.append((frames, offsets, codec.decode_host(frames, offsets, pcm.shape[2])))
+    problems = []
+
+    def work(i, release):
+        try:
+            frames, offsets = codec.encode_host(jobs[i])
+            back = codec.decode_host(frames, offsets, jobs[i].shape[2])
+            if not (np.array_equal(frames, expect[i][0]) and np.array_equal(offsets, expect[i][1]) and np.array_equal(back, expect[i][2])):
+                problems.append("job %d differs" % i)
+            if release:
+                lib.sela_hip_thread_release()
+        except Exception as e:  # noqa: BLE001 -- reported below, from the test's thread
+            problems.append("job %d: %r" % (i, e))
+
+    before = lib.sela_hip_debug_contexts_created()
+    for i in range(10):
+        t = threading.Thread(target=work, args=(i, i % 2 == 0))
+        t.start()
+        t.join(120)
+        assert not t.is_alive()
+    assert lib.sela_hip_debug_contexts_created() - before <= 1
+    assert not problems, problems
+    before = lib.sela_hip_debug_contexts_created()
+    threads = [threading.Thread(target=work, args=(i, False)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not any(t.is_alive() for t in threads)
+    assert lib.sela_hip_debug_contexts_created() - before <= 2  # (one was parked by the threads above)
+    assert not problems, problems
+    # shutdown frees the parked ones; the next call simply builds a new one
+    lib.sela_hip_shutdown()
+    frames, offsets = codec.encode_host(jobs[0])
+    assert np.array_equal(frames, expect[0][0]) and np.array_equal(offsets, expect[0][1])
+
+
 def test_batch_verbs_on_album_tracks_match_reference_digests(gpu, tmp_path, album_digests):
     """Tracks 0..11 of BASELINE.json configs[3] (four each at 44.1 / 48 / 96 kHz, 66,120 frames) written as WAV files to
     tmpfs, `sela_mi355x -E --devices 0,0` (two workers on the one GPU: the frame space is cut inside track 7, every

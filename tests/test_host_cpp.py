@@ -115,3 +115,38 @@ def test_cli_batch_of_files_equals_file_by_file(tmp_path):
     assert r.returncode == 0, r.stderr
     for s in selas:
         assert (backn / (s.stem + ".wav")).read_bytes() == (back1 / (s.stem + ".wav")).read_bytes(), s.stem
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [2, 1])
+def test_cli_play_hands_out_the_decoded_frames_in_order(tmp_path, channels):
+    """`-p`: the packets the reference's player would give to libao (src/sela/player.cpp:30-62: one interleaved int16 packet
+    per frame, in order) are the decoded data chunk cut into frames -- to a file and to standard output, and for a stream
+    that stops at a frame without its sync word (src/file/sela_file.cpp:54-56) only the frames before it."""
+    from oracle_lib import oracle
+
+    _build()
+    frames = 70
+    pcm = synth_pcm(frames * 2048, channels, 23).reshape(frames, 2048, channels)
+    blob, offs, _ = oracle().encode_frames(pcm, threads=4)
+    expect, _ = oracle().decode_frames(blob, offs, channels, threads=4)  # what the reference's decoder gives (lossy ties and all)
+    sela = tmp_path / "in.sela"
+    sela.write_bytes(b"SeLa" + struct.pack("<IHBI", 44100, 16, channels, frames) + blob.tobytes())
+    cli = os.path.join(HOST, "sela_mi355x")
+    out = tmp_path / "out.pcm"
+    r = subprocess.run([cli, "-p", str(sela), str(out)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == b""
+    assert f"{frames} frames".encode() in r.stderr
+    assert out.read_bytes() == np.ascontiguousarray(expect, dtype="<i2").tobytes()
+    r = subprocess.run([cli, "-p", str(sela)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == out.read_bytes()  # nothing but samples on standard output
+    # a stream broken in frame 41: frames 0..40 are played, like the reference's reader stops there
+    raw = bytearray(sela.read_bytes())
+    raw[15 + int(offs[41])] ^= 0xFF
+    cut = tmp_path / "cut.sela"
+    cut.write_bytes(bytes(raw))
+    r = subprocess.run([cli, "-p", str(cut)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == out.read_bytes()[: 41 * 2048 * channels * 2]
