@@ -32,6 +32,11 @@ void sela_hip_debug_mean_workers(int self_blocks);
 void sela_hip_debug_stage_wait(int naps);
 /* Debug hook: how many encode feeds of the calling thread were issued again through the copy-engine path so far. */
 int sela_hip_debug_reissued_feeds(void);
+/* Debug hook: the decoder runs a subframe's recurrence in one of two forms (same bits): the >> 3 of the prediction on the
+ * scalar unit (for workgroups that share their SIMDs with many others) or on the vector unit (for those that run nearly
+ * alone: small launches, the last workgroups of a launch).  0 / 1 force the first / second on every frame of the calling
+ * thread's decodes, -1 restores the choice by launch size. */
+void sela_hip_debug_decode_recurrence(int form);
 /* Debug hook: how many per-thread contexts (streams, events, staging buffers) this process has CREATED so far -- threads
  * that take over a parked one (sela_hip.h, sela_hip_thread_release) do not count. */
 int sela_hip_debug_contexts_created(void);

@@ -33,7 +33,7 @@ EXPORTS = [
 # the test hooks include/sela_hip_debug.h declares (not part of the boundary)
 DEBUG_EXPORTS = [
     "sela_hip_debug_phase_buffer", "sela_hip_debug_force_plain_fir", "sela_hip_debug_mean_workers", "sela_hip_debug_stage_wait",
-    "sela_hip_debug_reissued_feeds", "sela_hip_debug_contexts_created",
+    "sela_hip_debug_reissued_feeds", "sela_hip_debug_contexts_created", "sela_hip_debug_decode_recurrence",
 ]
 
 
@@ -111,6 +111,8 @@ def lib() -> C.CDLL:
     L.sela_hip_debug_stage_wait.restype = None
     L.sela_hip_debug_reissued_feeds.argtypes = []
     L.sela_hip_debug_reissued_feeds.restype = C.c_int
+    L.sela_hip_debug_decode_recurrence.argtypes = [C.c_int]
+    L.sela_hip_debug_decode_recurrence.restype = None
     L.sela_hip_debug_contexts_created.argtypes = []
     L.sela_hip_debug_contexts_created.restype = C.c_int
     L.sela_hip_host_alloc.argtypes = [sz]

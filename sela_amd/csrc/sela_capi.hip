@@ -25,7 +25,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles,
-    uint8_t* frame_flags);
+    uint8_t* frame_flags, int recurrence_form);
 int decode_waves(uint32_t channels);
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 uint32_t decode_max_channels();
@@ -367,6 +367,7 @@ thread_local int g_force_plain_fir = 0;          // debug: sela_hip_debug_force_
 thread_local int g_self_blocks = -1;             // debug: sela_hip_debug_mean_workers
 thread_local int g_stage_wait_naps = -1;         // debug: sela_hip_debug_stage_wait
 thread_local int g_reissued_feeds = 0;           // debug: sela_hip_debug_reissued_feeds
+thread_local int g_recurrence_form = -1;         // debug: sela_hip_debug_decode_recurrence
 
 // The staging kernel asks for whole CUs and the blocks that wait for it never leave theirs: two jobs staging on one
 // device at once (two host threads on one GPU) can keep each other's stagers off the device until the bounded waits run
@@ -756,7 +757,7 @@ int job_issue_decode(sela_hip_job* job, const uint8_t* frames, const uint64_t* o
     const uint8_t* d_base = static_cast<const uint8_t*>(c.frames.ptr) - offsets[0];
     uint8_t* flags = ctx().job_flags_mapped + (size_t)job->fed * sela::decode_waves(job->channels);
     e = sela::launch_decode(d_base, k_offsets, nf, job->channels, static_cast<int16_t*>(c.pcm.ptr), static_cast<uint32_t*>(ctx().status.ptr),
-        c.workspace.ptr, s, nullptr, nullptr, flags);
+        c.workspace.ptr, s, nullptr, nullptr, flags, g_recurrence_form);
     if (e != hipSuccess || (e = hipEventRecord(c.ran, s)) != hipSuccess)
         return job_fail(job, fail_hip(e, "decode launch"));
     const size_t frame_pcm = (size_t)sela::kBlock * job->channels * sizeof(int16_t);
@@ -1002,6 +1003,7 @@ void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks;
 void sela_hip_debug_stage_wait(int naps) { g_stage_wait_naps = naps; }
 
 int sela_hip_debug_reissued_feeds(void) { return g_reissued_feeds; }
+void sela_hip_debug_decode_recurrence(int form) { g_recurrence_form = form < 0 ? -1 : (form != 0); }
 int sela_hip_debug_contexts_created(void) { return g_contexts_created.load(std::memory_order_relaxed); }
 
 void sela_hip_enable_kernel_timing(int enable) { g_timing.enabled = enable != 0; }
@@ -1065,7 +1067,7 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 1 : 0;
     hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, d_workspace,
-        static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr);
+        static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_recurrence_form);
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
     return SELA_HIP_OK;

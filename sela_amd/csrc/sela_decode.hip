@@ -49,6 +49,8 @@
 // takes the GENERIC mode of the same kernel: a plain serial parse into the workspace, then the same synthesis.
 // Slow, complete, and never needed by files the encoder writes.  Frames of more than 8 channels (up to the 255 the
 // header's field carries) are decoded by k_decode_frames_wide, eight subframes at a time.
+#include <atomic>
+
 #include "sela_device.h"
 
 namespace sela {
@@ -492,16 +494,26 @@ __device__ inline uint32_t parse_stream_serial(const uint32_t* __restrict__ word
 // nothing: the caller puts the sums back as they were at the block's start and runs it -- and the rest of
 // the subframe -- in the exact form (v_readlane of r, v_mul_lo_u32 + v_add_u32).  16-bit audio never gets
 // there; crafted streams do (tests).
-template <bool kFold>
-__device__ __forceinline__ void synth_mac(uint32_t& zl, uint32_t& zh, uint64_t coef, int32_t s_i)
+// kShift: also hand back (new high word) >> 3, the next step's multiplier if the next step's sum is in this register
+// (kVecShift, see synth_steps).
+template <bool kFold, bool kShift>
+__device__ __forceinline__ void synth_mac(uint32_t& zl, uint32_t& zh, uint64_t coef, int32_t s_i, int32_t& shifted)
 {
     const int32_t al = (int32_t)(uint32_t)coef, ah = (int32_t)(uint32_t)(coef >> 32);
     const uint64_t z = ((uint64_t)zh << 32) | zl;
     const uint64_t lo = (uint64_t)((int64_t)z + (int64_t)al * (int64_t)s_i);
-    if (kFold) // both factors fit 24 bits in the folded form (checked)
-        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(zh) : "v"(ah), "s"(s_i), "v"((uint32_t)(lo >> 32)));
-    else
+    if (kFold) { // both factors fit 24 bits in the folded form (checked)
+        if (kShift)
+            asm("v_mad_i32_i24 %0, %2, %3, %4\n\tv_ashrrev_i32 %1, 3, %0" : "=v"(zh), "=v"(shifted) : "v"(ah), "s"(s_i), "v"((uint32_t)(lo >> 32)));
+        else
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(zh) : "v"(ah), "s"(s_i), "v"((uint32_t)(lo >> 32)));
+    } else {
         zh = (uint32_t)(lo >> 32) + (uint32_t)ah * (uint32_t)s_i;
+        if (kShift) {
+            shifted = (int32_t)zh >> 3;
+            asm volatile("" : "+v"(shifted)); // (stays a vector shift: the compiler would move it behind the readlane)
+        }
+    }
     zl = (uint32_t)lo;
 }
 
@@ -514,23 +526,32 @@ constexpr int kAhead = 4;
 
 // Steps M .. 63 of one block of 64 samples.  (cl, ch): the register whose sums finish in this block;
 // (ol, oh): the other register of the ring of 128 (R == 2).  tab_lane = table + lane.
-template <int R, bool kFold, int G, int M>
+//
+// kVecShift: where the >> 3 of the prediction happens.  false: on the scalar unit, behind the v_readlane (three vector
+// instructions per step: what a SIMD shared by seven waves, bound by vector issue, wants).  true: on the vector unit, in
+// front of it (four, but the step's dependency chain loses its detour through the scalar ALU: 36 instead of 50 cycles per
+// sample for a wave that has its SIMD to itself -- tools/chain_ubench.py -- which is how small batches and the last
+// workgroups of a launch run).  Same bits either way.
+template <int R, bool kFold, int G, bool kVecShift, int M>
 __device__ __forceinline__ void synth_steps(uint32_t& cl, uint32_t& ch, uint32_t& ol, uint32_t& oh, uint32_t& kept,
-    LdsTable tab_lane, int32_t r_block, uint32_t four, uint32_t zero, uint64_t (&pf_c)[kAhead], uint64_t (&pf_o)[kAhead])
+    LdsTable tab_lane, int32_t r_block, uint32_t four, uint32_t zero, uint64_t (&pf_c)[kAhead], uint64_t (&pf_o)[kAhead], int32_t& shifted)
 {
     // scalar side: the sum of this sample sits in lane M.  What goes back into the sums is -a_d * s_i; the table holds
     // +a_d, so the multiplier is -s_i: in the folded form that IS the shifted sum (s_i = -pred: one scalar operation
     // between the readlane and the multiply-adds instead of two), in the exact form pred - r_i.
-    const int32_t pred = __builtin_amdgcn_readlane((int)ch, M) >> 3;
+    // (kVecShift: `shifted` = ch >> 3 as of the end of the step before -- the lanes a step recycles are behind it)
+    const int32_t pred = kVecShift ? __builtin_amdgcn_readlane(shifted, M) : __builtin_amdgcn_readlane((int)ch, M) >> 3;
     int32_t m_i;
     if (kFold)
         m_i = pred;
     else
         m_i = (int32_t)((uint32_t)pred - (uint32_t)__builtin_amdgcn_readlane(r_block, M));
     // vector side: lane L adds a[(L - M) mod ring] * (-s_i)  (a[0] = 0: the finished sum stays)
-    synth_mac<kFold>(cl, ch, pf_c[M % kAhead], m_i);
-    if (R == 2)
-        synth_mac<kFold>(ol, oh, pf_o[M % kAhead], m_i);
+    synth_mac<kFold, kVecShift>(cl, ch, pf_c[M % kAhead], m_i, shifted);
+    if (R == 2) {
+        int32_t unused;
+        synth_mac<kFold, false>(ol, oh, pf_o[M % kAhead], m_i, unused);
+    }
     if constexpr (M + kAhead < 64) {
         pf_c[M % kAhead] = tab_lane[64 * R - (M + kAhead)];
         if (R == 2)
@@ -546,12 +567,12 @@ __device__ __forceinline__ void synth_steps(uint32_t& cl, uint32_t& ch, uint32_t
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (M < 63)
-        synth_steps<R, kFold, G, M + 1>(cl, ch, ol, oh, kept, tab_lane, r_block, four, zero, pf_c, pf_o);
+        synth_steps<R, kFold, G, kVecShift, M + 1>(cl, ch, ol, oh, kept, tab_lane, r_block, four, zero, pf_c, pf_o, shifted);
 }
 
 // One block of 64 samples with residues r_block (one per lane).  The folded form returns false if a sample
 // of the block left its range (s is then meaningless).
-template <int R, bool kFold, int G>
+template <int R, bool kFold, int G, bool kVecShift>
 __device__ __forceinline__ bool synth_block(int32_t r_block, int32_t& s, uint32_t& cl, uint32_t& ch, uint32_t& ol, uint32_t& oh,
     LdsTable tab_lane, uint32_t four, uint32_t zero)
 {
@@ -564,8 +585,13 @@ __device__ __forceinline__ bool synth_block(int32_t r_block, int32_t& s, uint32_
     if (kFold)
         ch -= (uint32_t)r_block << 3; // sample lane of this block: N -= r * 2^35
     uint32_t kept = 0;
+    int32_t shifted = 0;
+    if (kVecShift) {
+        shifted = (int32_t)ch >> 3;
+        asm volatile("" : "+v"(shifted)); // (stays a vector shift: the compiler would move it behind the readlane)
+    }
     __builtin_amdgcn_sched_barrier(0);
-    synth_steps<R, kFold, G, 0>(cl, ch, ol, oh, kept, tab_lane, r_block, four, zero, pf_c, pf_o);
+    synth_steps<R, kFold, G, kVecShift, 0>(cl, ch, ol, oh, kept, tab_lane, r_block, four, zero, pf_c, pf_o, shifted);
     s = (int32_t)((kFold ? 0u : (uint32_t)r_block) - (uint32_t)((int32_t)kept >> 3));
     // (the multiplier of a folded step is -s: both s and -s must fit the 24-bit operand)
     return !kFold || !__any((uint32_t)(s + (1 << 23) - 1) >= (1u << 24) - 1u);
@@ -576,8 +602,9 @@ __device__ __forceinline__ bool synth_block(int32_t r_block, int32_t& s, uint32_
 // from the codeword positions in pos_smp[] (ws == nullptr), the words fetched one block ahead -- or read from
 // the workspace array ws[] (generic mode).  Samples go to pos_smp[] as int16, over the positions of the
 // block just consumed.
-template <int R, int G>
-__device__ inline void synthesize(const uint32_t* words, uint32_t n_words, uint32_t k, uint16_t* pos_smp, const int32_t* ws,
+template <int R, int G, bool kVecShift>
+__device__ __attribute__((noinline)) void synthesize( // (a real call: six of these inlined into three kernels cost the kernels their registers)
+    const uint32_t* words, uint32_t n_words, uint32_t k, uint16_t* pos_smp, const int32_t* ws,
     const uint64_t* tab, bool fold, int lane)
 {
     static_assert(G == 4 || G == 16, "groups are DPP banks or rows");
@@ -632,7 +659,7 @@ __device__ inline void synthesize(const uint32_t* words, uint32_t n_words, uint3
         bool done = false;
         if (fold) {
             const uint32_t s0 = cl, s1 = ch, s2 = ol, s3 = oh;
-            done = synth_block<R, true, G>(r_block, s, cl, ch, ol, oh, tab_lane, four, zero);
+            done = synth_block<R, true, G, kVecShift>(r_block, s, cl, ch, ol, oh, tab_lane, four, zero);
             if (!done) { // back to the block's start, exact form from here on
                 cl = s0, ch = s1;
                 if (R == 2)
@@ -641,7 +668,7 @@ __device__ inline void synthesize(const uint32_t* words, uint32_t n_words, uint3
             }
         }
         if (!done)
-            synth_block<R, false, G>(r_block, s, cl, ch, ol, oh, tab_lane, four, zero);
+            synth_block<R, false, G, kVecShift>(r_block, s, cl, ch, ol, oh, tab_lane, four, zero);
         reinterpret_cast<int16_t*>(pos_smp)[64 * blk + lane] = (int16_t)(uint16_t)(uint32_t)s;
     };
     issue(0);
@@ -652,6 +679,19 @@ __device__ inline void synthesize(const uint32_t* words, uint32_t n_words, uint3
             run_block(pair + 1, zl[1], zh[1], zl[0], zh[0]);
     }
     wave_sync();
+}
+
+// ring / recycling group by order: <= 48: 64 / 16, <= 60: 64 / 4, else 128 / 16
+template <bool kVecShift>
+__device__ __forceinline__ void synthesize_by_order(uint32_t order, const uint32_t* words, uint32_t n_words, uint32_t k, uint16_t* pos_smp,
+    const int32_t* ws, const uint64_t* tab, bool fold, int lane)
+{
+    if (order <= 48)
+        synthesize<1, 16, kVecShift>(words, n_words, k, pos_smp, ws, tab, fold, lane);
+    else if (order <= 60)
+        synthesize<1, 4, kVecShift>(words, n_words, k, pos_smp, ws, tab, fold, lane);
+    else
+        synthesize<2, 16, kVecShift>(words, n_words, k, pos_smp, ws, tab, fold, lane);
 }
 
 // The coefficients a[d] (0 for d = 0 and beyond `order`), packed {al, ah}, ring-periodic and doubled, written
@@ -740,7 +780,8 @@ template <bool kProf>
 __global__ __launch_bounds__(kDecMaxWaves * 64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_decode_frames(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* __restrict__ pcm_out,
     uint32_t* __restrict__ status, int32_t* __restrict__ ws_residues, uint64_t* __restrict__ phase_cycles,
-    uint8_t* __restrict__ frame_flags /* or null: one byte per (frame, wave), written only when not zero */)
+    uint8_t* __restrict__ frame_flags /* or null: one byte per (frame, wave), written only when not zero */,
+    uint32_t vec_shift_from /* frames from this one on run the synthesis with the shift on the vector side (synth_steps) */)
 {
     long long stamp[10];
     for (int i = 0; i < 10; i++)
@@ -759,6 +800,7 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) __attribute__((amdgpu_waves_per_
     const uint32_t f = blockIdx.x;
     if (f >= n_frames)
         return;
+    const bool vec_shift = f >= vec_shift_from;
     const uint8_t* const fb = frames + frame_offsets[f];
     const uint64_t fbytes = frame_offsets[f + 1] - frame_offsets[f];
     uint32_t flags = 0;
@@ -823,13 +865,10 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) __attribute__((amdgpu_waves_per_
         const bool fits24 = build_synth_table(tables->a, tables->tab, (int)order, lane);
         if (kProf)
             stamp[7] = clock64();
-        // ring / recycling group by order: <= 48: 64 / 16, <= 60: 64 / 4, else 128 / 16
-        if (order <= 48)
-            synthesize<1, 16>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
-        else if (order <= 60)
-            synthesize<1, 4>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
+        if (vec_shift)
+            synthesize_by_order<true>(order, gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
         else
-            synthesize<2, 16>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
+            synthesize_by_order<false>(order, gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
         if (kProf)
             stamp[8] = clock64();
         if (lane == 0)
@@ -976,7 +1015,7 @@ constexpr uint32_t kNoSubframe = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames_wide(const uint8_t* __restrict__ frames,
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* __restrict__ pcm_out,
-    uint32_t* __restrict__ status, int32_t* __restrict__ ws_residues, uint8_t* __restrict__ frame_flags)
+    uint32_t* __restrict__ status, int32_t* __restrict__ ws_residues, uint8_t* __restrict__ frame_flags, uint32_t vec_shift_from)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
@@ -986,6 +1025,7 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames_wide(const 
     const uint32_t f = blockIdx.x;
     if (f >= n_frames)
         return;
+    const bool vec_shift = f >= vec_shift_from;
     const uint8_t* const fb = frames + frame_offsets[f];
     const uint64_t fbytes = frame_offsets[f + 1] - frame_offsets[f];
     uint32_t flags = 0;
@@ -1033,12 +1073,10 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) void k_decode_frames_wide(const 
         const double k_hi = (uint32_t)lane + 64 < order ? dequant(lane + 64, q_hi, flags) : 0.0;
         step_up_regs(k_lo, k_hi, tables->a, (int)order, lane, flags);
         const bool fits24 = build_synth_table(tables->a, tables->tab, (int)order, lane);
-        if (order <= 48)
-            synthesize<1, 16>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
-        else if (order <= 60)
-            synthesize<1, 4>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
+        if (vec_shift)
+            synthesize_by_order<true>(order, gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
         else
-            synthesize<2, 16>(gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
+            synthesize_by_order<false>(order, gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
         // the raw samples of this subframe, where its channel lies in the output (mod 2^16: src/file/wav_file.cpp:248-251)
         for (int i = lane; i < kBlock; i += kWave)
             out_frame[(size_t)i * channels + hd.channel] = sl->smp[i];
@@ -1101,9 +1139,44 @@ size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels)
     return (size_t)n_frames * channels * kBlock * sizeof(int32_t) + 256;
 }
 
+// Which workgroups of a launch run their recurrence in the form for a wave that has its SIMD (nearly) to itself
+// (synth_steps, kVecShift): all of them when the whole launch is at most kLonelyWaves waves, else those of the last, partial
+// round of resident workgroups if that round is as small -- they start when the rounds before them are done.
+constexpr uint32_t kLonelyWaves = 2560; // 2.5 per SIMD (tools/chain_ubench.py: the forms break even between 2 and 4)
+struct DecodeResidency {
+    std::atomic<uint32_t> frames[64][kDecMaxWaves + 1]; // [device][waves per workgroup]: workgroups the device holds at once, 0 = not asked yet
+};
+inline uint32_t resident_frames(const void* kernel, int n_waves, size_t lds)
+{
+    static DecodeResidency cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 0;
+    uint32_t have = cache.frames[dev][n_waves].load(std::memory_order_relaxed);
+    if (have == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, n_waves * 64, lds) != hipSuccess
+            || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu <= 0 || cus <= 0)
+            return 0;
+        have = (uint32_t)per_cu * (uint32_t)cus;
+        cache.frames[dev][n_waves].store(have, std::memory_order_relaxed);
+    }
+    return have;
+}
+inline uint32_t vec_shift_from_for(uint32_t n_frames, int n_waves, uint32_t resident)
+{
+    if ((uint64_t)n_frames * (uint32_t)n_waves <= kLonelyWaves)
+        return 0;
+    if (resident == 0)
+        return n_frames;
+    const uint32_t last_round = n_frames / resident * resident; // first frame of the last, partial round
+    return (uint64_t)(n_frames - last_round) * (uint32_t)n_waves <= kLonelyWaves ? last_round : n_frames;
+}
+
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev /* 2 events or nullptr */,
-    uint64_t* d_phase_cycles, uint8_t* frame_flags /* null: flags go to d_status, which is zeroed here */)
+    uint64_t* d_phase_cycles, uint8_t* frame_flags /* null: flags go to d_status, which is zeroed here */,
+    int recurrence_form /* -1: by launch size (vec_shift_from_for); 0 / 1: every frame in the scalar- / vector-shift form (tests) */)
 {
     hipError_t err = frame_flags ? hipSuccess : hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
     if (err != hipSuccess || n_frames == 0)
@@ -1118,8 +1191,10 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
         const size_t lds = (size_t)kDecMaxWaves * (sizeof(DecSubframeLds) + sizeof(DecWaveScratch)) + (size_t)channels * 4;
         if (ev)
             (void)hipEventRecord(ev[0], stream);
+        const uint32_t from = recurrence_form >= 0 ? (recurrence_form ? 0u : n_frames)
+                                                   : vec_shift_from_for(n_frames, kDecMaxWaves, resident_frames(reinterpret_cast<const void*>(k_decode_frames_wide), kDecMaxWaves, lds));
         hipLaunchKernelGGL(k_decode_frames_wide, dim3(n_frames), dim3(kDecMaxWaves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
-            d_pcm_out, d_status, ws, frame_flags);
+            d_pcm_out, d_status, ws, frame_flags, from);
         if (ev)
             (void)hipEventRecord(ev[1], stream);
         return hipGetLastError();
@@ -1135,14 +1210,16 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
         if (err != hipSuccess)
             return err;
     }
+    const uint32_t from = recurrence_form >= 0 ? (recurrence_form ? 0u : n_frames)
+                                                : vec_shift_from_for(n_frames, n_waves, resident_frames(reinterpret_cast<const void*>(k_decode_frames<false>), n_waves, lds));
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
         hipLaunchKernelGGL(k_decode_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
-            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags);
+            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags, from);
     else
         hipLaunchKernelGGL(k_decode_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
-            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags);
+            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags, from);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     return hipGetLastError();

@@ -309,6 +309,50 @@ def test_four_threads_encode_on_one_gpu(gpu):
     assert not problems, problems
 
 
+@pytest.mark.parametrize("form", [0, 1])
+def test_decoder_recurrence_forms_give_the_same_samples(gpu, kats, form):
+    """The decoder walks a subframe's recurrence in one of two forms, chosen by how alone the workgroup will be on its SIMDs
+    (sela_decode.hip, synth_steps kVecShift): small launches -- every test batch -- would only ever see one of them.  Forced
+    here, both forms go through the decode tests that reach every branch of the synthesis: the reference's golden frames,
+    the edge blocks (order 93 and 97: the ring of 128), full-scale difference channels, residues outside 16 bits (the exact
+    32-bit form and the switch to it in the middle of a subframe), unary runs of thousands of bits, random valid streams,
+    frames of more than eight channels; and one batch of more workgroups than the device holds (both forms in one launch
+    is what the size rule gives a 3875-frame batch: test_baseline_configs_by_digest)."""
+    import test_gpu_parity as parity
+    import test_gpu_round2 as round2
+    from sela_amd import capi, codec
+
+    torch = gpu
+    lib = capi.lib()
+    lib.sela_hip_debug_decode_recurrence(form)
+    try:
+        parity.test_frame_kats_encode_and_decode(gpu, kats)
+        parity.test_block_kats_as_frames(gpu, kats)
+        parity.test_extreme_stereo(gpu)
+        parity.test_long_unary_runs_round_trip(gpu)
+        parity.test_decoder_on_streams_no_encoder_would_write(gpu, kats)
+        parity.test_random_batches_match_oracle(gpu, 2, 12, 150)
+        parity.test_random_batches_match_oracle(gpu, 6, 14, 20)
+        round2.test_segment_parallel_parser_on_hard_streams(gpu, kats)
+        round2.test_parser_on_random_valid_streams(gpu, kats)
+        test_wide_frames_encode_and_decode(gpu, 32, 3)
+        test_wide_frames_with_difference_subframes_and_long_streams(gpu)
+        # more workgroups than fit at once, one form throughout
+        o = oracle()
+        pcm = synth_frames(400, 2, 31)
+        blob, offs, _ = o.encode_frames(pcm, threads=8)
+        many = np.tile(blob, 10)
+        many_offs = np.concatenate([offs[:-1] + np.uint64(i * len(blob)) for i in range(10)] + [np.array([10 * len(blob)], np.uint64)])
+        ref_back, _ = o.decode_frames(blob, offs, 2, threads=8)
+        dec = codec.Decoder(4000, 2)
+        back = dec.decode(torch.from_numpy(many).cuda(), torch.from_numpy(many_offs.astype(np.int64)).cuda(), 4000)
+        torch.cuda.synchronize()
+        dec.check()
+        assert np.array_equal(back.cpu().numpy().reshape(10, 400, 2048, 2), np.broadcast_to(ref_back, (10, 400, 2048, 2)))
+    finally:
+        lib.sela_hip_debug_decode_recurrence(-1)
+
+
 def test_threads_take_over_parked_contexts(gpu):
     """A thread's streams, events and staging buffers are parked when it ends (or calls sela_hip_thread_release) and taken
     over by the next thread on the device: ten threads one after the other create at most one context between them, three
