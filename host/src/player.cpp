@@ -137,6 +137,8 @@ size_t Player::playFile(const std::string& selaPath)
             what = e.exceptionMessage.empty() ? "decoding failed" : e.exceptionMessage;
         } catch (const std::exception& e) {
             what = e.what();
+        } catch (...) {
+            what = "decoding failed";
         }
         arrivals.end(what);
     });
@@ -179,6 +181,10 @@ size_t Player::playFile(const std::string& selaPath)
         }
     } catch (const data::Exception& e) {
         failure = e.exceptionMessage.empty() ? "the audio sink failed" : e.exceptionMessage;
+    } catch (const std::exception& e) { // (whatever a sink throws: the decoder is joined before it travels on)
+        failure = e.what();
+    } catch (...) {
+        failure = "the audio sink failed";
     }
     decoder.join();
     if (showProgress && failure.empty() && arrivals.error.empty())

@@ -340,6 +340,47 @@ int main(int argc, char** argv)
             for (size_t i = 0; i < (size_t)2300 * 2048 * ch; i++)
                 differing += std::memcmp(&wa[44 + 2 * i], &pcm[i], 2) != 0;
             CHECK(differing < 4096 * 4);
+            // the player on the same file: every frame of the decoded file, in order, as packets of one frame; a sink that
+            // fails in the middle surfaces as the reference's kind of exception, and the next job runs as if nothing had happened
+            struct Checking : sela::AudioSink {
+                const std::string* wav;
+                size_t at = 44, packets = 0, failAt = (size_t)-1;
+                bool same = true;
+                int opened = 0, closed = 0;
+                uint32_t rate = 0;
+                void open(const data::WavFormatSubChunk& f) override { opened++, rate = f.sampleRate; }
+                void play(const data::AudioPacket& p) override
+                {
+                    if (packets == failAt)
+                        throw data::Exception("the device went away");
+                    same = same && at + p.bufferSize <= wav->size() && std::memcmp(p.audio, wav->data() + at, p.bufferSize) == 0;
+                    at += p.bufferSize, packets++;
+                }
+                void close() override { closed++; }
+            };
+            {
+                Checking sink;
+                sink.wav = &wa;
+                sela::Player player(sink);
+                CHECK(player.playFile(dir + "/forms_obj.sela") == 2300);
+                CHECK(sink.same && sink.packets == 2300 && sink.at == wa.size() && sink.opened == 1 && sink.closed == 1 && sink.rate == 48000);
+                CHECK(player.firstPacketSeconds > 0 && player.packetsPlayed == 2300);
+            }
+            {
+                Checking sink;
+                sink.wav = &wa;
+                sink.failAt = 700;
+                sela::Player player(sink);
+                std::string what;
+                try {
+                    player.playFile(dir + "/forms_obj.sela");
+                } catch (const data::Exception& e) {
+                    what = e.exceptionMessage;
+                }
+                CHECK(what == "the device went away" && sink.packets == 700 && sink.same && sink.closed == 1);
+                sink.failAt = (size_t)-1, sink.at = 44, sink.packets = 0;
+                CHECK(player.playFile(dir + "/forms_obj.sela") == 2300 && sink.same && sink.at == wa.size());
+            }
         } catch (const data::Exception& e) {
             std::fprintf(stderr, "FAIL exception: %s\n", e.exceptionMessage.c_str());
             failures++;
