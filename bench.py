@@ -346,6 +346,14 @@ class ChainJob:
         self.ring = 0
         self.flag_acc = torch.zeros(8, dtype=torch.int32, device="cuda")  # OR of enc status[0], dec status[0]; max of enc [1], dec [1]
 
+    def renew_streams(self):
+        """New HIP streams for the lanes (the old ones are kept alive, so that the new ones are not the same queues again)."""
+        torch = self.b.torch
+        torch.cuda.synchronize()
+        self.retired = getattr(self, "retired", []) + [lane["stream"] for lane in self.lanes]
+        for lane in self.lanes:
+            lane["stream"] = torch.cuda.Stream()
+
     # -- status words: one slot per call, so that nothing a timed call reports is overwritten by the next -------------
     def size_rings(self, steps: int):
         torch = self.b.torch
@@ -448,14 +456,28 @@ def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=
         job.step()
     torch.cuda.synchronize()
     job.fold_status()
-    reps = bench.timed_repetitions(job.step, steps, after=job.fold_status, min_total_s=min_total_s)
-    snaps = job.snapshot_lanes()
-    timed_sizes = None
-    if job.exchange and job.last_set is not None:  # the layout the LAST TIMED step gathered
-        timed_sizes = job.last_set["all"].clone()
-    serial = bench.timed_repetitions(lambda: job.step(serial=True), steps, after=job.fold_status, min_total_s=0.15) if len(job.lanes) > 1 else reps
-    median_s, rep_stats = Bench.summarise(reps, steps)
-    serial_s, _ = Bench.summarise(serial, steps)
+    # The runtime multiplexes HIP streams onto a few hardware queues, and two lanes that land on ONE queue run one after
+    # the other (seen once, in a process that had created and destroyed streams before): if the lanes together are no
+    # faster than one lane alone, they get new streams and the measurement is taken again (recorded in the line).
+    renewals = 0
+    while True:
+        reps = bench.timed_repetitions(job.step, steps, after=job.fold_status, min_total_s=min_total_s)
+        snaps = job.snapshot_lanes()
+        timed_sizes = None
+        if job.exchange and job.last_set is not None:  # the layout the LAST TIMED step gathered
+            timed_sizes = job.last_set["all"].clone()
+        serial = bench.timed_repetitions(lambda: job.step(serial=True), steps, after=job.fold_status, min_total_s=0.15) if len(job.lanes) > 1 else reps
+        median_s, rep_stats = Bench.summarise(reps, steps)
+        serial_s, _ = Bench.summarise(serial, steps)
+        if len(job.lanes) == 1 or median_s < 0.97 * serial_s or renewals >= 2:
+            break
+        renewals += 1
+        job.renew_streams()
+        for _ in range(max(2, warmup)):
+            job.step()
+        torch.cuda.synchronize()
+        job.fold_status()
+    job.stream_renewals = renewals
 
     # ---- correctness of what was timed -------------------------------------------------------------------------------
     # One more step, serial and synchronised after every batch: its status words, its round trip, and -- batch by batch --
@@ -509,7 +531,8 @@ def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=
 
 
 def lanes_block(job: ChainJob, m, samples, steps):
-    return {"in_flight": len(job.lanes), "ms_per_step_one_lane": m["serial_s"] * 1e3, "value_one_lane": samples / m["serial_s"] / 1e6,
+    return {"in_flight": len(job.lanes), "stream_renewals": getattr(job, "stream_renewals", 0),
+            "ms_per_step_one_lane": m["serial_s"] * 1e3, "value_one_lane": samples / m["serial_s"] / 1e6,
             "what": "consecutive batches are independent encode->decode chains on alternating HIP streams; one lane = strictly serial"}
 
 
