@@ -346,6 +346,26 @@ class ChainJob:
         self.ring = 0
         self.flag_acc = torch.zeros(8, dtype=torch.int32, device="cuda")  # OR of enc status[0], dec status[0]; max of enc [1], dec [1]
 
+    def streams_overlap(self) -> bool:
+        """Do the lanes' streams run side by side?  One spinning workgroup on lane 0, then one on every lane at once."""
+        torch = self.b.torch
+        if len(self.lanes) < 2 or not hasattr(torch.cuda, "_sleep"):
+            return True
+
+        def spin(lanes):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for lane in lanes:
+                with torch.cuda.stream(lane["stream"]):
+                    torch.cuda._sleep(2_000_000)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        spin(self.lanes[:1])
+        alone = min(spin(self.lanes[:1]) for _ in range(3))
+        together = min(spin(self.lanes) for _ in range(3))
+        return together < 1.5 * alone
+
     def renew_streams(self):
         """New HIP streams for the lanes (the old ones are kept alive, so that the new ones are not the same queues again)."""
         torch = self.b.torch
@@ -457,20 +477,11 @@ def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=
     torch.cuda.synchronize()
     job.fold_status()
     # The runtime multiplexes HIP streams onto a few hardware queues, and two lanes that land on ONE queue run one after
-    # the other (seen once, in a process that had created and destroyed streams before): if the lanes together are no
-    # faster than one lane alone, they get new streams and the measurement is taken again (recorded in the line).
+    # the other (seen in a process that had created and destroyed streams before): if a probe -- one spinning workgroup
+    # per lane -- shows that the lanes' streams do not run side by side, they get new streams before anything is
+    # timed (recorded in the line).
     renewals = 0
-    while True:
-        reps = bench.timed_repetitions(job.step, steps, after=job.fold_status, min_total_s=min_total_s)
-        snaps = job.snapshot_lanes()
-        timed_sizes = None
-        if job.exchange and job.last_set is not None:  # the layout the LAST TIMED step gathered
-            timed_sizes = job.last_set["all"].clone()
-        serial = bench.timed_repetitions(lambda: job.step(serial=True), steps, after=job.fold_status, min_total_s=0.15) if len(job.lanes) > 1 else reps
-        median_s, rep_stats = Bench.summarise(reps, steps)
-        serial_s, _ = Bench.summarise(serial, steps)
-        if len(job.lanes) == 1 or median_s < 0.97 * serial_s or renewals >= 2:
-            break
+    while len(job.lanes) > 1 and renewals < 3 and not job.streams_overlap():
         renewals += 1
         job.renew_streams()
         for _ in range(max(2, warmup)):
@@ -478,6 +489,14 @@ def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=
         torch.cuda.synchronize()
         job.fold_status()
     job.stream_renewals = renewals
+    reps = bench.timed_repetitions(job.step, steps, after=job.fold_status, min_total_s=min_total_s)
+    snaps = job.snapshot_lanes()
+    timed_sizes = None
+    if job.exchange and job.last_set is not None:  # the layout the LAST TIMED step gathered
+        timed_sizes = job.last_set["all"].clone()
+    serial = bench.timed_repetitions(lambda: job.step(serial=True), steps, after=job.fold_status, min_total_s=0.15) if len(job.lanes) > 1 else reps
+    median_s, rep_stats = Bench.summarise(reps, steps)
+    serial_s, _ = Bench.summarise(serial, steps)
 
     # ---- correctness of what was timed -------------------------------------------------------------------------------
     # One more step, serial and synchronised after every batch: its status words, its round trip, and -- batch by batch --
