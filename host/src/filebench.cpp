@@ -17,12 +17,14 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
 
 #include "sela_hip.h"
 #include "sela_host/codec.hpp"
+#include "sela_host/frame.hpp"
 #include "sela_host/player.hpp"
 
 #include <mutex>
@@ -72,6 +74,65 @@ int main(int argc, char** argv)
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s in.wav scratch_dir [repeats] [e2e|all] [io threads]   (e2e: only the host-pointer leg, for traces)\n", argv[0]);
         return 2;
+    }
+    if (std::string(argv[1]) == "frames") {
+        // sela_filebench frames <threads> <frames per thread>: the reference's own fan-out (src/sela/encoder.cpp:58-73: T threads,
+        // each constructing a frame::FrameEncoder per frame of its share) on the host classes, then the decoders the same way
+        const int threads = std::max(1, std::atoi(argv[2])), per = argc > 3 ? std::max(1, std::atoi(argv[3])) : 16;
+        using clock = std::chrono::steady_clock;
+        std::vector<data::WavFrame> in;
+        uint32_t x = 2463534242u;
+        for (int i = 0; i < threads * per; i++) {
+            std::vector<std::vector<int32_t>> ch(2, std::vector<int32_t>(2048));
+            int v[2] = { 0, 0 };
+            for (int j = 0; j < 2048; j++)
+                for (int c = 0; c < 2; c++) {
+                    x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+                    v[c] += (int)(x % 601) - 300;
+                    v[c] = std::min(30000, std::max(-30000, v[c]));
+                    ch[c][j] = v[c];
+                }
+            in.emplace_back(16, std::move(ch));
+        }
+        std::vector<data::SelaFrame> coded(in.size(), data::SelaFrame(16));
+        std::vector<data::WavFrame> back(in.size(), data::WavFrame(16, {}));
+        std::vector<std::string> errors(threads);
+        auto fanOut = [&](bool encode) {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; t++)
+                pool.emplace_back([&, t] {
+                    try {
+                        for (int i = t * per; i < (t + 1) * per; i++) {
+                            if (encode)
+                                coded[i] = frame::FrameEncoder(in[i]).process();
+                            else
+                                back[i] = frame::FrameDecoder(coded[i]).process();
+                        }
+                    } catch (const data::Exception& e) {
+                        errors[t] = e.exceptionMessage;
+                    }
+                });
+            for (std::thread& th : pool)
+                th.join();
+        };
+        fanOut(true), fanOut(false); // (untimed: contexts, pinned memory)
+        const auto t0 = clock::now();
+        fanOut(true);
+        const auto t1 = clock::now();
+        fanOut(false);
+        const auto t2 = clock::now();
+        size_t differing = 0;
+        for (size_t i = 0; i < in.size(); i++)
+            differing += back[i].samples != in[i].samples;
+        for (const std::string& e : errors)
+            if (!e.empty()) {
+                std::fprintf(stderr, "%s\n", e.c_str());
+                return 1;
+            }
+        const double encMs = std::chrono::duration<double, std::milli>(t1 - t0).count(), decMs = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        std::printf("{\"threads\": %d, \"frames\": %zu, \"encode_ms\": %.3f, \"decode_ms\": %.3f, \"encode_msps\": %.1f, \"decode_msps\": %.1f, \"frames_not_lossless\": %zu}\n",
+            threads, in.size(), encMs, decMs, in.size() * 2048.0 / encMs / 1e3, in.size() * 2048.0 / decMs / 1e3, differing);
+        return 0;
     }
     if (std::string(argv[1]) == "batch") {
         // sela_filebench batch <scratch dir> <devices, e.g. 0 or 0,0> <repeats> a.wav b.wav ...: the batch verbs in-process (HIP

@@ -7,6 +7,7 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
 
 #include "sela_hip.h"
 #include "sela_host/fileio.hpp"
@@ -340,6 +341,60 @@ int main(int argc, char** argv)
             for (size_t i = 0; i < (size_t)2300 * 2048 * ch; i++)
                 differing += std::memcmp(&wa[44 + 2 * i], &pcm[i], 2) != 0;
             CHECK(differing < 4096 * 4);
+            // frame::FrameEncoder / FrameDecoder from many threads at once (the reference's own fan-out,
+            // src/sela/encoder.cpp:58-73): concurrent calls are coalesced into batches; every result is the bytes the same
+            // call gives alone, mono and stereo callers mixed, and a caller with a broken frame fails alone
+            {
+                const int threads = 24, per = 6;
+                std::vector<data::WavFrame> in;
+                uint32_t y = 88172645u;
+                for (int i = 0; i < threads * per; i++) {
+                    const size_t chn = (i / per) % 3 == 2 ? 1 : 2; // every third thread codes mono frames
+                    std::vector<std::vector<int32_t>> smp(chn, std::vector<int32_t>(2048));
+                    int v[2] = { 0, 0 };
+                    for (int j = 0; j < 2048; j++)
+                        for (size_t c = 0; c < chn; c++) {
+                            y ^= y << 13, y ^= y >> 17, y ^= y << 5;
+                            v[c] = std::min(32000, std::max(-32000, v[c] + (int)(y % 2001) - 1000));
+                            smp[c][j] = v[c];
+                        }
+                    in.emplace_back(16, std::move(smp));
+                }
+                std::vector<std::vector<uint8_t>> alone(in.size()), together(in.size());
+                std::vector<data::SelaFrame> coded(in.size(), data::SelaFrame(16));
+                for (size_t i = 0; i < in.size(); i++) {
+                    coded[i] = frame::FrameEncoder(in[i]).process();
+                    frame::appendFrame(coded[i], alone[i]);
+                }
+                std::vector<int> bad(threads, 0), threw(threads, 0);
+                std::vector<std::thread> pool;
+                for (int t = 0; t < threads; t++)
+                    pool.emplace_back([&, t] {
+                        for (int i = t * per; i < (t + 1) * per; i++) {
+                            try {
+                                const data::SelaFrame f = frame::FrameEncoder(in[i]).process();
+                                frame::appendFrame(f, together[i]);
+                                data::SelaFrame toDecode = f;
+                                if (t == 5 && i == t * per + 2)
+                                    toDecode.subFrames[0].channel = 9; // a subframe for a channel the frame does not have
+                                const data::WavFrame w = frame::FrameDecoder(toDecode).process();
+                                bad[t] += w.samples != in[i].samples;
+                            } catch (const data::Exception&) {
+                                threw[t]++;
+                            }
+                        }
+                    });
+                for (std::thread& th : pool)
+                    th.join();
+                size_t differing = 0, notLossless = 0, exceptions = 0;
+                for (size_t i = 0; i < in.size(); i++)
+                    differing += together[i] != alone[i];
+                for (int t = 0; t < threads; t++)
+                    notLossless += (size_t)bad[t], exceptions += (size_t)threw[t];
+                CHECK(differing == 0);
+                CHECK(notLossless == 0);
+                CHECK(exceptions == 1 && threw[5] == 1); // the broken frame's caller, nobody else
+            }
             // the player on the same file: every frame of the decoded file, in order, as packets of one frame; a sink that
             // fails in the middle surfaces as the reference's kind of exception, and the next job runs as if nothing had happened
             struct Checking : sela::AudioSink {
