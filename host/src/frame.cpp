@@ -2,11 +2,13 @@
 // FrameEncoder / FrameDecoder entry points on top of libsela_hip.so.
 #include "sela_host/frame.hpp"
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sela_hip.h"
@@ -116,6 +118,7 @@ class Coalescer {
     std::condition_variable cv;
     std::deque<FrameJob*> queue;
     bool busy = false;
+    size_t lastBatch = 0; // calls in the batch before this one
     // the leader's staging (one leader at a time): page-locked, reused from batch to batch
     sela_host::PinnedBuffer<uint8_t> in, out;
     std::vector<uint64_t> offsets;
@@ -192,7 +195,24 @@ public:
         cv.wait(lock, [&] { return job.done || job.lead; });
         if (job.done)
             return;
-        // this call leads: everything that is waiting with its channel count, itself included
+        // this call leads.  If the batch before held several calls, their threads are on their way back with their next
+        // frames right now: give them until the queue has stopped growing for a moment (bounded), a trip costs more than that
+        if (lastBatch > 1) {
+            const auto t0 = std::chrono::steady_clock::now();
+            size_t seen = queue.size();
+            auto lastGrowth = t0;
+            for (;;) {
+                lock.unlock();
+                std::this_thread::yield();
+                lock.lock();
+                const auto now = std::chrono::steady_clock::now();
+                if (queue.size() != seen)
+                    seen = queue.size(), lastGrowth = now;
+                if (seen >= lastBatch || now - lastGrowth > std::chrono::microseconds(20) || now - t0 > std::chrono::microseconds(150))
+                    break;
+            }
+        }
+        // everything that is waiting with its channel count, itself included
         std::vector<FrameJob*> batch;
         for (auto it = queue.begin(); it != queue.end() && batch.size() < kMaxBatch;) {
             if ((*it)->channels == job.channels) {
@@ -214,6 +234,7 @@ public:
         lock.lock();
         for (FrameJob* j : batch)
             j->done = true;
+        lastBatch = batch.size();
         if (queue.empty())
             busy = false;
         else
