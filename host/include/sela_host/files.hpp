@@ -27,10 +27,11 @@ public:
     uint16_t bitsPerSample = 16;
     uint16_t numChannels = 0;
     sela_host::PinnedBuffer<int16_t> pcm;   // interleaved, whole data chunk
-    std::vector<data::WavFrame> wavFrames;  // filled by demuxSamples()
     // The reference's view of the same file (src/include/file/wav_file.hpp:14): format fields, sizes, and the data
     // chunk as a pointer into `pcm` (no copy).  Refreshed by the readers, the constructors and syncChunk().
     data::WavChunk wavChunk;
+    // filled by demuxSamples(); the same vector the reference keeps at wavChunk.dataSubChunk.wavFrames (one copy, two names)
+    std::vector<data::WavFrame>& wavFrames = wavChunk.dataSubChunk.wavFrames;
     void syncChunk();
 
     WavFile() {}

@@ -9,10 +9,12 @@
 #include "sela_host/files.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <iterator>
 
 #include "sela_hip.h"
+#include "sela_host/fileio.hpp"
 #include "sela_host/frame.hpp"
 
 namespace {
@@ -40,13 +42,50 @@ void put(std::ofstream& out, T v)
     out.write(reinterpret_cast<const char*>(&v), sizeof v); // little-endian host, like the reference
 }
 
+// body(f) for every f in [0, n), in runs on the I/O pool's threads (the calling thread takes a share); the first
+// data::Exception of a body is rethrown here.
+template <typename Body>
+void forFrames(size_t n, Body body)
+{
+    const size_t workers = std::min<size_t>(sela_host::IoPool::instance().threads() + 1, 8), run = 64;
+    if (n < 4 * run || workers < 2) {
+        for (size_t f = 0; f < n; f++)
+            body(f);
+        return;
+    }
+    std::atomic<size_t> next{ 0 };
+    auto work = [&] {
+        for (;;) {
+            const size_t begin = next.fetch_add(run, std::memory_order_relaxed);
+            if (begin >= n)
+                return;
+            for (size_t f = begin; f < std::min(n, begin + run); f++)
+                body(f);
+        }
+    };
+    sela_host::IoGroup group;
+    for (size_t w = 1; w < workers; w++)
+        group.run(work);
+    std::string mine;
+    try {
+        work();
+    } catch (const data::Exception& e) {
+        mine = e.exceptionMessage.empty() ? "failed" : e.exceptionMessage;
+        next.store(n, std::memory_order_relaxed);
+    }
+    group.wait(); // (throws what a pool task threw)
+    if (!mine.empty())
+        throw data::Exception(mine);
+}
+
 } // namespace
 
 namespace file {
 
 WavFile::WavFile(uint32_t rate, uint16_t bps, uint16_t channels, std::vector<data::WavFrame>&& frames)
-    : sampleRate(rate), bitsPerSample(bps), numChannels(channels), wavFrames(std::move(frames))
+    : sampleRate(rate), bitsPerSample(bps), numChannels(channels)
 {
+    wavFrames = std::move(frames);
     size_t total = 0;
     for (const data::WavFrame& f : wavFrames)
         total += (f.samples.empty() ? 0 : f.samples[0].size()) * f.samples.size();
@@ -59,7 +98,6 @@ WavFile::WavFile(uint32_t rate, uint16_t bps, uint16_t channels, std::vector<dat
                 pcm[at++] = (int16_t)(uint16_t)f.samples[c][i];
     }
     syncChunk();
-    wavChunk.dataSubChunk.wavFrames = wavFrames;
 }
 
 WavFile::WavFile(uint32_t rate, uint16_t channels, std::vector<int16_t>&& interleaved)
@@ -80,8 +118,7 @@ WavFile& WavFile::operator=(const WavFile& o)
         samplesPerChannelPerFrame = o.samplesPerChannelPerFrame;
         sampleRate = o.sampleRate, bitsPerSample = o.bitsPerSample, numChannels = o.numChannels;
         pcm = o.pcm;
-        wavFrames = o.wavFrames;
-        wavChunk = o.wavChunk;
+        wavChunk = o.wavChunk; // (with it the frames: wavFrames is a name for wavChunk.dataSubChunk.wavFrames)
         wavChunk.dataSubChunk.samples = pcm.data();
     }
     return *this;
@@ -93,7 +130,6 @@ WavFile& WavFile::operator=(WavFile&& o) noexcept
         samplesPerChannelPerFrame = o.samplesPerChannelPerFrame;
         sampleRate = o.sampleRate, bitsPerSample = o.bitsPerSample, numChannels = o.numChannels;
         pcm = std::move(o.pcm);
-        wavFrames = std::move(o.wavFrames);
         wavChunk = std::move(o.wavChunk);
         wavChunk.dataSubChunk.samples = pcm.data();
         o.wavChunk.dataSubChunk.samples = nullptr, o.wavChunk.dataSubChunk.sampleCount = 0;
@@ -197,19 +233,20 @@ void WavFile::readFromFile(std::ifstream& in)
 
 void WavFile::demuxSamples()
 {
-    wavFrames.clear();
-    const size_t frames = frameCount(), n = samplesPerChannelPerFrame;
-    wavFrames.reserve(frames);
-    for (size_t f = 0; f < frames; f++) {
-        std::vector<std::vector<int32_t>> s(numChannels, std::vector<int32_t>(n));
-        const int16_t* src = pcm.data() + f * n * numChannels;
+    const size_t frames = frameCount(), n = samplesPerChannelPerFrame, channels = numChannels;
+    const uint8_t bps = (uint8_t)bitsPerSample;
+    wavFrames.assign(frames, data::WavFrame(bps, {}));
+    // 2048 x channels int32 per frame, each frame on its own: spread over the I/O pool's threads (a 3-minute track is
+    // 64 MB of them -- the objects cost more than the decode)
+    forFrames(frames, [&](size_t f) {
+        std::vector<std::vector<int32_t>> s(channels, std::vector<int32_t>(n));
+        const int16_t* src = pcm.data() + f * n * channels;
         for (size_t i = 0; i < n; i++)
-            for (size_t c = 0; c < numChannels; c++)
-                s[c][i] = src[i * numChannels + c];
-        wavFrames.emplace_back((uint8_t)bitsPerSample, std::move(s));
-    }
+            for (size_t c = 0; c < channels; c++)
+                s[c][i] = src[i * channels + c];
+        wavFrames[f].samples = std::move(s);
+    });
     syncChunk();
-    wavChunk.dataSubChunk.wavFrames = wavFrames; // (where reference-side code looks for them)
 }
 
 void WavFile::writeHeader(std::ofstream& out, uint32_t rate, uint16_t channels, uint16_t bps, uint32_t dataBytes)
@@ -295,15 +332,12 @@ void SelaFile::readFromFile(std::ifstream& in)
 
 void SelaFile::materializeFrames()
 {
-    selaFrames.clear();
     const size_t n = frameCount();
-    selaFrames.reserve(n);
-    for (size_t f = 0; f < n; f++) {
-        data::SelaFrame frame((uint8_t)selaHeader.bitsPerSample);
+    selaFrames.assign(n, data::SelaFrame((uint8_t)selaHeader.bitsPerSample));
+    forFrames(n, [&](size_t f) {
         frame::parseFrame(frameBytes.data() + frameOffsets[f], (size_t)(frameOffsets[f + 1] - frameOffsets[f]), selaHeader.channels,
-            (uint8_t)selaHeader.bitsPerSample, frame);
-        selaFrames.push_back(std::move(frame));
-    }
+            (uint8_t)selaHeader.bitsPerSample, selaFrames[f]);
+    });
 }
 
 void SelaFile::writeHeader(std::ofstream& out) const
