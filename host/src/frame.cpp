@@ -2,17 +2,11 @@
 // FrameEncoder / FrameDecoder entry points on top of libsela_hip.so.
 #include "sela_host/frame.hpp"
 
-#include <chrono>
-#include <condition_variable>
 #include <cstring>
-#include <deque>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "sela_hip.h"
-#include "sela_host/buffer.hpp"
 
 namespace {
 
@@ -94,169 +88,10 @@ void appendFrame(const data::SelaFrame& f, std::vector<uint8_t>& out)
     }
 }
 
-// ---- coalescing --------------------------------------------------------------------------------------------------
 // The reference calls these classes from hardware_concurrency() threads at once, one frame per call
-// (src/sela/encoder.cpp:58-73, src/sela/decoder.cpp:58-73).  One frame is a poor launch for a GPU: 3 of its 3072 slots.
-// So concurrent calls are coalesced the way databases group commits: a call finds nobody ahead of it and runs at once;
-// the calls that arrive while it is on the device queue up, and when it comes back ONE of them takes everything that
-// is waiting (with its channel count) to the device as a single batch -- and so on.  Nobody waits for a timer, a lone
-// caller pays nothing, and T busy threads end up in batches of about T frames.
-namespace {
-
-struct FrameJob {
-    uint32_t channels = 0;
-    const uint8_t* in = nullptr; // encode: interleaved int16 PCM of one frame; decode: the frame's on-disk bytes
-    size_t inBytes = 0;
-    std::vector<uint8_t> out;    // encode: the frame's on-disk bytes; decode: interleaved int16 PCM
-    bool done = false, lead = false;
-    std::string error;
-};
-
-class Coalescer {
-    const bool encode;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<FrameJob*> queue;
-    bool busy = false;
-    size_t lastBatch = 0; // calls in the batch before this one
-    // the leader's staging (one leader at a time): page-locked, reused from batch to batch
-    sela_host::PinnedBuffer<uint8_t> in, out;
-    std::vector<uint64_t> offsets;
-
-    static constexpr size_t kMaxBatch = 4096;
-
-    void runOne(FrameJob& j) // a batch of one, straight from and to the caller's memory
-    {
-        if (encode) {
-            j.out.resize(sela_hip_encode_bound_bytes(1, j.channels));
-            uint64_t offs[2] = { 0, 0 };
-            if (sela_hip_encode(reinterpret_cast<const int16_t*>(j.in), 1, j.channels, (uint32_t)kBlock, j.out.data(), j.out.size(), offs) != SELA_HIP_OK)
-                j.error = std::string("FrameEncoder: ") + sela_hip_last_error();
-            else
-                j.out.resize((size_t)offs[1]);
-        } else {
-            const uint64_t offs[2] = { 0, j.inBytes };
-            j.out.resize(kBlock * j.channels * 2);
-            if (sela_hip_decode(j.in, offs, 1, j.channels, reinterpret_cast<int16_t*>(j.out.data())) != SELA_HIP_OK)
-                j.error = std::string("FrameDecoder: ") + sela_hip_last_error();
-        }
-    }
-
-    void runBatch(const std::vector<FrameJob*>& batch)
-    {
-        const uint32_t channels = batch[0]->channels;
-        const size_t n = batch.size(), framePcm = kBlock * channels * 2;
-        if (n == 1)
-            return runOne(*batch[0]);
-        offsets.assign(n + 1, 0);
-        if (encode) {
-            in.resize(n * framePcm);
-            for (size_t i = 0; i < n; i++)
-                std::memcpy(in.data() + i * framePcm, batch[i]->in, framePcm);
-            out.resize(sela_hip_encode_bound_bytes((uint32_t)n, channels));
-            if (sela_hip_encode(reinterpret_cast<const int16_t*>(in.data()), (uint32_t)n, channels, (uint32_t)kBlock, out.data(), out.size(), offsets.data())
-                != SELA_HIP_OK) {
-                const std::string what = std::string("FrameEncoder: ") + sela_hip_last_error();
-                for (FrameJob* j : batch)
-                    j->error = what;
-                return;
-            }
-            for (size_t i = 0; i < n; i++)
-                batch[i]->out.assign(out.data() + offsets[i], out.data() + offsets[i + 1]);
-        } else {
-            size_t total = 0;
-            for (size_t i = 0; i < n; i++)
-                offsets[i] = total, total += (batch[i]->inBytes + 3) & ~(size_t)3; // (frames are whole words; keep every start aligned)
-            offsets[n] = total;
-            in.resize(total + 4);
-            for (size_t i = 0; i < n; i++)
-                std::memcpy(in.data() + offsets[i], batch[i]->in, batch[i]->inBytes);
-            out.resize(n * framePcm);
-            if (sela_hip_decode(in.data(), offsets.data(), (uint32_t)n, channels, reinterpret_cast<int16_t*>(out.data())) != SELA_HIP_OK) {
-                // one caller's malformed frame must not fail its neighbours': everyone on their own
-                for (FrameJob* j : batch)
-                    runOne(*j);
-                return;
-            }
-            for (size_t i = 0; i < n; i++)
-                batch[i]->out.assign(out.data() + i * framePcm, out.data() + (i + 1) * framePcm);
-        }
-    }
-
-public:
-    explicit Coalescer(bool enc) : encode(enc) {}
-
-    void submit(FrameJob& job)
-    {
-        std::unique_lock<std::mutex> lock(mu);
-        queue.push_back(&job);
-        if (!busy)
-            busy = job.lead = true;
-        cv.wait(lock, [&] { return job.done || job.lead; });
-        if (job.done)
-            return;
-        // this call leads.  If the batch before held several calls, their threads are on their way back with their next
-        // frames right now: give them until the queue has stopped growing for a moment (bounded), a trip costs more than that
-        if (lastBatch > 1) {
-            const auto t0 = std::chrono::steady_clock::now();
-            size_t seen = queue.size();
-            auto lastGrowth = t0;
-            for (;;) {
-                lock.unlock();
-                std::this_thread::yield();
-                lock.lock();
-                const auto now = std::chrono::steady_clock::now();
-                if (queue.size() != seen)
-                    seen = queue.size(), lastGrowth = now;
-                if (seen >= lastBatch || now - lastGrowth > std::chrono::microseconds(20) || now - t0 > std::chrono::microseconds(150))
-                    break;
-            }
-        }
-        // everything that is waiting with its channel count, itself included
-        std::vector<FrameJob*> batch;
-        for (auto it = queue.begin(); it != queue.end() && batch.size() < kMaxBatch;) {
-            if ((*it)->channels == job.channels) {
-                batch.push_back(*it);
-                it = queue.erase(it);
-            } else {
-                ++it;
-            }
-        }
-        lock.unlock();
-        try {
-            runBatch(batch);
-        } catch (...) { // (out of page-locked memory, ...: the callers hear of it, nobody is left waiting)
-            for (FrameJob* j : batch)
-                j->error = encode ? "FrameEncoder: the batch could not be staged" : "FrameDecoder: the batch could not be staged";
-        }
-        // (the device buffers and streams this thread used go to whoever leads next: any of the callers may)
-        sela_hip_thread_release();
-        lock.lock();
-        for (FrameJob* j : batch)
-            j->done = true;
-        lastBatch = batch.size();
-        if (queue.empty())
-            busy = false;
-        else
-            queue.front()->lead = true;
-        lock.unlock();
-        cv.notify_all();
-    }
-};
-
-Coalescer& encodeCoalescer()
-{
-    static Coalescer* c = new Coalescer(true); // (never destroyed: calls may outlive the statics)
-    return *c;
-}
-Coalescer& decodeCoalescer()
-{
-    static Coalescer* c = new Coalescer(false);
-    return *c;
-}
-
-} // namespace
-
+// (src/sela/encoder.cpp:58-73, src/sela/decoder.cpp:58-73).  One frame is a poor launch for a GPU; concurrent small calls
+// are coalesced into one device job per trip inside libsela_hip.so (sela_hip_encode / sela_hip_decode, sela_capi.hip), so
+// nothing of that needs to be done here.
 data::SelaFrame FrameEncoder::process()
 {
     const size_t channels = wavFrame.samples.size();
@@ -273,15 +108,12 @@ data::SelaFrame FrameEncoder::process()
             pcm[i * channels + c] = (int16_t)v;
         }
     }
-    FrameJob job;
-    job.channels = (uint32_t)channels;
-    job.in = reinterpret_cast<const uint8_t*>(pcm.data());
-    job.inBytes = pcm.size() * 2;
-    encodeCoalescer().submit(job);
-    if (!job.error.empty())
-        throw data::Exception(job.error);
+    std::vector<uint8_t> bytes(sela_hip_encode_bound_bytes(1, (uint32_t)channels));
+    uint64_t offsets[2] = { 0, 0 };
+    if (sela_hip_encode(pcm.data(), 1, (uint32_t)channels, (uint32_t)kBlock, bytes.data(), bytes.size(), offsets) != SELA_HIP_OK)
+        throw data::Exception(std::string("FrameEncoder: ") + sela_hip_last_error());
     data::SelaFrame frame(wavFrame.bitsPerSample);
-    parseFrame(job.out.data(), job.out.size(), (uint8_t)channels, wavFrame.bitsPerSample, frame);
+    parseFrame(bytes.data(), (size_t)offsets[1], (uint8_t)channels, wavFrame.bitsPerSample, frame);
     return frame;
 }
 
@@ -292,14 +124,10 @@ data::WavFrame FrameDecoder::process()
         throw data::Exception("FrameDecoder: a frame needs 1..255 subframes");
     std::vector<uint8_t> bytes;
     appendFrame(selaFrame, bytes);
-    FrameJob job;
-    job.channels = (uint32_t)channels;
-    job.in = bytes.data();
-    job.inBytes = bytes.size();
-    decodeCoalescer().submit(job);
-    if (!job.error.empty())
-        throw data::Exception(job.error);
-    const int16_t* pcm = reinterpret_cast<const int16_t*>(job.out.data());
+    const uint64_t offsets[2] = { 0, bytes.size() };
+    std::vector<int16_t> pcm(kBlock * channels);
+    if (sela_hip_decode(bytes.data(), offsets, 1, (uint32_t)channels, pcm.data()) != SELA_HIP_OK)
+        throw data::Exception(std::string("FrameDecoder: ") + sela_hip_last_error());
     std::vector<std::vector<int32_t>> samples(channels, std::vector<int32_t>(kBlock));
     for (size_t i = 0; i < kBlock; i++)
         for (size_t c = 0; c < channels; c++)

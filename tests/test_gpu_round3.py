@@ -567,3 +567,54 @@ def test_streaming_jobs_with_random_feeds(gpu, channels, pinned_io):
         if pinned_io:
             for p in (p_pcm, p_out, p_back):
                 lib.sela_hip_host_free(p)
+
+
+def test_small_calls_from_many_threads_are_coalesced_and_stay_their_own(gpu):
+    """sela_hip_encode / sela_hip_decode calls of a few frames from many threads at once (a binding that keeps the
+    reference's per-frame thread loop, src/sela/encoder.cpp:58-73) are merged into device batches inside the library: every
+    call gets the bytes the same call gets alone -- 1 to 9 frames, mono and stereo callers mixed --, a caller whose output
+    buffer is too small gets SELA_HIP_ECAPACITY and a caller with a malformed frame SELA_HIP_EFORMAT, each alone."""
+    import threading
+    from sela_amd import capi, codec
+
+    lib = capi.lib()
+    n_threads, rounds = 24, 5
+    jobs = [[synth_frames(1 + (t + r) % 9, 1 if t % 4 == 3 else 2, 900 + 16 * t + r) for r in range(rounds)] for t in range(n_threads)]
+    alone = [[codec.encode_host(p) for p in row] for row in jobs]
+    alone_back = [[codec.decode_host(f, o, p.shape[2]) for (f, o), p in zip(row, prow)] for row, prow in zip(alone, jobs)]
+    problems, outcomes = [], {}
+
+    def work(t):
+        try:
+            for r in range(rounds):
+                pcm = jobs[t][r]
+                n, ch = pcm.shape[0], pcm.shape[2]
+                if t == 7 and r == 2:  # an output buffer that cannot hold the frames
+                    frames = np.empty(64, np.uint8)
+                    offs = np.zeros(n + 1, np.uint64)
+                    outcomes["cap"] = lib.sela_hip_encode(pcm.ctypes.data, n, ch, 2048, frames.ctypes.data, frames.nbytes, offs.ctypes.data)
+                    continue
+                frames, offs = codec.encode_host(pcm)
+                if not (np.array_equal(frames, alone[t][r][0]) and np.array_equal(offs, alone[t][r][1])):
+                    problems.append("thread %d round %d: encode differs" % (t, r))
+                if t == 11 and r == 3:  # a frame without its sync word
+                    broken = frames.copy()
+                    broken[int(offs[n - 1])] ^= 0xFF
+                    back = np.empty((n, 2048, ch), np.int16)
+                    outcomes["format"] = lib.sela_hip_decode(broken.ctypes.data, offs.ctypes.data, n, ch, back.ctypes.data)
+                    if n > 1 and not np.array_equal(back[: n - 1], alone_back[t][r][: n - 1]):
+                        problems.append("the frames in front of the broken one differ")
+                    continue
+                if not np.array_equal(codec.decode_host(frames, offs, ch), alone_back[t][r]):
+                    problems.append("thread %d round %d: decode differs" % (t, r))
+        except Exception as e:  # noqa: BLE001 -- reported below, from the test's thread
+            problems.append("thread %d: %r" % (t, e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(180)
+    assert not any(th.is_alive() for th in threads), "a thread is stuck"
+    assert not problems, problems
+    assert outcomes == {"cap": -4, "format": -5}, outcomes
