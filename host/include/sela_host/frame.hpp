@@ -1,7 +1,7 @@
 // frame.hpp -- frame::FrameEncoder / frame::FrameDecoder with the reference's signatures
 // (src/include/frame.hpp:8-24), running on the MI355X through libsela_hip.so.  A call codes one frame, but calls made
 // from several threads at once -- which is how the reference uses these classes, src/sela/encoder.cpp:58-73 -- are
-// coalesced into one batch per trip to the device (frame.cpp), so keeping the reference's thread loop costs a factor,
+// coalesced into one job per trip to the device (inside libsela_hip.so), so keeping the reference's thread loop costs a factor,
 // not the GPU: the fast way in is still sela::Encoder / sela::Decoder (codec.hpp), which see the whole file.
 //
 // Also the flat <-> object conversions between the .sela frame byte stream (what the GPU path reads

@@ -137,7 +137,11 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
  * These are begin + feed(everything) + end of the streaming jobs below, on library-owned streams: an encode is ONE
  * kernel launch per feed (it fetches the PCM from page-locked memory itself and stores the finished frames into
  * frames_out), a decode a pipeline of 1024-frame chunks (copy in / kernel / copy out overlapped).  Results are
- * identical to one device-pointer call on the whole batch. */
+ * identical to one device-pointer call on the whole batch.
+ * Calls of at most 32 frames made from several threads at once -- a binding that keeps the reference's per-frame thread
+ * loop (src/sela/encoder.cpp:58-73) -- are coalesced: calls that arrive while another one is on the device go there
+ * together, as one job, when it returns.  Every call still gets exactly its own result and its own error (a buffer that
+ * is too small, a malformed frame); a lone caller is not delayed. */
 int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel,
     uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out /* [n_frames+1] */);
 int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels,
