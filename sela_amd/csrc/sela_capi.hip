@@ -1379,7 +1379,13 @@ public:
                 }
             }
             lock.unlock();
-            run_batch(batch);
+            try {
+                run_batch(batch);
+            } catch (...) { // (std::bad_alloc: the callers hear of it, nobody is left waiting)
+                for (SmallCall* c : batch)
+                    if (c->rc == SELA_HIP_OK)
+                        c->rc = SELA_HIP_ENOMEM, c->error = "out of memory while staging a coalesced batch";
+            }
             g_lease.give_back(); // the streams and buffers this thread used go to whoever leads next: any caller may
             lock.lock();
             for (SmallCall* c : batch)
