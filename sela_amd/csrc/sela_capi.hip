@@ -1418,7 +1418,7 @@ int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, ui
         return fail(SELA_HIP_EINVAL, "samples_per_channel must be 2048 (reference frame size)");
     if (channels == 0 || channels > 255 || !frame_offsets_out || (n_frames && (!pcm || !frames_out)))
         return fail(SELA_HIP_EINVAL, "bad argument");
-    if (n_frames == 0 || n_frames > kCoalesceFrames)
+    if (n_frames == 0 || n_frames > kCoalesceFrames || (g_lease.held && g_lease.held->job_open)) // (a thread in the middle of a job of its own hears about that itself)
         return encode_now(pcm, n_frames, channels, frames_out, frames_cap, frame_offsets_out);
     SmallCall call;
     if (hipGetDevice(&call.device) != hipSuccess)
@@ -1432,7 +1432,7 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
 {
     if (channels == 0 || channels > 255 || (n_frames && (!frames || !frame_offsets || !pcm_out)))
         return fail(SELA_HIP_EINVAL, "bad argument");
-    if (n_frames == 0 || n_frames > kCoalesceFrames)
+    if (n_frames == 0 || n_frames > kCoalesceFrames || (g_lease.held && g_lease.held->job_open))
         return decode_now(frames, frame_offsets, n_frames, channels, pcm_out);
     for (uint32_t f = 0; f < n_frames; f++) // (what the job would refuse is refused by the job, for this caller alone)
         if (frame_offsets[f + 1] < frame_offsets[f] || (frame_offsets[f] & 3))
