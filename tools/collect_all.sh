@@ -15,6 +15,8 @@ SELA_SWEEP_HOST=0 python tools/sweep.py > "$OUT/sweep.txt" 2>&1
 # the decoder's two forms of the recurrence step against the batch size, and the instruction-level chain walk behind them
 python tools/decode_forms.py 2>&1 | grep -v amdgpu.ids > "$OUT/decode_forms.txt"
 python tools/chain_ubench.py >> "$OUT/decode_forms.txt" 2>&1
+bash tools/config2_profile.sh > /dev/null 2>&1; cp "$ROOT/gpurun_out/config2_1000_frames.txt" "$OUT/config2_1000_frames.txt"   # BASELINE configs[2] under rocprofv3
+cd "$ROOT"
 python bench.py > "$OUT/bench.log" 2>&1
 tail -1 "$OUT/bench.log" > "$OUT/bench_line.json"
 SELA_BENCH_FORCE_EXCHANGE=1 python bench.py --workload album --steps 3 --warmup 1 > "$OUT/bench_album.log" 2>&1
