@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
     uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* __restrict__ frame_offsets,
     uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status)
 {
-    __shared__ uint64_t part[kPlanThreads];
+    __shared__ uint64_t part[kPlanThreads / kWave]; // the waves' totals of one tile
     __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of the frames of one tile
     __shared__ uint32_t acc[2];                      // flags, frames that do not fit frames_cap
     const uint32_t tid = threadIdx.x;
@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
     for (uint32_t tile0 = 0; tile0 < n_frames; tile0 += kPlanLdsFrames) {
         const uint32_t tile_n = min((uint32_t)kPlanLdsFrames, n_frames - tile0);
         __syncthreads(); // the previous tile's sizes have been read
-#pragma unroll 4
+#pragma unroll 8
         for (uint32_t i = tid; i < tile_n; i += kPlanThreads) {
             uint32_t choice;
             const uint32_t words = frame_words(meta + (size_t)(tile0 + i) * n_sig, channels, choice, flags);
@@ -1624,22 +1624,35 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
         uint64_t bytes = 0;
         for (uint32_t i = begin; i < end; i++)
             bytes += frame_size[i];
-        part[tid] = bytes;
-        __syncthreads();
-        for (uint32_t d = 1; d < (uint32_t)kPlanThreads; d <<= 1) { // Hillis-Steele inclusive scan
-            const uint64_t v = tid >= d ? part[tid - d] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
+        // inclusive scan of the threads' sums: inside every wave by shuffles, the waves' totals by every thread itself
+        // (at most 16 of them) -- two barriers, where the Hillis-Steele scan over 256 threads took sixteen
+        uint64_t incl = bytes;
+        const int lane = (int)(tid % kWave);
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, d, kWave), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d, kWave);
+            if (lane >= d)
+                incl += ((uint64_t)hi << 32) | lo;
         }
-        uint64_t off = base + part[tid] - bytes;
+        if (lane == kWave - 1)
+            part[tid / kWave] = incl; // this wave's total
+        __syncthreads();
+        uint64_t before = 0, tile_total = 0;
+#pragma unroll
+        for (int w = 0; w < kPlanThreads / kWave; w++) {
+            const uint64_t t = part[w];
+            before += w < (int)(tid / kWave) ? t : 0;
+            tile_total += t;
+        }
+        __syncthreads(); // (part[] is written again for the next tile)
+        uint64_t off = base + before + incl - bytes;
         for (uint32_t i = begin; i < end; i++) {
             frame_offsets[tile0 + i] = off;
             off += frame_size[i];
             if (off > frames_cap)
                 overflow++;
         }
-        base += part[kPlanThreads - 1];
+        base += tile_total;
     }
     if (tid == 0)
         frame_offsets[n_frames] = base;
