@@ -265,6 +265,7 @@ class Bench:
             torch.cuda.synchronize()
             _flush_c_stdio()
         self.lib = capi.lib()  # raises if the HIP library is missing: there is no CPU fallback
+        self.lib.sela_hip_debug_encode_teams(getattr(args, "encode_teams", -1))
         self.exchange = torch.cuda.Stream() if self.dist is not None else None
         self.n_lanes = max(1, args.lanes)
 
@@ -796,6 +797,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight: independent encode->decode chains on their own HIP streams")
+    ap.add_argument("--encode-teams", type=int, default=-1, choices=[-1, 0, 8, 16],
+                    help="experiments only: force the encoder's block kernel (0: k_encode_blocks, 8 / 16: k_encode_teams); -1: the library's own choice by launch size")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))

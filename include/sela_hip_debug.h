@@ -26,6 +26,10 @@ void sela_hip_debug_force_plain_fir(int enable);
  * workers).  Setting a small value makes small test batches take the worker path; -1 restores the default.
  * Results are identical by construction, which is what the tests check. */
 void sela_hip_debug_mean_workers(int self_blocks);
+/* Debug hook: which kernel analyses the blocks of the calling thread's *_device encodes: 0 = k_encode_blocks (one block per
+ * wave), 8 / 16 = k_encode_teams with teams of that many lanes (eight / four blocks side by side in a wave), -1 restores
+ * the choice by launch size.  Results are identical by construction, which is what the tests check. */
+void sela_hip_debug_encode_teams(int lanes);
 /* Debug hook: bound of an encode block's wait for its frame from the staging kernel, in naps of 2048 cycles; 0: every
  * block gives up without looking ("the stagers never showed up"), which flags the launch and sends the feed through
  * the copy-engine path again; -1 restores the default (~0.5 s). */

@@ -26,7 +26,7 @@ namespace sela {
 size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
-    hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override);
+    hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override, int team_lanes);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles,
     uint8_t* frame_flags, int recurrence_form);
@@ -369,6 +369,7 @@ thread_local KernelTiming g_timing;
 thread_local uint64_t* g_phase_cycles = nullptr; // debug: per-block phase cycle counts (sela_hip_debug_phase_buffer)
 thread_local int g_force_plain_fir = 0;          // debug: sela_hip_debug_force_plain_fir
 thread_local int g_self_blocks = -1;             // debug: sela_hip_debug_mean_workers
+thread_local int g_team_lanes = -1;              // debug: sela_hip_debug_encode_teams
 thread_local int g_stage_wait_naps = -1;         // debug: sela_hip_debug_stage_wait
 thread_local int g_reissued_feeds = 0;           // debug: sela_hip_debug_reissued_feeds
 thread_local int g_recurrence_form = -1;         // debug: sela_hip_debug_decode_recurrence
@@ -574,7 +575,7 @@ hipError_t issue_encode_feed(sela_hip_job* job, EncodeFeed& feed, size_t index, 
     }
     uint32_t* d_status = reinterpret_cast<uint32_t*>(pos + 2);
     e = sela::launch_encode(static_cast<const int16_t*>(ctx().enc_pcm.ptr), feed.n_frames, job->channels, job->out_mapped, job->frames_cap, nullptr, d_status,
-        ctx().enc_workspace.ptr, nullptr, s, nullptr, nullptr, &link, g_force_plain_fir, g_self_blocks);
+        ctx().enc_workspace.ptr, nullptr, s, nullptr, nullptr, &link, g_force_plain_fir, g_self_blocks, 0);
     if (e == hipSuccess && !feed.done)
         e = hipEventCreateWithFlags(&feed.done, hipEventDisableTiming);
     if (e == hipSuccess)
@@ -1003,6 +1004,7 @@ void sela_hip_debug_phase_buffer(uint64_t* d_cycles) { g_phase_cycles = d_cycles
 void sela_hip_debug_force_plain_fir(int enable) { g_force_plain_fir = enable != 0; }
 
 void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks; }
+void sela_hip_debug_encode_teams(int lanes) { g_team_lanes = lanes; }
 
 void sela_hip_debug_stage_wait(int naps) { g_stage_wait_naps = naps; }
 
@@ -1049,7 +1051,7 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 3 : 0;
     hipError_t e = sela::launch_encode(d_pcm, n_frames, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace,
-        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_force_plain_fir, g_self_blocks);
+        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_force_plain_fir, g_self_blocks, g_team_lanes);
     if (e != hipSuccess)
         return fail_hip(e, "encode launch");
     return SELA_HIP_OK;

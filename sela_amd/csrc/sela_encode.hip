@@ -1337,229 +1337,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         wave_sync(); // (sm->k is overwritten with the dequantised coefficients below)
     }
 
-    SELA_STAMP(5);
-    // ---- order (src/lpc/residue_generator.cpp:70-78): 1 + last i with |k[i]| > 0.05 ----------------
-    int order;
     {
-        const unsigned long long b_lo = __ballot(fabs(k_lo) > SELA_ORDER_THRESHOLD);
-        const unsigned long long b_hi = __ballot(lane < 36 && fabs(k_hi) > SELA_ORDER_THRESHOLD);
-        order = b_hi ? 128 - __clzll(b_hi) : (b_lo ? 64 - __clzll(b_lo) : 1);
-    }
-
-    // ---- quantise (src/lpc/residue_generator.cpp:80-96), dequantise (linear_predictor.cpp:16-28) ----
-    {
-        const double sqrt2 = SELA_SQRT2;
-        double v_lo;
-        if (lane == 0)
-            v_lo = floor(64 * (-1 + (sqrt2 * sqrt(k_lo + 1))));
-        else if (lane == 1)
-            v_lo = floor(64 * (-1 + (sqrt2 * sqrt(-k_lo + 1))));
-        else
-            v_lo = floor(64 * k_lo);
-        const double v_hi = floor(64 * k_hi);
-        const int32_t q_lo = isnan(v_lo) ? 0 : (int32_t)v_lo;
-        const int32_t q_hi = isnan(v_hi) ? 0 : (int32_t)v_hi;
-        if (lane < order) {
-            sm->q[lane] = q_lo;
-            sm->k[lane] = order <= 1 ? 0.0 : dequant(lane, q_lo, flags);
-        }
-        if (lane + 64 < order) {
-            sm->q[lane + 64] = q_hi;
-            sm->k[lane + 64] = dequant(lane + 64, q_hi, flags);
-        }
-        if (kTrace) {
-            sela_hip_trace* tr = trace + block_id;
-            if (lane == 0) {
-                tr->mean = mean;
-                tr->order = order;
-            }
-            for (int i = lane; i <= kMaxOrder; i += 64)
-                tr->ac[i] = sm->ac[i];
-            tr->k[lane] = k_lo;
-            if (lane < 36)
-                tr->k[lane + 64] = k_hi;
-        }
-    }
-    wave_sync();
-
-    SELA_STAMP(6);
-    // ---- step-up to the Q35 predictor (src/lpc/linear_predictor.cpp:30-61) ---------------------------
-    step_up(sm->k, sm->a, order, lane, flags);
-    __builtin_amdgcn_s_setprio(0);
-    if (kTrace) {
-        sela_hip_trace* tr = trace + block_id;
-        for (int i = lane; i <= order; i += 64)
-            tr->a[i] = sm->a[i];
-        for (int i = lane; i < order; i += 64)
-            tr->q[i] = sm->q[i];
-    }
-
-    SELA_STAMP(7);
-    // ---- residues (src/lpc/residue_generator.cpp:98-119) -----------------------------------------------
-    // r[i] = s[i] - (int32)((2^34 + sum_{j=1..order} a[j] s[i-j]) >> 35), samples before the block
-    // count as absent (0).  Integer wrap-around arithmetic is associative, so the taps are accumulated
-    // per sample in any order.
-    //
-    // Lane l owns the 32 CONSECUTIVE samples 32l .. 32l+31 (the layout the Rice packer wants) and
-    // slides a 32-register window over its history: tap j needs s[32l + t - j] for t = 0..31, i.e.
-    // the window of tap j-1 moved down by one, so every tap costs ONE new LDS word per lane (index
-    // i stored at i + i/32: the lanes' 32-word strides fall on different banks) and 32 multiply-adds
-    // (64 for the few large coefficients, see fir_taps).  The tap loop is unrolled by 32 so that the
-    // window registers are addressed statically.
-    int32_t* const sT = reinterpret_cast<int32_t*>(big);
-    for (int m = lane; m < kPadS; m += 64)
-        sT[m + (m >> 5)] = 0;
-#pragma unroll
-    for (int t = 0; t < kPerLane; t++) {
-        const int i = kPadS + lane + 64 * t;
-        sT[i + (i >> 5)] = s[t];
-    }
-    wave_sync();
-
-    uint32_t ru[kPerLane]; // zig-zagged residues of samples 32 lane + t
-    bool wide = false;
-    {
-        int32_t win[kPerLane];
-        const int32_t* mine_s = sT + (kPadS + 32 * lane) + ((kPadS + 32 * lane) >> 5); // &s[32 l], 32 words without a pad inside
-#pragma unroll
-        for (int t = 0; t < kPerLane; t++)
-            win[t] = mine_s[t];
-        int64_t acc[kPerLane];
-        uint32_t hi[kPerLane];
-#pragma unroll
-        for (int t = 0; t < kPerLane; t++)
-            acc[t] = (int64_t)1 << (SELA_Q_SHIFT - 1), hi[t] = 0;
-        // the 24-bit multiply of the high parts needs every a[j]'s high part inside 24 signed bits -- true of
-        // any predictor worth the name; a block that violates it takes a plain loop instead of the unrolled window
-        bool fits = true;
-        for (int j = 1 + lane; j <= order; j += 64)
-            fits &= fir_fits_fast(sm->a[j]);
-        // (the trace build, which only tests run, always takes the plain loop; so does every block while the
-        // debug hook sela_hip_debug_force_plain_fir is set)
-        const bool plain = kTrace || force_plain_fir != 0 || __any(!fits);
-        uint32_t* const plain_pred = slots + (size_t)block_id * kSlotWords; // 2048 words of the block's own slot
-        if (plain) {
-            fir_plain(order, lane, sT, sm->a, plain_pred);
-        } else {
-#pragma unroll 1
-            for (int j0 = 0; j0 < order; j0 += 32)
-                fir_taps<0>(j0, order, lane, sT, sm->a, win, acc, hi);
-        }
-#pragma unroll
-        for (int t = 0; t < kPerLane; t++) {
-            const uint64_t total = (uint64_t)acc[t] + ((uint64_t)hi[t] << 32);
-            const uint32_t pred = plain ? plain_pred[t * 64 + lane] : (uint32_t)(int32_t)((int64_t)total >> SELA_Q_SHIFT);
-            const int32_t rt = (int32_t)((uint32_t)mine_s[t] - pred);
-            ru[t] = zigzag32(rt);
-            wide |= (rt >= (1 << 30)) || (rt < -(1 << 30)); // zig-zag would not fit 32 bits
-        }
-    }
-    wave_sync(); // sT is dead
-
-    SELA_STAMP(8);
-    // ---- Rice parameters -----------------------------------------------------------------------------
-    // coefficients: value i of q[] sits in lane i / 2 slot i % 2 (lane-contiguous for packing)
-    uint32_t cu[2];
-    cu[0] = 2 * lane < order ? zigzag32(sm->q[2 * lane]) : 0u;
-    cu[1] = 2 * lane + 1 < order ? zigzag32(sm->q[2 * lane + 1]) : 0u;
-    uint32_t coef_k;
-    uint64_t coef_bits;
-    rice_plan<2>(cu, (uint32_t)order, coef_k, coef_bits);
-    const uint32_t coef_words = words_for_bits(coef_bits);
-
-    if (__any(wide))
-        flags |= SELA_HIP_FLAG_RICE_RANGE;
-    uint32_t res_k;
-    uint64_t res_bits;
-    rice_plan<kPerLane>(ru, (uint32_t)kBlock, res_k, res_bits);
-    uint32_t res_words = words_for_bits(res_bits);
-    if (res_words > (uint32_t)kResWordsCap || coef_words > (uint32_t)kCoefWordsCap) {
-        flags |= SELA_HIP_FLAG_WORDS_CAP;
-        res_words = 0;
-    }
-
-    SELA_STAMP(9);
-    // ---- pack the coefficient stream (<= 100 values) ----------------------------------------------
-    if (lane < kCoefWordsCap)
-        cw_buf[lane] = 0;
-    wave_sync();
-    if (!(flags & SELA_HIP_FLAG_WORDS_CAP)) {
-        const uint32_t n0 = 2 * lane < order ? (cu[0] >> coef_k) + 1 + coef_k : 0u;
-        const uint32_t n1 = 2 * lane + 1 < order ? (cu[1] >> coef_k) + 1 + coef_k : 0u;
-        uint32_t pos = wave_exclusive_scan(n0 + n1, lane);
-        if (n0)
-            pos = put_codeword(cw_buf, pos, cu[0], coef_k);
-        if (n1)
-            pos = put_codeword(cw_buf, pos, cu[1], coef_k);
-    }
-
-    SELA_STAMP(10);
-    // ---- pack the residue stream ----------------------------------------------------------------------
-    // Lane l already owns the 32 consecutive residues 32l .. 32l+31: scan the per-lane bit counts, then
-    // every lane appends its codewords.  The sample buffer is dead: out_words overlays it.
-    uint32_t* const out_words = reinterpret_cast<uint32_t*>(big); // over the dead sample buffer
-    for (uint32_t w = lane; w < res_words; w += 64)
-        out_words[w] = 0;
-    uint32_t lane_bits = 0;
-#pragma unroll
-    for (int t = 0; t < kPerLane; t++)
-        lane_bits += (ru[t] >> res_k) + 1 + res_k;
-    wave_sync();
-    if (res_words) {
-        // fully unrolled: the residues are addressed statically and stay in registers; codewords longer
-        // than a word go through an out-of-line helper
-        uint32_t pos = wave_exclusive_scan(lane_bits, lane);
-#pragma unroll
-        for (int t = 0; t < kPerLane; t++) {
-            const uint32_t u = ru[t], ones = u >> res_k, len = ones + 1 + res_k;
-            if (len <= 32) {
-                const uint32_t rem = res_k ? __brev(u << (32 - res_k)) : 0u; // low k bits of u, reversed
-                or_bits(out_words, pos, ((1u << ones) - 1u) | (rem << (ones + 1)), len);
-                pos += len;
-            } else {
-                pos = put_long_codeword(out_words, pos, u, res_k);
-            }
-        }
-    }
-    wave_sync();
-
-    SELA_STAMP(11);
-    // ---- slot + meta -------------------------------------------------------------------------------------
-    uint32_t* slot = slots + (size_t)block_id * kSlotWords;
-    if (kFused) { // host pipeline: the group's last block reads them in this launch -- through the L2 (store_through)
-        uint64_t* const slot2 = reinterpret_cast<uint64_t*>(slot);
-        if (lane < kCoefWordsCap / 2) // (all 32 coefficient words: what lies behind coef_words is never read)
-            store_through(slot2 + lane, (uint64_t)cw_buf[2 * lane] | ((uint64_t)cw_buf[2 * lane + 1] << 32));
-        const uint64_t* const out2 = reinterpret_cast<const uint64_t*>(out_words);
-        for (uint32_t w2 = lane; w2 < (res_words + 1) / 2; w2 += 64)
-            store_through(slot2 + kCoefWordsCap / 2 + w2, out2[w2]);
-    } else {
-        if (lane < (int)coef_words && lane < kCoefWordsCap)
-            slot[lane] = cw_buf[lane];
-        for (uint32_t w = lane; w < res_words; w += 64)
-            slot[kCoefWordsCap + w] = out_words[w];
-    }
-    const uint32_t all_flags = wave_or(flags);
-    if (lane == 0) {
-        BlockMeta bm;
-        bm.order = (uint8_t)order;
-        bm.coef_k = (uint8_t)coef_k;
-        bm.res_k = (uint8_t)res_k;
-        bm.flags = (uint8_t)all_flags;
-        bm.coef_words = (uint16_t)coef_words;
-        bm.res_words = (uint16_t)res_words;
-        if (kFused)
-            store_through(reinterpret_cast<uint64_t*>(meta + block_id), __builtin_bit_cast(uint64_t, bm));
-        else
-            meta[block_id] = bm;
-        if (kTrace) {
-            sela_hip_trace* tr = trace + block_id;
-            tr->coef_k = coef_k;
-            tr->coef_words = coef_words;
-            tr->res_k = res_k;
-            tr->res_words = res_words;
-            tr->flags = all_flags;
-        }
+        constexpr bool kAcInLds = true;
+#include "sela_encode_tail.inc"
     }
     SELA_STAMP(12);
     // ---- host pipeline: count this block into its group; the group's last block places and writes the group's frames
@@ -1579,6 +1359,442 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (kMode == 2 && lane == 0)
         for (int i = 0; i < 13; i++)
             phase_cycles[(size_t)block_id * 16 + i] = (uint64_t)(stamp[i + 1] - stamp[i]);
+}
+
+// ---- k_encode_teams: the analysis of SEVERAL blocks side by side in one wave (round 4) ------------------------------
+// k_encode_blocks gives a block a whole wave and keeps 51 of its 64 lanes busy through the autocorrelation (lane = a pair
+// of lags), all 64 through 100 divisions that serve one block, and the sequential mean of a block costs it 2048 adds on
+// every lane.  At the issue rate the kernel runs at, only fewer instructions help -- so here a wave takes B = 64 / P
+// blocks at once, P lanes (a "team") per block:
+//   autocorrelation   lane p of a team owns the G = ceil(101 / P) CONSECUTIVE lags G p .. G p + G - 1: G accumulators, and a
+//                     window of the block's centred samples c[j - G p - g] that slides through 16 registers (static
+//                     names: the loop is unrolled by 16 steps).  Per step and lane: one new window value and the team's
+//                     multiplier c[j], both read from LDS three steps ahead, and 2 G multiply / add instructions -- for B
+//                     blocks.  P = 8: 26 instructions per step for 8 blocks (3.25 per block and step, against 4); 104 of
+//                     104 lag slots used (k_encode_blocks: 102 of 128).  Every accumulator still sees its products in
+//                     ascending j, each product rounded before it is added (src/lpc/residue_generator.cpp:33-38).
+//                     The samples of B blocks do not fit LDS as FP64, and need not: a ring of 160 per block (the lags
+//                     reach 103 back, a chunk of 16 is being consumed, the next one is being written; P = 16: 256 and
+//                     64) is refilled from the PCM chunk by chunk -- L2 hits, no scalar-operand scratch in global
+//                     memory at all.
+//   mean              (:27-30) one chain per block as before, but the chains of the wave's B blocks advance together:
+//                     2048 adds per WAVE, on samples the lanes converted side by side.  No mean workers.
+//   Schur recursion   (:47-68) lane p holds columns G p .. G p + G - 1 of gen0 / gen1: the shift gen1[j+1] is the next
+//                     register (one DPP move per stage for the column that crosses to the next lane), and the division of a
+//                     stage serves B blocks.
+// Then the wave takes its blocks one after the other through the same tail as k_encode_blocks (sela_encode_tail.inc):
+// all 64 lanes on one block's order / quantisation / step-up / residues / Rice streams.
+// What this costs is granularity: a wave is B blocks' worth of work (P = 8: ~100 k instructions, ~0.2 ms), so launches
+// that do not fill the device several times over keep k_encode_blocks (launch_encode picks).
+constexpr int kTeamMirror = 24;                             // the ring's first entries again behind its last: a run of <= 19 reads may start at any entry
+constexpr int kTeamWin = 16;                                // window registers (a circular file: >= G + kTeamAhead)
+constexpr int kTeamAhead = 3;                               // steps a fetch runs ahead of its use
+constexpr int kTeamMeanChunk = 64;                          // the mean's chunks (two of them in a ring)
+
+template <int P>
+struct TeamPlan {
+    static constexpr int B = kWave / P;                        // blocks per wave
+    static constexpr int G = (kMaxOrder + 1 + P - 1) / P;      // lags (Schur: columns) per lane
+    // samples of a block staged at a time / resident in LDS (positions = sample index mod kRing).  The ring must hold the
+    // lags' reach, the chunk in use and the chunk being written; eight rings at once (P = 8) only fit a third of a CU's LDS
+    // share with the smallest chunk, one 16-step trip
+    static constexpr int kChunk = P == 8 ? 16 : 64;
+    static constexpr int kRing = P == 8 ? 160 : 256;
+    static constexpr int kStride = kRing + kTeamMirror;        // doubles; 184 and 280 are 24 mod 32: consecutive rings start 48 banks apart (team_ac_steps)
+    static constexpr int kPer = kChunk / P;                    // samples a lane stages per chunk
+    static constexpr int kMeanPer = kTeamMeanChunk / P;
+    static constexpr int kRingBytes = B * kStride * 8;
+    static constexpr int kCwBase = kBigBytes;                  // the tail's coefficient words behind its LDS plan (k_encode_blocks: a second array)
+    static constexpr int kLdsBytes = kRingBytes > kCwBase + kCoefWordsCap * 4 ? kRingBytes : kCwBase + kCoefWordsCap * 4;
+    static_assert(G + kTeamAhead <= kTeamWin && kChunk % kTeamWin == 0 && kRing % kChunk == 0 && kStride % 32 == 24, "team plan");
+    static_assert((G * P - 1) + kChunk + kChunk <= kRing && 2 * kTeamMeanChunk <= kRing, "the ring must hold the lags' reach, the chunk in use and the chunk being written");
+    static_assert(kLdsBytes * 12 <= 160 * 1024, "twelve waves per CU");
+};
+
+// every lane receives the value of lane 0 of its team
+template <int P>
+__device__ __forceinline__ uint32_t team_first(uint32_t v)
+{
+    if constexpr (P == 16) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 /* row_newbcast:0 */, 0xf, 0xf, true);
+    } else {
+        static_assert(P == 8, "teams of 8 or 16 lanes");
+        const int q = __builtin_amdgcn_mov_dpp((int)v, 0x00 /* quad_perm:[0,0,0,0] */, 0xf, 0xf, true);       // lanes 4 k .. 4 k + 3 <- lane 4 k
+        return (uint32_t)__builtin_amdgcn_update_dpp(q, q, 0x114 /* row_shr:4 */, 0xf, 0xa /* banks 1, 3 */, false); // lanes 4..7 <- 0..3, 12..15 <- 8..11
+    }
+}
+template <int P>
+__device__ __forceinline__ double team_first(double v)
+{
+    const uint64_t x = __builtin_bit_cast(uint64_t, v);
+    return __builtin_bit_cast(double, ((uint64_t)team_first<P>((uint32_t)(x >> 32)) << 32) | team_first<P>((uint32_t)x));
+}
+
+// the samples first .. first + kPer - 1 of signal `sig` of the frame at fp, as the integers the reference analyses
+// (src/frame/frame_encoder.cpp:22-24 for the difference signal)
+template <int kPer>
+__device__ __forceinline__ void team_load_raw(const int16_t* __restrict__ fp, uint32_t channels, uint32_t sig, int first, int32_t (&raw)[kPer])
+{
+    if (channels == 2) {
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(fp) + first; // (dword-aligned: unaligned vector loads are fine)
+        uint32_t w[kPer];
+        if constexpr (kPer % 4 == 0) {
+#pragma unroll
+            for (int u = 0; u < kPer / 4; u++) {
+                const uint4 v = reinterpret_cast<const uint4*>(pw)[u];
+                w[4 * u] = v.x, w[4 * u + 1] = v.y, w[4 * u + 2] = v.z, w[4 * u + 3] = v.w;
+            }
+        } else if constexpr (kPer % 2 == 0) {
+#pragma unroll
+            for (int u = 0; u < kPer / 2; u++) {
+                const uint2 v = reinterpret_cast<const uint2*>(pw)[u];
+                w[2 * u] = v.x, w[2 * u + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kPer; u++)
+                w[u] = pw[u];
+        }
+        const uint32_t first_shift = sig == 1 ? 16u : 0u;     // signal 0: l, 1: r, 2: l - r  as  a - (b & mask)
+        const uint32_t second_mask = sig == 2 ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int i = 0; i < kPer; i++) {
+            const int32_t a = (int32_t)(w[i] << (16 - first_shift)) >> 16, b = ((int32_t)w[i] >> 16) & (int32_t)second_mask;
+            raw[i] = a - b;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kPer; i++)
+            raw[i] = fp[(size_t)(first + i) * channels + sig];
+    }
+}
+
+// x = s / 32767 (kCentre: minus the block's mean) of a lane's kPer samples to ring positions pos ..; kMirror: the ring's
+// first entries also behind its end
+template <int kPer, bool kCentre, bool kMirror, int kRing>
+__device__ __forceinline__ void team_stage(double* ring_b, int pos, const int32_t (&raw)[kPer], double mean)
+{
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+        const double x = scale_sample(raw[i]);
+        const double c = kCentre ? x - mean : x;
+        ring_b[pos + i] = c;
+        if (kMirror && pos + i < kTeamMirror)
+            ring_b[kRing + pos + i] = c;
+    }
+}
+
+// sum + x[0] + x[1] + ... in that order (the mean's chain), sixteen values fetched at a time
+template <int kN>
+__device__ __forceinline__ double team_chain(const double* x, double sum)
+{
+#pragma unroll 1
+    for (int i0 = 0; i0 < kN; i0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = x[i0 + i];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            sum += v[i];
+    }
+    return sum;
+}
+
+// Steps R0 .. 15 of a 16-step trip of the autocorrelation.  At step j = j0 + r a lane holds c[j - G p - g] in W[(r - g) & 15]
+// and adds c[j] * c[j - G p - g] to acc[g], g = 0 .. G - 1; the fetch for step r + 3 (its new window value and its
+// multiplier: addr_w / addr_m are the LDS addresses of c[j0 - G p] and c[j0]) is issued first and lands -- the LDS
+// returns a wave's reads in order, so "at most six newer ones outstanding" is "the pair of three steps ago is there" --
+// right before its first use.  The compiler sees no load of its own in this loop.
+// Banks: a ds_read_b64 is served in two halves of 32 lanes = 4 teams of 8 (2 of 16); within a team the lanes read G
+// entries apart (26 p dwords mod 64 for G = 13: all different, and 14 p for G = 7), and the rings of consecutive blocks
+// start 48 dwords apart mod 64: the 32 lanes of a half touch 32 different bank pairs.
+template <int G, int R0>
+__device__ __forceinline__ void team_ac_steps(double (&W)[kTeamWin], double (&M)[4], double (&acc)[G], uint32_t addr_w, uint32_t addr_m)
+{
+    asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4"
+                 : "=&v"(W[(R0 + kTeamAhead) & (kTeamWin - 1)]), "=&v"(M[(R0 + kTeamAhead) & 3])
+                 : "v"(addr_w), "v"(addr_m), "n"(8 * (R0 + kTeamAhead)), "v"(acc[0]), "v"(acc[G - 1])
+                 : "memory");
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(W[R0 & (kTeamWin - 1)]), "+v"(M[R0 & 3]));
+    const double m = M[R0 & 3];
+    // (products a few at a time ahead of their additions: a product directly in front of the addition that needs it stalls a
+    // wave that has its SIMD to itself)
+    constexpr int kAheadOps = 5;
+#pragma unroll
+    for (int g0 = 0; g0 < G; g0 += kAheadOps) {
+        double t[kAheadOps];
+#pragma unroll
+        for (int u = 0; u < kAheadOps; u++)
+            if (g0 + u < G)
+                t[u] = m * W[(R0 - g0 - u) & (kTeamWin - 1)];
+#pragma unroll
+        for (int u = 0; u < kAheadOps; u++)
+            if (g0 + u < G)
+                acc[g0 + u] += t[u];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (R0 < kTeamWin - 1)
+        team_ac_steps<G, R0 + 1>(W, M, acc, addr_w, addr_m);
+}
+
+template <int kMode, int P>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_teams(
+    const int16_t* __restrict__ pcm, uint32_t n_frames, uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta,
+    uint32_t* __restrict__ slots, sela_hip_trace* __restrict__ trace, int force_plain_fir, uint64_t* __restrict__ phase_cycles)
+{
+    using Plan = TeamPlan<P>;
+    constexpr int B = Plan::B, G = Plan::G, kPer = Plan::kPer, kMeanPer = Plan::kMeanPer, kChunk = Plan::kChunk, kRing = Plan::kRing;
+    constexpr bool kTrace = kMode == 1;
+    constexpr bool kFused = false;
+    __shared__ __attribute__((aligned(32))) unsigned char lds[Plan::kLdsBytes];
+    unsigned char* const big = lds; // the tail's LDS plan (k_encode_blocks), over the dead rings
+    uint32_t* const cw_buf = reinterpret_cast<uint32_t*>(lds + Plan::kCwBase);
+
+    const int lane0 = threadIdx.x;
+    const int b = lane0 / P, p = lane0 % P;
+    // Which blocks: signal `sig` of B consecutive frames.  Workgroups that are equal mod 8 share an XCD (as observed; for
+    // speed only): the n_sig waves that take the signals of the same frames are 8 workgroups apart, so a frame's PCM comes
+    // into one L2.
+    const uint32_t wq = blockIdx.x % 8, wv = blockIdx.x / 8;
+    const uint32_t sig = wv % n_sig;
+    const uint32_t frame0 = ((wv / n_sig) * 8 + wq) * B;
+    if (frame0 >= n_frames)
+        return;
+    const bool team_live = frame0 + (uint32_t)b < n_frames;
+    const uint32_t my_frame = team_live ? frame0 + (uint32_t)b : n_frames - 1; // (a team beyond the last frame shadows it and writes nothing)
+    const int16_t* const fp = pcm + (size_t)my_frame * kBlock * channels;
+    double* const ring_b = reinterpret_cast<double*>(lds) + b * Plan::kStride;
+    // The team's reflection coefficients wait for the tail in its block's own output slot (global memory, 800 of its 8960
+    // bytes; the tail reads them back before it writes the slot): B x 100 doubles in LDS beside the tail's plan would cost
+    // a third of the waves a CU holds.
+    double* const k_b = reinterpret_cast<double*>(slots + ((size_t)my_frame * n_sig + sig) * kSlotWords);
+    long long wave_stamp[5];
+    if (kMode == 2)
+        wave_stamp[0] = clock64();
+
+    // ---- the mean (src/lpc/residue_generator.cpp:27-30): x = s / 32767 summed in order, the B chains side by side ----
+    // Chunks of 64 samples alternate between two places in the ring; the PCM of a chunk is fetched two chunks ahead.
+    double mean;
+    {
+        constexpr int kChunks = kBlock / kTeamMeanChunk;
+        const int mine = p * kMeanPer; // this lane's samples of a chunk
+        int32_t raw_a[kMeanPer], raw_b[kMeanPer];
+        team_load_raw<kMeanPer>(fp, channels, sig, mine, raw_a);
+        team_stage<kMeanPer, false, false, kRing>(ring_b, mine, raw_a, 0.0);
+        team_load_raw<kMeanPer>(fp, channels, sig, kTeamMeanChunk + mine, raw_a);
+        team_load_raw<kMeanPer>(fp, channels, sig, 2 * kTeamMeanChunk + mine, raw_b);
+        double sum = 0.0;
+        __builtin_amdgcn_s_setprio(2); // (a dependency chain: ahead of the co-resident waves' throughput-bound phases)
+#pragma unroll 1
+        for (int c = 0; c < kChunks; c += 2) {
+            // chunk c + 1 -> the second place, chunk c is summed from the first
+            team_stage<kMeanPer, false, false, kRing>(ring_b, kTeamMeanChunk + mine, raw_a, 0.0);
+            if (c + 3 < kChunks)
+                team_load_raw<kMeanPer>(fp, channels, sig, (c + 3) * kTeamMeanChunk + mine, raw_a);
+            wave_sync();
+            sum = team_chain<kTeamMeanChunk>(ring_b, sum);
+            wave_sync();
+            if (c + 2 < kChunks) {
+                team_stage<kMeanPer, false, false, kRing>(ring_b, mine, raw_b, 0.0);
+                if (c + 4 < kChunks)
+                    team_load_raw<kMeanPer>(fp, channels, sig, (c + 4) * kTeamMeanChunk + mine, raw_b);
+            }
+            wave_sync();
+            sum = team_chain<kTeamMeanChunk>(ring_b + kTeamMeanChunk, sum);
+            wave_sync();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        mean = sum / (double)kBlock;
+    }
+    if (kMode == 2)
+        wave_stamp[1] = clock64();
+
+    // ---- autocorrelation (src/lpc/residue_generator.cpp:33-38) ------------------------------------------------------------
+    double acc[G];
+    {
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            acc[g] = 0.0;
+        // "no sample" before the block: every position but chunk 0's stands for a negative index until its chunk arrives
+        for (int i = kChunk + p; i < Plan::kStride; i += P)
+            ring_b[i] = 0.0;
+        const int mine = p * kPer; // this lane's samples of a chunk
+        int32_t raw_a[kPer], raw_b[kPer];
+        team_load_raw<kPer>(fp, channels, sig, mine, raw_a);
+        team_stage<kPer, true, true, kRing>(ring_b, mine, raw_a, mean);
+        team_load_raw<kPer>(fp, channels, sig, kChunk + mine, raw_a);
+        team_load_raw<kPer>(fp, channels, sig, 2 * kChunk + mine, raw_b);
+        wave_sync();
+        const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)ring_b;
+        double W[kTeamWin], M[4];
+#pragma unroll
+        for (int i = 0; i < kTeamWin; i++)
+            W[i] = 0.0; // c[negative]
+        uint32_t idx_w = (uint32_t)((kRing - G * p) % kRing); // position of index -G p
+        uint32_t idx_m = 0, pos_stage = kChunk;               // positions of index j0 / of the chunk staged next
+        uint32_t addr_w = ring_addr + 8 * idx_w, addr_m = ring_addr;
+        // the fetches of steps 0, 1, 2
+        asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %3, %7\n\t"
+                     "ds_read_b64 %1, %6 offset:8\n\tds_read_b64 %4, %7 offset:8\n\t"
+                     "ds_read_b64 %2, %6 offset:16\n\tds_read_b64 %5, %7 offset:16"
+                     : "=&v"(W[0]), "=&v"(W[1]), "=&v"(W[2]), "=&v"(M[0]), "=&v"(M[1]), "=&v"(M[2])
+                     : "v"(addr_w), "v"(addr_m)
+                     : "memory");
+        M[3] = 0.0;
+        constexpr int kChunks = kBlock / kChunk;
+        auto trips = [&]() { // the kChunk steps of a chunk
+#pragma unroll 1
+            for (int it = 0; it < kChunk / kTeamWin; it++) {
+                team_ac_steps<G, 0>(W, M, acc, addr_w, addr_m);
+                idx_w += kTeamWin;
+                idx_w = idx_w >= (uint32_t)kRing ? idx_w - kRing : idx_w;
+                idx_m += kTeamWin;
+                idx_m = idx_m >= (uint32_t)kRing ? idx_m - kRing : idx_m;
+                addr_w = ring_addr + 8 * idx_w;
+                addr_m = ring_addr + 8 * idx_m;
+            }
+        };
+        auto stage_next = [&](const int32_t (&raw)[kPer]) { // the next chunk over the oldest one, which no lag reaches any more
+            team_stage<kPer, true, true, kRing>(ring_b, (int)pos_stage + mine, raw, mean);
+            pos_stage += kChunk;
+            pos_stage = pos_stage >= (uint32_t)kRing ? 0u : pos_stage;
+        };
+#pragma unroll 1
+        for (int c = 0; c < kChunks; c += 2) { // (two chunks per round: the PCM of a chunk is fetched two chunks ahead, into raw_a / raw_b in turn)
+            stage_next(raw_a); // chunk c + 1
+            if (c + 3 < kChunks)
+                team_load_raw<kPer>(fp, channels, sig, (c + 3) * kChunk + mine, raw_a);
+            trips();
+            if (c + 2 < kChunks) {
+                stage_next(raw_b); // chunk c + 2
+                if (c + 4 < kChunks)
+                    team_load_raw<kPer>(fp, channels, sig, (c + 4) * kChunk + mine, raw_b);
+            }
+            trips();
+        }
+        // (three fetches past the end are in flight: land them before the rings are reused)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(M[0]), "+v"(M[1]), "+v"(M[2]));
+    }
+    wave_sync(); // the rings are dead from here on
+    if (kMode == 2)
+        wave_stamp[2] = clock64();
+
+    // ---- normalise (src/lpc/residue_generator.cpp:41-44): lane p holds ac[G p + g] ---------------------------------------
+    {
+        const double ac0 = team_first<P>(acc[0]);
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            acc[g] = (p == 0 && g == 0) ? 1.0 : acc[g] / ac0;
+    }
+    if (kTrace && team_live) {
+        sela_hip_trace* tr = trace + (size_t)my_frame * n_sig + sig;
+        if (p == 0)
+            tr->mean = mean;
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            if (G * p + g <= kMaxOrder)
+                tr->ac[G * p + g] = acc[g];
+    }
+
+    // ---- Schur recursion (src/lpc/residue_generator.cpp:47-68), always 100 stages ------------------------------------------
+    // Lane p holds columns j = G p + r of gen0 / gen1.  Stage i reads gen1[j + 1] (old): the next register, and for the
+    // lane's last column the first register of the next lane.  Columns beyond 99 hold zeros (and what leaks in from the
+    // next team's first column); stage i only uses columns below 100 - i, and what is wrong moves down one column per
+    // stage from column G P - 1 >= 103: it never gets there.
+    __builtin_amdgcn_s_setprio(2); // latency-bound (100 dependent stages, one division each)
+    {
+        double g0[G], g1[G];
+        const double next_first = wave_shl1_zero(acc[0]); // ac[G (p + 1)]
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+            const double v = r + 1 < G ? acc[r + 1] : next_first; // ac[j + 1]
+            g0[r] = g1[r] = (G * p + r < kMaxOrder) ? v : 0.0;
+        }
+        double err = 1.0; // ac[0]
+        const bool keeper = p == 0 && team_live;
+        double g = team_first<P>(g1[0]);
+        double ki = -g / err;
+        err += g * ki;
+        if (keeper)
+            k_b[0] = ki;
+#pragma unroll 1
+        for (int i = 1; i < kMaxOrder; i++) {
+            const double crossing = wave_shl1_zero(g1[0]);
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const double sa = r + 1 < G ? g1[r + 1] : crossing; // gen1[j + 1], old
+                g1[r] = sa + ki * g0[r];
+                g0[r] = sa * ki + g0[r];
+            }
+            g = team_first<P>(g1[0]);
+            ki = -g / err;
+            err += g * ki;
+            if (keeper)
+                k_b[i] = ki;
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    wave_sync();
+    if (kMode == 2)
+        wave_stamp[3] = clock64();
+
+    // ---- the wave's blocks, one after the other: sela_encode_tail.inc ------------------------------------------------------
+    SmallArrays* const sm = reinterpret_cast<SmallArrays*>(big + kSmallBase);
+    long long stamp[14];
+#pragma unroll 1
+    for (int bb = 0; bb < B; bb++) {
+        const uint32_t frame = frame0 + (uint32_t)bb;
+        if (frame >= n_frames)
+            break;
+        // (the lane number as this round of the loop must see it: left visibly loop-invariant, the compiler computes every
+        // address the tail derives from it -- some three hundred values -- once in front of the loop and keeps or spills
+        // them through the analysis above: 256 VGPRs and 22 spilled instead of fitting the budget)
+        int lane_now = lane0;
+        asm volatile("" : "+v"(lane_now));
+        const int lane = lane_now;
+        const uint32_t block_id = frame * n_sig + sig;
+        const double* const k_mine = reinterpret_cast<const double*>(slots + (size_t)block_id * kSlotWords); // (left there by this wave's Schur recursion)
+        const double k_lo = k_mine[lane];
+        const double k_hi = lane < kMaxOrder - 64 ? k_mine[64 + lane] : 0.0;
+        const double mean = 0.0; // (the trace's mean has been written above; the tail only names it)
+        int32_t s[kPerLane];
+        {
+            const int16_t* fb = pcm + (size_t)frame * kBlock * channels;
+            if (channels == 2) {
+                const uint32_t* fp2 = reinterpret_cast<const uint32_t*>(fb);
+#pragma unroll
+                for (int t = 0; t < kPerLane; t++) {
+                    const uint32_t w = fp2[lane + 64 * t];
+                    const int32_t l = (int16_t)(w & 0xFFFFu), r = (int16_t)(w >> 16);
+                    s[t] = sig == 0 ? l : (sig == 1 ? r : l - r); // src/frame/frame_encoder.cpp:22-24
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < kPerLane; t++)
+                    s[t] = fb[(size_t)(lane + 64 * t) * channels + sig];
+            }
+        }
+        uint32_t flags = 0;
+        wave_sync(); // (the block before this one is through with the LDS plan)
+        {
+            constexpr bool kAcInLds = false;
+#include "sela_encode_tail.inc"
+        }
+        SELA_STAMP(12);
+        if (kMode == 2 && lane == 0) { // the wave's analysis phases (shared by its blocks) and this block's own tail
+            uint64_t* row = phase_cycles + (size_t)block_id * 16;
+            const long long now = clock64();
+            row[0] = 0;
+            row[1] = (uint64_t)(wave_stamp[1] - wave_stamp[0]);
+            row[2] = 0;
+            row[3] = (uint64_t)(wave_stamp[2] - wave_stamp[1]);
+            row[4] = (uint64_t)(wave_stamp[3] - wave_stamp[2]);
+            for (int i = 5; i < 12; i++)
+                row[i] = (uint64_t)(stamp[i + 1] - stamp[i]);
+            row[12] = (uint64_t)(now - wave_stamp[3]); // since the end of the analysis: the tails of the blocks before this one included
+        }
+    }
 }
 
 // ---- the device-pointer path's two small kernels behind k_encode_blocks -------------------------------------------
@@ -1757,11 +1973,27 @@ static uint32_t resident_encode_blocks()
 }
 
 
+// Lanes per team (k_encode_teams) for a launch of `blocks` blocks; 0: k_encode_blocks.
+// Measured on MI355X (tools/teams_sweep.py, stereo; kernel time of the block kernel, ms):
+//   frames   k_encode_blocks   teams of 16   teams of 8
+//     2000        0.264           0.319         0.419
+//     3875        0.448           0.430         0.549
+//    10000        0.948           0.913         0.937
+//    40000        3.64            3.32          3.07
+// A wave of k_encode_teams is 4 / 8 blocks' worth of work (~0.1 / ~0.2 ms): below one fill of the device it only adds
+// latency.  With two batches in flight (bench.py) teams of 16 give 15.7 G samples/s at 3875 frames against 14.5.
+static int team_lanes_for(size_t blocks)
+{
+    if (blocks < 9000)
+        return 0;
+    return blocks < 48000 ? 16 : 8;
+}
+
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames,
     size_t frames_cap, uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace,
     hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles,
     const EncodeHostLink* link /* the host pipeline's one-launch form; nullptr: three kernels */,
-    int force_plain_fir, int self_blocks_override)
+    int force_plain_fir, int self_blocks_override, int team_lanes /* -1: by launch size; 0: k_encode_blocks; 8, 16: k_encode_teams<P> */)
 {
     const uint32_t n_sig = sela_hip_signals_per_frame(channels);
     const size_t blocks = (size_t)n_frames * n_sig;
@@ -1857,6 +2089,37 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     fa.tag = ((uint64_t)nonce << 32) | ticket;
     if (ev)
         (void)hipEventRecord(ev[0], stream);
+    // Which kernel analyses the blocks: k_encode_teams (several blocks side by side in a wave: fewer instructions per block,
+    // but a wave is B blocks' worth of work) for launches that fill the device several times over, k_encode_blocks otherwise
+    // and for the host pipeline's one-launch form.
+    int teams = 0;
+    if (!link) {
+        teams = team_lanes >= 0 ? team_lanes : (d_phase_cycles ? 0 : team_lanes_for(blocks));
+        if (teams != 0 && teams != 8 && teams != 16)
+            return hipErrorInvalidValue;
+    }
+    if (teams) {
+        const uint32_t per_wave = 64u / (uint32_t)teams;
+        const uint32_t waves = ((n_frames + per_wave - 1) / per_wave + 7) / 8 * 8 * n_sig;
+#define SELA_LAUNCH_TEAMS(MODE, LANES) \
+    hipLaunchKernelGGL((k_encode_teams<MODE, LANES>), dim3(waves), wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, force_plain_fir, d_phase_cycles)
+        if (teams == 8) {
+            if (d_phase_cycles)
+                SELA_LAUNCH_TEAMS(2, 8);
+            else if (d_trace)
+                SELA_LAUNCH_TEAMS(1, 8);
+            else
+                SELA_LAUNCH_TEAMS(0, 8);
+        } else {
+            if (d_phase_cycles)
+                SELA_LAUNCH_TEAMS(2, 16);
+            else if (d_trace)
+                SELA_LAUNCH_TEAMS(1, 16);
+            else
+                SELA_LAUNCH_TEAMS(0, 16);
+        }
+#undef SELA_LAUNCH_TEAMS
+    } else
     if (d_phase_cycles)
         hipLaunchKernelGGL((k_encode_blocks<2, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     else if (d_trace)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of the encode/decode kernels on the bench workload (debug hook).
 
-    python tools/phase_profile.py [n_frames]
+    python tools/phase_profile.py [n_frames [team_lanes]]     (team_lanes 8 / 16: k_encode_teams, where the mean / autocorr /
+                                                              Schur columns are a WAVE's phases, shared by its 64 / team_lanes blocks,
+                                                              and the last column is the time since the end of the wave's analysis)
 
 Prints the mean s_memtime cycles each phase takes per block (encoder: per (frame, signal);
 decoder: per subframe).  Quoted in DESIGN.md; not part of the timed path.
@@ -25,6 +27,8 @@ DEC = ["headers + mode barrier", "stream -> LDS", "parse A (own zone)", "parse B
 def main():
     n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3875
     lib = capi.lib()
+    teams = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+    lib.sela_hip_debug_encode_teams(teams)
     pcm = torch.from_numpy(synth_frames(n_frames, 2, 0)).cuda()
     enc, dec = codec.Encoder(n_frames, 2), codec.Decoder(n_frames, 2)
     out = enc.encode(pcm)
@@ -33,7 +37,10 @@ def main():
     lib.sela_hip_debug_phase_buffer(buf.data_ptr())
     enc.encode(pcm)
     torch.cuda.synchronize()
-    e = buf.cpu().numpy().reshape(-1, 16)[:, :12].astype(np.float64)
+    raw = buf.cpu().numpy().reshape(-1, 16)
+    e = raw[:, :12].astype(np.float64)
+    if teams > 0:
+        print(f"k_encode_teams<{teams}>: since the end of the wave's analysis, per block (its own tail and those before it): mean {raw[:, 12].mean():.0f}, max {raw[:, 12].max()}")
     buf.zero_()
     dec.decode(out.frames, out.offsets, n_frames)
     torch.cuda.synchronize()
