@@ -1484,19 +1484,37 @@ __device__ __forceinline__ void team_stage(double* ring_b, int pos, const int32_
     }
 }
 
-// sum + x[0] + x[1] + ... in that order (the mean's chain), sixteen values fetched at a time
+// sum + x[0] + x[1] + ... in that order (the mean's chain); the values come eight at a time, each batch fetched while the
+// batch before it is being added (a chain that waits for its own reads walks at the LDS's latency, not at the adder's)
 template <int kN>
 __device__ __forceinline__ double team_chain(const double* x, double sum)
 {
-#pragma unroll 1
-    for (int i0 = 0; i0 < kN; i0 += 16) {
-        double v[16];
+    constexpr int kBatch = 8;
+    static_assert(kN % (2 * kBatch) == 0, "two batches per round");
+    double u[kBatch], v[kBatch];
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            v[i] = x[i0 + i];
+    for (int i = 0; i < kBatch; i++)
+        u[i] = x[i];
 #pragma unroll
-        for (int i = 0; i < 16; i++)
+    for (int i0 = 0; i0 < kN; i0 += 2 * kBatch) { // (straight-line code: as a loop the compiler copies one batch into the other's registers)
+#pragma unroll
+        for (int i = 0; i < kBatch; i++)
+            v[i] = x[i0 + kBatch + i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kBatch; i++)
+            sum += u[i];
+        __builtin_amdgcn_sched_barrier(0);
+        if (i0 + 2 * kBatch < kN) {
+#pragma unroll
+            for (int i = 0; i < kBatch; i++)
+                u[i] = x[i0 + 2 * kBatch + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kBatch; i++)
             sum += v[i];
+        __builtin_amdgcn_sched_barrier(0);
     }
     return sum;
 }
@@ -1587,21 +1605,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         double sum = 0.0;
         __builtin_amdgcn_s_setprio(2); // (a dependency chain: ahead of the co-resident waves' throughput-bound phases)
 #pragma unroll 1
-        for (int c = 0; c < kChunks; c += 2) {
-            // chunk c + 1 -> the second place, chunk c is summed from the first
-            team_stage<kMeanPer, false, false, kRing>(ring_b, kTeamMeanChunk + mine, raw_a, 0.0);
+        for (int c = 0; c < kChunks; c++) {
+            // chunk c + 1 -> the place chunk c - 1 was summed from, chunk c is summed from the other one
+            const int here = (c & 1) * kTeamMeanChunk, there = kTeamMeanChunk - here;
+            if (c + 1 < kChunks)
+                team_stage<kMeanPer, false, false, kRing>(ring_b, there + mine, raw_a, 0.0);
+#pragma unroll
+            for (int i = 0; i < kMeanPer; i++)
+                raw_a[i] = raw_b[i];
             if (c + 3 < kChunks)
-                team_load_raw<kMeanPer>(fp, channels, sig, (c + 3) * kTeamMeanChunk + mine, raw_a);
+                team_load_raw<kMeanPer>(fp, channels, sig, (c + 3) * kTeamMeanChunk + mine, raw_b);
             wave_sync();
-            sum = team_chain<kTeamMeanChunk>(ring_b, sum);
-            wave_sync();
-            if (c + 2 < kChunks) {
-                team_stage<kMeanPer, false, false, kRing>(ring_b, mine, raw_b, 0.0);
-                if (c + 4 < kChunks)
-                    team_load_raw<kMeanPer>(fp, channels, sig, (c + 4) * kTeamMeanChunk + mine, raw_b);
-            }
-            wave_sync();
-            sum = team_chain<kTeamMeanChunk>(ring_b + kTeamMeanChunk, sum);
+            sum = team_chain<kTeamMeanChunk>(ring_b + here, sum);
             wave_sync();
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1661,16 +1676,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             pos_stage = pos_stage >= (uint32_t)kRing ? 0u : pos_stage;
         };
 #pragma unroll 1
-        for (int c = 0; c < kChunks; c += 2) { // (two chunks per round: the PCM of a chunk is fetched two chunks ahead, into raw_a / raw_b in turn)
-            stage_next(raw_a); // chunk c + 1
+        for (int c = 0; c < kChunks; c++) { // (the PCM of a chunk is fetched two chunks ahead)
+            if (c + 1 < kChunks)
+                stage_next(raw_a); // chunk c + 1
+#pragma unroll
+            for (int i = 0; i < kPer; i++)
+                raw_a[i] = raw_b[i];
             if (c + 3 < kChunks)
-                team_load_raw<kPer>(fp, channels, sig, (c + 3) * kChunk + mine, raw_a);
-            trips();
-            if (c + 2 < kChunks) {
-                stage_next(raw_b); // chunk c + 2
-                if (c + 4 < kChunks)
-                    team_load_raw<kPer>(fp, channels, sig, (c + 4) * kChunk + mine, raw_b);
-            }
+                team_load_raw<kPer>(fp, channels, sig, (c + 3) * kChunk + mine, raw_b);
             trips();
         }
         // (three fetches past the end are in flight: land them before the rings are reused)
@@ -1986,7 +1999,7 @@ static int team_lanes_for(size_t blocks)
 {
     if (blocks < 9000)
         return 0;
-    return blocks < 48000 ? 16 : 8;
+    return blocks < 36000 ? 16 : 8;
 }
 
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames,
