@@ -47,7 +47,7 @@ public:
     // false when the file ends before n bytes at `offset`
     bool readAt(void* dst, size_t n, size_t offset) const;
     void writeAt(const void* src, size_t n, size_t offset) const;
-    void allocate(size_t from, size_t n) const; // the pages of [from, from + n), in one go (fallocate); the file then is at least from + n bytes long
+    void allocate(size_t from, size_t n) const; // the pages of [from, from + n), in one go (fallocate, FALLOC_FL_KEEP_SIZE: the file's LENGTH stays what the writes and truncate() make it)
     void truncate(size_t n) const;
     void close();
 };
@@ -57,8 +57,10 @@ class IoPool {
 public:
     static IoPool& instance();
     void submit(std::function<void()> task, bool first = false); // first: ahead of what is queued
-    unsigned threads() const { return count; }
-    void grow(unsigned atLeast); // more threads (never fewer): the batch verbs ask for a few per GPU worker
+    unsigned threads() const { return count.load(std::memory_order_relaxed); }
+    // more threads (never fewer): the batch verbs ask for a few per GPU worker.  A thread count the user configured
+    // (configure(n), --io-threads) is a decision, not a default: the pool then stays at n
+    void grow(unsigned atLeast);
     // Threads the pool starts with (before its first use; later calls are ignored).  0 = the default:
     // min(6, hardware threads / 2), at least 2 (reads of one file stop scaling at 4-8 threads; writes to one file
     // do not scale at all, see WriteBehind).
@@ -70,7 +72,8 @@ private:
     void run();
     struct Impl;
     Impl* impl;
-    unsigned count;
+    std::atomic<unsigned> count{ 0 };
+    bool userSized = false;
 };
 
 // A set of tasks submitted to the pool whose completion is awaited together; remembers the first failure
@@ -138,6 +141,9 @@ public:
     ~WriteBehind();
     // base[0, upTo) is final (the same base every time): whatever of it is not in the file yet gets written
     void drain(const void* base, size_t upTo);
+    // waits until nothing of base[] is being read (no write in flight): the caller may then move or free the buffer and
+    // drain() again from its new place -- what is in the file stays there
+    void quiesce();
     // waits for everything drained so far; with truncateTo, the file then ends at fileOffset + *truncateTo
     void finish(const size_t* truncateTo = nullptr);
 };

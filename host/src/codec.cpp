@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -43,14 +44,18 @@ size_t optimisticBytes(size_t frames, uint32_t channels)
 // Encode `frames` frames at pcm that are arriving in memory front to back: need(n) returns once the first n frames are
 // there (an ifstream read, or a wait for read-ahead tasks; a no-op for samples that are in memory already).  Every
 // `piece` frames are one feed = one kernel launch.  drain(bytes, n) is told whenever more of the output is final.
+// beforeRealloc(): called before `bytes` is moved to a larger block (the retry with the certain bound) -- a sink that
+// still READS the old block on another thread (WriteBehind) must be through with it by then.
 template <typename Need, typename Drain>
 void streamEncode(Need need, size_t piece, int16_t* pcm, size_t frames, uint32_t channels, sela_host::PinnedBuffer<uint8_t>& bytes,
-    std::vector<uint64_t>& offsets, Drain drain)
+    std::vector<uint64_t>& offsets, Drain drain, const std::function<void()>& beforeRealloc = {})
 {
     const size_t frameSamples = kBlock * channels;
     offsets.assign(frames + 1, 0);
     piece = std::max<size_t>(piece, 1);
     for (int attempt = 0; attempt < 2; attempt++) {
+        if (attempt == 1 && beforeRealloc)
+            beforeRealloc(); // (resize frees the block the sink was draining from)
         bytes.resize(attempt == 0 ? optimisticBytes(frames, channels) : sela_hip_encode_bound_bytes((uint32_t)frames, channels));
         sela_hip_job* job = nullptr;
         if (sela_hip_encode_begin(&job, channels, (uint32_t)frames, bytes.data(), bytes.size(), offsets.data()) != SELA_HIP_OK)
@@ -260,9 +265,11 @@ std::vector<std::vector<Piece>> partitionPieces(const std::vector<size_t>& track
     return out;
 }
 
-// Run work(worker, pieces) on one host thread per device; the first exception is rethrown in the caller.
+// Run work(worker, pieces) on one host thread per device; the first exception is rethrown in the caller.  onFailure() runs
+// in the failing worker's thread for ANY failure of that worker -- its device not coming up included -- before the others
+// are joined: workers that wait for each other (a track cut across GPUs) must hear of it, or join() never returns.
 template <typename Work>
-void runOnDevices(const std::vector<std::vector<Piece>>& pieces, const std::vector<int>& devs, Work work)
+void runOnDevices(const std::vector<std::vector<Piece>>& pieces, const std::vector<int>& devs, Work work, const std::function<void()>& onFailure = {})
 {
     std::vector<std::thread> pool;
     std::mutex errorMutex;
@@ -274,10 +281,14 @@ void runOnDevices(const std::vector<std::vector<Piece>>& pieces, const std::vect
                     gpuFailure("device");
                 work(w, pieces[w]);
             } catch (const data::Exception& e) {
+                if (onFailure)
+                    onFailure();
                 std::lock_guard<std::mutex> lock(errorMutex);
                 if (error.empty())
                     error = e.exceptionMessage;
             } catch (const std::exception& e) {
+                if (onFailure)
+                    onFailure();
                 std::lock_guard<std::mutex> lock(errorMutex);
                 if (error.empty())
                     error = e.what();
@@ -605,12 +616,12 @@ SelaInfo probeSela(const std::string& path)
 // kFeedFrames, sink(bytes, final) is told whenever more of the output is final.  Returns the total.
 template <typename Sink>
 size_t encodeRange(const sela_host::PosixFile& in, const WavInfo& info, size_t first, size_t n, sela_host::PinnedBuffer<int16_t>& pcm,
-    sela_host::PinnedBuffer<uint8_t>& bytes, std::vector<uint64_t>& offsets, Sink sink)
+    sela_host::PinnedBuffer<uint8_t>& bytes, std::vector<uint64_t>& offsets, Sink sink, const std::function<void()>& sinkQuiesce = {})
 {
     const size_t frameBytes = kBlock * info.channels * 2;
     pcm.resize(n * kBlock * info.channels);
     sela_host::ReadAhead ahead(in, pcm.data(), info.dataOffset + first * frameBytes, n * frameBytes, kFeedFrames * frameBytes, kIoSubBytes);
-    streamEncode([&](size_t upTo) { ahead.need(upTo * frameBytes); }, kFeedFrames, pcm.data(), n, info.channels, bytes, offsets, sink);
+    streamEncode([&](size_t upTo) { ahead.need(upTo * frameBytes); }, kFeedFrames, pcm.data(), n, info.channels, bytes, offsets, sink, sinkQuiesce);
     ahead.finish();
     return bytes.size();
 }
@@ -634,7 +645,7 @@ size_t encodeFile(const std::string& inPath, const std::string& outPath)
     std::vector<uint64_t> offsets;
     // (the pages of the output are allocated in one go while the input is read and coded: audio codes to about 3/4)
     sela_host::WriteBehind behind(out, 15, kIoSubBytes, expectedSelaBytes(info));
-    const size_t total = encodeRange(in, info, 0, info.frames, pcm, bytes, offsets, [&](const uint8_t* p, size_t done) { behind.drain(p, done); });
+    const size_t total = encodeRange(in, info, 0, info.frames, pcm, bytes, offsets, [&](const uint8_t* p, size_t done) { behind.drain(p, done); }, [&] { behind.quiesce(); });
     behind.finish(&total);
     return info.frames;
 }
@@ -842,7 +853,7 @@ void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
                                 po->out = sela_host::PosixFile::openForWrite(outputs[member]);
                                 po->behind.reset(new sela_host::WriteBehind(po->out, 15, kIoSubBytes, expectedSelaBytes(info[member])));
                                 sela_host::WriteBehind* const behind = po->behind.get();
-                                encodeRange(in, info[member], 0, pc.n, pcm, po->data, offsets, [behind](const uint8_t* b, size_t n) { behind->drain(b, n); });
+                                encodeRange(in, info[member], 0, pc.n, pcm, po->data, offsets, [behind](const uint8_t* b, size_t n) { behind->drain(b, n); }, [behind] { behind->quiesce(); });
                                 po->cut = pc.n == info[member].frames; // (the whole track: the file ends here)
                                 po->cutTo = po->data.size();
                                 shared.publish(pc.track, indexInTrack[w][p0], po->data.size());
@@ -909,7 +920,7 @@ void encodeFiles(const std::vector<std::string>& inputs, const std::vector<std::
                     shared.abort();
                     throw;
                 }
-            });
+            }, [&] { shared.abort(); }); // (also when a worker's device does not come up: the others may be waiting for its pieces' sizes)
         } catch (...) {
             shared.abort();
             throw;

@@ -128,7 +128,7 @@ void PosixFile::allocate(size_t from, size_t n) const
         return;
     int rc;
     do // (the Linux call, not posix_fallocate: where the file system cannot do it, that one writes zeros instead)
-        rc = ::fallocate(fd, 0, (off_t)from, (off_t)n);
+        rc = ::fallocate(fd, FALLOC_FL_KEEP_SIZE, (off_t)from, (off_t)n); // (KEEP_SIZE: a late call can never lengthen a file that has been cut to size)
     while (rc != 0 && errno == EINTR);
     if (rc != 0)
         ioFailure("allocating", name);
@@ -165,8 +165,11 @@ IoPool::IoPool() : impl(new Impl)
         const unsigned hw = std::thread::hardware_concurrency();
         n = std::min(6u, std::max(2u, hw / 2));
     }
-    count = std::min(n, 256u);
-    for (unsigned i = 0; i < count; i++)
+    else
+        userSized = true;
+    n = std::min(n, 256u);
+    count.store(n, std::memory_order_relaxed);
+    for (unsigned i = 0; i < n; i++)
         impl->workers.emplace_back([this] { run(); });
 }
 
@@ -184,11 +187,13 @@ IoPool::~IoPool()
 
 void IoPool::grow(unsigned atLeast)
 {
+    if (userSized)
+        return;
     atLeast = std::min(atLeast, 256u);
     std::lock_guard<std::mutex> lock(impl->mu);
-    while (count < atLeast) {
+    while (count.load(std::memory_order_relaxed) < atLeast) {
         impl->workers.emplace_back([this] { run(); });
-        count++;
+        count.fetch_add(1, std::memory_order_relaxed);
     }
 }
 
@@ -396,6 +401,12 @@ void WriteBehind::drain(const void* from, size_t upTo)
     }
 }
 
+void WriteBehind::quiesce()
+{
+    std::unique_lock<std::mutex> lock(mu);
+    cv.wait(lock, [this] { return !active; });
+}
+
 void WriteBehind::finish(const size_t* truncateTo)
 {
     Traced t("wait for writes", 0);
@@ -405,7 +416,7 @@ void WriteBehind::finish(const size_t* truncateTo)
         if (failed)
             throw data::Exception(error);
     }
-    if (truncateTo && expect && *truncateTo != expect)
+    if (truncateTo && expect) // (the allocation keeps the file's size: the length is set here, once)
         file.truncate(fileOffset + *truncateTo);
 }
 

@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "sela_coalescer.h"
 #include "sela_device.h"
 
 namespace sela {
@@ -213,6 +214,7 @@ struct HostContext {
     hipStream_t s_in = nullptr, s_out = nullptr, s_run[kRunStreams] = { nullptr, nullptr };
     int device = -1;
     bool job_open = false;
+    int staged_device = -1; // the device whose staging path this context's open job holds (staged_path_acquire), or -1
     // the buffers belong to the device that was current when they were allocated
     bool bind_current_device()
     {
@@ -300,6 +302,8 @@ ContextPark& park()
 std::atomic<int> g_contexts_created{ 0 }; // debug: sela_hip_debug_contexts_created
 constexpr size_t kParkedContexts = 16; // more than this many idle ones are freed instead (a context holds up to a few hundred MB of HBM)
 
+void staged_path_release(int device); // (below)
+
 struct ContextLease {
     HostContext* held = nullptr;
     HostContext& get()
@@ -333,6 +337,9 @@ struct ContextLease {
             c->sync_all();
             c->release();
             c->job_open = false;
+            if (c->staged_device >= 0) // (its job held the device's staging path: nobody else will give it back)
+                staged_path_release(c->staged_device);
+            c->staged_device = -1;
         }
         ContextPark& p = park();
         {
@@ -878,6 +885,7 @@ int job_begin(sela_hip_job** out, bool encode, uint32_t channels, uint32_t total
     job->channels = channels;
     job->total_frames = total_frames;
     job->staged = job->holds_staged_path = encode && channels == 2 && staged_path_acquire(ctx().device);
+    ctx().staged_device = job->holds_staged_path ? ctx().device : -1;
     ctx().job_open = true;
     *out = job;
     return SELA_HIP_OK;
@@ -928,6 +936,7 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
     ctx().job_open = false;
     if (job->holds_staged_path)
         staged_path_release(ctx().device);
+    ctx().staged_device = -1;
     delete job;
     if (rc != SELA_HIP_OK)
         return rc;
@@ -1214,203 +1223,45 @@ int decode_now(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_
     return rc_end;
 }
 
-// ---- small calls from many threads are coalesced -----------------------------------------------------------------
-// The reference hands its frames to hardware_concurrency() threads, one frame per call (src/sela/encoder.cpp:58-73,
-// src/sela/decoder.cpp:58-73), and a binding that keeps that loop calls sela_hip_encode / sela_hip_decode the same way.
-// One frame is a poor launch (3 of the device's 3072 block slots), and every calling thread would want streams and
-// buffers of its own.  So one-shot calls of at most kCoalesceFrames frames group the way databases group commits: a call
-// that finds nobody ahead of it runs at once, as it is; calls that arrive while it is on the device queue up, and when
-// it returns ONE of them takes everything that is waiting for the same device and channel count to the device as a
-// single job, hands every call its part of the result, and parks the streams it used for the next leader.  A lone caller
-// pays nothing; T busy threads end up in batches of about T calls.  A call's own failure (output buffer too small, a
-// malformed frame) stays its own.
-constexpr uint32_t kCoalesceFrames = 32;
-
-struct SmallCall {
-    int device = 0;
-    uint32_t channels = 0, n_frames = 0;
-    const int16_t* pcm = nullptr; // encode
-    uint8_t* frames_out = nullptr;
-    size_t frames_cap = 0;
-    uint64_t* offsets_out = nullptr;
-    const uint8_t* frames = nullptr; // decode
-    const uint64_t* offsets_in = nullptr;
-    int16_t* pcm_out = nullptr;
-    int rc = SELA_HIP_OK;
-    std::string error;
-    bool done = false, lead = false;
+// ---- small calls from many threads are coalesced: sela_coalescer.h, on this backend ---------------------------------------
+struct HipBackend {
+    static int encode_now(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint8_t* frames_out, size_t frames_cap, uint64_t* offsets_out)
+    {
+        return ::encode_now(pcm, n_frames, channels, frames_out, frames_cap, offsets_out);
+    }
+    static int decode_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm_out)
+    {
+        return ::decode_now(frames, offsets, n_frames, channels, pcm_out);
+    }
+    static size_t encode_bound_bytes(uint32_t n_frames, uint32_t channels) { return sela_hip_encode_bound_bytes(n_frames, channels); }
+    static void* take(size_t bytes) { return pool().take(bytes); }
+    static void give(void* p) { pool().give(p); }
+    static std::string last_error() { return sela_hip_last_error(); }
+    static void after_batch() { g_lease.give_back(); }
 };
+using sela::kCoalesceFrames;
+using sela::SmallCall;
+typedef sela::CallCoalescer<HipBackend> Coalescer;
 
-class CallCoalescer {
-    const bool encode;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<SmallCall*> queue;
-    bool busy = false;
-    size_t last_batch = 0;
-    static constexpr size_t kMaxCalls = 4096;
-
-    void run_one(SmallCall& c)
-    {
-        c.rc = encode ? encode_now(c.pcm, c.n_frames, c.channels, c.frames_out, c.frames_cap, c.offsets_out)
-                      : decode_now(c.frames, c.offsets_in, c.n_frames, c.channels, c.pcm_out);
-        if (c.rc != SELA_HIP_OK)
-            c.error = sela_hip_last_error();
-    }
-
-    void run_batch(const std::vector<SmallCall*>& batch)
-    {
-        if (batch.size() == 1)
-            return run_one(*batch[0]);
-        const uint32_t channels = batch[0]->channels;
-        const size_t frame_pcm = (size_t)sela::kBlock * channels * sizeof(int16_t);
-        size_t total = 0;
-        for (const SmallCall* c : batch)
-            total += c->n_frames;
-        std::vector<uint64_t> offsets(total + 1, 0);
-        void *in = nullptr, *out = nullptr;
-        int rc = SELA_HIP_OK;
-        if (encode) {
-            const size_t cap = sela_hip_encode_bound_bytes((uint32_t)total, channels);
-            in = pool().take(total * frame_pcm);
-            out = pool().take(cap);
-            if (!in || !out) {
-                rc = fail(SELA_HIP_ENOMEM, "no page-locked memory for a coalesced batch");
-            } else {
-                size_t at = 0;
-                for (const SmallCall* c : batch) {
-                    std::memcpy(static_cast<uint8_t*>(in) + at * frame_pcm, c->pcm, c->n_frames * frame_pcm);
-                    at += c->n_frames;
-                }
-                rc = encode_now(static_cast<const int16_t*>(in), (uint32_t)total, channels, static_cast<uint8_t*>(out), cap, offsets.data());
-            }
-            const std::string msg = rc != SELA_HIP_OK ? sela_hip_last_error() : "";
-            size_t at = 0;
-            for (SmallCall* c : batch) {
-                const uint64_t base = offsets[at], bytes = offsets[at + c->n_frames] - base;
-                if (rc != SELA_HIP_OK) {
-                    c->rc = rc, c->error = msg;
-                } else if (bytes > c->frames_cap) {
-                    c->rc = SELA_HIP_ECAPACITY, c->error = "frames_out too small (see sela_hip_encode_bound_bytes)";
-                } else {
-                    std::memcpy(c->frames_out, static_cast<const uint8_t*>(out) + base, (size_t)bytes);
-                    for (uint32_t f = 0; f <= c->n_frames; f++)
-                        c->offsets_out[f] = offsets[at + f] - base;
-                }
-                at += c->n_frames;
-            }
-        } else {
-            size_t bytes = 0;
-            for (const SmallCall* c : batch)
-                bytes += (size_t)(c->offsets_in[c->n_frames] - c->offsets_in[0] + 3) & ~(size_t)3;
-            in = pool().take(bytes + 4);
-            out = pool().take(total * frame_pcm);
-            if (!in || !out) {
-                rc = fail(SELA_HIP_ENOMEM, "no page-locked memory for a coalesced batch");
-            } else {
-                size_t at = 0, pos = 0;
-                for (const SmallCall* c : batch) {
-                    const uint64_t first = c->offsets_in[0], len = c->offsets_in[c->n_frames] - first;
-                    std::memcpy(static_cast<uint8_t*>(in) + pos, c->frames + first, (size_t)len);
-                    for (uint32_t f = 0; f < c->n_frames; f++)
-                        offsets[at + f] = pos + (c->offsets_in[f] - first);
-                    at += c->n_frames;
-                    pos += ((size_t)len + 3) & ~(size_t)3; // (frames are whole words: every call's first frame stays aligned)
-                    offsets[at] = pos; // (the padding, if a malformed frame left any, belongs to the call's last frame)
-                }
-                rc = decode_now(static_cast<const uint8_t*>(in), offsets.data(), (uint32_t)total, channels, static_cast<int16_t*>(out));
-            }
-            if (rc == SELA_HIP_EFORMAT) {
-                // somebody's malformed frame must not fail its neighbours' calls: everyone on their own
-                for (SmallCall* c : batch)
-                    run_one(*c);
-            } else {
-                const std::string msg = rc != SELA_HIP_OK ? sela_hip_last_error() : "";
-                size_t at = 0;
-                for (SmallCall* c : batch) {
-                    if (rc != SELA_HIP_OK)
-                        c->rc = rc, c->error = msg;
-                    else
-                        std::memcpy(c->pcm_out, static_cast<const uint8_t*>(out) + at * frame_pcm, c->n_frames * frame_pcm);
-                    at += c->n_frames;
-                }
-            }
-        }
-        if (in)
-            pool().give(in);
-        if (out)
-            pool().give(out);
-    }
-
-public:
-    explicit CallCoalescer(bool enc) : encode(enc) {}
-
-    int submit(SmallCall& call)
-    {
-        std::unique_lock<std::mutex> lock(mu);
-        queue.push_back(&call);
-        if (!busy)
-            busy = call.lead = true;
-        cv.wait(lock, [&] { return call.done || call.lead; });
-        if (!call.done) {
-            // this call leads.  If the batch before held several calls, their threads are on their way back with their
-            // next frames right now: give them until the queue has stopped growing for a moment (bounded) -- a trip to
-            // the device costs more than that
-            if (last_batch > 1) {
-                const auto t0 = std::chrono::steady_clock::now();
-                size_t seen = queue.size();
-                auto last_growth = t0;
-                for (;;) {
-                    lock.unlock();
-                    std::this_thread::yield();
-                    lock.lock();
-                    const auto now = std::chrono::steady_clock::now();
-                    if (queue.size() != seen)
-                        seen = queue.size(), last_growth = now;
-                    if (seen >= last_batch || now - last_growth > std::chrono::microseconds(20) || now - t0 > std::chrono::microseconds(150))
-                        break;
-                }
-            }
-            std::vector<SmallCall*> batch; // everything that waits for this device with this channel count, this call included
-            for (auto it = queue.begin(); it != queue.end() && batch.size() < kMaxCalls;) {
-                if ((*it)->channels == call.channels && (*it)->device == call.device) {
-                    batch.push_back(*it);
-                    it = queue.erase(it);
-                } else {
-                    ++it;
-                }
-            }
-            lock.unlock();
-            try {
-                run_batch(batch);
-            } catch (...) { // (std::bad_alloc: the callers hear of it, nobody is left waiting)
-                for (SmallCall* c : batch)
-                    if (c->rc == SELA_HIP_OK)
-                        c->rc = SELA_HIP_ENOMEM, c->error = "out of memory while staging a coalesced batch";
-            }
-            g_lease.give_back(); // the streams and buffers this thread used go to whoever leads next: any caller may
-            lock.lock();
-            for (SmallCall* c : batch)
-                c->done = true;
-            last_batch = batch.size();
-            if (queue.empty())
-                busy = false;
-            else
-                queue.front()->lead = true;
-            lock.unlock();
-            cv.notify_all();
-        }
-        return call.rc == SELA_HIP_OK ? SELA_HIP_OK : fail(call.rc, call.error);
-    }
-};
-
-CallCoalescer* coalescer(bool encode)
+// One coalescer per device and direction: calls for different GPUs (one thread per GPU, each coding frame by frame) can never
+// share a batch, so they do not wait for each other's leaders either.
+Coalescer* coalescer(bool encode, int device)
 {
-    static CallCoalescer* enc = new CallCoalescer(true); // (never destroyed: calls may outlive the statics)
-    static CallCoalescer* dec = new CallCoalescer(false);
-    return encode ? enc : dec;
+    static std::mutex mu;
+    static Coalescer* table[2][64] = {};
+    const int d = device >= 0 && device < 64 ? device : 0;
+    std::lock_guard<std::mutex> lock(mu);
+    Coalescer*& c = table[encode ? 1 : 0][d];
+    if (!c)
+        c = new Coalescer(encode); // (never destroyed: calls may outlive the statics)
+    return c;
 }
 
+int submit_small(bool encode, SmallCall& call)
+{
+    const int rc = coalescer(encode, call.device)->submit(call);
+    return rc == SELA_HIP_OK ? SELA_HIP_OK : fail(rc, call.error);
+}
 } // namespace
 
 int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel, uint8_t* frames_out,
@@ -1427,7 +1278,7 @@ int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, ui
         return encode_now(pcm, n_frames, channels, frames_out, frames_cap, frame_offsets_out); // (reports the missing device)
     call.channels = channels, call.n_frames = n_frames;
     call.pcm = pcm, call.frames_out = frames_out, call.frames_cap = frames_cap, call.offsets_out = frame_offsets_out;
-    return coalescer(true)->submit(call);
+    return submit_small(true, call);
 }
 
 int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm_out)
@@ -1444,7 +1295,7 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
         return decode_now(frames, frame_offsets, n_frames, channels, pcm_out);
     call.channels = channels, call.n_frames = n_frames;
     call.frames = frames, call.offsets_in = frame_offsets, call.pcm_out = pcm_out;
-    return coalescer(false)->submit(call);
+    return submit_small(false, call);
 }
 
 uint32_t sela_hip_index_frames(const uint8_t* frames, size_t frames_bytes, uint32_t n_frames, uint32_t channels, uint64_t* frame_offsets)

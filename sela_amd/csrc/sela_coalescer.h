@@ -1,0 +1,223 @@
+// sela_coalescer.h -- one-frame calls from many threads become device jobs (the host-pointer API of libsela_hip.so).
+//
+// Header-only and written against a BACKEND (what runs a job, where staging memory comes from), so that the locking can be
+// built on its own: libsela_hip.so instantiates it with the HIP backend (sela_capi.hip), tests/c/coalescer_stress.cpp with a
+// CPU stub under -fsanitize=thread (tests/test_sanitizers.py).  Nothing of the stub is compiled into the library.
+//
+//   struct Backend {
+//       static int encode_now(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint8_t* frames_out, size_t frames_cap, uint64_t* offsets_out);
+//       static int decode_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm_out);
+//       static size_t encode_bound_bytes(uint32_t n_frames, uint32_t channels);
+//       static void* take(size_t bytes);  static void give(void* p);      // staging memory of a batch
+//       static std::string last_error();                                  // of the calling thread's last *_now
+//       static void after_batch();                                        // the leader is through with the device
+//   };
+#ifndef SELA_COALESCER_H_
+#define SELA_COALESCER_H_
+
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sela_hip.h"
+
+namespace sela {
+
+// The reference hands its frames to hardware_concurrency() threads, one frame per call (src/sela/encoder.cpp:58-73,
+// src/sela/decoder.cpp:58-73), and a binding that keeps that loop calls sela_hip_encode / sela_hip_decode the same way.
+// One frame is a poor launch (3 of the device's 3072 block slots), and every calling thread would want streams and
+// buffers of its own.  So one-shot calls of at most kCoalesceFrames frames group the way databases group commits: a call
+// that finds nobody ahead of it runs at once, as it is; calls that arrive while it is on the device queue up, and when
+// it returns ONE of them takes everything that is waiting for the same device and channel count to the device as a
+// single job, hands every call its part of the result, and parks the streams it used for the next leader.  A lone caller
+// pays nothing; T busy threads end up in batches of about T calls.  A call's own failure (output buffer too small, a
+// malformed frame) stays its own.
+constexpr uint32_t kCoalesceFrames = 32;
+
+struct SmallCall {
+    int device = 0;
+    uint32_t channels = 0, n_frames = 0;
+    const int16_t* pcm = nullptr; // encode
+    uint8_t* frames_out = nullptr;
+    size_t frames_cap = 0;
+    uint64_t* offsets_out = nullptr;
+    const uint8_t* frames = nullptr; // decode
+    const uint64_t* offsets_in = nullptr;
+    int16_t* pcm_out = nullptr;
+    int rc = SELA_HIP_OK;
+    std::string error;
+    bool done = false, lead = false;
+};
+
+template <class Backend>
+class CallCoalescer {
+    const bool encode;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<SmallCall*> queue;
+    bool busy = false;
+    size_t last_batch = 0;
+    static constexpr size_t kMaxCalls = 4096;
+
+    void run_one(SmallCall& c)
+    {
+        c.rc = encode ? Backend::encode_now(c.pcm, c.n_frames, c.channels, c.frames_out, c.frames_cap, c.offsets_out)
+                      : Backend::decode_now(c.frames, c.offsets_in, c.n_frames, c.channels, c.pcm_out);
+        if (c.rc != SELA_HIP_OK)
+            c.error = Backend::last_error();
+    }
+
+    void run_batch(const std::vector<SmallCall*>& batch)
+    {
+        if (batch.size() == 1)
+            return run_one(*batch[0]);
+        const uint32_t channels = batch[0]->channels;
+        const size_t frame_pcm = (size_t)SELA_HIP_SAMPLES_PER_FRAME * channels * sizeof(int16_t);
+        size_t total = 0;
+        for (const SmallCall* c : batch)
+            total += c->n_frames;
+        std::vector<uint64_t> offsets(total + 1, 0);
+        void *in = nullptr, *out = nullptr;
+        int rc = SELA_HIP_OK;
+        bool oom = false;
+        if (encode) {
+            const size_t cap = Backend::encode_bound_bytes((uint32_t)total, channels);
+            in = Backend::take(total * frame_pcm);
+            out = Backend::take(cap);
+            if (!in || !out) {
+                rc = SELA_HIP_ENOMEM, oom = true;
+            } else {
+                size_t at = 0;
+                for (const SmallCall* c : batch) {
+                    std::memcpy(static_cast<uint8_t*>(in) + at * frame_pcm, c->pcm, c->n_frames * frame_pcm);
+                    at += c->n_frames;
+                }
+                rc = Backend::encode_now(static_cast<const int16_t*>(in), (uint32_t)total, channels, static_cast<uint8_t*>(out), cap, offsets.data());
+            }
+            const std::string msg = rc == SELA_HIP_OK ? std::string() : (oom ? std::string("no page-locked memory for a coalesced batch") : Backend::last_error());
+            size_t at = 0;
+            for (SmallCall* c : batch) {
+                const uint64_t base = offsets[at], bytes = offsets[at + c->n_frames] - base;
+                if (rc != SELA_HIP_OK) {
+                    c->rc = rc, c->error = msg;
+                } else if (bytes > c->frames_cap) {
+                    c->rc = SELA_HIP_ECAPACITY, c->error = "frames_out too small (see sela_hip_encode_bound_bytes)";
+                } else {
+                    std::memcpy(c->frames_out, static_cast<const uint8_t*>(out) + base, (size_t)bytes);
+                    for (uint32_t f = 0; f <= c->n_frames; f++)
+                        c->offsets_out[f] = offsets[at + f] - base;
+                }
+                at += c->n_frames;
+            }
+        } else {
+            size_t bytes = 0;
+            for (const SmallCall* c : batch)
+                bytes += (size_t)(c->offsets_in[c->n_frames] - c->offsets_in[0] + 3) & ~(size_t)3;
+            in = Backend::take(bytes + 4);
+            out = Backend::take(total * frame_pcm);
+            if (!in || !out) {
+                rc = SELA_HIP_ENOMEM, oom = true;
+            } else {
+                size_t at = 0, pos = 0;
+                for (const SmallCall* c : batch) {
+                    const uint64_t first = c->offsets_in[0], len = c->offsets_in[c->n_frames] - first;
+                    std::memcpy(static_cast<uint8_t*>(in) + pos, c->frames + first, (size_t)len);
+                    for (uint32_t f = 0; f < c->n_frames; f++)
+                        offsets[at + f] = pos + (c->offsets_in[f] - first);
+                    at += c->n_frames;
+                    pos += ((size_t)len + 3) & ~(size_t)3; // (frames are whole words: every call's first frame stays aligned)
+                    offsets[at] = pos; // (the padding, if a malformed frame left any, belongs to the call's last frame)
+                }
+                rc = Backend::decode_now(static_cast<const uint8_t*>(in), offsets.data(), (uint32_t)total, channels, static_cast<int16_t*>(out));
+            }
+            if (rc == SELA_HIP_EFORMAT) {
+                // somebody's malformed frame must not fail its neighbours' calls: everyone on their own
+                for (SmallCall* c : batch)
+                    run_one(*c);
+            } else {
+                const std::string msg = rc == SELA_HIP_OK ? std::string() : (oom ? std::string("no page-locked memory for a coalesced batch") : Backend::last_error());
+                size_t at = 0;
+                for (SmallCall* c : batch) {
+                    if (rc != SELA_HIP_OK)
+                        c->rc = rc, c->error = msg;
+                    else
+                        std::memcpy(c->pcm_out, static_cast<const uint8_t*>(out) + at * frame_pcm, c->n_frames * frame_pcm);
+                    at += c->n_frames;
+                }
+            }
+        }
+        if (in)
+            Backend::give(in);
+        if (out)
+            Backend::give(out);
+    }
+
+public:
+    explicit CallCoalescer(bool enc) : encode(enc) {}
+
+    int submit(SmallCall& call)
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        queue.push_back(&call);
+        if (!busy)
+            busy = call.lead = true;
+        cv.wait(lock, [&] { return call.done || call.lead; });
+        if (!call.done) {
+            // this call leads.  If the batch before held several calls, their threads are on their way back with their
+            // next frames right now: give them until the queue has stopped growing for a moment (bounded) -- a trip to
+            // the device costs more than that
+            if (last_batch > 1) {
+                const auto t0 = std::chrono::steady_clock::now();
+                size_t seen = queue.size();
+                auto last_growth = t0;
+                for (;;) {
+                    lock.unlock();
+                    std::this_thread::yield();
+                    lock.lock();
+                    const auto now = std::chrono::steady_clock::now();
+                    if (queue.size() != seen)
+                        seen = queue.size(), last_growth = now;
+                    if (seen >= last_batch || now - last_growth > std::chrono::microseconds(20) || now - t0 > std::chrono::microseconds(150))
+                        break;
+                }
+            }
+            std::vector<SmallCall*> batch; // everything that waits for this device with this channel count, this call included
+            for (auto it = queue.begin(); it != queue.end() && batch.size() < kMaxCalls;) {
+                if ((*it)->channels == call.channels && (*it)->device == call.device) {
+                    batch.push_back(*it);
+                    it = queue.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            lock.unlock();
+            try {
+                run_batch(batch);
+            } catch (...) { // (std::bad_alloc: the callers hear of it, nobody is left waiting)
+                for (SmallCall* c : batch)
+                    if (c->rc == SELA_HIP_OK)
+                        c->rc = SELA_HIP_ENOMEM, c->error = "out of memory while staging a coalesced batch";
+            }
+            Backend::after_batch(); // the streams and buffers this thread used go to whoever leads next: any caller may
+            lock.lock();
+            for (SmallCall* c : batch)
+                c->done = true;
+            last_batch = batch.size();
+            if (queue.empty())
+                busy = false;
+            else
+                queue.front()->lead = true;
+            lock.unlock();
+            cv.notify_all();
+        }
+        return call.rc; // (call.error says why; the caller turns it into its thread's last error)
+    }
+};
+
+} // namespace sela
+#endif // SELA_COALESCER_H_

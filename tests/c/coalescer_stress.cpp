@@ -1,0 +1,136 @@
+// tests/c/coalescer_stress.cpp -- the call coalescer of libsela_hip.so (sela_amd/csrc/sela_coalescer.h) on a CPU stub
+// backend, built with -fsanitize=thread by tests/test_sanitizers.py: many threads submit one- to four-frame calls of two
+// channel counts, every call must get back ITS OWN result and error (a too-small output buffer, a "malformed" frame that
+// fails a whole batch and is then retried call by call), and the thread sanitizer must see no race in the hand-overs
+// (queue, leader election, results written by the leader and read by the callers).
+//
+// TEST INFRASTRUCTURE: the stub stands in for the device; nothing here is compiled into the library.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "sela_coalescer.h"
+
+namespace {
+
+constexpr uint32_t kFrame = SELA_HIP_SAMPLES_PER_FRAME;
+std::atomic<int> g_jobs{ 0 }, g_frames{ 0 }, g_leaders_done{ 0 };
+thread_local std::string t_error;
+
+// "encoding" = 8 bytes per frame: the frame's first sample and a checksum of the rest; "decoding" = the inverse filling
+// the frame with the first sample.  A frame whose first sample is -32768 is "malformed" (decode only).
+struct StubBackend {
+    static size_t encode_bound_bytes(uint32_t n_frames, uint32_t) { return (size_t)n_frames * 8; }
+    static int encode_now(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint8_t* out, size_t cap, uint64_t* offsets)
+    {
+        g_jobs++, g_frames += (int)n_frames;
+        if (cap < (size_t)n_frames * 8) {
+            t_error = "frames_out too small";
+            return SELA_HIP_ECAPACITY;
+        }
+        for (uint32_t f = 0; f < n_frames; f++) {
+            const int16_t* p = pcm + (size_t)f * kFrame * channels;
+            uint32_t sum = 0;
+            for (size_t i = 0; i < (size_t)kFrame * channels; i++)
+                sum = sum * 31u + (uint16_t)p[i];
+            const uint32_t first = (uint16_t)p[0] | (channels << 16);
+            std::memcpy(out + 8 * f, &first, 4);
+            std::memcpy(out + 8 * f + 4, &sum, 4);
+            offsets[f] = 8 * (uint64_t)f;
+        }
+        offsets[n_frames] = 8 * (uint64_t)n_frames;
+        std::this_thread::sleep_for(std::chrono::microseconds(30)); // (a trip to the device)
+        return SELA_HIP_OK;
+    }
+    static int decode_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm)
+    {
+        g_jobs++, g_frames += (int)n_frames;
+        for (uint32_t f = 0; f < n_frames; f++) {
+            uint32_t first;
+            std::memcpy(&first, frames + offsets[f], 4);
+            if ((int16_t)(uint16_t)first == -32768) {
+                t_error = "malformed frame";
+                return SELA_HIP_EFORMAT;
+            }
+            for (size_t i = 0; i < (size_t)kFrame * channels; i++)
+                pcm[(size_t)f * kFrame * channels + i] = (int16_t)(uint16_t)first;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(30));
+        return SELA_HIP_OK;
+    }
+    static void* take(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+    static void give(void* p) { std::free(p); }
+    static std::string last_error() { return t_error; }
+    static void after_batch() { g_leaders_done++; }
+};
+
+typedef sela::CallCoalescer<StubBackend> Coalescer;
+
+int worker(Coalescer& enc, Coalescer& dec, int id, int rounds, std::atomic<int>& failures)
+{
+    std::mt19937 rng(1000 + id);
+    for (int r = 0; r < rounds; r++) {
+        const uint32_t channels = (id & 1) ? 2 : 1, n = 1 + rng() % 4;
+        std::vector<int16_t> pcm((size_t)n * kFrame * channels);
+        for (uint32_t f = 0; f < n; f++) {
+            const int16_t v = (int16_t)(id * 100 + r * 7 + (int)f);
+            for (size_t i = 0; i < (size_t)kFrame * channels; i++)
+                pcm[(size_t)f * kFrame * channels + i] = v;
+        }
+        // encode; every 11th call with a buffer that is too small: that caller's error, nobody else's
+        const bool small = r % 11 == 5;
+        std::vector<uint8_t> bytes(small ? 4 : (size_t)n * 8);
+        std::vector<uint64_t> offsets(n + 1, ~0ull);
+        sela::SmallCall e;
+        e.device = id % 3 == 0 ? 1 : 0, e.channels = channels, e.n_frames = n;
+        e.pcm = pcm.data(), e.frames_out = bytes.data(), e.frames_cap = bytes.size(), e.offsets_out = offsets.data();
+        const int rc = enc.submit(e);
+        if (small) {
+            if (rc != SELA_HIP_ECAPACITY || e.error.empty())
+                failures++, std::fprintf(stderr, "thread %d round %d: a too-small buffer gave rc %d\n", id, r, rc);
+            continue;
+        }
+        if (rc != SELA_HIP_OK || offsets[n] != 8ull * n) {
+            failures++, std::fprintf(stderr, "thread %d round %d: encode rc %d\n", id, r, rc);
+            continue;
+        }
+        for (uint32_t f = 0; f < n; f++) {
+            uint32_t first;
+            std::memcpy(&first, bytes.data() + offsets[f], 4);
+            if ((int16_t)(uint16_t)first != pcm[(size_t)f * kFrame * channels] || (first >> 16) != channels)
+                failures++, std::fprintf(stderr, "thread %d round %d: frame %u came back as somebody else's\n", id, r, f);
+        }
+        // decode; every 13th call carries a "malformed" frame: the batch fails, is retried call by call, only this caller hears of it
+        const bool bad = r % 13 == 7;
+        if (bad) {
+            const uint32_t poison = 0x8000u | (channels << 16);
+            std::memcpy(bytes.data() + offsets[n - 1], &poison, 4);
+        }
+        std::vector<int16_t> back(pcm.size(), 12345);
+        sela::SmallCall d;
+        d.device = e.device, d.channels = channels, d.n_frames = n;
+        d.frames = bytes.data(), d.offsets_in = offsets.data(), d.pcm_out = back.data();
+        const int rd = dec.submit(d);
+        if (bad ? rd != SELA_HIP_EFORMAT : (rd != SELA_HIP_OK || back != pcm))
+            failures++, std::fprintf(stderr, "thread %d round %d: decode rc %d (bad frame: %d)\n", id, r, rd, (int)bad);
+    }
+    return 0;
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    const int threads = argc > 1 ? std::atoi(argv[1]) : 16, rounds = argc > 2 ? std::atoi(argv[2]) : 120;
+    Coalescer enc(true), dec(false);
+    std::atomic<int> failures{ 0 };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back(worker, std::ref(enc), std::ref(dec), t, rounds, std::ref(failures));
+    for (std::thread& t : pool)
+        t.join();
+    std::printf("%d threads x %d rounds: %d device jobs for %d frames, %d batches led, %d failures\n", threads, rounds, g_jobs.load(), g_frames.load(),
+        g_leaders_done.load(), failures.load());
+    return failures.load() ? 1 : 0;
+}

@@ -30,6 +30,9 @@ class LpcTrace(C.Structure):
 
 
 def build_oracle() -> str:
+    override = os.environ.get("SELA_ORACLE_LIB")  # tests/test_sanitizers.py: the sanitizer build of the same source
+    if override:
+        return override
     path = os.path.join(ORACLE_DIR, "libsela_oracle.so")
     src = os.path.join(ORACLE_DIR, "sela_oracle.c")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):

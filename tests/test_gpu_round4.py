@@ -90,3 +90,33 @@ def test_team_kernels_on_baseline_configs_by_digest(gpu, digests, teams, label):
     assert len(frames) == d["frames_blob_bytes"]
     assert hashlib.sha256(frames.tobytes()).hexdigest() == d["frames_blob_sha256"]
     assert hashlib.sha256(offsets.astype("<u8").tobytes()).hexdigest() == d["offsets_sha256"]
+
+
+# ---- the binding of INTEGRATION.md section 2, compiled against the reference's own headers (oracle/binding/) ----------
+BOUND = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "sela_ref_bound")
+
+
+@pytest.mark.parametrize("label", ["config0_mono_10s", "config1_stereo_3min", "stereo_48k_tail", "three_channel_96k", "shorter_than_a_frame"])
+def test_reference_classes_bound_to_the_library_write_the_reference_files(tmp_path, file_digests, label):
+    """oracle/_ref/sela_ref_bound = the reference's own sela::Encoder / sela::Decoder class declarations and its unmodified
+    file classes (src/file/*.cpp), with processFrames() replaced by one call into libsela_hip.so (oracle/binding/bound.cpp,
+    built by `make -C oracle bound` in the build container; src/lpc, src/rice, src/frame are not linked).  Its -e / -d
+    write the very files the unmodified reference wrote (tests/golden/file_digests.json)."""
+    import subprocess
+
+    from sela_amd.synth import synth_pcm
+    from test_gpu_round2 import _sha_file, _write_wav
+
+    if not os.path.exists(BOUND):
+        pytest.fail("oracle/_ref/sela_ref_bound is missing: run `make -C oracle bound` in the build container (it travels to the GPU box)")
+    d = file_digests[label]
+    pcm = synth_pcm(d["samples_per_channel"], d["channels"], d["track"])
+    wav, sela, back = tmp_path / "in.wav", tmp_path / "out.sela", tmp_path / "back.wav"
+    _write_wav(wav, pcm, d["sample_rate"])
+    assert _sha_file(wav) == d["wav_sha256"], "input drifted"
+    r = subprocess.run([BOUND, "-e", str(wav), str(sela)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(sela) == d["sela_bytes"] and _sha_file(sela) == d["sela_sha256"]
+    r = subprocess.run([BOUND, "-d", str(sela), str(back)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(back) == d["decoded_wav_bytes"] and _sha_file(back) == d["decoded_wav_sha256"]

@@ -252,3 +252,30 @@ def test_bench_with_more_than_one_gpu_and_no_launcher_starts_its_own():
     assert r.returncode != 0
     assert "AssertionError: --gpus" not in r.stderr
     assert not [t for t in r.stdout.splitlines() if t.startswith("{")]
+
+
+def test_reference_binding_is_built_and_fails_loudly_without_a_gpu(tmp_path):
+    """oracle/_ref/sela_ref_bound (oracle/binding/bound.cpp: the reference's sela::Encoder / Decoder declarations with
+    processFrames() bound to libsela_hip.so, built where /root/reference exists) links, and -- no GPU here -- reports the
+    library's error through the reference's data::Exception instead of falling back to anything."""
+    import os
+    import shutil
+    import subprocess
+
+    import torch
+
+    from sela_amd.synth import synth_pcm
+    from test_host_cpp import _write_wav
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "sela_ref_bound")
+    if not os.path.exists(exe):
+        if not os.path.isdir("/root/reference/src") or shutil.which("g++") is None:
+            pytest.skip("no reference checkout here: the binding is built in the build container")
+        subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "bound"])
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: tests/test_gpu_round4.py runs the binding for real")
+    wav = tmp_path / "in.wav"
+    _write_wav(wav, synth_pcm(5000, 2, 1), 44100)
+    r = subprocess.run([exe, "-e", str(wav), str(tmp_path / "out.sela")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
