@@ -165,6 +165,37 @@ def _newest_profile(name):
     return files[-1] if files else None
 
 
+def kernel_sources_sha256():
+    """SHA-256 over the device sources the library is built from (sela_amd/csrc/*, include/*), file names included.  The
+    profile collector (tools/collect_r04.sh) leaves the same digest beside its summaries: a counter file whose digest differs
+    from the tree's was collected on other kernels."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "sela_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*"))):
+        if os.path.isfile(path):
+            h.update(os.path.relpath(path, ROOT).encode() + b"\0")
+            with open(path, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def profiles_state(*sources):
+    """{"profiles_stale": bool, ...} for the committed profile files a line quotes: stale = the collector's digest of the kernel
+    sources (sources.sha256 in the same directory) is missing or differs from the tree's."""
+    now = kernel_sources_sha256()
+    dirs = sorted({os.path.dirname(src) for src in sources if src})
+    recorded = {}
+    for d in dirs:
+        try:
+            with open(os.path.join(ROOT, d, "sources.sha256")) as f:
+                recorded[d] = f.read().split()[0]
+        except (OSError, IndexError):
+            recorded[d] = None
+    return {"profiles_stale": bool(not dirs or any(v != now for v in recorded.values())), "kernel_sources_sha256": now, "recorded": recorded}
+
+
 def committed_valu_instructions(kernel: str):
     """(instructions per launch, source file): SQ_INSTS_VALU of `kernel` from the newest COMMITTED counter
     summary (profiles/rNN/valu_counters.txt, written by tools/valu_counters.sh) -- not measured in this run."""
@@ -184,18 +215,23 @@ def committed_valu_instructions(kernel: str):
 
 
 def committed_traffic(kernel: str):
-    """(HBM bytes per launch, source file) of `kernel` from the newest COMMITTED PMC summary
-    (profiles/rNN/traffic.json, written by tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes of
-    this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md) -- not measured in this run."""
+    """(HBM bytes per launch, source file, how) of `kernel` from the newest COMMITTED PMC summary (profiles/rNN/traffic.json,
+    written by tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes of this same command) -- not measured in
+    this run.  `how`: the counters scaled by the factors measured on known-byte kernels (traffic_calibration.json beside it:
+    tools/traffic_calib.hip, FETCH_SIZE x 2.0 and WRITE_SIZE x 1.0 at every access width on gfx950), else FETCH doubled per
+    MI355X_MICROARCH.md."""
     path = _newest_profile("traffic.json")
     if not path:
-        return None, None
+        return None, None, None
     with open(path) as f:
         data = json.load(f)
     for name, d in data.items():
-        if kernel in name and "hbm_bytes_per_launch_fetch_x2" in d:
-            return d["hbm_bytes_per_launch_fetch_x2"], os.path.relpath(path, ROOT)
-    return None, None
+        if kernel in name:
+            if "hbm_bytes_per_launch_calibrated" in d:
+                return d["hbm_bytes_per_launch_calibrated"], os.path.relpath(path, ROOT), "calibrated: " + str(data.get("_calibration", {}).get("file"))
+            if "hbm_bytes_per_launch_fetch_x2" in d:
+                return d["hbm_bytes_per_launch_fetch_x2"], os.path.relpath(path, ROOT), "FETCH_SIZE doubled (MI355X_MICROARCH.md)"
+    return None, None, None
 
 
 def host_legs(pcm_host, repeats=9):
@@ -692,8 +728,31 @@ def workload_decode10k(bench: Bench, steps: int, warmup: int):
     if bench.dist is not None:
         bench.dist.all_reduce(t)
     samples = n_total * 2048
+    share8 = None
+    if bench.world == 1:
+        # What this workload becomes per GPU on eight of them: rank 0's contiguous eighth (1250 frames), decoded the way a
+        # rank would decode it -- same code, same lanes.  One GPU, so a PREDICTION of the eight-GPU line, not a measurement:
+        # eight ranks take what the slowest takes, and every rank's share is this size.
+        b8, e8 = bench.sharding.my_range(n_total, 0, 8)
+        pcm8 = pcm[b8:e8].contiguous()
+        enc8 = bench.codec.Encoder(e8 - b8, CHANNELS)
+        out8 = enc8.encode(pcm8)
+        torch.cuda.synchronize()
+        out8.check()
+        job8 = ChainJob(bench, [pcm8], e8 - b8, exchange=False, pre_encoded=[(out8.frames, out8.offsets)])
+        m8 = run_chain(bench, job8, steps, warmup, min_total_s=0.2)
+        assert torch.equal(m8["last"][2], m["last"][2][: e8 - b8]), "decode10k: a rank's share decodes differently on its own"
+        share8 = {
+            "frames": e8 - b8, "ms_per_step": m8["median_s"] * 1e3, "value": (e8 - b8) * 2048 / m8["median_s"] / 1e6,
+            "unit": "Msamples/s decode only, ONE GPU on one rank's share of an 8-GPU job",
+            "predicted_value_8_gpus": samples / m8["median_s"] / 1e6,
+            "predicted_strong_scaling_efficiency_8": m["median_s"] / (8 * m8["median_s"]),
+            "what": "rank 0's contiguous 1/8 of the 10,000 frames, timed on this GPU like the full workload; a prediction, not an 8-GPU measurement",
+        }
+        del job8, enc8, out8
     rec = {
         "value": samples / m["median_s"] / 1e6, "unit": "Msamples/s decode only", "ms_per_step": m["median_s"] * 1e3, "scaling": "strong",
+        "per_rank_share_8": share8,
         "steps": steps, "warmup": warmup,
         "config": {
             "workload": (f"BASELINE.json configs[4]: decode-only, {n_total} pre-encoded stereo frames (encoded outside the timed region), "
@@ -746,37 +805,50 @@ def kernel_blocks(bench: Bench, k_enc, k_dec, n0: int, sela_bytes0: int, counter
     pcm_bytes0 = n0 * 2048 * CHANNELS * 2
     algo_bytes = pcm_bytes0 + sela_bytes0  # PCM16 read + .sela frame bytes written, one launch
     achieved = algo_bytes / (enc_blocks_ms * 1e-3) / 1e9
-    traffic, traffic_src = committed_traffic("k_encode_blocks")
-    valu_instr, valu_src = committed_valu_instructions("k_encode_blocks")
+    # which kernel analysed the blocks of this launch: the library picks by launch size (sela_encode.hip, team_lanes_for)
+    team_lanes = int(bench.lib.sela_hip_debug_encode_kernel(n0, CHANNELS))
+    enc_kernel = f"k_encode_teams<0, {team_lanes}>" if team_lanes else "k_encode_blocks<0, false>"
+    traffic, traffic_src, traffic_how = committed_traffic(enc_kernel)
+    valu_instr, valu_src = committed_valu_instructions(enc_kernel)
+    dec_instr, dec_src = committed_valu_instructions("k_decode_frames<false>")
     if not counters_apply:
-        valu_instr = traffic = None  # the committed counter passes are of the single-track launch
+        valu_instr = traffic = dec_instr = None  # the committed counter passes are of the single-track launch
     samples0 = n0 * 2048
     enc_ms = float(k_enc.sum(axis=1).mean())
     dec_ms = float(k_dec.sum(axis=1).mean())
     fp64 = FP64_OPS_PER_BLOCK * n0 * 3 / (enc_blocks_ms * 1e-3) / 1e12
-    valu = None if valu_instr is None else {
-        "achieved": valu_instr / (enc_blocks_ms * 1e-3) / 1e9, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instructions/s",
-        "frac": valu_instr / (enc_blocks_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GIPS,
-        "instructions_per_launch_from_profiles": valu_instr, "profiles_source": valu_src,
-        "note": f"SQ_INSTS_VALU from the committed counter pass named in profiles_source / live kernel time; peak = 1024 SIMDs x {PEAK_CLOCK_GHZ} GHz / 4 cycles per wave64 instruction",
-    }
+
+    def issue(instr, ms, src, kernel):
+        if instr is None:
+            return None
+        return {
+            "kernel": kernel, "achieved": instr / (ms * 1e-3) / 1e9, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instructions/s",
+            "frac": instr / (ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GIPS,
+            "instructions_per_launch_from_profiles": instr, "profiles_source": src,
+            "note": f"SQ_INSTS_VALU from the committed counter pass named in profiles_source / live kernel time; peak = 1024 SIMDs x {PEAK_CLOCK_GHZ} GHz / 4 cycles per wave64 instruction",
+        }
+
+    valu = issue(valu_instr, enc_blocks_ms, valu_src, enc_kernel)
+    valu_dec = issue(dec_instr, dec_ms, dec_src, "k_decode_frames<false>")
     return {
         "encode_msps": samples0 / (enc_ms * 1e-3) / 1e6,   # kernels of the first batch, HBM resident
         "decode_msps": samples0 / (dec_ms * 1e-3) / 1e6,
         "encode_target": {"msps": ENCODE_TARGET_MSPS, "met": bool(samples0 / (enc_ms * 1e-3) / 1e6 >= ENCODE_TARGET_MSPS),
                           "ratio": samples0 / (enc_ms * 1e-3) / 1e6 / ENCODE_TARGET_MSPS},
-        "kernel_ms": {"encode_blocks": enc_blocks_ms, "encode_plan": float(k_enc[:, 1].mean()),
+        "kernel_ms": {"encode_blocks": enc_blocks_ms, "encode_blocks_kernel": enc_kernel, "encode_plan": float(k_enc[:, 1].mean()),
                       "encode_assemble": float(k_enc[:, 2].mean()), "decode_frames": dec_ms, "frames_in_launch": n0},
         "fp64_valu": {  # the arithmetic the bit-exact analysis cannot avoid, against the vector FP64 rate
             "achieved": fp64, "peak": FP64_UNFUSED_PEAK_TOPS, "unit": "T unfused FP64 op/s", "frac": fp64 / FP64_UNFUSED_PEAK_TOPS,
         },
-        # what binds the kernel in practice: issue slots of the vector ALU (a wave64 instruction takes 4 cycles of a SIMD)
+        # what binds the kernels in practice: issue slots of the vector ALU (a wave64 instruction takes 4 cycles of a SIMD)
         "valu_issue": valu,
+        "valu_issue_decode": valu_dec,
+        "profiles": profiles_state(valu_src, traffic_src, dec_src),
         "roofline": {
-            "kernel": "k_encode_blocks", "bound": "valu_issue",
+            "kernel": enc_kernel, "bound": "valu_issue",
             # the HBM figures the contract asks for: algorithmic bytes per launch / live kernel time against the HBM peak
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_from_profiles": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
+            "traffic": traffic, "traffic_from_profiles": traffic_src, "traffic_counters": traffic_how, "algorithmic_bytes_per_launch": algo_bytes,
             # ... and the resource that binds it
             "binding": None if valu is None else {"resource": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]},
             "note": "achieved/peak/frac are the HBM numbers (7 B per stereo sample: the path cannot be HBM bound, SURVEY.md 8(d)); the kernel is bound by "
@@ -824,6 +896,7 @@ def main():
         result.update({k: v for k, v in rec.items() if k not in ("value", "unit", "ms_per_step", "scaling", "steps", "warmup")})
         if kern is not None:
             result.update(kern)
+            result["profiles_stale"] = kern["profiles"]["profiles_stale"]
     pcm_host = None
     if headline == "track" and bench.rank == 0:
         pcm_host = pcm0.cpu().numpy()

@@ -2002,6 +2002,11 @@ static int team_lanes_for(size_t blocks)
     return blocks < 36000 ? 16 : 8;
 }
 
+int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced)
+{
+    return forced >= 0 ? forced : team_lanes_for((size_t)n_frames * sela_hip_signals_per_frame(channels));
+}
+
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames,
     size_t frames_cap, uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace,
     hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles,

@@ -120,3 +120,93 @@ def test_reference_classes_bound_to_the_library_write_the_reference_files(tmp_pa
     r = subprocess.run([BOUND, "-d", str(sela), str(back)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.getsize(back) == d["decoded_wav_bytes"] and _sha_file(back) == d["decoded_wav_sha256"]
+
+
+# ---- eight-way readiness on one GPU (no 8-GPU node has been available: SCALE_r01..r03 are `skipped` records) ----------------
+def test_batch_verbs_eight_workers_on_album_tracks(gpu, tmp_path, album_digests):  # noqa: F811
+    """Tracks 0..22 of BASELINE.json configs[3] (eight / eight / seven at 44.1 / 48 / 96 kHz, 123,803 frames; 24 tracks would
+    put every eighth of the frame space exactly on a track boundary) through
+    `sela_mi355x -E / -D --devices 0,0,0,0,0,0,0,0`: EIGHT workers bound to the one GPU, the frame space cut in eight
+    contiguous ranges -- the reference's static partition (src/sela/encoder.cpp:58-73) with GPUs for threads -- seven cuts,
+    most of them inside a track, every worker reading, coding and writing its own pieces.  Every .sela file and every decoded
+    PCM against the unmodified reference's SHA-256s (tests/golden/album_digests.json)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    from sela_amd.synth import album_tracks, synth_frames_torch
+    from test_gpu_round2 import _sha_file
+    from test_host_cpp import HOST, _build, _write_wav
+
+    _build()
+    scratch = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else str(tmp_path)
+    work = tempfile.mkdtemp(dir=scratch)
+    try:
+        tracks = album_tracks()[:23]
+        total = sum(frames for _, _, frames in tracks)
+        cuts = [total * w // 8 for w in range(1, 8)]
+        edges = np.cumsum([0] + [frames for _, _, frames in tracks])
+        assert sum(1 for c in cuts if c not in edges) >= 5, "the cuts are supposed to fall inside tracks"
+        wavs = []
+        for track, rate, frames in tracks:
+            pcm = synth_frames_torch(frames, 2, track, device="cuda").cpu().numpy().reshape(-1, 2)
+            p = os.path.join(work, f"track{track:02d}.wav")
+            _write_wav(p, pcm, rate)
+            wavs.append(p)
+        enc_dir, dec_dir = os.path.join(work, "enc"), os.path.join(work, "dec")
+        os.mkdir(enc_dir), os.mkdir(dec_dir)
+        cli = os.path.join(HOST, "sela_mi355x")
+        devices = ",".join(["0"] * 8)
+        r = subprocess.run([cli, "-E", enc_dir, "--devices", devices] + wavs, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for p in wavs:
+            os.remove(p)
+        selas = []
+        for track, rate, frames in tracks:
+            g = album_digests["tracks"][track]
+            p = os.path.join(enc_dir, f"track{track:02d}.sela")
+            assert os.path.getsize(p) == g["sela_bytes"], track
+            assert _sha_file(p) == g["sela_sha256"], track
+            selas.append(p)
+        r = subprocess.run([cli, "-D", dec_dir, "--devices", devices] + selas, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for track, rate, frames in tracks:
+            g = album_digests["tracks"][track]
+            with open(os.path.join(dec_dir, f"track{track:02d}.wav"), "rb") as f:
+                wav = f.read()
+            assert len(wav) == 44 + frames * 2048 * 2 * 2
+            assert hashlib.sha256(wav[44:]).hexdigest() == g["decoded_sha256"], track
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def test_bench_with_eight_ranks_sharing_the_gpu():
+    """bench.py --gpus 8 as the driver launches it, on a one-GPU box: eight ranks under torch.distributed.run, all on GPU 0,
+    talking over gloo (SELA_BENCH_RANKS_SHARE_GPU=1).  Rank r's track (album track 3 r) against the reference's digests on
+    every rank; the gathered layout of the eight tracks; the album cut in eight contiguous ranges with the gathered layout
+    against the reference's; 10,000 frames decoded in eighths; ONE JSON line, from rank 0, with n_gpus = 8.  Not a
+    measurement (the ranks share the device): what it proves is that every code path of an 8-rank job runs and agrees."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SELA_BENCH_RANKS_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-host-legs", "--extra-steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [t for t in r.stdout.strip().splitlines() if t.startswith("{")]
+    assert len(lines) == 1, "one JSON line, from rank 0"
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["frames_total"] == 8 * 3875
+    assert line["layout_matches_reference"] is True and line["digests_match_reference"] is True
+    assert line["timed_outputs"]["equal_to_serial_step"] is True and line["cpu_baseline"]["bit_exact_vs_gpu"] is True
+    assert line["album"]["layout_matches_reference"] is True and line["album"]["config"]["frames_rank0"] in (68670, 68671)
+    assert line["album"]["roundtrip_lossy_frames"] == 39  # (the reference's own lossy frames on the album, summed over the ranks)
+    assert line["decode10k"]["config"]["frames_rank0"] == 1250 and line["decode10k"]["bit_exact_vs_cpu_decode"] is True
+    assert line["decode10k"]["per_rank_share_8"] is None  # (the one-GPU line's prediction; an 8-rank line IS the thing)

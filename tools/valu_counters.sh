@@ -23,3 +23,24 @@ for k, d in sorted(acc.items()):
     print(k, {c: round(sum(v) / len(v)) for c, v in d.items()})
 PY
 done
+# The same counters with the bench's default TWO lanes (both streams in flight): counter collection serialises the
+# dispatches it instruments, so what this pass shows is (a) that the per-kernel instruction counts do not depend on the
+# lanes, and (b) the step time the bench itself reports under instrumentation, next to the un-instrumented one.
+rm -rf /tmp/pc_two
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc_two -o pmc -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-host-legs --no-extra-legs --lanes 2 > /tmp/pc_two.log 2>&1
+python - <<'PY'
+import csv, glob, json, collections
+fs = glob.glob("/tmp/pc_two/**/*counter_collection.csv", recursive=True)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in (csv.DictReader(open(fs[0])) if fs else []):
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    if "sela::" in k:
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in sorted(acc.items()):
+    print("two lanes:", k, {c: round(sum(v) / len(v)) for c, v in d.items()})
+try:
+    line = json.loads(open("/tmp/pc_two.log").read().strip().splitlines()[-1])
+    print("two lanes: bench under --pmc reports ms_per_step", round(line["ms_per_step"], 4), "one lane", round(line["lanes"]["ms_per_step_one_lane"], 4))
+except Exception as e:  # noqa: BLE001
+    print("two lanes: no bench line under --pmc:", e)
+PY
