@@ -74,6 +74,7 @@ FP64_UNFUSED_PEAK_TOPS = 256 * 4 * 16 * PEAK_CLOCK_GHZ / 1e3  # vector FP64, one
 FP64_OPS_PER_BLOCK = 2 * sum(2048 - i for i in range(101)) + 4 * 4950
 TRACK_SECONDS, SAMPLE_RATE, CHANNELS = 180, 44100, 2
 ALBUM_BATCH_FRAMES = 65536
+DECODE_RESIDENT_WAVES = 7 * 1024  # k_decode_frames: seven waves per SIMD (72 VGPRs, 5.7 KB of LDS per subframe)
 DECODE10K_FRAMES, DECODE10K_TRACK = 10000, 2
 ENCODE_TARGET_MSPS = 1000.0  # BASELINE.json north_star: >= 1 G stereo samples/s encode on one MI355X
 METRIC = "Msamples/s encode+decode, 16-bit stereo 44.1kHz, 1/2/4/8 GPU; bit-exact vs CPU"  # BASELINE.json "metric"
@@ -302,8 +303,10 @@ class Bench:
             _flush_c_stdio()
         self.lib = capi.lib()  # raises if the HIP library is missing: there is no CPU fallback
         self.lib.sela_hip_debug_encode_teams(getattr(args, "encode_teams", -1))
+        self.lib.sela_hip_debug_encode_fused(1 if getattr(args, "encode_fused", False) else 0)
         self.exchange = torch.cuda.Stream() if self.dist is not None else None
         self.n_lanes = max(1, args.lanes)
+        self.lanes_forced = "--lanes" in sys.argv
 
     def barrier(self):
         if self.dist is not None:
@@ -364,7 +367,14 @@ class ChainJob:
         self.pre = pre_encoded  # decode-only: [(frames, offsets)] per batch, produced outside the timed region
         self.max_batch = max([int(x.shape[0]) for x in batches] + [1])
         self.lanes = []
-        for _ in range(bench.n_lanes):
+        n_lanes = bench.n_lanes
+        if self.pre is not None and not bench.lanes_forced:
+            # Decode-only batches that leave most of the device's wave slots empty (a rank's share of configs[4] on eight
+            # GPUs: 2,500 subframe waves where 7 x 1024 fit) are bound by one subframe's latency, not by issue: as many of
+            # them in flight as fill the slots once, four at most (the runtime has four hardware queues)
+            waves = 2 * self.max_batch
+            n_lanes = min(4, max(n_lanes, -(-DECODE_RESIDENT_WAVES // max(waves, 1))))
+        for _ in range(n_lanes):
             lane = {"dec": codec.Decoder(self.max_batch, CHANNELS), "stream": torch.cuda.Stream(), "calls": 0, "last": None}
             if self.pre is None:
                 lane["enc"] = codec.Encoder(self.max_batch, CHANNELS)
@@ -789,7 +799,7 @@ def kernel_leg(bench: Bench, job: ChainJob, pcm0, steps: int):
         for _ in range(2):
             dec.decode(o2.frames, o2.offsets, n0)
             o2 = enc.encode(pcm0)
-        k_enc.append(capi.kernel_times(3))
+        k_enc.append((capi.kernel_times(3) + [0.0, 0.0])[:3])  # (--encode-fused: one kernel, no plan / assemble)
         for _ in range(2):
             o2 = enc.encode(pcm0)
             dec.decode(o2.frames, o2.offsets, n0)
@@ -871,6 +881,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight: independent encode->decode chains on their own HIP streams")
     ap.add_argument("--encode-teams", type=int, default=-1, choices=[-1, 0, 8, 16],
                     help="experiments only: force the encoder's block kernel (0: k_encode_blocks, 8 / 16: k_encode_teams); -1: the library's own choice by launch size")
+    ap.add_argument("--encode-fused", action="store_true",
+                    help="experiments only: the encoder's one-launch form (the host pipeline's) on device pointers, no plan / assemble kernels")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))

@@ -33,6 +33,11 @@ void sela_hip_debug_encode_teams(int lanes);
 /* Which of them a *_device encode of n_frames frames of `channels` channels by the calling thread runs right now (the hook
  * above included): 0 = k_encode_blocks, 8 / 16 = k_encode_teams<.., 8 / 16>.  (bench.py names the kernel it reports on.) */
 int sela_hip_debug_encode_kernel(uint32_t n_frames, uint32_t channels);
+/* Debug hook (measurements only): while set, the calling thread's *_device encodes take the ONE-LAUNCH form of the host
+ * pipeline (k_encode_blocks<0, true>: the blocks count themselves into groups of frames, a group's last block places and
+ * writes the group's bytes -- no plan / assemble kernels) on device pointers.  Same bytes; bench.py --encode-fused times it
+ * beside the default. */
+void sela_hip_debug_encode_fused(int enable);
 /* Debug hook: bound of an encode block's wait for its frame from the staging kernel, in naps of 2048 cycles; 0: every
  * block gives up without looking ("the stagers never showed up"), which flags the launch and sends the feed through
  * the copy-engine path again; -1 restores the default (~0.5 s). */

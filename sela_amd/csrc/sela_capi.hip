@@ -378,6 +378,7 @@ thread_local uint64_t* g_phase_cycles = nullptr; // debug: per-block phase cycle
 thread_local int g_force_plain_fir = 0;          // debug: sela_hip_debug_force_plain_fir
 thread_local int g_self_blocks = -1;             // debug: sela_hip_debug_mean_workers
 thread_local int g_team_lanes = -1;              // debug: sela_hip_debug_encode_teams
+thread_local int g_fused_device = 0;             // debug: sela_hip_debug_encode_fused
 thread_local int g_stage_wait_naps = -1;         // debug: sela_hip_debug_stage_wait
 thread_local int g_reissued_feeds = 0;           // debug: sela_hip_debug_reissued_feeds
 thread_local int g_recurrence_form = -1;         // debug: sela_hip_debug_decode_recurrence
@@ -1015,6 +1016,7 @@ void sela_hip_debug_force_plain_fir(int enable) { g_force_plain_fir = enable != 
 
 void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks; }
 void sela_hip_debug_encode_teams(int lanes) { g_team_lanes = lanes; }
+void sela_hip_debug_encode_fused(int enable) { g_fused_device = enable != 0; }
 int sela_hip_debug_encode_kernel(uint32_t n_frames, uint32_t channels) { return sela::encode_team_lanes(n_frames, channels, g_team_lanes); }
 
 void sela_hip_debug_stage_wait(int naps) { g_stage_wait_naps = naps; }
@@ -1061,8 +1063,13 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
         return fail(SELA_HIP_ECAPACITY, "workspace smaller than sela_hip_encode_workspace_bytes()");
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 3 : 0;
+    sela::EncodeHostLink fused = {}; // (debug hook: the one-launch form on device pointers -- nothing mirrored, no stream position, no stagers)
+    fused.wait_naps = -1;
+    const bool use_fused = g_fused_device && !d_trace && !g_phase_cycles;
+    if (use_fused)
+        g_timing.recorded = ev ? 1 : 0;
     hipError_t e = sela::launch_encode(d_pcm, n_frames, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace,
-        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_force_plain_fir, g_self_blocks, g_team_lanes);
+        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, use_fused ? &fused : nullptr, g_force_plain_fir, g_self_blocks, g_team_lanes);
     if (e != hipSuccess)
         return fail_hip(e, "encode launch");
     return SELA_HIP_OK;

@@ -1405,10 +1405,14 @@ struct TeamPlan {
     static constexpr int kMeanPer = kTeamMeanChunk / P;
     static constexpr int kRingBytes = B * kStride * 8;
     static constexpr int kCwBase = kBigBytes;                  // the tail's coefficient words behind its LDS plan (k_encode_blocks: a second array)
+    static constexpr int kKStride = 104;                       // doubles per block: its reflection coefficients, in the dead rings until they are quantised
+    static constexpr int kQBase = kSmallBase;                  // the quantised coefficients of the wave's blocks wait for their tails where the tail's plan keeps
+    static constexpr int kQStride = 104;                       //   ac[] for k_encode_blocks (832 bytes it does not use here): 100 x int8, the order, an escape mark
     static constexpr int kLdsBytes = kRingBytes > kCwBase + kCoefWordsCap * 4 ? kRingBytes : kCwBase + kCoefWordsCap * 4;
     static_assert(G + kTeamAhead <= kTeamWin && kChunk % kTeamWin == 0 && kRing % kChunk == 0 && kStride % 32 == 24, "team plan");
     static_assert((G * P - 1) + kChunk + kChunk <= kRing && 2 * kTeamMeanChunk <= kRing, "the ring must hold the lags' reach, the chunk in use and the chunk being written");
     static_assert(kLdsBytes * 12 <= 160 * 1024, "twelve waves per CU");
+    static_assert(B * kKStride * 8 <= kQBase && B * kKStride * 8 <= kRingBytes && B * kQStride <= 104 * 8, "k[] in the dead rings below the q store; the q store inside SmallArrays::ac");
 };
 
 // every lane receives the value of lane 0 of its team
@@ -1583,10 +1587,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const uint32_t my_frame = team_live ? frame0 + (uint32_t)b : n_frames - 1; // (a team beyond the last frame shadows it and writes nothing)
     const int16_t* const fp = pcm + (size_t)my_frame * kBlock * channels;
     double* const ring_b = reinterpret_cast<double*>(lds) + b * Plan::kStride;
-    // The team's reflection coefficients wait for the tail in its block's own output slot (global memory, 800 of its 8960
-    // bytes; the tail reads them back before it writes the slot): B x 100 doubles in LDS beside the tail's plan would cost
-    // a third of the waves a CU holds.
-    double* const k_b = reinterpret_cast<double*>(slots + ((size_t)my_frame * n_sig + sig) * kSlotWords);
+    // The team's reflection coefficients go to the dead rings (LDS), are quantised there block by block right behind the
+    // Schur recursion, and 100 bytes per block wait for the block's tail (TeamPlan::kQBase).  (First version: the 800 bytes
+    // of k[] waited in the block's own output slot in global memory -- 9.3 MB more written and read back per 3875-frame
+    // launch, PMC.)
+    double* const k_b = reinterpret_cast<double*>(lds) + b * Plan::kKStride;
     long long wave_stamp[5];
     if (kMode == 2)
         wave_stamp[0] = clock64();
@@ -1725,7 +1730,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             g0[r] = g1[r] = (G * p + r < kMaxOrder) ? v : 0.0;
         }
         double err = 1.0; // ac[0]
-        const bool keeper = p == 0 && team_live;
+        const bool keeper = p == 0;
         double g = team_first<P>(g1[0]);
         double ki = -g / err;
         err += g * ki;
@@ -1752,6 +1757,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (kMode == 2)
         wave_stamp[3] = clock64();
 
+    // ---- order and quantisation of every block (src/lpc/residue_generator.cpp:70-96), lane = coefficient ------------------
+    // What a block's tail needs of its analysis: the order and <= 100 quantised coefficients.  They fit int8 (q = floor(64 k),
+    // |k| <= 1, and the two square-root forms stay within [-64, 64]) unless the recursion went astray on a degenerate block;
+    // such a block keeps its 32-bit values in its own output slot (global memory; the tail reads them back before it
+    // writes the slot) and says so in its escape mark.
+    int8_t* const q_all = reinterpret_cast<int8_t*>(lds + Plan::kQBase);
+#pragma unroll 1
+    for (int bb = 0; bb < B; bb++) {
+        const uint32_t frame = frame0 + (uint32_t)bb;
+        if (frame >= n_frames)
+            break;
+        int lane_now = lane0;
+        asm volatile("" : "+v"(lane_now));
+        const int lane = lane_now;
+        const double* const k_mine = reinterpret_cast<const double*>(lds) + bb * Plan::kKStride;
+        const double k_lo = k_mine[lane];
+        const double k_hi = lane < kMaxOrder - 64 ? k_mine[64 + lane] : 0.0;
+        int order;
+        {
+            const unsigned long long b_lo = __ballot(fabs(k_lo) > SELA_ORDER_THRESHOLD);
+            const unsigned long long b_hi = __ballot(lane < 36 && fabs(k_hi) > SELA_ORDER_THRESHOLD);
+            order = b_hi ? 128 - __clzll(b_hi) : (b_lo ? 64 - __clzll(b_lo) : 1);
+        }
+        const double sqrt2 = SELA_SQRT2;
+        double v_lo;
+        if (lane == 0)
+            v_lo = floor(64 * (-1 + (sqrt2 * sqrt(k_lo + 1))));
+        else if (lane == 1)
+            v_lo = floor(64 * (-1 + (sqrt2 * sqrt(-k_lo + 1))));
+        else
+            v_lo = floor(64 * k_lo);
+        const double v_hi = floor(64 * k_hi);
+        const int32_t q_lo = isnan(v_lo) ? 0 : (int32_t)v_lo;
+        const int32_t q_hi = isnan(v_hi) ? 0 : (int32_t)v_hi;
+        const bool wide = (lane < order && (q_lo < -128 || q_lo > 127)) || (lane + 64 < order && (q_hi < -128 || q_hi > 127));
+        const bool escape = __any(wide);
+        int8_t* const q_mine = q_all + bb * Plan::kQStride;
+        q_mine[lane] = (int8_t)q_lo;
+        if (lane < kMaxOrder - 64)
+            q_mine[64 + lane] = (int8_t)q_hi;
+        if (lane == 0) {
+            q_mine[100] = (int8_t)order;
+            q_mine[101] = escape ? 1 : 0;
+        }
+        if (escape) {
+            int32_t* const q_wide = reinterpret_cast<int32_t*>(slots + ((size_t)frame * n_sig + sig) * kSlotWords);
+            q_wide[lane] = q_lo;
+            if (lane < kMaxOrder - 64)
+                q_wide[64 + lane] = q_hi;
+        }
+        if (kTrace) {
+            sela_hip_trace* tr = trace + (size_t)frame * n_sig + sig;
+            tr->k[lane] = k_lo;
+            if (lane < 36)
+                tr->k[lane + 64] = k_hi;
+        }
+    }
+    wave_sync();
+
     // ---- the wave's blocks, one after the other: sela_encode_tail.inc ------------------------------------------------------
     SmallArrays* const sm = reinterpret_cast<SmallArrays*>(big + kSmallBase);
     long long stamp[14];
@@ -1767,9 +1831,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         asm volatile("" : "+v"(lane_now));
         const int lane = lane_now;
         const uint32_t block_id = frame * n_sig + sig;
-        const double* const k_mine = reinterpret_cast<const double*>(slots + (size_t)block_id * kSlotWords); // (left there by this wave's Schur recursion)
-        const double k_lo = k_mine[lane];
-        const double k_hi = lane < kMaxOrder - 64 ? k_mine[64 + lane] : 0.0;
+        const int8_t* const q_mine = q_all + bb * Plan::kQStride;
+        const int order = (uint8_t)q_mine[100];
+        int32_t q_lo = q_mine[lane], q_hi = lane < kMaxOrder - 64 ? q_mine[64 + lane] : 0;
+        if (__builtin_amdgcn_readfirstlane((int)q_mine[101])) { // (a degenerate block: its 32-bit values, from its own slot)
+            const int32_t* const q_wide = reinterpret_cast<const int32_t*>(slots + (size_t)block_id * kSlotWords);
+            q_lo = q_wide[lane];
+            q_hi = lane < kMaxOrder - 64 ? q_wide[64 + lane] : 0;
+        }
         const double mean = 0.0; // (the trace's mean has been written above; the tail only names it)
         int32_t s[kPerLane];
         {
@@ -1792,7 +1861,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         wave_sync(); // (the block before this one is through with the LDS plan)
         {
             constexpr bool kAcInLds = false;
+#define SELA_TAIL_HAVE_Q
 #include "sela_encode_tail.inc"
+#undef SELA_TAIL_HAVE_Q
         }
         SELA_STAMP(12);
         if (kMode == 2 && lane == 0) { // the wave's analysis phases (shared by its blocks) and this block's own tail

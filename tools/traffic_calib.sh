@@ -4,8 +4,8 @@
 #   factor = true bytes / (counter x 1024)   per access width (b32 / b64 / b128), for reads and for writes.
 OUT=${1:-gpurun_out/calib}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-mkdir -p "$ROOT/$OUT" 2>/dev/null || mkdir -p "$OUT"
-[ -d "$ROOT/$OUT" ] && OUT="$ROOT/$OUT"
+case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT" ;; esac
+mkdir -p "$OUT"
 MIB=${2:-1024}
 cd /tmp && export TMPDIR=/tmp
 [ -x "$ROOT/tools/traffic_calib" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o "$ROOT/tools/traffic_calib" "$ROOT/tools/traffic_calib.hip"
