@@ -1,0 +1,8 @@
+// host/compat/include/file/sela_file.hpp -- the reference's header path (src/include/file/sela_file.hpp) over this host's classes:
+// a program written against the reference's tree -- its own src/main.cpp -- compiles against this host with
+//     g++ -I host/compat -I- -I host/include -I include ...
+// (-I-: quoted includes are looked up in the -I directories instead of beside the including file).
+#ifndef SELA_COMPAT_FILE_SELA_FILE_HPP
+#define SELA_COMPAT_FILE_SELA_FILE_HPP
+#include "sela_host/files.hpp"
+#endif

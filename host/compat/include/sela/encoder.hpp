@@ -1,0 +1,8 @@
+// host/compat/include/sela/encoder.hpp -- the reference's header path (src/include/sela/encoder.hpp) over this host's classes:
+// a program written against the reference's tree -- its own src/main.cpp -- compiles against this host with
+//     g++ -I host/compat -I- -I host/include -I include ...
+// (-I-: quoted includes are looked up in the -I directories instead of beside the including file).
+#ifndef SELA_COMPAT_SELA_ENCODER_HPP
+#define SELA_COMPAT_SELA_ENCODER_HPP
+#include "sela_host/codec.hpp"
+#endif

@@ -47,7 +47,11 @@ public:
     // Parse up to the data chunk and leave `in` at its first byte; returns the chunk's size in bytes
     // (clipped to the file).  Throws data::Exception with the reference's messages.
     size_t readHeader(std::ifstream& in);
-    void readFromFile(std::ifstream& in);   // readHeader + the whole data chunk
+    void readFromFile(std::ifstream& in);   // readHeader + the whole data chunk (+ demuxSamples(), like the reference's, while demuxOnRead)
+    // The reference's readFromFile ends by de-interleaving the samples into wavFrames (src/file/wav_file.cpp:178); on by default
+    // for that fidelity.  The codec classes never need the copies (the GPU reads `pcm` as it lies in the file): tools that read
+    // a file only to code it switch this off, or use Encoder / encodeFile, which do not go through here.
+    static bool demuxOnRead;
     void writeToFile(std::ofstream& out);   // canonical 44-byte header + data
     static void writeHeader(std::ofstream& out, uint32_t rate, uint16_t channels, uint16_t bps, uint32_t dataBytes);
     void demuxSamples();                    // pcm -> wavFrames (whole frames only, tail dropped)

@@ -46,6 +46,9 @@ public:
     size_t packetsPlayed = 0;  // of the last play() / playFile()
     double firstPacketSeconds = 0; // playFile(): from the call to the first packet handed to the sink
     explicit Player(AudioSink& s) : sink(s) {}
+    // The reference's `sela::Player player;` (src/main.cpp:49): no libao here, so the packets go to standard output as they are
+    // (RawPcmSink on descriptor 1: `sela -p in.sela | aplay -f S16_LE ...`).
+    Player();
     // One packet per whole frame of wavFile (2048 samples of every channel, interleaved), in order.
     void play(const file::WavFile& wavFile);
     // main.cpp:43-51 (decode, then play) as one overlapped job: returns the number of frames played.

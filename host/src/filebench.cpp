@@ -201,6 +201,7 @@ int main(int argc, char** argv)
             std::ifstream in(wavPath, std::ios::binary);
             if (!in)
                 throw data::Exception("cannot open " + wavPath);
+            file::WavFile::demuxOnRead = false; // (the samples are all this tool needs)
             wav.readFromFile(in);
         }
         const uint32_t ch = wav.numChannels;

@@ -228,8 +228,12 @@ void WavFile::readFromFile(std::ifstream& in)
         throw data::Exception("data subChunk is shorter than its header says");
     const uint32_t chunkSize = wavChunk.chunkSize;
     syncChunk();
+    if (demuxOnRead)
+        demuxSamples();
     wavChunk.chunkSize = chunkSize; // (what the file's header says)
 }
+
+bool WavFile::demuxOnRead = true;
 
 void WavFile::demuxSamples()
 {

@@ -33,6 +33,12 @@ data::WavFormatSubChunk formatOf(uint32_t rate, uint16_t channels, uint16_t bps)
     return f;
 }
 
+RawPcmSink& standardOutputSink()
+{
+    static RawPcmSink sink(1);
+    return sink;
+}
+
 // What the decoding thread tells the playing thread.
 struct Arrivals : DecodedStream {
     std::mutex mu;
@@ -70,6 +76,8 @@ struct Arrivals : DecodedStream {
 };
 
 } // namespace
+
+Player::Player() : sink(standardOutputSink()) {}
 
 void RawPcmSink::play(const data::AudioPacket& packet)
 {

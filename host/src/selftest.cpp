@@ -78,7 +78,8 @@ int main(int argc, char** argv)
         CHECK(r.wavChunk.formatSubChunk.blockAlign == 4 && r.wavChunk.formatSubChunk.byteRate == 44100 * 4 && r.wavChunk.formatSubChunk.audioFormat == 1);
         CHECK(r.wavChunk.dataSubChunk.subChunkSize == pcm.size() * 2 && r.wavChunk.dataSubChunk.channels == 2);
         CHECK(r.wavChunk.dataSubChunk.samples == r.pcm.data() && r.wavChunk.dataSubChunk.sampleCount == pcm.size());
-        r.demuxSamples();
+        CHECK(r.wavChunk.dataSubChunk.wavFrames.size() == 2); // readFromFile de-interleaves like the reference's (demuxOnRead)
+        r.demuxSamples(); // (again: idempotent)
         CHECK(r.wavChunk.dataSubChunk.wavFrames.size() == 2);
         CHECK(r.wavFrames.size() == 2 && r.wavFrames[1].samples[1][5] == pcm[(2048 + 5) * 2 + 1]);
     }

@@ -92,6 +92,78 @@ def test_team_kernels_on_baseline_configs_by_digest(gpu, digests, teams, label):
     assert hashlib.sha256(offsets.astype("<u8").tobytes()).hexdigest() == d["offsets_sha256"]
 
 
+def test_team_kernels_plain_fir_branch(gpu, teams):  # noqa: F811
+    """sela_hip_debug_force_plain_fir sends every block of k_encode_teams<0, P> down the 64-bit FIR loop that predictors beyond
+    the fast FIR's coefficient range take (its predictions go through the block's own slot in global memory -- the same
+    words a degenerate block's wide coefficients wait in): same bytes."""
+    from sela_amd import capi
+
+    pcm = synth_frames(37, 2, 91)
+    lib = capi.lib()
+    lib.sela_hip_debug_force_plain_fir(1)
+    try:
+        frames, offsets, _, _ = _encode(gpu, pcm)
+    finally:
+        lib.sela_hip_debug_force_plain_fir(0)
+    ref_frames, ref_offsets, _ = oracle().encode_frames(pcm, threads=8)
+    assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames)
+
+
+@pytest.mark.parametrize("channels,n_frames", [(9, 11), (64, 3), (255, 2)])
+def test_team_kernels_many_channels(gpu, teams, channels, n_frames):  # noqa: F811
+    """One signal per channel, up to the 255 the header's field carries: a wave takes one signal of B consecutive frames, so
+    with few frames most teams of a wave shadow the last frame and must leave nothing behind."""
+    pcm = synth_frames(n_frames, channels, 500 + channels)
+    frames, offsets, _, _ = _encode(gpu, pcm)
+    ref_frames, ref_offsets, _ = oracle().encode_frames(pcm, threads=8)
+    assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames)
+
+
+def test_team_kernels_hostile_audio(gpu, teams):  # noqa: F811
+    """Full-scale white noise, silence, DC, a square wave at the Nyquist rate and small noise, interleaved over 300 stereo
+    frames (silent and constant blocks make 0 / 0 = NaN autocorrelations and orders of 1; the square wave drives the
+    reflection coefficients to +-1): frames and decoded samples against the oracle."""
+    from test_gpu_parity import _decode
+
+    rng = np.random.default_rng(77)
+    pcm = np.zeros((300, 2048, 2), np.int16)
+    for f in range(300):
+        kind = f % 6
+        if kind == 0:
+            pcm[f] = rng.integers(-32768, 32768, (2048, 2))
+        elif kind == 1:
+            pcm[f] = 0
+        elif kind == 2:
+            pcm[f, :, 0], pcm[f, :, 1] = 12345, -32768
+        elif kind == 3:
+            pcm[f, ::2], pcm[f, 1::2] = 32767, -32768
+        elif kind == 4:
+            pcm[f] = rng.integers(-2, 3, (2048, 2))
+        else:
+            pcm[f, :, 0] = rng.integers(-32768, 32768, 2048)
+            pcm[f, :, 1] = pcm[f, :, 0]  # (the difference signal is silence)
+    o = oracle()
+    frames, offsets, _, _ = _encode(gpu, pcm)
+    ref_frames, ref_offsets, _ = o.encode_frames(pcm, threads=16)
+    assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames)
+    ref_back, _ = o.decode_frames(ref_frames, ref_offsets, 2, threads=16)
+    assert np.array_equal(_decode(gpu, frames, offsets, 2), ref_back)
+
+
+def test_the_library_picks_a_team_kernel_by_launch_size(gpu):  # noqa: F811
+    """launch_encode's choice (team_lanes_for): k_encode_blocks below 3000 stereo frames, teams of 16 up to 12,000, teams of 8
+    beyond; the hook overrides it; mono counts blocks, not frames."""
+    from sela_amd import capi
+
+    lib = capi.lib()
+    lib.sela_hip_debug_encode_teams(-1)
+    assert [lib.sela_hip_debug_encode_kernel(n, 2) for n in (1, 1000, 2999, 3000, 3875, 11999, 12000, 61000)] == [0, 0, 0, 16, 16, 16, 8, 8]
+    assert [lib.sela_hip_debug_encode_kernel(n, 1) for n in (8999, 9000, 36000)] == [0, 16, 8]
+    lib.sela_hip_debug_encode_teams(8)
+    assert lib.sela_hip_debug_encode_kernel(1, 2) == 8
+    lib.sela_hip_debug_encode_teams(-1)
+
+
 # ---- the binding of INTEGRATION.md section 2, compiled against the reference's own headers (oracle/binding/) ----------
 BOUND = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "sela_ref_bound")
 
@@ -120,6 +192,41 @@ def test_reference_classes_bound_to_the_library_write_the_reference_files(tmp_pa
     r = subprocess.run([BOUND, "-d", str(sela), str(back)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.getsize(back) == d["decoded_wav_bytes"] and _sha_file(back) == d["decoded_wav_sha256"]
+
+
+MAIN_ON_HOST = os.path.join(os.path.dirname(BOUND), "sela_ref_main_on_host")
+
+
+@pytest.mark.parametrize("label", ["config0_mono_10s", "config1_stereo_3min", "stereo_48k_tail", "three_channel_96k", "shorter_than_a_frame"])
+def test_reference_main_compiled_against_this_host_writes_the_reference_files(tmp_path, file_digests, label):
+    """The other direction of the boundary: oracle/_ref/sela_ref_main_on_host = the reference's UNCHANGED src/main.cpp
+    (/root/reference/src/main.cpp:29-51: `sela::Encoder encoder = sela::Encoder(inputFile); file::SelaFile selaFile =
+    encoder.process(); selaFile.writeToFile(outputFile);` ...) compiled against THIS repo's host classes through the
+    reference's own header paths (host/compat/include, `make -C oracle main_on_host`).  Its -e / -d write the reference's
+    files; its -p plays through sela::Player's default sink (the packets, as they are, on standard output)."""
+    import subprocess
+
+    from sela_amd.synth import synth_pcm
+    from test_gpu_round2 import _sha_file, _write_wav
+
+    if not os.path.exists(MAIN_ON_HOST):
+        pytest.fail("oracle/_ref/sela_ref_main_on_host is missing: run `make -C oracle main_on_host` in the build container")
+    d = file_digests[label]
+    pcm = synth_pcm(d["samples_per_channel"], d["channels"], d["track"])
+    wav, sela, back = tmp_path / "in.wav", tmp_path / "out.sela", tmp_path / "back.wav"
+    _write_wav(wav, pcm, d["sample_rate"])
+    r = subprocess.run([MAIN_ON_HOST, "-e", str(wav), str(sela)], capture_output=True, text=True)
+    assert r.returncode == 0 and "Encoding: " in r.stdout, (r.stdout, r.stderr)
+    assert os.path.getsize(sela) == d["sela_bytes"] and _sha_file(sela) == d["sela_sha256"]
+    r = subprocess.run([MAIN_ON_HOST, "-d", str(sela), str(back)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(back) == d["decoded_wav_bytes"] and _sha_file(back) == d["decoded_wav_sha256"]
+    if label == "stereo_48k_tail":  # the player's feed: banner lines, then every decoded frame's interleaved int16 bytes
+        r = subprocess.run([MAIN_ON_HOST, "-p", str(sela)], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        with open(back, "rb") as f:
+            decoded = f.read()[44:]
+        assert r.stdout.endswith(decoded) and len(decoded) > 0
 
 
 # ---- eight-way readiness on one GPU (no 8-GPU node has been available: SCALE_r01..r03 are `skipped` records) ----------------
