@@ -84,6 +84,16 @@ __device__ __forceinline__ void or_bits(uint32_t* buf, uint32_t pos, uint32_t v,
         atomicOr(&buf[w + 1], v >> (32 - sh));
 }
 
+// The same for a value of at most 32 bits without a branch: both words get an OR, the second one often of zero (the buffer
+// has a word to spare behind the stream's last).
+__device__ __forceinline__ void or_bits_both(uint32_t* buf, uint32_t pos, uint32_t v)
+{
+    const uint64_t wide = (uint64_t)v << (pos & 31);
+    uint32_t* const w = buf + (pos >> 5);
+    atomicOr(w, (uint32_t)wide);
+    atomicOr(w + 1, (uint32_t)(wide >> 32));
+}
+
 // Append one Golomb-Rice codeword (src/rice/rice_encoder.cpp:41-53): u >> k ones, a zero, then the
 // low k bits MSB first.  Stream bit t lives at bit t%32 of word t/32, so the MSB-first remainder is
 // the bit-reversed remainder in stream order.
@@ -126,47 +136,73 @@ __device__ __attribute__((noinline)) uint32_t put_long_codeword(uint32_t* buf, u
 // non-decreasing.  Hence the first minimum is the smallest k with d(k) <= n (k = 19 if there is none),
 // found by walking from a guess near log2(mean u).  Exact 64-bit sums throughout.
 template <int V>
-__device__ __forceinline__ uint64_t rice_shifted_sum(const uint32_t (&u)[V], uint32_t k)
+__device__ __forceinline__ uint64_t rice_shifted_sum(const uint32_t (&u)[V], uint32_t k, bool small, uint32_t& lane_part)
 {
+    if (small) { // every value below 2^20 (rice_plan): a lane's sum and the wave's fit 32 bits
+        uint32_t part = 0;
+#pragma unroll
+        for (int t = 0; t < V; t++)
+            part += u[t] >> k;
+        lane_part = part;
+        return wave_sum_small(part);
+    }
     uint64_t part = 0;
 #pragma unroll
     for (int t = 0; t < V; t++)
         part += u[t] >> k;
+    lane_part = (uint32_t)part; // (a lane's V <= 32 quotients only count when they are short: a block with longer ones is not packed)
     return wave_sum_40(part); // V <= 32 values below 2^32 each
 }
 
+// lane_or = the OR of the lane's values (an upper bound of each); lane_quotients = sum(u >> best_k) of THIS lane's values
+// (what the packer's scan needs).
 template <int V>
-__device__ __forceinline__ void rice_plan(const uint32_t (&u)[V], uint32_t n, uint32_t& best_k, uint64_t& best_bits)
+__device__ __forceinline__ void rice_plan(const uint32_t (&u)[V], uint32_t n, uint32_t& best_k, uint64_t& best_bits, uint32_t& lane_or, uint32_t& lane_quotients)
 {
     constexpr uint32_t kLast = SELA_MAX_RICE_PARAM - 1;
-    const uint64_t t0 = rice_shifted_sum<V>(u, 0);
+    lane_or = 0;
+#pragma unroll
+    for (int t = 0; t < V; t++)
+        lane_or |= u[t];
+    // 16-bit audio leaves residues below 2^19: then every sum below fits 32 bits (2048 values below 2^20), and the adds of
+    // a lane go two to an instruction
+    const bool small = !__any((lane_or >> 20) != 0);
+    uint32_t p0, pa, pb, pc;
+    const uint64_t t0 = rice_shifted_sum<V>(u, 0, small, p0);
     const uint64_t mean = n ? t0 / n : 0;
     uint32_t k = mean ? 63u - (uint32_t)__clzll(mean) : 0u; // floor(log2(mean))
     k = k > kLast - 1 ? kLast - 1 : k;
-    uint64_t ta = k ? rice_shifted_sum<V>(u, k) : t0; // T(k)
-    uint64_t tb = rice_shifted_sum<V>(u, k + 1);      // T(k + 1)
+    uint64_t ta = t0; // T(k)
+    pa = p0;
+    if (k)
+        ta = rice_shifted_sum<V>(u, k, small, pa);
+    uint64_t tb = rice_shifted_sum<V>(u, k + 1, small, pb); // T(k + 1)
     if (ta - tb <= n) { // bits(k+1) >= bits(k): the first minimum is at or below k
         while (k > 0) {
-            const uint64_t tc = k == 1 ? t0 : rice_shifted_sum<V>(u, k - 1);
+            uint64_t tc = t0;
+            pc = p0;
+            if (k != 1)
+                tc = rice_shifted_sum<V>(u, k - 1, small, pc);
             if (tc - ta > n)
                 break;
             k--;
-            tb = ta;
-            ta = tc;
+            tb = ta, pb = pa;
+            ta = tc, pa = pc;
         }
     } else { // still descending: move up
         for (;;) {
             k++;
-            ta = tb;
+            ta = tb, pa = pb;
             if (k == kLast)
                 break;
-            tb = rice_shifted_sum<V>(u, k + 1);
+            tb = rice_shifted_sum<V>(u, k + 1, small, pb);
             if (ta - tb <= n)
                 break;
         }
     }
     best_k = k;
     best_bits = ta + (uint64_t)n * (1 + k);
+    lane_quotients = pa;
 }
 
 // x = s / 32767 (src/lpc/residue_generator.cpp:12-18) without the ~30-instruction IEEE division:
