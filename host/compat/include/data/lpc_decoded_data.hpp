@@ -1,8 +1,8 @@
-// host/compat/include/rice.hpp -- the reference's header path (src/include/rice.hpp) over this host's classes:
+// host/compat/include/data/lpc_decoded_data.hpp -- the reference's header path (src/include/data/lpc_decoded_data.hpp) over this host's classes:
 // a program written against the reference's tree -- its own src/main.cpp -- compiles against this host with
 //     g++ -I host/compat -I- -I host/include -I include ...
 // (-I-: quoted includes are looked up in the -I directories instead of beside the including file).
-#ifndef SELA_COMPAT_RICE_HPP
-#define SELA_COMPAT_RICE_HPP
-#include "sela_host/stages.hpp"
+#ifndef SELA_COMPAT_DATA_LPC_DECODED_DATA_HPP
+#define SELA_COMPAT_DATA_LPC_DECODED_DATA_HPP
+#include "sela_host/data.hpp"
 #endif

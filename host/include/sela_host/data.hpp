@@ -43,6 +43,34 @@ public:
     }
 };
 
+// What the stages hand each other (src/include/data/rice_decoded_data.hpp:8-17, lpc_decoded_data.hpp:8-19,
+// lpc_encoded_data.hpp:8-21): names, members and constructor shapes as in the reference.
+class RiceDecodedData {
+public:
+    std::vector<int32_t> decodedData;
+    explicit RiceDecodedData(std::vector<int32_t> values) : decodedData(std::move(values)) {}
+};
+
+class LpcDecodedData {
+public:
+    uint8_t bitsPerSample;
+    std::vector<int32_t> samples;
+    LpcDecodedData(uint8_t bitsPerSample, std::vector<int32_t> samples) : bitsPerSample(bitsPerSample), samples(std::move(samples)) {}
+};
+
+class LpcEncodedData {
+public:
+    uint8_t optimalLpcOrder;
+    uint8_t bitsPerSample;
+    std::vector<int32_t> quantizedReflectionCoefficients;
+    std::vector<int32_t> residues;
+    LpcEncodedData(uint8_t optimalLpcOrder, uint8_t bitsPerSample, std::vector<int32_t> quantizedReflectionCoefficients, std::vector<int32_t> residues)
+        : optimalLpcOrder(optimalLpcOrder), bitsPerSample(bitsPerSample), quantizedReflectionCoefficients(std::move(quantizedReflectionCoefficients)),
+          residues(std::move(residues))
+    {
+    }
+};
+
 // One channel of a frame as stored on disk (field widths are the on-disk widths).
 class SelaSubFrame {
 public:

@@ -13,6 +13,7 @@
 #include "sela_host/fileio.hpp"
 #include "sela_host/codec.hpp"
 #include "sela_host/player.hpp"
+#include "sela_host/stages.hpp"
 #include "sela_host/files.hpp"
 #include "sela_host/frame.hpp"
 
@@ -267,6 +268,36 @@ int main(int argc, char** argv)
             CHECK(coded.subFrames[1].optimumLpcOrder == 1 && coded.subFrames[1].encodedResidues.size() == 64);
             data::WavFrame output = frame::FrameDecoder(coded).process();
             CHECK(output.samples.size() == 2 && output.samples[0] == sine && output.samples[1] == sine);
+            // the reference's stage tests (test/ricetests.cpp:7-25, test/lpctests.cpp:10-32) through the L1 classes
+            {
+                std::vector<int32_t> values;
+                for (size_t i = 0; i < 100; i++)
+                    values.push_back(200 + (std::rand() % (201)));
+                data::RiceDecodedData plain = data::RiceDecodedData(std::vector<int32_t>(values));
+                rice::RiceEncoder enc = rice::RiceEncoder(plain);
+                data::RiceEncodedData encodedData = enc.process();
+                CHECK(encodedData.dataCount == 100 && encodedData.optimumRiceParam < MAX_RICE_PARAM && !encodedData.encodedData.empty());
+                rice::RiceDecoder dec = rice::RiceDecoder(encodedData);
+                data::RiceDecodedData decodedData = dec.process();
+                CHECK(plain.decodedData.size() == decodedData.decodedData.size() && plain.decodedData == decodedData.decodedData);
+
+                data::LpcDecodedData block = data::LpcDecodedData((uint8_t)16, std::vector<int32_t>(sine));
+                lpc::ResidueGenerator resGen = lpc::ResidueGenerator(block);
+                data::LpcEncodedData encoded = resGen.process();
+                CHECK(encoded.optimalLpcOrder == 17 && encoded.quantizedReflectionCoefficients.size() == 17 && encoded.residues.size() == 2048);
+                lpc::SampleGenerator sampleGen = lpc::SampleGenerator(encoded);
+                data::LpcDecodedData decoded = sampleGen.process();
+                CHECK(block.samples.size() == decoded.samples.size() && block.samples == decoded.samples);
+                lpc::LinearPredictor predictor(encoded.quantizedReflectionCoefficients, encoded.optimalLpcOrder);
+                predictor.dequantizeReflectionCoefficients();
+                predictor.generatelinearPredictionCoefficients();
+                CHECK(predictor.linearPredictionCoefficients.size() == 18 && predictor.linearPredictionCoefficients[0] == 0);
+                // the Rice coder on what the LPC stage left, against the frame coder's subframe of the same signal
+                data::RiceEncodedData residueWords = rice::RiceEncoder(data::RiceDecodedData(std::vector<int32_t>(encoded.residues))).process();
+                CHECK(residueWords.optimumRiceParam == coded.subFrames[0].residueRiceParam && residueWords.encodedData == coded.subFrames[0].encodedResidues);
+                data::RiceEncodedData coefWords = rice::RiceEncoder(data::RiceDecodedData(std::vector<int32_t>(encoded.quantizedReflectionCoefficients))).process();
+                CHECK(coefWords.optimumRiceParam == coded.subFrames[0].reflectionCoefficientRiceParam && coefWords.encodedData == coded.subFrames[0].encodedReflectionCoefficients);
+            }
             // mono + a sample outside 16 bits is rejected loudly
             std::vector<int32_t> wide(2048, 40000);
             bool threw = false;

@@ -1,0 +1,92 @@
+// stages.cpp -- see stages.hpp.
+#include "sela_host/stages.hpp"
+
+#include <string>
+
+#include "sela_hip.h"
+
+namespace {
+
+constexpr size_t kBlock = SELA_HIP_SAMPLES_PER_FRAME;
+constexpr size_t kMaxOrder = 100;
+
+[[noreturn]] void stageFailure(const char* what)
+{
+    throw data::Exception(std::string(what) + ": " + sela_hip_last_error());
+}
+
+} // namespace
+
+namespace rice {
+
+data::RiceEncodedData RiceEncoder::process()
+{
+    const uint64_t valueOffsets[2] = { 0, input.size() };
+    uint64_t wordOffsets[2] = { 0, 0 };
+    uint32_t k = 0, words = 0;
+    // the word count first (no room: the call reports SELA_HIP_ECAPACITY and the count), then the words
+    int rc = sela_hip_rice_encode(input.data(), valueOffsets, 1, &k, &words, nullptr, wordOffsets);
+    if (rc != SELA_HIP_OK && rc != SELA_HIP_ECAPACITY)
+        stageFailure("RiceEncoder");
+    std::vector<uint32_t> out(words);
+    wordOffsets[1] = words;
+    if (words && sela_hip_rice_encode(input.data(), valueOffsets, 1, &k, &words, out.data(), wordOffsets) != SELA_HIP_OK)
+        stageFailure("RiceEncoder");
+    return data::RiceEncodedData(k, (uint32_t)input.size(), std::move(out));
+}
+
+data::RiceDecodedData RiceDecoder::process()
+{
+    const uint64_t wordOffsets[2] = { 0, input.size() }, valueOffsets[2] = { 0, dataCount };
+    std::vector<int32_t> out(dataCount);
+    if (sela_hip_rice_decode(input.data(), wordOffsets, &optimumRiceParam, valueOffsets, 1, out.data()) != SELA_HIP_OK)
+        stageFailure("RiceDecoder");
+    return data::RiceDecodedData(std::move(out));
+}
+
+} // namespace rice
+
+namespace lpc {
+
+void LinearPredictor::generatelinearPredictionCoefficients()
+{
+    const int32_t order = optimalLpcOrder;
+    if ((size_t)order > kMaxOrder || quantizedReflectionCoefficients.size() < (size_t)order)
+        throw data::Exception("LinearPredictor: order beyond 100 or fewer coefficients than the order");
+    std::vector<int32_t> q(kMaxOrder, 0);
+    for (int32_t i = 0; i < order; i++)
+        q[(size_t)i] = quantizedReflectionCoefficients[(size_t)i];
+    std::vector<int64_t> a(kMaxOrder + 1, 0);
+    if (sela_hip_lpc_decode(&order, q.data(), nullptr, 1, nullptr, a.data()) != SELA_HIP_OK)
+        stageFailure("LinearPredictor");
+    linearPredictionCoefficients.assign(a.begin(), a.begin() + order + 1);
+}
+
+data::LpcEncodedData ResidueGenerator::process()
+{
+    if (samples.size() != kBlock)
+        throw data::Exception("ResidueGenerator: a block is 2048 samples");
+    int32_t order = 0;
+    std::vector<int32_t> q(kMaxOrder, 0), residues(kBlock);
+    if (sela_hip_lpc_encode(samples.data(), 1, &order, q.data(), residues.data()) != SELA_HIP_OK)
+        stageFailure("ResidueGenerator");
+    q.resize((size_t)order);
+    return data::LpcEncodedData((uint8_t)order, bitsPerSample, std::move(q), std::move(residues));
+}
+
+data::LpcDecodedData SampleGenerator::process()
+{
+    if (residues.size() != kBlock)
+        throw data::Exception("SampleGenerator: a block is 2048 residues");
+    const int32_t order = linearPredictor.optimalLpcOrder;
+    if ((size_t)order > kMaxOrder || linearPredictor.quantizedReflectionCoefficients.size() < (size_t)order)
+        throw data::Exception("SampleGenerator: order beyond 100 or fewer coefficients than the order");
+    std::vector<int32_t> q(kMaxOrder, 0), out(kBlock);
+    for (int32_t i = 0; i < order; i++)
+        q[(size_t)i] = linearPredictor.quantizedReflectionCoefficients[(size_t)i];
+    if (sela_hip_lpc_decode(&order, q.data(), residues.data(), 1, out.data(), nullptr) != SELA_HIP_OK)
+        stageFailure("SampleGenerator");
+    return data::LpcDecodedData(bitsPerSample, std::move(out));
+}
+
+} // namespace lpc

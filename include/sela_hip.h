@@ -180,6 +180,35 @@ int sela_hip_decode_end(sela_hip_job* job, uint32_t* frames_final);
 uint32_t sela_hip_index_frames(const uint8_t* frames, size_t frames_bytes, uint32_t n_frames, uint32_t channels,
     uint64_t* frame_offsets);
 
+/* ---- the stages on their own -------------------------------------------------------------------------------
+ * The reference's public L1 classes (src/include/lpc.hpp:73-117, src/include/rice.hpp:9-43; its tests call them directly:
+ * test/lpctests.cpp:10-32, test/ricetests.cpp:7-25), batched, on HOST pointers.  Not the fast path -- a frame goes through
+ * all of them inside one kernel (sela_hip_encode / sela_hip_decode) -- but the same device code, for callers and tests of
+ * a stage by itself.  Every call synchronises.
+ *
+ * lpc::ResidueGenerator::process (src/lpc/residue_generator.cpp:121-134): n_blocks blocks of 2048 samples (int32, |s| <=
+ * 65535: 16-bit channels and their difference; SELA_HIP_EINVAL beyond) -> per block the order, the quantised reflection
+ * coefficients (q_out[block][0 .. order), the rest untouched) and 2048 residues. */
+int sela_hip_lpc_encode(const int32_t* samples, uint32_t n_blocks, int32_t* order_out, int32_t* q_out /* [n_blocks][100] */, int32_t* residues_out);
+/* lpc::SampleGenerator::process (src/lpc/sample_generator.cpp:11-39): the inverse.  q[block][0 .. order[block]); samples_out
+ * [n_blocks][2048] as the 32-bit values the reference returns.  coefs_out (or NULL): [n_blocks][101], the Q35 predictor
+ * a[0 .. order] of lpc::LinearPredictor::generatelinearPredictionCoefficients (src/lpc/linear_predictor.cpp:30-61);
+ * samples_out may be NULL when only the predictor is wanted. */
+int sela_hip_lpc_decode(const int32_t* order, const int32_t* q /* [n_blocks][100] */, const int32_t* residues, uint32_t n_blocks, int32_t* samples_out,
+    int64_t* coefs_out);
+/* rice::RiceEncoder::process (src/rice/rice_encoder.cpp:73-81): n_streams streams of int32 values, stream i =
+ * values[value_offsets[i] .. value_offsets[i + 1]) -> its Rice parameter k_out[i] (the first minimum over 0..19), its
+ * word count word_counts_out[i] (ceil((float)bits / 32) as the reference computes it) and its words at
+ * words_out[word_offsets[i] ..] (word_offsets[i + 1] - word_offsets[i] words of room: SELA_HIP_ECAPACITY if a stream needs
+ * more -- the counts are valid then).  |value| >= 2^30 (the reference's int32 zig-zag overflows there): SELA_HIP_ERANGE. */
+int sela_hip_rice_encode(const int32_t* values, const uint64_t* value_offsets, uint32_t n_streams, uint32_t* k_out, uint32_t* word_counts_out,
+    uint32_t* words_out, const uint64_t* word_offsets);
+/* rice::RiceDecoder::process (src/rice/rice_decoder.cpp:54-61): stream i = words[word_offsets[i] .. word_offsets[i + 1]) with
+ * parameter k[i] (< 32) -> value_offsets[i + 1] - value_offsets[i] values at values_out[value_offsets[i] ..].  A stream that
+ * ends before its values do decodes the missing bits as zeros and the call returns SELA_HIP_EFORMAT. */
+int sela_hip_rice_decode(const uint32_t* words, const uint64_t* word_offsets, const uint32_t* k, const uint64_t* value_offsets, uint32_t n_streams,
+    int32_t* values_out);
+
 /* ---- per-kernel timing (measurement hook used by bench.py) ------------------------------------------
  * When enabled, the *_device calls of the calling thread bracket each kernel launch with HIP events
  * recorded on the caller's stream.  sela_hip_kernel_times() waits for the events of the most recent

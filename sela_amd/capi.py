@@ -24,6 +24,7 @@ EXPORTS = [
     "sela_hip_encode_bound_bytes", "sela_hip_encode_device", "sela_hip_decode_device",
     "sela_hip_encode", "sela_hip_decode", "sela_hip_index_frames",
     "sela_hip_enable_kernel_timing", "sela_hip_kernel_times",
+    "sela_hip_lpc_encode", "sela_hip_lpc_decode", "sela_hip_rice_encode", "sela_hip_rice_decode",
     "sela_hip_host_alloc", "sela_hip_host_free", "sela_hip_decode_max_channels",
     "sela_hip_encode_begin", "sela_hip_encode_feed", "sela_hip_encode_end",
     "sela_hip_decode_begin", "sela_hip_decode_feed", "sela_hip_decode_end",
@@ -101,6 +102,12 @@ def lib() -> C.CDLL:
     L.sela_hip_enable_kernel_timing.restype = None
     L.sela_hip_kernel_times.argtypes = [C.POINTER(C.c_float), C.c_int]
     L.sela_hip_kernel_times.restype = C.c_int
+    L.sela_hip_lpc_encode.argtypes = [vp, u32, vp, vp, vp]
+    L.sela_hip_lpc_decode.argtypes = [vp, vp, vp, u32, vp, vp]
+    L.sela_hip_rice_encode.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    L.sela_hip_rice_decode.argtypes = [vp, vp, vp, vp, u32, vp]
+    for name in ("sela_hip_lpc_encode", "sela_hip_lpc_decode", "sela_hip_rice_encode", "sela_hip_rice_decode"):
+        getattr(L, name).restype = C.c_int
     L.sela_hip_debug_phase_buffer.argtypes = [C.c_void_p]
     L.sela_hip_debug_phase_buffer.restype = None
     L.sela_hip_debug_force_plain_fir.argtypes = [C.c_int]

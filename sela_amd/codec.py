@@ -145,3 +145,67 @@ def index_frames(frames: np.ndarray, n_frames: int, channels: int) -> np.ndarray
     offs = np.zeros(n_frames + 1, np.uint64)
     found = lib.sela_hip_index_frames(fr.ctypes.data, fr.nbytes, n_frames, channels, offs.ctypes.data)
     return offs[: found + 1]
+
+
+# ---- the stages on their own (sela_hip_lpc_* / sela_hip_rice_*: the reference's L1 classes, batched) -----------------------
+def lpc_encode(samples: np.ndarray):
+    """samples: int32 [n_blocks, 2048] -> (order int32[n], q int32[n, 100] (first order[i] entries valid), residues int32[n, 2048])."""
+    lib = capi.lib()
+    s = np.ascontiguousarray(samples, dtype=np.int32)
+    n = s.shape[0]
+    assert s.ndim == 2 and s.shape[1] == BLOCK
+    order, q, res = np.zeros(n, np.int32), np.zeros((n, 100), np.int32), np.zeros((n, BLOCK), np.int32)
+    capi.check(lib.sela_hip_lpc_encode(C.c_void_p(s.ctypes.data), n, C.c_void_p(order.ctypes.data), C.c_void_p(q.ctypes.data), C.c_void_p(res.ctypes.data)))
+    return order, q, res
+
+
+def lpc_decode(order: np.ndarray, q: np.ndarray, residues: np.ndarray, want_coefficients: bool = False):
+    """The inverse: -> samples int32 [n_blocks, 2048] (and, if asked, the Q35 predictors int64 [n_blocks, 101])."""
+    lib = capi.lib()
+    o = np.ascontiguousarray(order, dtype=np.int32)
+    n = o.shape[0]
+    qq = np.ascontiguousarray(q, dtype=np.int32).reshape(n, 100)
+    r = np.ascontiguousarray(residues, dtype=np.int32).reshape(n, BLOCK)
+    out = np.zeros((n, BLOCK), np.int32)
+    coefs = np.zeros((n, 101), np.int64) if want_coefficients else None
+    capi.check(lib.sela_hip_lpc_decode(C.c_void_p(o.ctypes.data), C.c_void_p(qq.ctypes.data), C.c_void_p(r.ctypes.data), n, C.c_void_p(out.ctypes.data),
+                                       C.c_void_p(coefs.ctypes.data) if coefs is not None else None))
+    return (out, coefs) if want_coefficients else out
+
+
+def rice_encode(streams):
+    """streams: list of int32 arrays -> list of (k, words uint32[...]) as rice::RiceEncoder gives them."""
+    lib = capi.lib()
+    n = len(streams)
+    vals = [np.ascontiguousarray(v, dtype=np.int32).ravel() for v in streams]
+    voff = np.zeros(n + 1, np.uint64)
+    voff[1:] = np.cumsum([len(v) for v in vals])
+    flat = np.concatenate(vals) if n and voff[n] else np.zeros(0, np.int32)
+    # room: a codeword is at most 1 + 19 + (|value| << 1 >> 19) bits... sized by a first call that only asks for the counts
+    woff = np.zeros(n + 1, np.uint64)
+    k, counts = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    rc = lib.sela_hip_rice_encode(C.c_void_p(flat.ctypes.data), C.c_void_p(voff.ctypes.data), n, C.c_void_p(k.ctypes.data), C.c_void_p(counts.ctypes.data),
+                                  None, C.c_void_p(woff.ctypes.data))
+    if rc not in (capi.OK, -4):
+        capi.check(rc)
+    woff[1:] = np.cumsum(counts.astype(np.uint64))
+    words = np.zeros(int(woff[n]), np.uint32)
+    capi.check(lib.sela_hip_rice_encode(C.c_void_p(flat.ctypes.data), C.c_void_p(voff.ctypes.data), n, C.c_void_p(k.ctypes.data), C.c_void_p(counts.ctypes.data),
+                                        C.c_void_p(words.ctypes.data), C.c_void_p(woff.ctypes.data)))
+    return [(int(k[i]), words[int(woff[i]): int(woff[i + 1])].copy()) for i in range(n)]
+
+
+def rice_decode(streams):
+    """streams: list of (k, words uint32 array, count) -> list of int32 arrays (rice::RiceDecoder)."""
+    lib = capi.lib()
+    n = len(streams)
+    ws = [np.ascontiguousarray(w, dtype=np.uint32).ravel() for _, w, _ in streams]
+    woff, voff = np.zeros(n + 1, np.uint64), np.zeros(n + 1, np.uint64)
+    woff[1:] = np.cumsum([len(w) for w in ws])
+    voff[1:] = np.cumsum([c for _, _, c in streams])
+    flat = np.concatenate(ws) if n and woff[n] else np.zeros(0, np.uint32)
+    k = np.array([kk for kk, _, _ in streams], np.uint32)
+    out = np.zeros(int(voff[n]), np.int32)
+    capi.check(lib.sela_hip_rice_decode(C.c_void_p(flat.ctypes.data), C.c_void_p(woff.ctypes.data), C.c_void_p(k.ctypes.data), C.c_void_p(voff.ctypes.data), n,
+                                        C.c_void_p(out.ctypes.data)))
+    return [out[int(voff[i]): int(voff[i + 1])].copy() for i in range(n)]

@@ -28,7 +28,14 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
-    hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override, int team_lanes);
+    hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override, int team_lanes,
+    int32_t* d_trace_residues = nullptr);
+hipError_t launch_stage_rice_encode(const int32_t* d_values, const uint64_t* d_value_offsets, uint32_t n_streams, uint32_t* d_k, uint32_t* d_word_counts,
+    uint32_t* d_words, const uint64_t* d_word_offsets, uint32_t* d_status, hipStream_t stream);
+hipError_t launch_stage_lpc_decode(const int32_t* d_order, const int32_t* d_q, const int32_t* d_residues, uint32_t n_blocks, int32_t* d_samples,
+    int64_t* d_coefs, uint32_t* d_status, hipStream_t stream);
+hipError_t launch_stage_rice_decode(const uint32_t* d_words, const uint64_t* d_word_offsets, const uint32_t* d_k, const uint64_t* d_value_offsets,
+    uint32_t n_streams, int32_t* d_values, uint32_t* d_status, hipStream_t stream);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles,
     uint8_t* frame_flags, int recurrence_form);
@@ -951,6 +958,47 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
 
 } // namespace
 
+// ---- the stages on their own (sela_hip.h): plain synchronous calls, device buffers of their own -----------------------------
+namespace {
+
+// device memory for the length of one call
+struct Scratch {
+    std::vector<void*> blocks;
+    ~Scratch()
+    {
+        for (void* b : blocks)
+            (void)hipFree(b);
+    }
+    template <typename T>
+    T* take(size_t count, hipError_t& err)
+    {
+        void* p = nullptr;
+        if (err == hipSuccess)
+            err = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (p)
+            blocks.push_back(p);
+        return static_cast<T*>(p);
+    }
+    template <typename T>
+    T* upload(const T* host, size_t count, hipError_t& err)
+    {
+        T* d = take<T>(count, err);
+        if (err == hipSuccess && count)
+            err = hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice);
+        return d;
+    }
+};
+
+int stage_device_ready()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SELA_HIP_ENODEV, "no HIP device visible (the SELA MI355X path has no CPU fallback)");
+    return SELA_HIP_OK;
+}
+
+} // namespace
+
 extern "C" {
 
 const char* sela_hip_last_error(void) { return g_error.c_str(); }
@@ -1305,6 +1353,187 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
     call.channels = channels, call.n_frames = n_frames;
     call.frames = frames, call.offsets_in = frame_offsets, call.pcm_out = pcm_out;
     return submit_small(false, call);
+}
+
+int sela_hip_lpc_encode(const int32_t* samples, uint32_t n_blocks, int32_t* order_out, int32_t* q_out, int32_t* residues_out)
+{
+    if (n_blocks && (!samples || !order_out || !q_out || !residues_out))
+        return fail(SELA_HIP_EINVAL, "null pointer");
+    if (stage_device_ready() != SELA_HIP_OK)
+        return SELA_HIP_ENODEV;
+    if (n_blocks == 0)
+        return SELA_HIP_OK;
+    // A block is analysed as the DIFFERENCE signal of a stereo frame (left - right = the block's samples): that is how 17-bit
+    // samples reach the kernels, whose input is the 16-bit PCM of a WAV file.  The trace build of k_encode_blocks leaves the
+    // order and the quantised coefficients of every signal in its trace, and here the residues too.
+    constexpr size_t kBlk = SELA_HIP_SAMPLES_PER_FRAME;
+    std::vector<int16_t> pcm((size_t)n_blocks * kBlk * 2);
+    for (size_t i = 0; i < (size_t)n_blocks * kBlk; i++) {
+        const int32_t s = samples[i];
+        if (s < -65535 || s > 65535)
+            return fail(SELA_HIP_EINVAL, "lpc_encode: samples must lie within 16-bit channels and their difference (|s| <= 65535)");
+        const int32_t left = s > 32767 ? 32767 : (s < -32768 ? -32768 : s);
+        pcm[2 * i] = (int16_t)left;
+        pcm[2 * i + 1] = (int16_t)(left - s);
+    }
+    hipError_t e = hipSuccess;
+    Scratch mem;
+    const size_t ws = sela::encode_workspace_bytes(n_blocks, 2), cap = sela_hip_encode_bound_bytes(n_blocks, 2);
+    int16_t* d_pcm = mem.upload(pcm.data(), pcm.size(), e);
+    uint8_t* d_frames = mem.take<uint8_t>(cap, e);
+    uint64_t* d_offsets = mem.take<uint64_t>((size_t)n_blocks + 1, e);
+    uint32_t* d_status = mem.take<uint32_t>(4, e);
+    uint8_t* d_ws = mem.take<uint8_t>(ws, e);
+    sela_hip_trace* d_trace = mem.take<sela_hip_trace>((size_t)n_blocks * 3, e);
+    int32_t* d_res = mem.take<int32_t>((size_t)n_blocks * 3 * kBlk, e);
+    if (e == hipSuccess)
+        e = sela::launch_encode(d_pcm, n_blocks, 2, d_frames, cap, d_offsets, d_status, d_ws, d_trace, nullptr, nullptr, nullptr, nullptr, 0, -1, 0, d_res);
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    std::vector<sela_hip_trace> trace((size_t)n_blocks * 3);
+    if (e == hipSuccess)
+        e = hipMemcpy(trace.data(), d_trace, trace.size() * sizeof(sela_hip_trace), hipMemcpyDeviceToHost);
+    for (uint32_t b = 0; b < n_blocks && e == hipSuccess; b++) // signal 2 of frame b
+        e = hipMemcpy(residues_out + (size_t)b * kBlk, d_res + ((size_t)b * 3 + 2) * kBlk, kBlk * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail_hip(e, "lpc_encode");
+    uint32_t flags = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const sela_hip_trace& t = trace[(size_t)b * 3 + 2];
+        order_out[b] = t.order;
+        for (int i = 0; i < t.order && i < SELA_MAX_LPC_ORDER; i++)
+            q_out[(size_t)b * SELA_MAX_LPC_ORDER + i] = t.q[i];
+        flags |= t.flags;
+    }
+    if (flags & (SELA_HIP_FLAG_RICE_RANGE | SELA_HIP_FLAG_COEF_OVERFLOW))
+        return fail(SELA_HIP_ERANGE, "lpc_encode: a block left the range the format can carry");
+    return SELA_HIP_OK;
+}
+
+int sela_hip_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* residues, uint32_t n_blocks, int32_t* samples_out, int64_t* coefs_out)
+{
+    if (n_blocks && (!order || !q || (samples_out && !residues) || (!samples_out && !coefs_out)))
+        return fail(SELA_HIP_EINVAL, "null pointer");
+    if (stage_device_ready() != SELA_HIP_OK)
+        return SELA_HIP_ENODEV;
+    if (n_blocks == 0)
+        return SELA_HIP_OK;
+    constexpr size_t kBlk = SELA_HIP_SAMPLES_PER_FRAME, kCoefs = SELA_MAX_LPC_ORDER + 1;
+    hipError_t e = hipSuccess;
+    Scratch mem;
+    int32_t* d_order = mem.upload(order, n_blocks, e);
+    int32_t* d_q = mem.upload(q, (size_t)n_blocks * SELA_MAX_LPC_ORDER, e);
+    int32_t* d_res = samples_out ? mem.upload(residues, (size_t)n_blocks * kBlk, e) : nullptr;
+    int32_t* d_out = samples_out ? mem.take<int32_t>((size_t)n_blocks * kBlk, e) : nullptr;
+    int64_t* d_coefs = coefs_out ? mem.take<int64_t>((size_t)n_blocks * kCoefs, e) : nullptr;
+    uint32_t* d_status = mem.take<uint32_t>(4, e);
+    if (e == hipSuccess)
+        e = hipMemset(d_status, 0, 16);
+    if (e == hipSuccess && d_coefs)
+        e = hipMemset(d_coefs, 0, (size_t)n_blocks * kCoefs * sizeof(int64_t));
+    if (e == hipSuccess)
+        e = sela::launch_stage_lpc_decode(d_order, d_q, d_res, n_blocks, d_out, d_coefs, d_status, nullptr);
+    uint32_t status[4] = {};
+    if (e == hipSuccess)
+        e = hipMemcpy(status, d_status, 16, hipMemcpyDeviceToHost); // (synchronises)
+    if (e == hipSuccess && samples_out)
+        e = hipMemcpy(samples_out, d_out, (size_t)n_blocks * kBlk * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && coefs_out)
+        e = hipMemcpy(coefs_out, d_coefs, (size_t)n_blocks * kCoefs * sizeof(int64_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail_hip(e, "lpc_decode");
+    if (status[0] & SELA_HIP_FLAG_BAD_FRAME)
+        return fail(SELA_HIP_EINVAL, "lpc_decode: order outside 0..100");
+    if (status[0] & SELA_HIP_FLAG_COEF_OVERFLOW)
+        return fail(SELA_HIP_ERANGE, "lpc_decode: a predictor coefficient left the int64 range");
+    return SELA_HIP_OK;
+}
+
+int sela_hip_rice_encode(const int32_t* values, const uint64_t* value_offsets, uint32_t n_streams, uint32_t* k_out, uint32_t* word_counts_out,
+    uint32_t* words_out, const uint64_t* word_offsets)
+{
+    if (n_streams && (!value_offsets || !k_out || !word_counts_out || !word_offsets))
+        return fail(SELA_HIP_EINVAL, "null pointer");
+    if (stage_device_ready() != SELA_HIP_OK)
+        return SELA_HIP_ENODEV;
+    if (n_streams == 0)
+        return SELA_HIP_OK;
+    for (uint32_t i = 0; i < n_streams; i++)
+        if (value_offsets[i + 1] < value_offsets[i] || word_offsets[i + 1] < word_offsets[i])
+            return fail(SELA_HIP_EINVAL, "offsets must not decrease");
+    const size_t n_values = (size_t)value_offsets[n_streams], n_words = (size_t)word_offsets[n_streams];
+    if ((n_values && !values) || (n_words && !words_out))
+        return fail(SELA_HIP_EINVAL, "null pointer");
+    hipError_t e = hipSuccess;
+    Scratch mem;
+    int32_t* d_values = mem.upload(values, n_values, e);
+    uint64_t* d_voff = mem.upload(value_offsets, (size_t)n_streams + 1, e);
+    uint64_t* d_woff = mem.upload(word_offsets, (size_t)n_streams + 1, e);
+    uint32_t* d_k = mem.take<uint32_t>(n_streams, e);
+    uint32_t* d_counts = mem.take<uint32_t>(n_streams, e);
+    uint32_t* d_words = mem.take<uint32_t>(n_words, e);
+    uint32_t* d_status = mem.take<uint32_t>(4, e);
+    if (e == hipSuccess)
+        e = hipMemset(d_status, 0, 16);
+    if (e == hipSuccess && n_words)
+        e = hipMemset(d_words, 0, n_words * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = sela::launch_stage_rice_encode(d_values, d_voff, n_streams, d_k, d_counts, d_words, d_woff, d_status, nullptr);
+    uint32_t status[4] = {};
+    if (e == hipSuccess)
+        e = hipMemcpy(status, d_status, 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(k_out, d_k, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(word_counts_out, d_counts, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n_words)
+        e = hipMemcpy(words_out, d_words, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail_hip(e, "rice_encode");
+    if (status[0] & SELA_HIP_FLAG_RICE_RANGE)
+        return fail(SELA_HIP_ERANGE, "rice_encode: a value is beyond the reference's int32 zig-zag (|value| >= 2^30)");
+    if (status[0] & SELA_HIP_FLAG_WORDS_CAP)
+        return fail(SELA_HIP_ECAPACITY, "rice_encode: a stream needs more words than its range of words_out (see word_counts_out)");
+    return SELA_HIP_OK;
+}
+
+int sela_hip_rice_decode(const uint32_t* words, const uint64_t* word_offsets, const uint32_t* k, const uint64_t* value_offsets, uint32_t n_streams,
+    int32_t* values_out)
+{
+    if (n_streams && (!word_offsets || !k || !value_offsets))
+        return fail(SELA_HIP_EINVAL, "null pointer");
+    if (stage_device_ready() != SELA_HIP_OK)
+        return SELA_HIP_ENODEV;
+    if (n_streams == 0)
+        return SELA_HIP_OK;
+    for (uint32_t i = 0; i < n_streams; i++)
+        if (value_offsets[i + 1] < value_offsets[i] || word_offsets[i + 1] < word_offsets[i] || k[i] >= 32)
+            return fail(SELA_HIP_EINVAL, "offsets must not decrease; Rice parameters are below 32");
+    const size_t n_values = (size_t)value_offsets[n_streams], n_words = (size_t)word_offsets[n_streams];
+    if ((n_values && !values_out) || (n_words && !words))
+        return fail(SELA_HIP_EINVAL, "null pointer");
+    hipError_t e = hipSuccess;
+    Scratch mem;
+    uint32_t* d_words = mem.upload(words, n_words, e);
+    uint64_t* d_woff = mem.upload(word_offsets, (size_t)n_streams + 1, e);
+    uint64_t* d_voff = mem.upload(value_offsets, (size_t)n_streams + 1, e);
+    uint32_t* d_k = mem.upload(k, n_streams, e);
+    int32_t* d_values = mem.take<int32_t>(n_values, e);
+    uint32_t* d_status = mem.take<uint32_t>(4, e);
+    if (e == hipSuccess)
+        e = hipMemset(d_status, 0, 16);
+    if (e == hipSuccess)
+        e = sela::launch_stage_rice_decode(d_words, d_woff, d_k, d_voff, n_streams, d_values, d_status, nullptr);
+    uint32_t status[4] = {};
+    if (e == hipSuccess)
+        e = hipMemcpy(status, d_status, 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n_values)
+        e = hipMemcpy(values_out, d_values, n_values * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail_hip(e, "rice_decode");
+    if (status[0] & (SELA_HIP_FLAG_RICE_OVERRUN | SELA_HIP_FLAG_BAD_FRAME))
+        return fail(SELA_HIP_EFORMAT, "rice_decode: a stream ended before all its values were read");
+    return SELA_HIP_OK;
 }
 
 uint32_t sela_hip_index_frames(const uint8_t* frames, size_t frames_bytes, uint32_t n_frames, uint32_t channels, uint64_t* frame_offsets)

@@ -602,11 +602,14 @@ __device__ __forceinline__ bool synth_block(int32_t r_block, int32_t& s, uint32_
 // from the codeword positions in pos_smp[] (ws == nullptr), the words fetched one block ahead -- or read from
 // the workspace array ws[] (generic mode).  Samples go to pos_smp[] as int16, over the positions of the
 // block just consumed.
-template <int R, int G, bool kVecShift>
+template <int R, int G, bool kVecShift, bool kOut32 = false>
 __device__ __attribute__((noinline)) void synthesize( // (a real call: six of these inlined into three kernels cost the kernels their registers)
     const uint32_t* words, uint32_t n_words, uint32_t k, uint16_t* pos_smp, const int32_t* ws,
     const uint64_t* tab, bool fold, int lane)
 {
+    // kOut32 (the stage on its own, k_stage_lpc_decode): pos_smp is really an int32_t* in global memory and takes the samples
+    // as the 32-bit values lpc::SampleGenerator returns (ws != nullptr there: no positions are read from it).  A template
+    // parameter rather than one more argument: the frame kernels' instantiations stay exactly what they were.
     static_assert(G == 4 || G == 16, "groups are DPP banks or rows");
     const StreamWords sw = { words, n_words };
     const __amdgpu_buffer_rsrc_t rs = stream_rsrc(sw);
@@ -669,7 +672,10 @@ __device__ __attribute__((noinline)) void synthesize( // (a real call: six of th
         }
         if (!done)
             synth_block<R, false, G, kVecShift>(r_block, s, cl, ch, ol, oh, tab_lane, four, zero);
-        reinterpret_cast<int16_t*>(pos_smp)[64 * blk + lane] = (int16_t)(uint16_t)(uint32_t)s;
+        if constexpr (kOut32)
+            reinterpret_cast<int32_t*>(pos_smp)[64 * blk + lane] = s;
+        else
+            reinterpret_cast<int16_t*>(pos_smp)[64 * blk + lane] = (int16_t)(uint16_t)(uint32_t)s;
     };
     issue(0);
 #pragma unroll 1
@@ -682,16 +688,16 @@ __device__ __attribute__((noinline)) void synthesize( // (a real call: six of th
 }
 
 // ring / recycling group by order: <= 48: 64 / 16, <= 60: 64 / 4, else 128 / 16
-template <bool kVecShift>
+template <bool kVecShift, bool kOut32 = false>
 __device__ __forceinline__ void synthesize_by_order(uint32_t order, const uint32_t* words, uint32_t n_words, uint32_t k, uint16_t* pos_smp,
     const int32_t* ws, const uint64_t* tab, bool fold, int lane)
 {
     if (order <= 48)
-        synthesize<1, 16, kVecShift>(words, n_words, k, pos_smp, ws, tab, fold, lane);
+        synthesize<1, 16, kVecShift, kOut32>(words, n_words, k, pos_smp, ws, tab, fold, lane);
     else if (order <= 60)
-        synthesize<1, 4, kVecShift>(words, n_words, k, pos_smp, ws, tab, fold, lane);
+        synthesize<1, 4, kVecShift, kOut32>(words, n_words, k, pos_smp, ws, tab, fold, lane);
     else
-        synthesize<2, 16, kVecShift>(words, n_words, k, pos_smp, ws, tab, fold, lane);
+        synthesize<2, 16, kVecShift, kOut32>(words, n_words, k, pos_smp, ws, tab, fold, lane);
 }
 
 // The coefficients a[d] (0 for d = 0 and beyond `order`), packed {al, ah}, ring-periodic and doubled, written
@@ -1171,6 +1177,84 @@ inline uint32_t vec_shift_from_for(uint32_t n_frames, int n_waves, uint32_t resi
         return n_frames;
     const uint32_t last_round = n_frames / resident * resident; // first frame of the last, partial round
     return (uint64_t)(n_frames - last_round) * (uint32_t)n_waves <= kLonelyWaves ? last_round : n_frames;
+}
+
+// ---- the decoder's stages on their own (the reference's public L1 classes) -------------------------------------------------
+// lpc::SampleGenerator (src/include/lpc.hpp:106-117, src/lpc/sample_generator.cpp:11-39): order + quantised reflection
+// coefficients + 2048 residues -> 2048 samples, one wave per block, through the very dequantisation, step-up, table and
+// recurrence the frame kernels run (the residues come from memory as in the generic mode; the samples go out as the 32-bit
+// values the reference's class returns -- a difference signal needs 17 bits).
+__global__ __launch_bounds__(64) void k_stage_lpc_decode(const int32_t* __restrict__ order_in, const int32_t* __restrict__ q_in,
+    const int32_t* __restrict__ residues, uint32_t n_blocks, int32_t* __restrict__ samples_out, int64_t* __restrict__ coefs_out /* [block][101] or null */,
+    uint32_t* __restrict__ status)
+{
+    __shared__ DecWaveScratch scratch;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks)
+        return;
+    const int lane = threadIdx.x;
+    uint32_t flags = 0;
+    const int32_t o = order_in[b];
+    if (o < 0 || o > kMaxOrder) {
+        if (lane == 0)
+            atomicOr(&status[0], (uint32_t)SELA_HIP_FLAG_BAD_FRAME);
+        return;
+    }
+    const uint32_t order = (uint32_t)o;
+    const int32_t q_lo = (uint32_t)lane < order ? q_in[(size_t)b * kMaxOrder + lane] : 0;
+    const int32_t q_hi = (uint32_t)lane + 64 < order ? q_in[(size_t)b * kMaxOrder + lane + 64] : 0;
+    const double k_lo = (uint32_t)lane < order ? (order <= 1 ? 0.0 : dequant(lane, q_lo, flags)) : 0.0;
+    const double k_hi = (uint32_t)lane + 64 < order ? dequant(lane + 64, q_hi, flags) : 0.0;
+    SynthTables* const tables = &scratch.t;
+    step_up_regs(k_lo, k_hi, tables->a, (int)order, lane, flags);
+    if (coefs_out) // lpc::LinearPredictor::linearPredictionCoefficients (src/lpc/linear_predictor.cpp:57-60)
+        for (uint32_t i = lane; i <= order; i += kWave)
+            coefs_out[(size_t)b * (kMaxOrder + 1) + i] = tables->a[i];
+    if (samples_out) {
+        const bool fits24 = build_synth_table(tables->a, tables->tab, (int)order, lane);
+        synthesize_by_order<false, true>(order, nullptr, 0, 0, reinterpret_cast<uint16_t*>(samples_out + (size_t)b * kBlock), residues + (size_t)b * kBlock,
+            tables->tab, fits24, lane);
+    }
+    flags = wave_or(flags);
+    if (lane == 0 && flags)
+        atomicOr(&status[0], flags);
+}
+
+// rice::RiceDecoder (src/include/rice.hpp:29-43, src/rice/rice_decoder.cpp:11-61): one wave per stream, the serial parse of the
+// generic mode -- count the ones up to the first zero, read k bits MSB first -- for any number of values.
+__global__ __launch_bounds__(64) void k_stage_rice_decode(const uint32_t* __restrict__ words, const uint64_t* __restrict__ word_offsets,
+    const uint32_t* __restrict__ k_in, const uint64_t* __restrict__ value_offsets, uint32_t n_streams, int32_t* __restrict__ values_out,
+    uint32_t* __restrict__ status)
+{
+    const uint32_t s = blockIdx.x;
+    if (s >= n_streams)
+        return;
+    const int lane = threadIdx.x;
+    const uint64_t nw = word_offsets[s + 1] - word_offsets[s], count = value_offsets[s + 1] - value_offsets[s];
+    const uint32_t k = k_in[s];
+    uint32_t flags = 0;
+    if (k >= 32 || nw >= (1ull << 26) || count >= (1ull << 31))
+        flags = SELA_HIP_FLAG_BAD_FRAME;
+    else
+        flags = parse_stream_serial(words + word_offsets[s], 0, (uint32_t)(32 * nw), (uint32_t)nw, k, (uint32_t)count, values_out + value_offsets[s], lane);
+    if (lane == 0 && flags)
+        atomicOr(&status[0], flags);
+}
+
+hipError_t launch_stage_lpc_decode(const int32_t* d_order, const int32_t* d_q, const int32_t* d_residues, uint32_t n_blocks, int32_t* d_samples,
+    int64_t* d_coefs, uint32_t* d_status, hipStream_t stream)
+{
+    if (n_blocks)
+        hipLaunchKernelGGL(k_stage_lpc_decode, dim3(n_blocks), dim3(64), 0, stream, d_order, d_q, d_residues, n_blocks, d_samples, d_coefs, d_status);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_rice_decode(const uint32_t* d_words, const uint64_t* d_word_offsets, const uint32_t* d_k, const uint64_t* d_value_offsets,
+    uint32_t n_streams, int32_t* d_values, uint32_t* d_status, hipStream_t stream)
+{
+    if (n_streams)
+        hipLaunchKernelGGL(k_stage_rice_decode, dim3(n_streams), dim3(64), 0, stream, d_words, d_word_offsets, d_k, d_value_offsets, n_streams, d_values, d_status);
+    return hipGetLastError();
 }
 
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,

@@ -716,6 +716,7 @@ struct FuseArgs {
     const uint64_t* pcm_ready; // [n_frames]: launch ticket | checksum of every frame k_stage_in has copied in; or null (the PCM is there)
     uint64_t* groups_done;   // count_mark | groups finished, for the stagers (see the end of k_stage_in); or null
     uint32_t n_frames, channels, n_sig, ticket;
+    int32_t* trace_residues; // the trace build also stores every block's residues here ([block][2048]); or null (sela_hip_lpc_encode)
     uint32_t nap_limit;      // bound of a block's wait for its frame (await_frame)
     uint64_t tag;            // process nonce << 32 | ticket (see launch_encode): what marks a cell as written by THIS launch
 };
@@ -1375,7 +1376,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     {
         constexpr bool kAcInLds = true;
+#define SELA_TAIL_TRACE_RESIDUES fa.trace_residues
 #include "sela_encode_tail.inc"
+#undef SELA_TAIL_TRACE_RESIDUES
     }
     SELA_STAMP(12);
     // ---- host pipeline: count this block into its group; the group's last block places and writes the group's frames
@@ -2053,6 +2056,77 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_frames(const BlockMeta
     }
 }
 
+// ---- rice::RiceEncoder on its own (src/rice/rice_encoder.cpp:12-81): any number of int32 values per stream ------------------
+// The reference's public L1 class (src/include/rice.hpp:9-27); here one wave per stream, for callers and tests of the stage
+// itself (sela_hip_rice_encode) -- the frame path packs its residues inside k_encode_blocks / k_encode_teams.  All 20
+// candidates are summed (no walk: a stream may be a single value), the first minimum taken, requiredInts =
+// ceil((float)bits / 32) as the reference computes it, and the codewords are OR-ed into the caller's zeroed words.
+__global__ __launch_bounds__(64) void k_stage_rice_encode(const int32_t* __restrict__ values, const uint64_t* __restrict__ value_offsets,
+    uint32_t n_streams, uint32_t* __restrict__ k_out, uint32_t* __restrict__ word_counts, uint32_t* __restrict__ words_out,
+    const uint64_t* __restrict__ word_offsets, uint32_t* __restrict__ status)
+{
+    const uint32_t s = blockIdx.x;
+    if (s >= n_streams)
+        return;
+    const int lane = threadIdx.x;
+    const int32_t* v = values + value_offsets[s];
+    const uint64_t n = value_offsets[s + 1] - value_offsets[s];
+    uint32_t* out = words_out + word_offsets[s];
+    const uint64_t cap = word_offsets[s + 1] - word_offsets[s];
+    uint64_t sum[SELA_MAX_RICE_PARAM];
+#pragma unroll
+    for (int k = 0; k < SELA_MAX_RICE_PARAM; k++)
+        sum[k] = 0;
+    bool wide = false;
+    for (uint64_t i = lane; i < n; i += 64) {
+        const int32_t x = v[i];
+        wide |= (x >= (1 << 30)) || (x < -(1 << 30)); // (the reference's int32 zig-zag overflows: undefined there)
+        const uint32_t u = zigzag32(x);
+#pragma unroll
+        for (int k = 0; k < SELA_MAX_RICE_PARAM; k++)
+            sum[k] += u >> k;
+    }
+    uint32_t best_k = 0;
+    uint64_t best_bits = ~0ull;
+#pragma unroll
+    for (int k = 0; k < SELA_MAX_RICE_PARAM; k++) {
+        const uint64_t bits = wave_sum_u64(sum[k]) + n * (uint64_t)(1 + k);
+        if (bits < best_bits) // strict: the FIRST minimum (src/rice/rice_encoder.cpp:26-31)
+            best_bits = bits, best_k = (uint32_t)k;
+    }
+    uint32_t flags = __any(wide) ? (uint32_t)SELA_HIP_FLAG_RICE_RANGE : 0u;
+    const uint32_t words = best_bits < (1ull << 31) ? words_for_bits(best_bits) : 0xFFFFFFFFu;
+    if (words > cap)
+        flags |= SELA_HIP_FLAG_WORDS_CAP;
+    if (lane == 0) {
+        k_out[s] = best_k;
+        word_counts[s] = words;
+        if (flags)
+            atomicOr(&status[0], flags);
+    }
+    if (flags)
+        return;
+    uint32_t base = 0;
+    for (uint64_t i0 = 0; i0 < n; i0 += 64) {
+        const bool valid = i0 + lane < n;
+        const uint32_t u = valid ? zigzag32(v[i0 + lane]) : 0u;
+        const uint32_t len = valid ? (u >> best_k) + 1 + best_k : 0u;
+        const uint32_t before = wave_exclusive_scan(len, lane);
+        if (valid)
+            (void)put_codeword(out, base + before, u, best_k);
+        base += (uint32_t)__builtin_amdgcn_readlane((int)(before + len), 63);
+    }
+}
+
+hipError_t launch_stage_rice_encode(const int32_t* d_values, const uint64_t* d_value_offsets, uint32_t n_streams, uint32_t* d_k, uint32_t* d_word_counts,
+    uint32_t* d_words, const uint64_t* d_word_offsets, uint32_t* d_status, hipStream_t stream)
+{
+    if (n_streams)
+        hipLaunchKernelGGL(k_stage_rice_encode, dim3(n_streams), dim3(64), 0, stream, d_values, d_value_offsets, n_streams, d_k, d_word_counts, d_words,
+            d_word_offsets, d_status);
+    return hipGetLastError();
+}
+
 } // namespace sela
 
 // ---- host-side launchers (called from sela_capi.hip) ---------------------------------------------------
@@ -2118,7 +2192,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     size_t frames_cap, uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace,
     hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles,
     const EncodeHostLink* link /* the host pipeline's one-launch form; nullptr: three kernels */,
-    int force_plain_fir, int self_blocks_override, int team_lanes /* -1: by launch size; 0: k_encode_blocks; 8, 16: k_encode_teams<P> */)
+    int force_plain_fir, int self_blocks_override, int team_lanes /* -1: by launch size; 0: k_encode_blocks; 8, 16: k_encode_teams<P> */,
+    int32_t* d_trace_residues /* with d_trace and team_lanes 0: every block's residues, [block][2048]; or nullptr */)
 {
     const uint32_t n_sig = sela_hip_signals_per_frame(channels);
     const size_t blocks = (size_t)n_frames * n_sig;
@@ -2206,6 +2281,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
             const_cast<int16_t*>(d_pcm), n_frames, link->pcm_ready, ticket, link->stage_started, ((uint64_t)nonce << 32) | ticket, (uint32_t)n_groups);
         hipLaunchKernelGGL(k_stage_gate, dim3(1), dim3(64), 0, stream, link->stage_started, ticket, link->stage_workgroups, ((uint64_t)nonce << 32) | ticket);
     }
+    fa.trace_residues = d_trace_residues;
     fa.nap_limit = link && link->wait_naps >= 0 ? (uint32_t)link->wait_naps : kFuseNapLimit;
     fa.n_frames = n_frames;
     fa.channels = channels;
@@ -2217,6 +2293,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     // Which kernel analyses the blocks: k_encode_teams (several blocks side by side in a wave: fewer instructions per block,
     // but a wave is B blocks' worth of work) for launches that fill the device several times over, k_encode_blocks otherwise
     // and for the host pipeline's one-launch form.
+    if (d_trace_residues && (!d_trace || team_lanes != 0))
+        return hipErrorInvalidValue;
     int teams = 0;
     if (!link) {
         teams = team_lanes >= 0 ? team_lanes : (d_phase_cycles ? 0 : team_lanes_for(blocks));

@@ -317,3 +317,93 @@ def test_bench_with_eight_ranks_sharing_the_gpu():
     assert line["album"]["roundtrip_lossy_frames"] == 39  # (the reference's own lossy frames on the album, summed over the ranks)
     assert line["decode10k"]["config"]["frames_rank0"] == 1250 and line["decode10k"]["bit_exact_vs_cpu_decode"] is True
     assert line["decode10k"]["per_rank_share_8"] is None  # (the one-GPU line's prediction; an 8-rank line IS the thing)
+
+
+# ---- the stages on their own: the reference's L1 classes on the device (sela_hip_lpc_* / sela_hip_rice_*) -------------------
+def test_rice_stage_on_the_known_answers(gpu, kats):  # noqa: F811
+    """rice::RiceEncoder / RiceDecoder by themselves (the reference's test/ricetests.cpp:7-25 calls them directly): the
+    reference's parameter and words for every Rice KAT of tests/golden/kats.npz -- a single value, runs of ones longer than a
+    word, values near 2^20 -- in ONE batched call each way, and the values back."""
+    from sela_amd import codec
+
+    names = [str(n) for n in kats["rice_names"]]
+    values = [kats[f"rice/{n}/values"] for n in names]
+    got = codec.rice_encode(values)
+    for n, (k, words) in zip(names, got):
+        assert k == int(kats[f"rice/{n}/k"]), n
+        assert np.array_equal(words, kats[f"rice/{n}/words"]), n
+    back = codec.rice_decode([(k, w, len(v)) for (k, w), v in zip(got, values)])
+    for n, v, b in zip(names, values, back):
+        assert np.array_equal(b, v), n
+
+
+def test_rice_stage_against_the_oracle_on_random_streams(gpu):  # noqa: F811
+    """Streams of 1 .. 5000 values of every magnitude up to 2^29, empty streams among them, against the oracle's coder."""
+    from sela_amd import capi, codec
+
+    o = oracle()
+    rng = np.random.default_rng(5)
+    streams = [np.zeros(0, np.int32)]
+    for i in range(60):
+        n = int(rng.integers(1, 5000)) if i % 7 else int(rng.integers(1, 4))
+        scale = int(rng.integers(1, 30))
+        streams.append(rng.integers(-(1 << scale), 1 << scale, n).astype(np.int32))
+    got = codec.rice_encode(streams)
+    for v, (k, words) in zip(streams, got):
+        if len(v) == 0:
+            continue
+        rk, rw = o.rice_encode(v)
+        assert k == rk and np.array_equal(words, rw), (len(v), int(np.abs(v).max()))
+    back = codec.rice_decode([(k, w, len(v)) for (k, w), v in zip(got, streams)])
+    for v, b in zip(streams, back):
+        assert np.array_equal(b, v)
+    with pytest.raises(capi.SelaHipError) as e:  # the reference's int32 zig-zag overflows: flagged, not wrapped
+        codec.rice_encode([np.array([1 << 30], np.int32)])
+    assert e.value.code == -6
+    with pytest.raises(capi.SelaHipError) as e:  # a stream that ends before its values do
+        codec.rice_decode([(3, np.array([0xFFFFFFFF], np.uint32), 5)])
+    assert e.value.code == -5
+
+
+def test_lpc_stage_on_the_known_answers(gpu, kats):  # noqa: F811
+    """lpc::ResidueGenerator / SampleGenerator / LinearPredictor by themselves (test/lpctests.cpp:10-32): order, quantised
+    coefficients, Q35 predictor and residues of every block KAT -- the 17-bit difference signal included -- and the samples
+    back from them, in one batched call each way."""
+    from sela_amd import codec
+
+    names = [str(n) for n in kats["blk_names"]]
+    samples = np.stack([kats[f"blk/{n}/samples"] for n in names]).astype(np.int32)
+    order, q, residues = codec.lpc_encode(samples)
+    for i, n in enumerate(names):
+        assert order[i] == int(kats[f"blk/{n}/order"]), n
+        assert np.array_equal(q[i, : order[i]], kats[f"blk/{n}/q"]), n
+        assert np.array_equal(residues[i], kats[f"blk/{n}/residues"]), n
+    back, coefs = codec.lpc_decode(order, q, residues, want_coefficients=True)
+    o = oracle()
+    for i, n in enumerate(names):
+        assert np.array_equal(coefs[i, : order[i] + 1], kats[f"blk/{n}/a"]), n
+        ref = o.lpc_synth(int(order[i]), q[i, : order[i]], residues[i]) if hasattr(o, "lpc_synth") else None
+        if ref is not None:
+            assert np.array_equal(back[i], ref), n  # (the reference's own decoder: off by one where ITS rounding differs from its encoder's)
+        else:
+            assert np.array_equal(back[i], samples[i]), n
+
+
+def test_lpc_stage_against_the_oracle_on_random_blocks(gpu):  # noqa: F811
+    """64 blocks of the synthetic album's left, right and difference signals through the stage entries against the oracle's
+    analysis and synthesis; samples beyond a 16-bit difference are refused."""
+    from sela_amd import capi, codec
+
+    o = oracle()
+    pcm = synth_frames(22, 2, 8).astype(np.int32)
+    blocks = np.concatenate([pcm[:, :, 0], pcm[:, :, 1], pcm[:, :, 0] - pcm[:, :, 1]])[:64]
+    order, q, residues = codec.lpc_encode(blocks)
+    for i in range(len(blocks)):
+        ro, rq, rr, ra, _, _ = o.lpc_analyze(blocks[i], with_trace=True)
+        assert order[i] == ro and np.array_equal(q[i, :ro], rq) and np.array_equal(residues[i], rr), i
+    back = codec.lpc_decode(order, q, residues)
+    for i in range(len(blocks)):
+        assert np.array_equal(back[i], o.lpc_synth(int(order[i]), q[i, : order[i]], residues[i])), i
+    with pytest.raises(capi.SelaHipError) as e:
+        codec.lpc_encode(np.full((1, 2048), 70000, np.int32))
+    assert e.value.code == -2
