@@ -304,6 +304,9 @@ class Bench:
         self.lib = capi.lib()  # raises if the HIP library is missing: there is no CPU fallback
         self.lib.sela_hip_debug_encode_teams(getattr(args, "encode_teams", -1))
         self.lib.sela_hip_debug_encode_fused(1 if getattr(args, "encode_fused", False) else 0)
+        if getattr(args, "priorities", None):
+            q, d = args.priorities.split(":")
+            self.lib.sela_hip_debug_priorities(int(q, 16), int(d))
         self.exchange = torch.cuda.Stream() if self.dist is not None else None
         self.n_lanes = max(1, args.lanes)
         self.lanes_forced = "--lanes" in sys.argv
@@ -881,6 +884,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight: independent encode->decode chains on their own HIP streams")
     ap.add_argument("--encode-teams", type=int, default=-1, choices=[-1, 0, 8, 16],
                     help="experiments only: force the encoder's block kernel (0: k_encode_blocks, 8 / 16: k_encode_teams); -1: the library's own choice by launch size")
+    ap.add_argument("--priorities", type=str, default=None,
+                    help="experiments only: 'QQQQQQQQ:D' = the team kernel's quarter priorities (hex, e.g. 00010203) and the decoder's priority")
     ap.add_argument("--encode-fused", action="store_true",
                     help="experiments only: the encoder's one-launch form (the host pipeline's) on device pointers, no plan / assemble kernels")
     args = ap.parse_args()

@@ -61,6 +61,17 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// s_setprio with a run-time level (the instruction takes an immediate)
+__device__ __forceinline__ void set_wave_priority(int level)
+{
+    switch (level & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 // ---- cross-lane moves (DPP on the GFX9 family: the shift crosses all four rows) ----------------
 // lane l <- lane l+1 ; lane 63 receives `fill`.
 __device__ __forceinline__ int wave_shl1(int fill, int v)

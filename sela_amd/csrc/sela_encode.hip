@@ -1599,6 +1599,10 @@ __device__ __forceinline__ void team_ac_steps(double (&W)[kTeamWin], double (&M)
         team_ac_steps<G, R0 + 1>(W, M, acc, addr_w, addr_m);
 }
 
+// The priorities (s_setprio) of a wave of k_encode_teams in the four quarters of its work, one byte each from the low end;
+// sela_hip_debug_priorities sets them (device-wide, measurements).  Default: none -- see the note at the autocorrelation's loop.
+__device__ uint32_t g_team_priorities = 0;
+
 template <int kMode, int P>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_teams(
     const int16_t* __restrict__ pcm, uint32_t n_frames, uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta,
@@ -1614,16 +1618,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     const int lane0 = threadIdx.x;
     const int b = lane0 / P, p = lane0 % P;
-    // Which blocks: signal `sig` of B consecutive frames.  Workgroups that are equal mod 8 share an XCD (as observed; for
-    // speed only): the n_sig waves that take the signals of the same frames are 8 workgroups apart, so a frame's PCM comes
-    // into one L2.
+    // Which blocks: signal `sig` of B frames.  Workgroups that are equal mod 8 share an XCD (as observed; for speed only):
+    // the n_sig waves that take the signals of the same frames are 8 workgroups apart, so a frame's PCM comes into one L2.
+    // The B frames of a wave lie a B-th of the batch APART (frame0, frame0 + stride, ...): what a block costs behind its
+    // analysis goes with its order (a residue filter of 17 taps or of 100), consecutive frames of a track have like orders,
+    // and a launch that fills the device about once ends with its slowest wave -- four or eight blocks from different
+    // places of the batch add up to nearly the same everywhere (waves of 0.51 .. 0.97 M cycles with consecutive frames,
+    // tools/ramp_profile.py).
     const uint32_t wq = blockIdx.x % 8, wv = blockIdx.x / 8;
     const uint32_t sig = wv % n_sig;
-    const uint32_t frame0 = ((wv / n_sig) * 8 + wq) * B;
+    const uint32_t frame0 = (wv / n_sig) * 8 + wq;
+    const uint32_t frame_stride = ((n_frames + B - 1) / B + 7) / 8 * 8; // (= the launch's waves per signal)
     if (frame0 >= n_frames)
         return;
-    const bool team_live = frame0 + (uint32_t)b < n_frames;
-    const uint32_t my_frame = team_live ? frame0 + (uint32_t)b : n_frames - 1; // (a team beyond the last frame shadows it and writes nothing)
+    const bool team_live = frame0 + (uint32_t)b * frame_stride < n_frames;
+    const uint32_t my_frame = team_live ? frame0 + (uint32_t)b * frame_stride : frame0; // (a team beyond the last frame shadows the wave's first and writes nothing)
     const int16_t* const fp = pcm + (size_t)my_frame * kBlock * channels;
     double* const ring_b = reinterpret_cast<double*>(lds) + b * Plan::kStride;
     // The team's reflection coefficients go to the dead rings (LDS), are quantised there block by block right behind the
@@ -1647,7 +1656,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         team_load_raw<kMeanPer>(fp, channels, sig, kTeamMeanChunk + mine, raw_a);
         team_load_raw<kMeanPer>(fp, channels, sig, 2 * kTeamMeanChunk + mine, raw_b);
         double sum = 0.0;
-        __builtin_amdgcn_s_setprio(2); // (a dependency chain: ahead of the co-resident waves' throughput-bound phases)
+        const uint32_t quarter_priorities = g_team_priorities;
+        set_wave_priority((int)(quarter_priorities & 0xFF)); // (see the note on priorities at the autocorrelation's loop)
 #pragma unroll 1
         for (int c = 0; c < kChunks; c++) {
             // chunk c + 1 -> the place chunk c - 1 was summed from, chunk c is summed from the other one
@@ -1663,7 +1673,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             sum = team_chain<kTeamMeanChunk>(ring_b + here, sum);
             wave_sync();
         }
-        __builtin_amdgcn_s_setprio(0);
         mean = sum / (double)kBlock;
     }
     if (kMode == 2)
@@ -1719,8 +1728,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             pos_stage += kChunk;
             pos_stage = pos_stage >= (uint32_t)kRing ? 0u : pos_stage;
         };
+        // Priorities (g_team_priorities; off by default).  The SIMD's arbiter serves the OLDEST of its waves first, at equal
+        // priority: of three waves that start together, the first keeps nearly the whole SIMD to itself, finishes after 0.51 M
+        // cycles and leaves the last one to walk its second half alone, at a lone wave's issue rate, until 0.96 M
+        // (tools/ramp_profile.py: a launch that fills the device once takes as long as that last wave).  With a priority that
+        // FALLS with a wave's progress (3, 2, 1, 0 by quarters: whoever is ahead yields) the waves of a SIMD finish together,
+        // 0.65 .. 0.86 M cycles, and a 3875-frame launch ON ITS OWN takes 0.396 ms instead of 0.427 (12.25 G samples/s
+        // strictly serial instead of 11.65) -- but beside another stream's kernels, which is how throughput is had, the same
+        // priorities starve the other kernel's waves: 14.97 G samples/s with two batches in flight against 15.71 without
+        // (raising the decoder's priority as well: 15.26; milder schedules: 15.3 .. 15.6).  Off.
+        constexpr int kPrio2From = (int)(0.27 * kChunks), kPrio1From = (int)(0.71 * kChunks);
 #pragma unroll 1
         for (int c = 0; c < kChunks; c++) { // (the PCM of a chunk is fetched two chunks ahead)
+            if (c == kPrio2From)
+                set_wave_priority((int)((g_team_priorities >> 8) & 0xFF));
+            if (c == kPrio1From)
+                set_wave_priority((int)((g_team_priorities >> 16) & 0xFF));
             if (c + 1 < kChunks)
                 stage_next(raw_a); // chunk c + 1
 #pragma unroll
@@ -1759,7 +1782,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // lane's last column the first register of the next lane.  Columns beyond 99 hold zeros (and what leaks in from the
     // next team's first column); stage i only uses columns below 100 - i, and what is wrong moves down one column per
     // stage from column G P - 1 >= 103: it never gets there.
-    __builtin_amdgcn_s_setprio(2); // latency-bound (100 dependent stages, one division each)
     {
         double g0[G], g1[G];
         const double next_first = wave_shl1_zero(acc[0]); // ac[G (p + 1)]
@@ -1791,7 +1813,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 k_b[i] = ki;
         }
     }
-    __builtin_amdgcn_s_setprio(0);
     wave_sync();
     if (kMode == 2)
         wave_stamp[3] = clock64();
@@ -1804,9 +1825,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     int8_t* const q_all = reinterpret_cast<int8_t*>(lds + Plan::kQBase);
 #pragma unroll 1
     for (int bb = 0; bb < B; bb++) {
-        const uint32_t frame = frame0 + (uint32_t)bb;
+        const uint32_t frame = frame0 + (uint32_t)bb * frame_stride;
         if (frame >= n_frames)
-            break;
+            break; // (the frames of a wave ascend)
         int lane_now = lane0;
         asm volatile("" : "+v"(lane_now));
         const int lane = lane_now;
@@ -1860,9 +1881,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     long long stamp[14];
 #pragma unroll 1
     for (int bb = 0; bb < B; bb++) {
-        const uint32_t frame = frame0 + (uint32_t)bb;
+        const uint32_t frame = frame0 + (uint32_t)bb * frame_stride;
         if (frame >= n_frames)
-            break;
+            break; // (the frames of a wave ascend)
         // (the lane number as this round of the loop must see it: left visibly loop-invariant, the compiler computes every
         // address the tail derives from it -- some three hundred values -- once in front of the loop and keeps or spills
         // them through the analysis above: 256 VGPRs and 22 spilled instead of fitting the budget)
@@ -1870,6 +1891,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         asm volatile("" : "+v"(lane_now));
         const int lane = lane_now;
         const uint32_t block_id = frame * n_sig + sig;
+        if (4 * (bb + 1) > B) // (the last three quarters of the tails: the wave is through most of its work -- lowest priority)
+            set_wave_priority((int)((g_team_priorities >> 24) & 0xFF));
         const int8_t* const q_mine = q_all + bb * Plan::kQStride;
         const int order = (uint8_t)q_mine[100];
         int32_t q_lo = q_mine[lane], q_hi = lane < kMaxOrder - 64 ? q_mine[64 + lane] : 0;
@@ -1916,6 +1939,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for (int i = 5; i < 12; i++)
                 row[i] = (uint64_t)(stamp[i + 1] - stamp[i]);
             row[12] = (uint64_t)(now - wave_stamp[3]); // since the end of the analysis: the tails of the blocks before this one included
+            row[13] = (uint64_t)wave_stamp[0];         // absolute: when the wave started ...
+            row[14] = (uint64_t)now;                   // ... and when this block was done (tools/phase_profile.py: the launch's ramp)
         }
     }
 }
@@ -2182,6 +2207,8 @@ static int team_lanes_for(size_t blocks)
         return 0;
     return blocks < 36000 ? 16 : 8;
 }
+
+hipError_t set_team_priorities(uint32_t quarters) { return hipMemcpyToSymbol(HIP_SYMBOL(g_team_priorities), &quarters, sizeof(quarters)); }
 
 int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced)
 {
