@@ -305,8 +305,7 @@ class Bench:
         self.lib.sela_hip_debug_encode_teams(getattr(args, "encode_teams", -1))
         self.lib.sela_hip_debug_encode_fused(1 if getattr(args, "encode_fused", False) else 0)
         if getattr(args, "priorities", None):
-            q, d = args.priorities.split(":")
-            self.lib.sela_hip_debug_priorities(int(q, 16), int(d))
+            self.lib.sela_hip_debug_priorities(int(args.priorities.split(":")[0], 16))
         self.exchange = torch.cuda.Stream() if self.dist is not None else None
         self.n_lanes = max(1, args.lanes)
         self.lanes_forced = "--lanes" in sys.argv
@@ -885,7 +884,7 @@ def main():
     ap.add_argument("--encode-teams", type=int, default=-1, choices=[-1, 0, 8, 16],
                     help="experiments only: force the encoder's block kernel (0: k_encode_blocks, 8 / 16: k_encode_teams); -1: the library's own choice by launch size")
     ap.add_argument("--priorities", type=str, default=None,
-                    help="experiments only: 'QQQQQQQQ:D' = the team kernel's quarter priorities (hex, e.g. 00010203) and the decoder's priority")
+                    help="experiments only: the team kernel's wave priorities by quarters of a wave's work (hex, e.g. 00010203: falling from 3 to 0)")
     ap.add_argument("--encode-fused", action="store_true",
                     help="experiments only: the encoder's one-launch form (the host pipeline's) on device pointers, no plan / assemble kernels")
     args = ap.parse_args()

@@ -39,8 +39,8 @@ int sela_hip_debug_encode_kernel(uint32_t n_frames, uint32_t channels);
  * beside the default. */
 void sela_hip_debug_encode_fused(int enable);
 /* Debug hook (measurements only; device-wide): the wave priorities (s_setprio 0..3) of k_encode_teams' waves in the four quarters
- * of their work, one byte each from the low end, and the priority k_decode_frames' waves run at. */
-void sela_hip_debug_priorities(uint32_t team_quarters, uint32_t decode_level);
+ * of their work, one byte each from the low end (0x00010203: falling from 3 to 0; default 0: none -- DESIGN.md section 9). */
+void sela_hip_debug_priorities(uint32_t team_quarters);
 /* Debug hook: bound of an encode block's wait for its frame from the staging kernel, in naps of 2048 cycles; 0: every
  * block gives up without looking ("the stagers never showed up"), which flags the launch and sends the feed through
  * the copy-engine path again; -1 restores the default (~0.5 s). */

@@ -118,7 +118,7 @@ def lib() -> C.CDLL:
     L.sela_hip_debug_encode_teams.restype = None
     L.sela_hip_debug_encode_fused.argtypes = [C.c_int]
     L.sela_hip_debug_encode_fused.restype = None
-    L.sela_hip_debug_priorities.argtypes = [C.c_uint32, C.c_uint32]
+    L.sela_hip_debug_priorities.argtypes = [C.c_uint32]
     L.sela_hip_debug_priorities.restype = None
     L.sela_hip_debug_encode_kernel.argtypes = [C.c_uint32, C.c_uint32]
     L.sela_hip_debug_encode_kernel.restype = C.c_int

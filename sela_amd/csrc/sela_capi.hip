@@ -27,7 +27,6 @@ namespace sela {
 size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced);
 hipError_t set_team_priorities(uint32_t quarters);
-hipError_t set_decode_priority(uint32_t level);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
     hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override, int team_lanes,
@@ -1067,11 +1066,7 @@ void sela_hip_debug_force_plain_fir(int enable) { g_force_plain_fir = enable != 
 void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks; }
 void sela_hip_debug_encode_teams(int lanes) { g_team_lanes = lanes; }
 void sela_hip_debug_encode_fused(int enable) { g_fused_device = enable != 0; }
-void sela_hip_debug_priorities(uint32_t team_quarters, uint32_t decode_level)
-{
-    (void)sela::set_team_priorities(team_quarters);
-    (void)sela::set_decode_priority(decode_level);
-}
+void sela_hip_debug_priorities(uint32_t team_quarters) { (void)sela::set_team_priorities(team_quarters); }
 int sela_hip_debug_encode_kernel(uint32_t n_frames, uint32_t channels) { return sela::encode_team_lanes(n_frames, channels, g_team_lanes); }
 
 void sela_hip_debug_stage_wait(int naps) { g_stage_wait_naps = naps; }

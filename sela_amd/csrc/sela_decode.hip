@@ -781,9 +781,6 @@ __host__ __device__ inline size_t decode_lds_bytes_for(uint32_t channels, int n_
     return (size_t)channels * sizeof(DecSubframeLds) + (size_t)n_waves * sizeof(DecWaveScratch) + (size_t)channels * 4 + (size_t)n_waves * 4;
 }
 
-// (experiment: the priority the decoder's waves run at; sela_hip_debug_priorities)
-__device__ uint32_t g_decode_priority = 0;
-
 // kProf: also write per-phase cycle counts (debug hook sela_hip_debug_phase_buffer; 16 uint64 per subframe).
 template <bool kProf>
 __global__ __launch_bounds__(kDecMaxWaves * 64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_decode_frames(const uint8_t* __restrict__ frames,
@@ -795,7 +792,6 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) __attribute__((amdgpu_waves_per_
     long long stamp[10];
     for (int i = 0; i < 10; i++)
         stamp[i] = 0;
-    set_wave_priority((int)g_decode_priority);
     uint32_t prof_sub = 0xFFFFFFFFu;
     if (kProf)
         stamp[0] = clock64();
@@ -1244,8 +1240,6 @@ __global__ __launch_bounds__(64) void k_stage_rice_decode(const uint32_t* __rest
     if (lane == 0 && flags)
         atomicOr(&status[0], flags);
 }
-
-hipError_t set_decode_priority(uint32_t level) { return hipMemcpyToSymbol(HIP_SYMBOL(g_decode_priority), &level, sizeof(level)); }
 
 hipError_t launch_stage_lpc_decode(const int32_t* d_order, const int32_t* d_q, const int32_t* d_residues, uint32_t n_blocks, int32_t* d_samples,
     int64_t* d_coefs, uint32_t* d_status, hipStream_t stream)

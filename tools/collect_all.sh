@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/collect_all.sh <round-tag>  (run ON THE GPU BOX through gpurun): everything profiles/<tag>/ holds.
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -9,8 +9,18 @@ bash tools/collect_profiles.sh "$TAG" > "$OUT/collect.log" 2>&1
 bash tools/valu_counters.sh > "$OUT/valu_counters.txt" 2>&1
 bash tools/timeline.sh > "$OUT/timeline.txt" 2>&1
 LANES=2 bash tools/timeline.sh > "$OUT/timeline_two_lanes.txt" 2>&1
-python tools/phase_profile.py > "$OUT/phase_cycles.txt" 2>&1
-python tools/phase_profile.py 1000 > "$OUT/phase_cycles_1000_frames.txt" 2>&1
+python tools/phase_profile.py 2>&1 | grep -v amdgpu.ids > "$OUT/phase_cycles.txt"
+python tools/phase_profile.py 1000 2>&1 | grep -v amdgpu.ids > "$OUT/phase_cycles_1000_frames.txt"
+# round 4: k_encode_teams against k_encode_blocks (kernel and wall time by batch size, the kernels forced), the teams' phases,
+# when the waves of a launch start and end, and the instruction counters of the three block kernels at 10,000 frames
+python tools/teams_sweep.py 500 1000 2000 3000 3875 6000 10000 20000 40000 2>&1 | grep -v amdgpu.ids > "$OUT/teams_sweep.txt"
+for T in 16 8; do python tools/phase_profile.py 3875 $T 2>&1 | grep -v amdgpu.ids | sed -n "/^k_encode_teams/,/store slot/p"; done > "$OUT/phase_cycles_teams.txt"
+for T in 16 8; do echo "teams of $T, 3875 frames:"; python tools/ramp_profile.py 3875 $T 2>&1 | grep -v amdgpu.ids; done > "$OUT/ramp_teams.txt"
+bash tools/teams_counters.sh 10000 2>&1 | grep -v amdgpu.ids > "$OUT/teams_counters_10000_frames.txt"
+# what the block kernel, the lanes and the wave priorities do to the headline (experiments; the first line is the default)
+for CFG in "" "--lanes 1" "--encode-teams 0" "--encode-teams 8" "--encode-teams 8 --lanes 4" "--encode-fused" "--encode-fused --lanes 1" "--encode-teams 0 --lanes 1" "--priorities 00010203" "--priorities 00010203 --lanes 1"; do
+  python bench.py --no-cpu-baseline --no-host-legs --no-extra-legs $CFG 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print('bench.py %-40s %6.0f M samples/s  %.4f ms/step  one lane %6.0f  kernels %s' % ('$CFG', d['value'], d['ms_per_step'], d['lanes']['value_one_lane'], {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d['kernel_ms'].items()}))"
+done > "$OUT/headline_variants.txt" 2>&1
 SELA_SWEEP_HOST=0 python tools/sweep.py > "$OUT/sweep.txt" 2>&1
 # the decoder's two forms of the recurrence step against the batch size, and the instruction-level chain walk behind them
 python tools/decode_forms.py 2>&1 | grep -v amdgpu.ids > "$OUT/decode_forms.txt"
