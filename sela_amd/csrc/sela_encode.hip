@@ -1074,6 +1074,10 @@ __device__ __attribute__((noinline)) void finish_group(const FuseArgs& fa, uint3
             stamp[n] = clock64();     \
     } while (0)
 
+// The priorities (s_setprio) of a wave of k_encode_teams in the four quarters of its work, one byte each from the low end;
+// sela_hip_debug_priorities sets them (device-wide, measurements).  Default: none -- see the note at the autocorrelation's loop.
+__device__ uint32_t g_team_priorities = 0;
+
 // kFused: the host pipeline's one-launch form (await_frame, finish_group); compiled out of the device-pointer path's kernel
 template <int kMode, bool kFused>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_blocks(const int16_t* __restrict__ pcm, uint32_t n_frames,
@@ -1274,8 +1278,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // once the registers it overwrites are dead.  (The last fetch of the block lands behind the
         // ring's half B and in LDS behind the parity arrays; it is never used.)
         constexpr int kSwitch = kBlock / 2 / kRingHalf; // chunk at which the second half of c[] takes over
+        // (the hook of k_encode_teams' note on priorities, for a launch of at most one fill of this kernel: 2 and 1 through the
+        // autocorrelation, 1 through the Schur recursion, 0 behind it.  1000 frames on their own: 0.158 -> 0.148 ms; off by default
+        // for the same reason -- beside another stream's kernels it costs what it gains here)
+        const bool falling = n_workers == 0 && g_team_priorities != 0;
 #pragma unroll 1
         for (int k = 0; k < kBlock / kRingHalf; k++) {
+            if (falling && k == 0)
+                __builtin_amdgcn_s_setprio(2);
+            if (falling && k == kSwitch)
+                __builtin_amdgcn_s_setprio(1);
             if (k == kSwitch) {
                 // steps 0 .. 1023 are done, the window fetch in flight was issued from the first half
                 // (LDS serves a wave's reads and writes in order): recompute c[896 ..] over it
@@ -1331,7 +1343,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // Column j of gen[0]/gen[1] lives in lane j (j < 64) and lane j - 64 of a second register.
     // Stage i reads gen1[j+1] (old) -> a one-lane shift; all columns update from old values.
     double k_lo = 0.0, k_hi = 0.0; // k[lane], k[lane + 64]
-    __builtin_amdgcn_s_setprio(2); // latency-bound (100 dependent stages, one division each)
+    if (n_workers == 0 && g_team_priorities != 0)
+        __builtin_amdgcn_s_setprio(1);
+    else
+        __builtin_amdgcn_s_setprio(2); // latency-bound (100 dependent stages, one division each)
     {
         double g0a = sm->ac[lane + 1], g1a = g0a;
         double g0b = lane < 36 ? sm->ac[lane + 65] : 0.0, g1b = g0b;
@@ -1598,10 +1613,6 @@ __device__ __forceinline__ void team_ac_steps(double (&W)[kTeamWin], double (&M)
     if constexpr (R0 < kTeamWin - 1)
         team_ac_steps<G, R0 + 1>(W, M, acc, addr_w, addr_m);
 }
-
-// The priorities (s_setprio) of a wave of k_encode_teams in the four quarters of its work, one byte each from the low end;
-// sela_hip_debug_priorities sets them (device-wide, measurements).  Default: none -- see the note at the autocorrelation's loop.
-__device__ uint32_t g_team_priorities = 0;
 
 template <int kMode, int P>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_teams(
