@@ -1629,17 +1629,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     const int lane0 = threadIdx.x;
     const int b = lane0 / P, p = lane0 % P;
-    // Which blocks: signal `sig` of B frames.  Workgroups that are equal mod 8 share an XCD (as observed; for speed only):
-    // the n_sig waves that take the signals of the same frames are 8 workgroups apart, so a frame's PCM comes into one L2.
-    // The B frames of a wave lie a B-th of the batch APART (frame0, frame0 + stride, ...): what a block costs behind its
-    // analysis goes with its order (a residue filter of 17 taps or of 100), consecutive frames of a track have like orders,
-    // and a launch that fills the device about once ends with its slowest wave -- four or eight blocks from different
-    // places of the batch add up to nearly the same everywhere (waves of 0.51 .. 0.97 M cycles with consecutive frames,
-    // tools/ramp_profile.py).
+    // Which blocks: signal `sig` of B consecutive frames.  Workgroups that are equal mod 8 share an XCD (as observed; for
+    // speed only): the n_sig waves that take the signals of the same frames are 8 workgroups apart, so a frame's PCM comes
+    // into one L2.  (A wave's frames a B-th of the batch apart instead -- so that no wave gets B blocks of one passage, all
+    // with long predictors -- changed nothing: the waves of a launch do differ by a factor of two in duration, 0.51 .. 0.97 M
+    // cycles at 3875 frames, but that is the arbiter's doing, see the note on priorities below.)
     const uint32_t wq = blockIdx.x % 8, wv = blockIdx.x / 8;
     const uint32_t sig = wv % n_sig;
-    const uint32_t frame0 = (wv / n_sig) * 8 + wq;
-    const uint32_t frame_stride = ((n_frames + B - 1) / B + 7) / 8 * 8; // (= the launch's waves per signal)
+    const uint32_t frame0 = ((wv / n_sig) * 8 + wq) * B;
+    constexpr uint32_t frame_stride = 1;
     if (frame0 >= n_frames)
         return;
     const bool team_live = frame0 + (uint32_t)b * frame_stride < n_frames;
@@ -2204,19 +2202,21 @@ static uint32_t resident_encode_blocks()
 
 
 // Lanes per team (k_encode_teams) for a launch of `blocks` blocks; 0: k_encode_blocks.
-// Measured on MI355X (tools/teams_sweep.py, stereo; kernel time of the block kernel, ms):
+// Measured on MI355X (tools/teams_sweep.py, profiles/r04/teams_sweep.txt: stereo, kernel time of the block kernel, ms):
 //   frames   k_encode_blocks   teams of 16   teams of 8
-//     2000        0.264           0.319         0.419
-//     3875        0.448           0.430         0.549
-//    10000        0.948           0.913         0.937
-//    40000        3.64            3.32          3.07
-// A wave of k_encode_teams is 4 / 8 blocks' worth of work (~0.1 / ~0.2 ms): below one fill of the device it only adds
-// latency.  With two batches in flight (bench.py) teams of 16 give 15.7 G samples/s at 3875 frames against 14.5.
+//     2000        0.273           0.315         0.415
+//     3000        0.367           0.404         0.534
+//     3875        0.455           0.411         0.554
+//    10000        0.975           0.903         0.923
+//    20000        2.00            1.68          1.68
+//    40000        3.74            3.30          3.09
+// A wave of k_encode_teams is 4 / 8 blocks' worth of work (~0.1 / ~0.2 ms on its own): below one fill of the device it only
+// adds latency.  With two batches in flight (bench.py) teams of 16 give 15.9 G samples/s at 3875 frames against 14.4.
 static int team_lanes_for(size_t blocks)
 {
-    if (blocks < 9000)
+    if (blocks < 10500)
         return 0;
-    return blocks < 36000 ? 16 : 8;
+    return blocks < 60000 ? 16 : 8;
 }
 
 hipError_t set_team_priorities(uint32_t quarters) { return hipMemcpyToSymbol(HIP_SYMBOL(g_team_priorities), &quarters, sizeof(quarters)); }

@@ -151,14 +151,14 @@ def test_team_kernels_hostile_audio(gpu, teams):  # noqa: F811
 
 
 def test_the_library_picks_a_team_kernel_by_launch_size(gpu):  # noqa: F811
-    """launch_encode's choice (team_lanes_for): k_encode_blocks below 3000 stereo frames, teams of 16 up to 12,000, teams of 8
+    """launch_encode's choice (team_lanes_for): k_encode_blocks below 3500 stereo frames, teams of 16 up to 20,000, teams of 8
     beyond; the hook overrides it; mono counts blocks, not frames."""
     from sela_amd import capi
 
     lib = capi.lib()
     lib.sela_hip_debug_encode_teams(-1)
-    assert [lib.sela_hip_debug_encode_kernel(n, 2) for n in (1, 1000, 2999, 3000, 3875, 11999, 12000, 61000)] == [0, 0, 0, 16, 16, 16, 8, 8]
-    assert [lib.sela_hip_debug_encode_kernel(n, 1) for n in (8999, 9000, 36000)] == [0, 16, 8]
+    assert [lib.sela_hip_debug_encode_kernel(n, 2) for n in (1, 1000, 3499, 3500, 3875, 19999, 20000, 61000)] == [0, 0, 0, 16, 16, 16, 8, 8]
+    assert [lib.sela_hip_debug_encode_kernel(n, 1) for n in (10499, 10500, 60000)] == [0, 16, 8]
     lib.sela_hip_debug_encode_teams(8)
     assert lib.sela_hip_debug_encode_kernel(1, 2) == 8
     lib.sela_hip_debug_encode_teams(-1)
