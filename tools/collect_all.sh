@@ -15,7 +15,8 @@ python tools/phase_profile.py 1000 2>&1 | grep -v amdgpu.ids > "$OUT/phase_cycle
 # when the waves of a launch start and end, and the instruction counters of the three block kernels at 10,000 frames
 python tools/teams_sweep.py 500 1000 2000 3000 3875 6000 10000 20000 40000 2>&1 | grep -v amdgpu.ids > "$OUT/teams_sweep.txt"
 for T in 16 8; do python tools/phase_profile.py 3875 $T 2>&1 | grep -v amdgpu.ids | sed -n "/^k_encode_teams/,/store slot/p"; done > "$OUT/phase_cycles_teams.txt"
-for T in 16 8; do echo "teams of $T, 3875 frames:"; python tools/ramp_profile.py 3875 $T 2>&1 | grep -v amdgpu.ids; done > "$OUT/ramp_teams.txt"
+{ for T in 16 8; do echo "teams of $T, 3875 frames:"; python tools/ramp_profile.py 3875 $T 2>&1 | grep -v amdgpu.ids; done
+  echo "teams of 16, 10000 frames:"; python tools/ramp_profile.py 10000 16 2>&1 | grep -v amdgpu.ids; } > "$OUT/ramp_teams.txt"
 bash tools/teams_counters.sh 10000 2>&1 | grep -v amdgpu.ids > "$OUT/teams_counters_10000_frames.txt"
 # what the block kernel, the lanes and the wave priorities do to the headline (experiments; the first line is the default)
 for CFG in "" "--lanes 1" "--encode-teams 0" "--encode-teams 8" "--encode-teams 8 --lanes 4" "--encode-fused" "--encode-fused --lanes 1" "--encode-teams 0 --lanes 1" "--priorities 00010203" "--priorities 00010203 --lanes 1"; do

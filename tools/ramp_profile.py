@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""When the waves of a k_encode_teams launch start and end (s_memtime, absolute), from the instrumented build:
+"""How long the waves of a k_encode_teams launch run (s_memtime at a wave's start and end), from the instrumented build:
     python tools/ramp_profile.py [n_frames [team_lanes]]
-Prints the spread of the start times (the dispatcher's ramp), of the end times, and the waves' own durations."""
+Prints the spread of the waves' own durations."""
 import os
 import sys
 
@@ -31,12 +31,12 @@ raw = buf.cpu().numpy().reshape(-1, 16)
 start, end = raw[:, 13].astype(np.float64), raw[:, 14].astype(np.float64)
 ok = start > 0
 start, end = start[ok], end[ok]
-t0 = start.min()
+# s_memtime has a base of its own per XCD (and, by what the start times show, per shader engine): start times of waves on
+# different ones are not comparable, and no grouping by gaps separates them reliably -- only a wave's OWN duration is
+# printed (start and end are read by the same wave).
 per_wave_start = np.unique(start)
-print(f"{len(per_wave_start)} waves; launch spans {(end.max() - t0):.0f} cycles of s_memtime (100 MHz ticks x ... see below)")
-q = lambda a, p: float(np.percentile(a, p))
-print("wave start after the first wave's: p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % tuple(q(per_wave_start - t0, p) for p in (10, 50, 90, 100)))
 last_end = np.array([end[start == s0].max() for s0 in per_wave_start])
-print("wave end   after the first wave's start: p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % tuple(q(last_end - t0, p) for p in (10, 50, 90, 100)))
 dur = last_end - per_wave_start
-print("wave duration: p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % tuple(q(dur, p) for p in (10, 50, 90, 100)))
+q = lambda a, p: float(np.percentile(a, p))
+print(f"{len(per_wave_start)} waves; duration in s_memtime ticks (= shader clocks here: the slowest wave is the launch's length): "
+      "min %.0f  p10 %.0f  p50 %.0f  p90 %.0f  max %.0f  mean %.0f" % (dur.min(), q(dur, 10), q(dur, 50), q(dur, 90), dur.max(), dur.mean()))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/timeline.sh  (run ON THE GPU BOX): kernel start/end times of the LAST bench step, relative to
-# its k_encode_blocks start, from a rocprofv3 kernel trace (encode: three kernels; decode: a memset and one kernel).
+# its encode kernel's start, from a rocprofv3 kernel trace (encode: three kernels; decode: a memset and one kernel).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_tl
@@ -11,7 +11,7 @@ f = glob.glob("/tmp/prof_tl/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "sela::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # bench's timed steps come before its per-kernel timing pass; take the 6th encode from the end of the timed run
-enc = [i for i, r in enumerate(rows) if "k_encode_blocks" in r["Kernel_Name"]]
+enc = [i for i, r in enumerate(rows) if "k_encode_blocks" in r["Kernel_Name"] or "k_encode_teams" in r["Kernel_Name"]]
 i0 = enc[5]
 t0 = int(rows[i0]["Start_Timestamp"])
 for r in rows[i0:i0 + 8]:
