@@ -1061,7 +1061,7 @@ void sela_hip_host_free(void* p)
 
 void sela_hip_debug_phase_buffer(uint64_t* d_cycles) { g_phase_cycles = d_cycles; }
 
-void sela_hip_debug_force_plain_fir(int enable) { g_force_plain_fir = enable != 0; }
+void sela_hip_debug_force_plain_fir(int enable) { g_force_plain_fir = enable & 3; }
 
 void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks; }
 void sela_hip_debug_encode_teams(int lanes) { g_team_lanes = lanes; }

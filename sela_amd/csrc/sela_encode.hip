@@ -366,6 +366,27 @@ __device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int3
         fir_taps<JJ + 1>(j0, order, lane, sT, a, win, acc, hi);
 }
 
+// The same taps in FP64 (round 4): v_mad_i64_i32 issues at half rate, v_fma_f64 at full rate, and a fused multiply-add of
+// integers is EXACT while every partial sum stays below 2^53 -- which the caller has checked for the block (sum |a[j]| x
+// max |s| + 2^34 < 2^53: true of every block of the bench track; a block that fails takes fir_taps).  a_f[j] = (double)a[j],
+// the window holds the samples as doubles; acc starts at 2^34 and ends as the exact 64-bit sum the reference computes.
+template <int JJ>
+__device__ __forceinline__ void fir_taps_f64(int j0, int order, int lane, const int32_t* sT, const double* a_f,
+    double (&win)[kPerLane], double (&acc)[kPerLane])
+{
+    const int j = j0 + JJ + 1;
+    if (j > order)
+        return;
+    const double aj = read_first_lane(a_f[j]);
+    const int e = kPadS + 32 * lane - j;
+    win[(32 - JJ - 1) & 31] = (double)sT[e + (e >> 5)];
+#pragma unroll
+    for (int t = 0; t < kPerLane; t++)
+        acc[t] = __builtin_fma(aj, win[(t - JJ - 1) & 31], acc[t]); // s[32 lane + t - j]
+    if constexpr (JJ < 31)
+        fir_taps_f64<JJ + 1>(j0, order, lane, sT, a_f, win, acc);
+}
+
 // Whether coefficient a splits as a_hi 2^32 + a_lo (a_lo = (int32)a, signed) with a_hi inside the signed 24 bits of
 // v_mad_i32_i24 -- the same split fir_taps makes (a in [2^55 - 2^31, 2^55) has a_hi = 2^23: it does NOT fit).
 __device__ __forceinline__ bool fir_fits_fast(int64_t a)

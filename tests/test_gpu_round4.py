@@ -109,6 +109,56 @@ def test_team_kernels_plain_fir_branch(gpu, teams):  # noqa: F811
     assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames)
 
 
+def _polyphonic_frames(n, seed):
+    """Loud sums of 3..40 sinusoids over a little noise: long predictors with large coefficients at large amplitudes -- the
+    blocks on which sum |a[j]| x max |s| passes 2^53, where FP64 multiply-adds of integers stop being exact."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(2048)
+    pcm = np.zeros((n, 2048, 2), np.int16)
+    for f in range(n):
+        for ch in range(2):
+            k = int(rng.integers(3, 40))
+            x = sum((30000 / k) * np.sin(2 * np.pi * fr * t / 44100 + ph) for fr, ph in zip(rng.uniform(50, 20000, k), rng.uniform(0, 6.28, k)))
+            x = x * rng.choice([1.0, 1.0, 0.2]) + rng.normal(0, rng.choice([0.3, 1, 3]), 2048)
+            pcm[f, :, ch] = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    return pcm
+
+
+@pytest.mark.parametrize("team_lanes", [0, 16, 8])
+def test_residue_filter_forms(gpu, team_lanes):  # noqa: F811
+    """The encoder's residue filter has three forms (sela_encode_tail.inc): FP64 multiply-adds where they are exact (no partial
+    sum can reach 2^53: 2^34 + sum |a[j]| x max |s| < 2^53, decided per block), the 64-bit integer taps, the plain loop.  On
+    40 loud polyphonic frames -- the oracle confirms that some of their blocks are beyond the FP64 bound and some within -- and on
+    the corner blocks: the bytes by the block's own choice and with every block forced down the integer taps and down the plain
+    loop, against the oracle's, in all three encode kernels."""
+    from sela_amd import capi
+
+    o = oracle()
+    pcm = _polyphonic_frames(40, 2)
+    beyond = within = 0
+    for f in range(0, 40, 3):
+        l, r = pcm[f, :, 0].astype(np.int32), pcm[f, :, 1].astype(np.int32)
+        for sig in (l, r, l - r):
+            order, q = o.lpc_analyze(sig)[:2]
+            a = np.asarray(o.lpc_coeffs(order, q), dtype=np.int64)
+            bound = int(np.abs(a[1:order + 1]).sum()) * int(np.abs(sig).max()) + (1 << 34)
+            beyond += bound >= (1 << 53)
+            within += bound < (1 << 53)
+    assert beyond >= 3 and within >= 3, (beyond, within)
+    lib = capi.lib()
+    lib.sela_hip_debug_encode_teams(team_lanes)
+    try:
+        for data in (pcm, np.repeat(_hard_blocks(), 2, axis=2)):
+            ref_frames, ref_offsets, _ = o.encode_frames(data, threads=8)
+            for form in (0, 2, 1):
+                lib.sela_hip_debug_force_plain_fir(form)
+                frames, offsets, _, _ = _encode(gpu, data)
+                assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames), (team_lanes, form)
+    finally:
+        lib.sela_hip_debug_force_plain_fir(0)
+        lib.sela_hip_debug_encode_teams(-1)
+
+
 @pytest.mark.parametrize("channels,n_frames", [(9, 11), (64, 3), (255, 2)])
 def test_team_kernels_many_channels(gpu, teams, channels, n_frames):  # noqa: F811
     """One signal per channel, up to the 255 the header's field carries: a wave takes one signal of B consecutive frames, so
