@@ -2223,21 +2223,49 @@ static uint32_t resident_encode_blocks()
 
 
 // Lanes per team (k_encode_teams) for a launch of `blocks` blocks; 0: k_encode_blocks.
-// Measured on MI355X (tools/teams_sweep.py, profiles/r04/teams_sweep.txt: stereo, kernel time of the block kernel, ms):
-//   frames   k_encode_blocks   teams of 16   teams of 8
-//     2000        0.273           0.315         0.415
-//     3000        0.367           0.404         0.534
-//     3875        0.455           0.411         0.554
-//    10000        0.975           0.903         0.923
-//    20000        2.00            1.68          1.68
-//    40000        3.74            3.30          3.09
-// A wave of k_encode_teams is 4 / 8 blocks' worth of work (~0.1 / ~0.2 ms on its own): below one fill of the device it only
-// adds latency.  With two batches in flight (bench.py) teams of 16 give 15.9 G samples/s at 3875 frames against 14.4.
+//
+// A wave of k_encode_teams is 4 / 8 blocks' worth of work, a SIMD holds three, and a launch ends with its last wave: the
+// kernel time of the team kernels is a staircase over the batch size -- one step per wave that the fullest SIMD holds in the
+// launch's last round (tools/teams_sweep.py on a fine grid, profiles/r04/teams_fine_sweep.txt; stereo, kernel alone, ms):
+//   frames   k_encode_blocks   teams of 16   teams of 8        frames   k_encode_blocks   teams of 16   teams of 8
+//     3300        0.389           0.421         0.502           8192        0.805           0.708         0.691
+//     3875        0.434           0.405         0.514           8300        0.801           0.777         0.854
+//     4096        0.461           0.409         0.514          12288        1.252           1.049         1.055
+//     4200        0.464           0.492         0.646          12500        1.281           1.120         1.059
+//     4700        0.520           0.511         0.669          16384        1.628           1.366         1.255
+//     6000        0.621           0.602         0.678          16600        1.668           1.440         1.422
+// (one fill of teams of 16 = 3072 waves = 4096 stereo frames, of teams of 8 = 8192), while k_encode_blocks -- a block per
+// wave -- grows evenly.  So the choice is made by a model of the three kernels' times, in waves per SIMD of the last round,
+// with the constants of that sweep (they scale with the device's clock and CU count together, and only their ratios
+// matter): it reproduces the sweep's times to within 5 % and its choice everywhere but at near-ties.  With two batches in
+// flight (bench.py) teams of 16 give 16.3 G samples/s at 3875 frames against 14.4 for k_encode_blocks.
+struct TeamCost {
+    double first[3], next[3], per_fill, first_fill; // ms: a last round with <= 1, 2, 3 waves on the fullest SIMD, alone / behind full rounds
+};
+static double team_kernel_ms(size_t waves, size_t slots, const TeamCost& c)
+{
+    const size_t full = waves / slots, rem = waves % slots, per_simd = slots / 3;
+    const int step = rem == 0 ? -1 : (rem <= per_simd ? 0 : (rem <= 2 * per_simd ? 1 : 2));
+    if (full == 0)
+        return step < 0 ? 0.0 : c.first[step];
+    return c.first_fill + c.per_fill * (double)(full - 1) + (step < 0 ? 0.0 : c.next[step]);
+}
 static int team_lanes_for(size_t blocks)
 {
-    if (blocks < 10500)
+    const size_t slots = resident_encode_blocks(); // 12 waves per CU = 3 per SIMD
+    const double scale = 3072.0 / (double)slots;   // (the constants are those of 256 CUs)
+    const double kb = (double)blocks / 1000.0 * scale;
+    const double t_blocks = kb <= 27.0 ? 0.10 + 0.0292 * kb : 0.0332 * kb;
+    static const TeamCost c16 = {{0.215, 0.305, 0.405}, {0.10, 0.19, 0.30}, 0.32, 0.41};
+    static const TeamCost c8 = {{0.36, 0.58, 0.69}, {0.175, 0.365, 0.56}, 0.564, 0.69};
+    const double t16 = team_kernel_ms((blocks + 3) / 4, slots, c16);
+    const double t8 = team_kernel_ms((blocks + 7) / 8, slots, c8);
+    // (near ties go to the kernel with fewer instructions per block -- 16.2 k / 14.5 k / 13.3 k -- which is what counts once
+    // another stream's kernels fill the launch's idle slots)
+    const double s16 = 0.97 * t16, s8 = 0.94 * t8;
+    if (t_blocks < s16 && t_blocks < s8)
         return 0;
-    return blocks < 60000 ? 16 : 8;
+    return s8 <= s16 ? 8 : 16;
 }
 
 hipError_t set_team_priorities(uint32_t quarters) { return hipMemcpyToSymbol(HIP_SYMBOL(g_team_priorities), &quarters, sizeof(quarters)); }

@@ -201,14 +201,17 @@ def test_team_kernels_hostile_audio(gpu, teams):  # noqa: F811
 
 
 def test_the_library_picks_a_team_kernel_by_launch_size(gpu):  # noqa: F811
-    """launch_encode's choice (team_lanes_for): k_encode_blocks below 3500 stereo frames, teams of 16 up to 20,000, teams of 8
-    beyond; the hook overrides it; mono counts blocks, not frames."""
+    """launch_encode's choice (team_lanes_for, a model of the three kernels' times in waves per SIMD of the launch's last
+    round): k_encode_blocks for small launches and just behind a full round of team waves (4200 stereo frames = one fill of
+    teams of 16 and a few waves), teams of 16 around one and one and a half fills, teams of 8 where their rounds are full
+    or the launch is large; the hook overrides it; mono counts blocks, not frames."""
     from sela_amd import capi
 
     lib = capi.lib()
     lib.sela_hip_debug_encode_teams(-1)
-    assert [lib.sela_hip_debug_encode_kernel(n, 2) for n in (1, 1000, 3499, 3500, 3875, 19999, 20000, 61000)] == [0, 0, 0, 16, 16, 16, 8, 8]
-    assert [lib.sela_hip_debug_encode_kernel(n, 1) for n in (10499, 10500, 60000)] == [0, 16, 8]
+    picks = {n: lib.sela_hip_debug_encode_kernel(n, 2) for n in (1, 1000, 3000, 3875, 4096, 4200, 5000, 8192, 9000, 16384, 61041)}
+    assert picks == {1: 0, 1000: 0, 3000: 0, 3875: 16, 4096: 16, 4200: 0, 5000: 16, 8192: 8, 9000: 16, 16384: 8, 61041: 8}, picks
+    assert [lib.sela_hip_debug_encode_kernel(n, 1) for n in (3000, 11625, 12288, 49152)] == [0, 16, 16, 8] # (mono: 3875 stereo frames' blocks)
     lib.sela_hip_debug_encode_teams(8)
     assert lib.sela_hip_debug_encode_kernel(1, 2) == 8
     lib.sela_hip_debug_encode_teams(-1)

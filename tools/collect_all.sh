@@ -14,6 +14,7 @@ python tools/phase_profile.py 1000 2>&1 | grep -v amdgpu.ids > "$OUT/phase_cycle
 # round 4: k_encode_teams against k_encode_blocks (kernel and wall time by batch size, the kernels forced), the teams' phases,
 # when the waves of a launch start and end, and the instruction counters of the three block kernels at 10,000 frames
 python tools/teams_sweep.py 500 1000 2000 3000 3875 6000 10000 20000 40000 2>&1 | grep -v amdgpu.ids > "$OUT/teams_sweep.txt"
+python tools/teams_sweep.py 3300 3500 3875 4096 4200 4400 4700 5000 5500 6000 7000 8192 8300 9000 10000 12288 12500 15000 16384 16600 2>&1 | grep -v amdgpu.ids > "$OUT/teams_fine_sweep.txt"
 for T in 16 8; do python tools/phase_profile.py 3875 $T 2>&1 | grep -v amdgpu.ids | sed -n "/^k_encode_teams/,/store slot/p"; done > "$OUT/phase_cycles_teams.txt"
 { for T in 16 8; do echo "teams of $T, 3875 frames:"; python tools/ramp_profile.py 3875 $T 2>&1 | grep -v amdgpu.ids; done
   echo "teams of 16, 10000 frames:"; python tools/ramp_profile.py 10000 16 2>&1 | grep -v amdgpu.ids; } > "$OUT/ramp_teams.txt"

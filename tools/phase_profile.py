@@ -50,9 +50,18 @@ def main():
     print(f"encoder, mean cycles per (frame, signal) block over {len(e)} blocks (total {e.sum(1).mean():.0f}):")
     for name, v in zip(ENC, e.mean(0)):
         print(f"  {name:28s} {v:10.0f}  {100 * v / e.sum(1).mean():5.1f}%")
+    if teams <= 0:
+        tot = e.sum(1)
+        print("  a block's total: " + "  ".join(f"p{q} {np.percentile(tot, q):.0f}" for q in (0, 10, 50, 90, 100))
+              + "   (p100 against the kernel's duration = what the launch and the dispatch of its waves add)")
+        for name, col in (("mean chain", 1), ("autocorr", 3), ("FIR residues", 7)):
+            print(f"  {name}: " + "  ".join(f"p{q} {np.percentile(e[:, col], q):.0f}" for q in (0, 10, 50, 90, 100)))
     print(f"decoder (k_decode_frames), mean cycles per subframe over {len(d)} subframes (total {d.sum(1).mean():.0f}):")
     for name, v in zip(DEC, d.mean(0)):
         print(f"  {name:28s} {v:10.0f}  {100 * v / d.sum(1).mean():5.1f}%")
+    tot = d.sum(1)
+    print("  a subframe's total: " + "  ".join(f"p{q} {np.percentile(tot, q):.0f}" for q in (0, 10, 50, 90, 100)))
+    print("  synthesis: " + "  ".join(f"p{q} {np.percentile(d[:, 7], q):.0f}" for q in (0, 10, 50, 90, 100)))
 
 
 if __name__ == "__main__":

@@ -24,6 +24,8 @@ def main():
         pcm = torch.from_numpy(synth_frames(n, 2, 1)).cuda()
         enc = codec.Encoder(n, 2)
         ref = None
+        lib.sela_hip_debug_encode_teams(-1)
+        pick = lib.sela_hip_debug_encode_kernel(n, 2) # the library's own choice for this size (team_lanes_for)
         for teams in (0, 16, 8):
             lib.sela_hip_debug_encode_teams(teams)
             out = enc.encode(pcm)
@@ -48,7 +50,7 @@ def main():
                 ks.append(ms[0] if k else float("nan"))
             lib.sela_hip_enable_kernel_timing(0)
             ks.sort()
-            print(f"{n:8d} {teams:6d} {ks[len(ks) // 2]:17.4f} {wall * 1e3:15.4f} {n * 2048 / wall / 1e9:12.2f}", flush=True)
+            print(f"{n:8d} {teams:6d} {ks[len(ks) // 2]:17.4f} {wall * 1e3:15.4f} {n * 2048 / wall / 1e9:12.2f}" + ("   <- the library's pick" if teams == pick else ""), flush=True)
         lib.sela_hip_debug_encode_teams(-1)
 
 
