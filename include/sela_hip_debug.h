@@ -43,6 +43,10 @@ void sela_hip_debug_encode_fused(int enable);
 /* Debug hook (measurements only; device-wide): the wave priorities (s_setprio 0..3) of k_encode_teams' waves in the four quarters
  * of their work, one byte each from the low end (0x00010203: falling from 3 to 0; default 0: none -- DESIGN.md section 9). */
 void sela_hip_debug_priorities(uint32_t team_quarters);
+/* Debug hook (process-wide): 1 = write the slots of BOTH candidates for an exactly-stereo frame's second channel (the channel
+ * itself and the difference signal), as rounds 1-3 did; 0 (default) = the candidate that knows it has lost does not write
+ * its slot (sela_encode_tail.inc).  Same bytes either way, which is what the tests check; the difference is HBM traffic. */
+void sela_hip_debug_keep_both_candidates(int on);
 /* Debug hook: bound of an encode block's wait for its frame from the staging kernel, in naps of 2048 cycles; 0: every
  * block gives up without looking ("the stagers never showed up"), which flags the launch and sends the feed through
  * the copy-engine path again; -1 restores the default (~0.5 s). */

@@ -27,6 +27,7 @@ namespace sela {
 size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced);
 hipError_t set_team_priorities(uint32_t quarters);
+void set_keep_both_candidates(int on);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
     hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override, int team_lanes,
@@ -1067,6 +1068,7 @@ void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks;
 void sela_hip_debug_encode_teams(int lanes) { g_team_lanes = lanes; }
 void sela_hip_debug_encode_fused(int enable) { g_fused_device = enable != 0; }
 void sela_hip_debug_priorities(uint32_t team_quarters) { (void)sela::set_team_priorities(team_quarters); }
+void sela_hip_debug_keep_both_candidates(int on) { sela::set_keep_both_candidates(on); }
 int sela_hip_debug_encode_kernel(uint32_t n_frames, uint32_t channels) { return sela::encode_team_lanes(n_frames, channels, g_team_lanes); }
 
 void sela_hip_debug_stage_wait(int naps) { g_stage_wait_naps = naps; }

@@ -740,6 +740,8 @@ struct FuseArgs {
     int32_t* trace_residues; // the trace build also stores every block's residues here ([block][2048]); or null (sela_hip_lpc_encode)
     uint32_t nap_limit;      // bound of a block's wait for its frame (await_frame)
     uint64_t tag;            // process nonce << 32 | ticket (see launch_encode): what marks a cell as written by THIS launch
+    uint64_t* sizes_pub;     // [blocks]: the stereo candidates' sizes (sela_encode_tail.inc), sizes_tag | words; or null
+    uint64_t sizes_tag;      // 20 bits of the nonce << 44 | ticket << 12
 };
 
 __device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t channels, uint32_t& choice, uint32_t& flags)
@@ -1412,6 +1414,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     {
         constexpr bool kAcInLds = true;
+        uint64_t* const sizes_pub = fa.sizes_pub;
+        const uint64_t sizes_tag = fa.sizes_tag;
 #define SELA_TAIL_TRACE_RESIDUES fa.trace_residues
 #include "sela_encode_tail.inc"
 #undef SELA_TAIL_TRACE_RESIDUES
@@ -1638,7 +1642,8 @@ __device__ __forceinline__ void team_ac_steps(double (&W)[kTeamWin], double (&M)
 template <int kMode, int P>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_teams(
     const int16_t* __restrict__ pcm, uint32_t n_frames, uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta,
-    uint32_t* __restrict__ slots, sela_hip_trace* __restrict__ trace, int force_plain_fir, uint64_t* __restrict__ phase_cycles)
+    uint32_t* __restrict__ slots, sela_hip_trace* __restrict__ trace, int force_plain_fir, uint64_t* __restrict__ phase_cycles,
+    uint64_t* __restrict__ sizes_pub, uint64_t sizes_tag)
 {
     using Plan = TeamPlan<P>;
     constexpr int B = Plan::B, G = Plan::G, kPer = Plan::kPer, kMeanPer = Plan::kMeanPer, kChunk = Plan::kChunk, kRing = Plan::kRing;
@@ -2200,6 +2205,7 @@ size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
     bytes += (size_t)kXcds * kRingsPerXcd * 4 + 256;                          // ... and their owner words
     const size_t padded = (((size_t)n_frames + 63) / 64) * 64 * n_sig;        // encode indices (frames rounded up to a span of 64)
     bytes += 2 * ((padded * sizeof(double) + 255) & ~(size_t)255); // worker means + ready words (64-bit launch tags)
+    bytes += (blocks * sizeof(uint64_t) + 255) & ~(size_t)255;     // the stereo candidates' sizes (sela_encode_tail.inc)
     return bytes + 256;
 }
 
@@ -2268,6 +2274,11 @@ static int team_lanes_for(size_t blocks)
     return s8 <= s16 ? 8 : 16;
 }
 
+// debug (sela_hip_debug_keep_both_candidates): write both stereo candidates' slots as round 3 did -- for the comparison of
+// the traffic and for the tests, which check that the bytes do not depend on it
+static std::atomic<int> g_keep_both_candidates{0};
+void set_keep_both_candidates(int on) { g_keep_both_candidates.store(on, std::memory_order_relaxed); }
+
 hipError_t set_team_priorities(uint32_t quarters) { return hipMemcpyToSymbol(HIP_SYMBOL(g_team_priorities), &quarters, sizeof(quarters)); }
 
 int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced)
@@ -2303,6 +2314,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     double* mean_out = reinterpret_cast<double*>(ws);
     ws += (padded * sizeof(double) + 255) & ~(size_t)255;
     uint64_t* mean_ready = reinterpret_cast<uint64_t*>(ws);
+    ws += (padded * sizeof(uint64_t) + 255) & ~(size_t)255;
+    uint64_t* sizes_pub = reinterpret_cast<uint64_t*>(ws);
 
     if (link && (d_trace || d_phase_cycles))
         return hipErrorInvalidValue; // (the analysis trace and the phase counts are the device-pointer path's)
@@ -2375,6 +2388,12 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     fa.n_sig = n_sig;
     fa.ticket = ticket;
     fa.tag = ((uint64_t)nonce << 32) | ticket;
+    // (the stereo candidates' sizes: 20 bits of the nonce and the ticket above the 12 bits of a size, sela_encode_tail.inc)
+    const uint64_t sizes_tag = ((uint64_t)(nonce & 0xFFFFFu) << 44) | ((uint64_t)ticket << 12);
+    if (g_keep_both_candidates.load(std::memory_order_relaxed))
+        sizes_pub = nullptr;
+    fa.sizes_pub = sizes_pub;
+    fa.sizes_tag = sizes_tag;
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     // Which kernel analyses the blocks: k_encode_teams (several blocks side by side in a wave: fewer instructions per block,
@@ -2392,7 +2411,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         const uint32_t per_wave = 64u / (uint32_t)teams;
         const uint32_t waves = ((n_frames + per_wave - 1) / per_wave + 7) / 8 * 8 * n_sig;
 #define SELA_LAUNCH_TEAMS(MODE, LANES) \
-    hipLaunchKernelGGL((k_encode_teams<MODE, LANES>), dim3(waves), wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, force_plain_fir, d_phase_cycles)
+    hipLaunchKernelGGL((k_encode_teams<MODE, LANES>), dim3(waves), wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, force_plain_fir, d_phase_cycles, sizes_pub, sizes_tag)
         if (teams == 8) {
             if (d_phase_cycles)
                 SELA_LAUNCH_TEAMS(2, 8);

@@ -159,6 +159,55 @@ def test_residue_filter_forms(gpu, team_lanes):  # noqa: F811
         lib.sela_hip_debug_encode_teams(-1)
 
 
+@pytest.mark.parametrize("team_lanes", [0, 16, 8])
+def test_the_losing_stereo_candidate_leaves_its_slot_unwritten(gpu, team_lanes):  # noqa: F811
+    """Of an exactly-stereo frame's second channel and its difference signal the frame keeps the smaller; the blocks tell each
+    other their sizes and the one that knows it has lost does not write its slot (sela_encode_tail.inc).  The workspace --
+    slots, metadata and the words the sizes travel in -- is filled with a pattern first: the bytes equal the oracle's with
+    the hand-over on, and off (sela_hip_debug_keep_both_candidates); no first channel's and no winner's slot is ever left
+    unwritten, never both of a pair; with the hook nothing is skipped; and the hand-over does skip a fair share of the losers
+    (how many depends on which of the two waves gets there first)."""
+    import torch
+
+    from sela_amd import capi, codec
+
+    n = 256
+    pcm = synth_frames(n, 2, 17)
+    ref_frames, ref_offsets, _ = oracle().encode_frames(pcm, threads=8)
+    lib = capi.lib()
+    lib.sela_hip_debug_encode_teams(team_lanes)
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    try:
+        for keep_both in (0, 1):
+            lib.sela_hip_debug_keep_both_candidates(keep_both)
+            enc = codec.Encoder(n, 2)
+            enc.workspace.fill_(0xA5)
+            out = enc.encode(d_pcm)
+            torch.cuda.synchronize()
+            frames, offsets = out.to_host()
+            assert np.array_equal(offsets, ref_offsets) and np.array_equal(frames, ref_frames), (team_lanes, keep_both)
+            ws = enc.workspace.cpu().numpy()
+            base = (-enc.workspace.data_ptr()) % 256
+            meta = ws[base: base + n * 3 * 8].view(np.uint16).reshape(n * 3, 4) # order|coef_k, res_k|flags, coef_words, res_words
+            words = meta[:, 2].astype(np.int64) + meta[:, 3]
+            slots_at = base + (n * 3 * 8 + 255) // 256 * 256
+            slots = ws[slots_at: slots_at + n * 3 * 2240 * 4].view(np.uint32).reshape(n * 3, 2240)
+            unwritten = (slots[:, 32] == 0xA5A5A5A5) & (slots[:, 33] == 0xA5A5A5A5) # (the first residue words)
+            assert not unwritten[0::3].any()
+            second, diff = unwritten[1::3], unwritten[2::3]
+            assert not (second & diff).any()
+            diff_wins = words[2::3] < words[1::3]
+            assert not (second & ~diff_wins).any() and not (diff & diff_wins).any() # only losers
+            skipped = int(second.sum() + diff.sum())
+            if keep_both:
+                assert skipped == 0
+            else:
+                assert skipped >= n // 4, skipped
+    finally:
+        lib.sela_hip_debug_keep_both_candidates(0)
+        lib.sela_hip_debug_encode_teams(-1)
+
+
 @pytest.mark.parametrize("channels,n_frames", [(9, 11), (64, 3), (255, 2)])
 def test_team_kernels_many_channels(gpu, teams, channels, n_frames):  # noqa: F811
     """One signal per channel, up to the 255 the header's field carries: a wave takes one signal of B consecutive frames, so
