@@ -18,6 +18,7 @@ python tools/teams_sweep.py 3300 3500 3875 4096 4200 4400 4700 5000 5500 6000 70
 for T in 16 8; do python tools/phase_profile.py 3875 $T 2>&1 | grep -v amdgpu.ids | sed -n "/^k_encode_teams/,/store slot/p"; done > "$OUT/phase_cycles_teams.txt"
 { for T in 16 8; do echo "teams of $T, 3875 frames:"; python tools/ramp_profile.py 3875 $T 2>&1 | grep -v amdgpu.ids; done
   echo "teams of 16, 10000 frames:"; python tools/ramp_profile.py 10000 16 2>&1 | grep -v amdgpu.ids; } > "$OUT/ramp_teams.txt"
+python tools/skip_rate.py 2>&1 | grep -v amdgpu.ids > "$OUT/skip_rate.txt"
 bash tools/teams_counters.sh 10000 2>&1 | grep -v amdgpu.ids > "$OUT/teams_counters_10000_frames.txt"
 # what the block kernel, the lanes and the wave priorities do to the headline (experiments; the first line is the default)
 for CFG in "" "--lanes 1" "--encode-teams 0" "--encode-teams 8" "--encode-teams 8 --lanes 4" "--encode-fused" "--encode-fused --lanes 1" "--encode-teams 0 --lanes 1" "--priorities 00010203" "--priorities 00010203 --lanes 1"; do

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""How many losing stereo candidates leave their slot unwritten (sela_encode_tail.inc): the workspace is filled with a pattern,
+one encode runs, the slots that still hold the pattern are counted.  python tools/skip_rate.py"""
 import sys, numpy as np, torch
 sys.path.insert(0,'.')
 from sela_amd import capi, codec
