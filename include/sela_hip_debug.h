@@ -17,11 +17,11 @@ extern "C" {
  * (frame, signal) for the encoder and per (frame, subframe) for the decoder.  Slower; never set
  * in the timed path. */
 void sela_hip_debug_phase_buffer(uint64_t* d_cycles);
-/* Debug hook: the three forms of the encoder's residue filter.  0: by the block (FP64 taps where they are exact --
- * sum |a[j]| x max |s| below 2^53 --, else the integer taps, else the plain loop).  1: every block of the calling
- * thread's encodes takes the plain 64-bit loop that predictors beyond the fast forms' coefficient range take (never
- * reached by 16-bit audio).  2: every block the integer taps (v_mad_i64_i32), never the FP64 ones.  Results are
- * identical by construction, which is what the tests check. */
+/* Debug hook: the three forms of the encoder's residue filter (sela_encode_tail.inc).  0: by the block -- one pass of FP64
+ * taps where that is exact (2^34 + sum |a[j]| x max |s| below 2^53), else two passes (the coefficients' low 20 bits, then the
+ * rest), else the plain 64-bit wrap-around loop (predictors beyond 2^49 / order: never reached by 16-bit audio).  1: every
+ * block of the calling thread's encodes takes the plain loop.  2: two passes wherever one would do.  Results are identical by
+ * construction, which is what the tests check. */
 void sela_hip_debug_force_plain_fir(int enable);
 /* Debug hook: the encoder hands the sequential mean of every block beyond the first `self_blocks` of a launch
  * to "mean worker" workgroups (normally self_blocks = what the device holds at once, so small batches never use

@@ -335,41 +335,14 @@ __device__ __forceinline__ void ac_steps_tail(const AcFetch& f, double& A, doubl
     ac_step(d[7], f.e3[1], A, B, acc_e, acc_o);
 }
 
-// Taps j0 + JJ + 1 .. j0 + 32 of the residue FIR (see k_encode_blocks), stopping at `order`.  JJ is a
-// template parameter so that the 32-register sample window is addressed statically: tap j uses
-// win[(t - j) mod 32] = s[32 lane + t - j] and loads the one new element s[32 lane - j].
-// a = a_hi 2^32 + a_lo with a_lo = (int32)a:  a s mod 2^64 = a_lo s [v_mad_i64_i32] + (a_hi s mod 2^32) << 32;
-// a_hi is zero -- and its 32 multiply-adds are skipped, a wave-uniform branch -- whenever the Q35
-// coefficient fits 32 signed bits, i.e. |coefficient| < 1/16: 85 % of the taps on the bench track.
-// (The caller has checked that every a_hi fits the 24-bit multiplier; see fir_fits_fast.)
-template <int JJ>
-__device__ __forceinline__ void fir_taps(int j0, int order, int lane, const int32_t* sT, const int64_t* a,
-    int32_t (&win)[kPerLane], int64_t (&acc)[kPerLane], uint32_t (&hi)[kPerLane])
-{
-    const int j = j0 + JJ + 1;
-    if (j > order)
-        return;
-    const uint64_t aj = read_first_lane((uint64_t)a[j]);
-    const int32_t a_lo = (int32_t)(uint32_t)aj;
-    const int32_t a_hi = (int32_t)(uint32_t)((aj - (uint64_t)(int64_t)a_lo) >> 32);
-    const int e = kPadS + 32 * lane - j;
-    win[(32 - JJ - 1) & 31] = sT[e + (e >> 5)];
-#pragma unroll
-    for (int t = 0; t < kPerLane; t++)
-        acc[t] += (int64_t)a_lo * (int64_t)win[(t - JJ - 1) & 31]; // s[32 lane + t - j]
-    if (a_hi != 0) { // only the low 32 bits of a_hi s matter; both factors fit 24 bits (fir_fits_fast)
-#pragma unroll
-        for (int t = 0; t < kPerLane; t++)
-            asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(hi[t]) : "s"(a_hi), "v"(win[(t - JJ - 1) & 31]));
-    }
-    if constexpr (JJ < 31)
-        fir_taps<JJ + 1>(j0, order, lane, sT, a, win, acc, hi);
-}
-
-// The same taps in FP64 (round 4): v_mad_i64_i32 issues at half rate, v_fma_f64 at full rate, and a fused multiply-add of
-// integers is EXACT while every partial sum stays below 2^53 -- which the caller has checked for the block (sum |a[j]| x
-// max |s| + 2^34 < 2^53: true of every block of the bench track; a block that fails takes fir_taps).  a_f[j] = (double)a[j],
-// the window holds the samples as doubles; acc starts at 2^34 and ends as the exact 64-bit sum the reference computes.
+// Taps j0 + JJ + 1 .. j0 + 32 of the residue FIR (see sela_encode_tail.inc), stopping at `order`.  JJ is a template
+// parameter so that the 32-register sample window is addressed statically: tap j uses win[(t - j) mod 32] =
+// s[32 lane + t - j] and loads the one new element s[32 lane - j].  In FP64 (round 4; rounds 1-3 ran the same window on
+// 64-bit integers: a = a_hi 2^32 + a_lo, v_mad_i64_i32 -- which issues at half rate -- for the low part and a v_mad_i32_i24
+// for the high part of the 15 % of the taps that have one): v_fma_f64 issues at full rate, and a fused multiply-add of
+// integers is EXACT while every partial sum stays below 2^53 -- which the caller has checked for the block, for the whole
+// coefficients (one pass) or for their halves (two passes).  coef[j] = the coefficient (or its half) as a double, the window
+// holds the samples as doubles, acc the exact sum.
 template <int JJ>
 __device__ __forceinline__ void fir_taps_f64(int j0, int order, int lane, const int32_t* sT, const double* a_f,
     double (&win)[kPerLane], double (&acc)[kPerLane])
@@ -383,20 +356,12 @@ __device__ __forceinline__ void fir_taps_f64(int j0, int order, int lane, const 
 #pragma unroll
     for (int t = 0; t < kPerLane; t++)
         acc[t] = __builtin_fma(aj, win[(t - JJ - 1) & 31], acc[t]); // s[32 lane + t - j]
+    __builtin_amdgcn_sched_barrier(0); // (taps are not interleaved: the window and the sums already fill the register file)
     if constexpr (JJ < 31)
         fir_taps_f64<JJ + 1>(j0, order, lane, sT, a_f, win, acc);
 }
 
-// Whether coefficient a splits as a_hi 2^32 + a_lo (a_lo = (int32)a, signed) with a_hi inside the signed 24 bits of
-// v_mad_i32_i24 -- the same split fir_taps makes (a in [2^55 - 2^31, 2^55) has a_hi = 2^23: it does NOT fit).
-__device__ __forceinline__ bool fir_fits_fast(int64_t a)
-{
-    const int32_t a_lo = (int32_t)(uint32_t)(uint64_t)a;
-    const int64_t a_hi = (int64_t)((uint64_t)a - (uint64_t)(int64_t)a_lo) >> 32;
-    return a_hi >= -(1 << 23) && a_hi < (1 << 23);
-}
-
-// The predictions for a predictor with coefficients beyond 2^55: one multiply-add per (sample, tap) in
+// The predictions for a predictor the FP64 taps cannot carry exactly (sela_encode_tail.inc): one multiply-add per (sample, tap) in
 // full 64-bit wrap-around arithmetic, samples straight from LDS; (int32)((2^34 + sum) >> 35) of sample
 // 32 lane + t goes to pred_out[t * 64 + lane] (global scratch: the block's own output slot, unused so
 // far).  Slow, out of line, and never needed by 16-bit audio (its predictors stay below 2^37: the

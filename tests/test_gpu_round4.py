@@ -126,11 +126,12 @@ def _polyphonic_frames(n, seed):
 
 @pytest.mark.parametrize("team_lanes", [0, 16, 8])
 def test_residue_filter_forms(gpu, team_lanes):  # noqa: F811
-    """The encoder's residue filter has three forms (sela_encode_tail.inc): FP64 multiply-adds where they are exact (no partial
-    sum can reach 2^53: 2^34 + sum |a[j]| x max |s| < 2^53, decided per block), the 64-bit integer taps, the plain loop.  On
-    40 loud polyphonic frames -- the oracle confirms that some of their blocks are beyond the FP64 bound and some within -- and on
-    the corner blocks: the bytes by the block's own choice and with every block forced down the integer taps and down the plain
-    loop, against the oracle's, in all three encode kernels."""
+    """The encoder's residue filter has three forms (sela_encode_tail.inc): one pass of FP64 multiply-adds where that is exact
+    (no partial sum can reach 2^53: 2^34 + sum |a[j]| x max |s| < 2^53, decided per block), two passes (the coefficients' low
+    20 bits, then the rest) beyond that, the plain 64-bit loop for what neither carries.  On 40 loud polyphonic frames -- the
+    oracle confirms that some of their blocks are beyond the one-pass bound and some within -- and on the corner blocks: the
+    bytes by the block's own choice, with two passes forced wherever one would do, and with every block down the plain loop,
+    against the oracle's, in all three encode kernels."""
     from sela_amd import capi
 
     o = oracle()

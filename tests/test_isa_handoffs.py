@@ -122,7 +122,13 @@ def test_device_path_kernel_has_none_of_it(functions):
     f = _one(functions, "k_encode_blocksILi0ELb0E")
     assert not any("atomic_cmpswap_x2" in x[1] for x in f)
     assert not any(x[1] == "buffer_inv" for x in f)
-    assert sum(1 for x in f if _is_store(x) and "sc1" in x[2]) == 0, "write-through stores on the device-pointer path"
+    # (round 4) exactly ONE store goes through the L2 on the device-pointer path: the word in which a stereo
+    # candidate tells the other its size (sela_encode_tail.inc) -- 8 bytes each; every slot and BlockMeta store stays plain
+    through = [x for x in f if _is_store(x) and "sc1" in x[2]]
+    assert len(through) == 1 and through[0][1] in ("global_store_dwordx2", "flat_store_dwordx2"), through
+    # (its loads past the L2 are the other candidate's word and the mean workers' ready words, all 8 bytes)
+    past = [x for x in f if x[1].startswith(("global_load", "flat_load")) and "sc1" in x[2]]
+    assert past and all(x[1] in ("global_load_dwordx2", "flat_load_dwordx2") for x in past), past
 
 
 def test_mean_worker_publishes_mean_then_mark(functions):
