@@ -290,11 +290,20 @@ class Bench:
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", str(self.rank))
             os.environ.setdefault("WORLD_SIZE", str(self.world))
+            # One node, rendezvous on 127.0.0.1: the bootstrap sockets of RCCL / gloo go over the loopback interface instead of
+            # whichever interface the container's hostname resolves to (it may not resolve at all), and a rendezvous that does
+            # not complete fails after five minutes instead of the default thirty.
+            if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost") and os.path.isdir("/sys/class/net/lo"):
+                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            import datetime
+
+            limit = datetime.timedelta(seconds=300)
             if self.share_gpu:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=limit)
                 self.coll_device = "cpu"
             else:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))  # nccl == RCCL on ROCm
+                dist.init_process_group("nccl", timeout=limit, device_id=torch.device("cuda", self.local_rank))  # nccl == RCCL on ROCm
             self.dist = dist
             # RCCL prints its version banner through C stdio when the communicator comes up; get it out NOW, on every rank,
             # so that nothing but rank 0's JSON line is left to appear at the end of stdout

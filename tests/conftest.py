@@ -13,6 +13,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _child_processes_are_bounded(monkeypatch):
+    """Every child a test starts with subprocess.run (the CLI, the bound reference binaries, torch.distributed.run) gets a
+    limit of five minutes unless the test sets its own: a child that hangs fails ITS test (TimeoutExpired, the child is
+    killed) and the run goes on."""
+    import subprocess
+
+    real_run = subprocess.run
+
+    def run(*args, **kwargs):
+        kwargs.setdefault("timeout", 300)
+        return real_run(*args, **kwargs)
+
+    monkeypatch.setattr(subprocess, "run", run)
+
+
 @pytest.fixture(scope="session")
 def kats():
     import numpy as np

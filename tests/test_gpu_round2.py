@@ -377,7 +377,11 @@ def test_sharded_encode_over_rccl_world_of_one(gpu, tmp_path):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29571")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    if os.path.isdir("/sys/class/net/lo"): # (the bootstrap sockets over the loopback interface: the container's hostname may not resolve)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    import datetime
+
+    dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), device_id=torch.device("cuda", 0))
     try:
         track_frames = [40, 0, 25]
         pcm = torch.cat([synth_frames_torch(n, 2, 90 + i, device="cuda") for i, n in enumerate(track_frames) if n])
