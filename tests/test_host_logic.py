@@ -110,6 +110,71 @@ def test_scale_division_is_exact(tmp_path):
     assert subprocess.check_output([str(exe)]).decode().strip() == "0"
 
 
+def test_residue_filter_in_fp64_is_exact_under_its_bounds():
+    """What sela_encode_tail.inc relies on (round 4).  One pass: while 2^34 + sum |a[j]| x max |s| < 2^53 every partial sum of
+    2^34 + sum a[j] s[i-j] is an integer below 2^53, so float64 arithmetic carries it exactly and floor(sum / 2^35) is the
+    reference's (int64 sum) >> 35.  Two passes: with a = a_hi 2^20 + a_lo (0 <= a_lo < 2^20) and L = 2^34 + sum a_lo s,
+    (sum a_hi s 2^20 + L) >> 35 == (sum a_hi s + (L >> 20)) >> 15 -- the dropped fraction of L cannot carry -- and with
+    order x (max |a| / 2^20 + 1) x max |s| < 2^52 the second pass stays below 2^53 too.  Checked against Python integers on
+    random predictors at the edges of both bounds, negative coefficients and samples included."""
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        order = int(rng.integers(1, 101))
+        s_mag = int(rng.choice([1, 300, 32768, 65536]))
+        s = rng.integers(-s_mag, s_mag + 1, 64 + order).astype(np.int64)
+        s[int(rng.integers(0, len(s)))] = s_mag * int(rng.choice([-1, 1]))
+        two_pass = trial % 2 == 1
+        if not two_pass: # one pass: sum |a| as large as the bound allows
+            budget = ((1 << 53) - (1 << 34) - 1) // s_mag
+            w = rng.random(order) + 1e-3
+            a = np.minimum((w / w.sum() * budget).astype(np.float64), float((1 << 39) - 1)).astype(np.int64)
+            a = a * rng.choice([-1, 1], order)
+            assert int(np.abs(a).sum()) * s_mag + (1 << 34) < (1 << 53)
+        else:            # two passes: max |a| as large as THAT bound allows (up to 2^55)
+            top = min(((1 << 52) // (order * s_mag) - 1) << 20, (1 << 55) - 1)
+            a = rng.integers(-top, top + 1, order).astype(np.int64)
+            a[int(rng.integers(0, order))] = top * int(rng.choice([-1, 1]))
+            a_top = int(np.bitwise_or.reduce(np.abs(a)))
+            if not (a_top < (1 << 55) and order * ((a_top >> 20) + 1) * s_mag < (1 << 52)):
+                continue # (the OR of the magnitudes may exceed the maximum: such a block takes the plain loop)
+        for i in range(order, len(s)):
+            taps = [(int(a[j - 1]), int(s[i - j])) for j in range(1, order + 1)]
+            want = ((1 << 34) + sum(c * x for c, x in taps)) >> 35
+            if not two_pass:
+                acc = float(1 << 34)
+                for c, x in taps:
+                    acc = float(c) * float(x) + acc
+                    assert abs(acc) < 2.0 ** 53 and acc == int(acc)
+                got = int(np.floor(acc * 2.0 ** -35))
+            else:
+                acc = float(1 << 34)
+                for c, x in taps:
+                    acc = float(c & 0xFFFFF) * float(x) + acc
+                    assert abs(acc) < 2.0 ** 53
+                acc = float(np.floor(acc * 2.0 ** -20))
+                for c, x in taps:
+                    acc = float(c >> 20) * float(x) + acc
+                    assert abs(acc) < 2.0 ** 53
+                got = int(np.floor(acc * 2.0 ** -15))
+            assert got == want, (trial, i)
+
+
+def test_launch_size_model_of_the_encode_kernels():
+    """team_lanes_for (sela_encode.hip): which of the three encode kernels launch_encode takes for a batch -- a host-side
+    model of their times (the team kernels' times are a staircase in waves per SIMD of the last round); no GPU needed to ask.
+    k_encode_blocks for small launches and just behind a full round of team waves, teams of 16 around one fill, teams of 8
+    where their rounds are full and for large launches; monotone in nothing, so the landmarks are spelled out."""
+    from sela_amd import capi
+
+    lib = capi.lib()
+    lib.sela_hip_debug_encode_teams(-1)
+    picks = {n: lib.sela_hip_debug_encode_kernel(n, 2) for n in (1, 1000, 3000, 3875, 4096, 4200, 5000, 8192, 9000, 16384, 61041)}
+    assert picks == {1: 0, 1000: 0, 3000: 0, 3875: 16, 4096: 16, 4200: 0, 5000: 16, 8192: 8, 9000: 16, 16384: 8, 61041: 8}, picks
+    for n in range(1, 70000, 997):
+        assert lib.sela_hip_debug_encode_kernel(n, 2) in (0, 8, 16)
+        assert lib.sela_hip_debug_encode_kernel(n, 1) in (0, 8, 16)
+
+
 def test_torch_synth_matches_numpy():
     """The torch generator (album-sized workloads, any device) is bit-identical to the numpy one, at any offset."""
     import numpy as np
