@@ -19,7 +19,7 @@ extern "C" {
 void sela_hip_debug_phase_buffer(uint64_t* d_cycles);
 /* Debug hook: the three forms of the encoder's residue filter (sela_encode_tail.inc).  0: by the block -- one pass of FP64
  * taps where that is exact (2^34 + sum |a[j]| x max |s| below 2^53), else two passes (the coefficients' low 20 bits, then the
- * rest), else the plain 64-bit wrap-around loop (predictors beyond 2^49 / order: never reached by 16-bit audio).  1: every
+ * rest), else the plain 64-bit wrap-around loop (predictors beyond 2^39: never reached by 16-bit audio).  1: every
  * block of the calling thread's encodes takes the plain loop.  2: two passes wherever one would do.  Results are identical by
  * construction, which is what the tests check. */
 void sela_hip_debug_force_plain_fir(int enable);

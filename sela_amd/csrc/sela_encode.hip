@@ -1,13 +1,17 @@
 // sela_encode.hip -- MI355X (gfx950) encoder kernels of the SELA frame path.
 //
-// ONE launch for a batch of frames, k_encode_blocks:
+// The blocks of a batch are analysed and coded by ONE of two kernels, picked by launch size (team_lanes_for):
+// k_encode_teams (round 4: a wave takes four or eight blocks through mean, autocorrelation and Schur recursion side by
+// side, see its own header further down) for launches that fill the device, k_encode_blocks -- a wave per block -- for
+// small ones and for the host pipeline's one-launch form.  Both end in the same tail (sela_encode_tail.inc).  k_encode_blocks:
 //
 //   a block           one WAVE per (frame, signal): the whole of lpc::ResidueGenerator +
 //                     rice::RiceEncoder x2 for that signal (reference src/lpc/residue_generator.cpp:
 //                     121-134, src/rice/rice_encoder.cpp:73-81).  A stereo frame has three signals
 //                     (ch0, ch1, ch0-ch1; src/frame/frame_encoder.cpp:18-60); all three are coded and
-//                     the loser is simply not copied out.  Output: a fixed-stride slot of Rice
-//                     words + an 8-byte BlockMeta per signal.
+//                     the loser is simply not copied out (and, round 4, mostly not even written: the two
+//                     candidates tell each other their sizes, see the tail).  Output: a fixed-stride slot of
+//                     Rice words + an 8-byte BlockMeta per signal.
 //   a group's last    the block that finishes LAST among those of 16 consecutive frames (finish_group):
 //   block             per frame the stereo decision of src/frame/frame_encoder.cpp:64-72 (strict < on
 //                     u32 word counts) and the frame's on-disk size; the group's place in the stream by a

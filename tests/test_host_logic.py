@@ -115,7 +115,8 @@ def test_residue_filter_in_fp64_is_exact_under_its_bounds():
     2^34 + sum a[j] s[i-j] is an integer below 2^53, so float64 arithmetic carries it exactly and floor(sum / 2^35) is the
     reference's (int64 sum) >> 35.  Two passes: with a = a_hi 2^20 + a_lo (0 <= a_lo < 2^20) and L = 2^34 + sum a_lo s,
     (sum a_hi s 2^20 + L) >> 35 == (sum a_hi s + (L >> 20)) >> 15 -- the dropped fraction of L cannot carry -- and with
-    order x (max |a| / 2^20 + 1) x max |s| < 2^52 the second pass stays below 2^53 too.  Checked against Python integers on
+    order x (max |a| / 2^20 + 1) x max |s| < 2^42 the whole sum stays below 2^63 (the reference's int64 does not wrap) and the
+    prediction inside 32 bits.  Checked against Python integers on
     random predictors at the edges of both bounds, negative coefficients and samples included."""
     rng = np.random.default_rng(5)
     for trial in range(300):
@@ -131,15 +132,18 @@ def test_residue_filter_in_fp64_is_exact_under_its_bounds():
             a = a * rng.choice([-1, 1], order)
             assert int(np.abs(a).sum()) * s_mag + (1 << 34) < (1 << 53)
         else:            # two passes: max |a| as large as THAT bound allows (up to 2^55)
-            top = min(((1 << 52) // (order * s_mag) - 1) << 20, (1 << 55) - 1)
+            top = min(((1 << 42) // (order * s_mag) - 1) << 20, (1 << 55) - 1)
             a = rng.integers(-top, top + 1, order).astype(np.int64)
             a[int(rng.integers(0, order))] = top * int(rng.choice([-1, 1]))
             a_top = int(np.bitwise_or.reduce(np.abs(a)))
-            if not (a_top < (1 << 55) and order * ((a_top >> 20) + 1) * s_mag < (1 << 52)):
+            if not (a_top < (1 << 55) and order * ((a_top >> 20) + 1) * s_mag < (1 << 42)):
                 continue # (the OR of the magnitudes may exceed the maximum: such a block takes the plain loop)
         for i in range(order, len(s)):
             taps = [(int(a[j - 1]), int(s[i - j])) for j in range(1, order + 1)]
-            want = ((1 << 34) + sum(c * x for c, x in taps)) >> 35
+            total = (1 << 34) + sum(c * x for c, x in taps)
+            assert abs(total) < (1 << 63)                       # the reference's int64 does not wrap ...
+            want = total >> 35
+            assert -(1 << 31) <= want < (1 << 31)               # ... and its (int32) cast keeps the value
             if not two_pass:
                 acc = float(1 << 34)
                 for c, x in taps:
