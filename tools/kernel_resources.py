@@ -1,4 +1,6 @@
 import subprocess,os,re,sys
+# scratch files go under tools/tmp/ (git-ignored), never the cwd
+TMP=os.path.join(os.path.dirname(os.path.abspath(__file__)),"tmp"); os.makedirs(TMP,exist_ok=True); os.chdir(TMP)
 LLVM="/opt/rocm/lib/llvm/bin"; LIB="/root/repo/sela_amd/libsela_hip.so"
 subprocess.check_call([LLVM+"/llvm-objcopy","--dump-section",".hip_fatbin=fat.bin",LIB])
 blob=open("fat.bin","rb").read(); magic=b"__CLANG_OFFLOAD_BUNDLE__"; starts=[];at=0
