@@ -54,7 +54,7 @@ extern "C" {
 
 #define SELA_HIP_OK 0
 #define SELA_HIP_ENODEV (-1)   /* no usable HIP device / HIP runtime error (see last_error) */
-#define SELA_HIP_EINVAL (-2)   /* bad argument (channels == 0, samples_per_channel != 2048, ...) */
+#define SELA_HIP_EINVAL (-2)   /* bad argument (channels == 0, samples_per_channel == 0 or > 65535, ...) */
 #define SELA_HIP_ENOMEM (-3)   /* device or host allocation failed */
 #define SELA_HIP_ECAPACITY (-4) /* caller-provided output or workspace too small */
 #define SELA_HIP_EFORMAT (-5)  /* malformed frame stream (bad sync word, inconsistent sizes) */
@@ -146,6 +146,44 @@ int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, ui
     uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out /* [n_frames+1] */);
 int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* pcm_out);
+/* Blocks of any length.  The reference's frame path does not know the number 2048: lpc::ResidueGenerator loops over
+ * samples.size() (src/lpc/residue_generator.cpp:12-45,98-119) and a subframe carries its own samplesPerChannel, a u16
+ * (src/include/data/sela_sub_frame.hpp:27, src/frame/frame_decoder.cpp:24-25,48-49); only its WAV reader cuts 2048-sample
+ * frames.  So:
+ *   sela_hip_encode() takes any samples_per_channel in 1 .. 65535 (pcm = [n_frames][samples_per_channel][channels]); other
+ *     than 2048 goes through the any-length kernels (sela_generic.hip: the same arithmetic with a run-time length, one wave
+ *     per block, not tuned).  frames_out needs sela_hip_encode_bound_bytes_n().  A block that is not longer than the
+ *     predictor order its own analysis picks makes the reference read past its vector (residue_generator.cpp:104-110):
+ *     SELA_HIP_ERANGE.
+ *   sela_hip_decode() takes a stream whose frames say anything in 0 .. 65535: when one says something other than 2048 the
+ *     whole call goes through the any-length kernels, frame f's samples land at pcm_out + sample_offsets[f] * channels with
+ *     sample_offsets[] as sela_hip_index_samples() reports them (for 2048 everywhere that is f * 2048, the layout above), and
+ *     a frame whose channels disagree about the length is malformed (SELA_HIP_EFORMAT; the reference's WAV writer indexes
+ *     past the shorter ones, src/file/wav_file.cpp:248-262).
+ * The streaming jobs and the device-pointer calls below stay what they are: the fast path for what the reference's CLI writes
+ * (2048 everywhere); a stream with another length gets SELA_HIP_EFORMAT from them, and the caller comes here. */
+size_t sela_hip_encode_bound_bytes_n(uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel);
+/* sample_offsets[f] = samples per channel before frame f (its first subframe's samplesPerChannel counts for the frame),
+ * [n_frames + 1] entries; returns the largest samplesPerChannel any subframe of the stream names (0 for a stream the walk
+ * cannot follow: the decode calls report that as SELA_HIP_EFORMAT). */
+uint32_t sela_hip_index_samples(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels,
+    uint64_t* sample_offsets);
+
+/* ---- the frame classes' own value types: 32-bit samples, any length ---------------------------------------------------------
+ * frame::FrameEncoder(const data::WavFrame&).process() and frame::FrameDecoder(const data::SelaFrame&).process()
+ * (src/include/frame.hpp:8-24) on what they really take and return: data::WavFrame = int32 samples per channel
+ * (src/include/data/wav_frame.hpp:8-16), nothing narrowed (src/frame/frame_decoder.cpp:64-71; only file::WavFile::writeToFile
+ * truncates to 16 bits).  Always the any-length kernels; results identical to the calls above wherever both apply.
+ *   samples      [n_frames][channels][samples_per_channel] (planar per frame: WavFrame.samples[c][i]), 1 .. 65535 per channel.
+ *   samples_out  [n_frames][channels][stride]: channel c of frame f at ((f * channels) + c) * stride, counts_out[f * channels + c]
+ *                of them valid (0 for a channel no subframe of the frame names); stride >= the largest samplesPerChannel in the
+ *                stream (sela_hip_index_samples() returns it) or SELA_HIP_ECAPACITY.
+ * Errors as above; values whose int32 zig-zag overflows in the reference (|residue| >= 2^30) and Rice streams beyond the u16
+ * word count of a subframe are SELA_HIP_ERANGE. */
+int sela_hip_encode_i32(const int32_t* samples, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel,
+    uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out /* [n_frames+1] */);
+int sela_hip_decode_i32(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels,
+    int32_t* samples_out, uint32_t stride, uint32_t* counts_out /* [n_frames * channels] */);
 
 /* ---- streaming jobs (host pointers) -------------------------------------------------------------------
  * For callers that produce their input piece by piece (a file being read): feed() enqueues a piece and
@@ -186,16 +224,25 @@ uint32_t sela_hip_index_frames(const uint8_t* frames, size_t frames_bytes, uint3
  * all of them inside one kernel (sela_hip_encode / sela_hip_decode) -- but the same device code, for callers and tests of
  * a stage by itself.  Every call synchronises.
  *
- * lpc::ResidueGenerator::process (src/lpc/residue_generator.cpp:121-134): n_blocks blocks of 2048 samples (int32, |s| <=
- * 65535: 16-bit channels and their difference; SELA_HIP_EINVAL beyond) -> per block the order, the quantised reflection
- * coefficients (q_out[block][0 .. order), the rest untouched) and 2048 residues. */
+ * lpc::ResidueGenerator::process (src/lpc/residue_generator.cpp:121-134): n_blocks blocks of 2048 samples (int32) -> per block the order, the quantised reflection
+ * coefficients (q_out[block][0 .. order), the rest zeroed) and 2048 residues.  Samples beyond 17 bits are taken too (through the
+ * any-length kernels, like sela_hip_lpc_encode_n).  A Rice stream too long for a frame's slot is not this stage's business:
+ * the residues are returned whatever their size. */
 int sela_hip_lpc_encode(const int32_t* samples, uint32_t n_blocks, int32_t* order_out, int32_t* q_out /* [n_blocks][100] */, int32_t* residues_out);
+/* The same for blocks of samples_per_block samples (1 .. 2^24) of any 32-bit value -- the class takes any vector
+ * (src/lpc/residue_generator.cpp:6-10).  q_out[block][order .. 100) is zeroed.  A block not longer than the order its analysis
+ * picks: SELA_HIP_ERANGE (the reference reads past its vector, residue_generator.cpp:104-110). */
+int sela_hip_lpc_encode_n(const int32_t* samples, uint32_t n_blocks, uint32_t samples_per_block, int32_t* order_out, int32_t* q_out /* [n_blocks][100] */,
+    int32_t* residues_out);
 /* lpc::SampleGenerator::process (src/lpc/sample_generator.cpp:11-39): the inverse.  q[block][0 .. order[block]); samples_out
  * [n_blocks][2048] as the 32-bit values the reference returns.  coefs_out (or NULL): [n_blocks][101], the Q35 predictor
  * a[0 .. order] of lpc::LinearPredictor::generatelinearPredictionCoefficients (src/lpc/linear_predictor.cpp:30-61);
  * samples_out may be NULL when only the predictor is wanted. */
 int sela_hip_lpc_decode(const int32_t* order, const int32_t* q /* [n_blocks][100] */, const int32_t* residues, uint32_t n_blocks, int32_t* samples_out,
     int64_t* coefs_out);
+/* The same for blocks of samples_per_block residues (1 .. 2^24). */
+int sela_hip_lpc_decode_n(const int32_t* order, const int32_t* q /* [n_blocks][100] */, const int32_t* residues, uint32_t n_blocks, uint32_t samples_per_block,
+    int32_t* samples_out, int64_t* coefs_out);
 /* rice::RiceEncoder::process (src/rice/rice_encoder.cpp:73-81): n_streams streams of int32 values, stream i =
  * values[value_offsets[i] .. value_offsets[i + 1]) -> its Rice parameter k_out[i] (the first minimum over 0..19), its
  * word count word_counts_out[i] (ceil((float)bits / 32) as the reference computes it) and its words at
@@ -225,6 +272,8 @@ int sela_hip_kernel_times(float* ms_out, int capacity);
 #define SELA_HIP_FLAG_WORDS_CAP 16u    /* a Rice stream exceeded the per-block slot (encoder) */
 #define SELA_HIP_FLAG_BAD_FRAME 32u    /* bad sync word / inconsistent subframe header (decoder) */
 #define SELA_HIP_FLAG_INTERNAL 64u     /* a bounded wait inside a kernel ran out (never expected; reported as SELA_HIP_ENODEV) */
+#define SELA_HIP_FLAG_SHORT_BLOCK 128u /* a block no longer than its own predictor order: the reference's warm-up loop reads past
+                                        * its vector there (src/lpc/residue_generator.cpp:104-110); reported as SELA_HIP_ERANGE */
 
 #ifdef __cplusplus
 }

@@ -165,6 +165,33 @@ size_t ref_frame_decode(const uint8_t* in, uint32_t channels, int16_t* pcm)
     return used;
 }
 
+// The same two on the reference's own value type (data::WavFrame: int32 samples per channel, any number of them,
+// src/include/data/wav_frame.hpp:8-16).  planar = [channels][n].
+size_t ref_frame_encode_i32(const int32_t* planar, uint32_t channels, uint32_t n, uint8_t* out)
+{
+    std::vector<std::vector<int32_t>> s(channels);
+    for (uint32_t c = 0; c < channels; c++)
+        s[c].assign(planar + (size_t)c * n, planar + (size_t)(c + 1) * n);
+    data::WavFrame wf((uint8_t)16, std::move(s));
+    data::SelaFrame sf = frame::FrameEncoder(wf).process();
+    return put_frame(sf, out);
+}
+
+// out[c][0 .. counts[c]) = WavFrame.samples[c] exactly as frame::FrameDecoder::process returns them (32-bit, every
+// channel with its own length); out is [channels][stride].  Returns bytes consumed.
+size_t ref_frame_decode_i32(const uint8_t* in, uint32_t channels, int32_t* out, uint32_t stride, uint32_t* counts)
+{
+    size_t used = 0;
+    data::SelaFrame sf = get_frame(in, channels, &used);
+    data::WavFrame wf = frame::FrameDecoder(sf).process();
+    for (uint32_t c = 0; c < channels; c++) {
+        const size_t n = c < wf.samples.size() ? wf.samples[c].size() : 0;
+        counts[c] = (uint32_t)n;
+        std::memcpy(out + (size_t)c * stride, wf.samples[c].data(), 4 * (n < stride ? n : stride));
+    }
+    return used;
+}
+
 // Batch encode with the reference's thread fan-out (src/sela/encoder.cpp:40-92): T threads,
 // static contiguous ranges, last thread takes the remainder.  offsets[n_frames+1] receives
 // byte offsets of each frame in out.  Returns seconds spent in the fan-out (frames are

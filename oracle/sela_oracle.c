@@ -362,21 +362,21 @@ size_t sela_oracle_frame_bound(uint32_t channels, uint32_t n)
     return 4 + (size_t)channels * (SELA_SUBFRAME_HEADER_BYTES + 4 * 128 + 8 * (size_t)n + 256);
 }
 
-size_t sela_oracle_frame_encode(const int16_t* pcm, uint32_t channels, uint32_t n, uint8_t* out, uint32_t* flags)
+size_t sela_oracle_frame_encode_i32(const int32_t* planar, uint32_t channels, uint32_t n, uint8_t* out, uint32_t* flags)
 {
+    /* data::WavFrame carries int32 samples per channel (src/include/data/wav_frame.hpp:8-16) and nothing in
+     * src/frame/frame_encoder.cpp:11-102 depends on their number or range: any n, any 32-bit values. */
     uint8_t* p = out;
     const uint32_t sync = SELA_SYNC_WORD;
     memcpy(p, &sync, 4), p += 4;
-    int32_t* cur = (int32_t*)malloc(sizeof(int32_t) * n);
-    int32_t* dif = (int32_t*)malloc(sizeof(int32_t) * n);
+    int32_t* dif = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
     for (uint32_t c = 0; c < channels; c++) {
-        for (uint32_t j = 0; j < n; j++)
-            cur[j] = pcm[(size_t)j * channels + c];
+        const int32_t* cur = planar + (size_t)c * n;
         coded_block act;
         code_block(cur, (int)n, &act, flags);
         if (c == 1 && channels == 2) { /* frame_encoder.cpp:18 -- exactly-stereo second channel */
-            for (uint32_t j = 0; j < n; j++) /* :22-24 */
-                dif[j] = (int32_t)pcm[(size_t)j * channels] - (int32_t)pcm[(size_t)j * channels + 1];
+            for (uint32_t j = 0; j < n; j++) /* :22-24, int32 subtraction (wraps like the x86 build) */
+                dif[j] = (int32_t)((uint32_t)planar[j] - (uint32_t)planar[(size_t)n + j]);
             coded_block dc;
             code_block(dif, (int)n, &dc, flags);
             if ((size_t)dc.cwords + (size_t)dc.rwords < (size_t)act.cwords + (size_t)act.rwords) /* :64-66 */
@@ -391,9 +391,20 @@ size_t sela_oracle_frame_encode(const int16_t* pcm, uint32_t channels, uint32_t 
         free(act.cw);
         free(act.rw);
     }
-    free(cur);
     free(dif);
     return (size_t)(p - out);
+}
+
+size_t sela_oracle_frame_encode(const int16_t* pcm, uint32_t channels, uint32_t n, uint8_t* out, uint32_t* flags)
+{
+    /* the demux of src/file/wav_file.cpp:194-200, then the frame encoder */
+    int32_t* planar = (int32_t*)malloc(sizeof(int32_t) * ((size_t)channels * n + 1));
+    for (uint32_t c = 0; c < channels; c++)
+        for (uint32_t j = 0; j < n; j++)
+            planar[(size_t)c * n + j] = pcm[(size_t)j * channels + c];
+    const size_t used = sela_oracle_frame_encode_i32(planar, channels, n, out, flags);
+    free(planar);
+    return used;
 }
 
 /* ---- frame decode ---------------------------------------------------------------------------
@@ -439,33 +450,60 @@ static void decode_sub(const sub_view* v, int32_t* s, uint32_t* flags)
     free(r);
 }
 
+size_t sela_oracle_frame_decode_i32(const uint8_t* in, uint32_t channels, int32_t* out, uint32_t stride, uint32_t* counts, uint32_t* flags)
+{
+    /* out[c][0 .. counts[c]) = allSamples[c] of src/frame/frame_decoder.cpp:13-71: every subframe brings its own
+     * samplesPerChannel (:24-25, :48-49), the values stay 32-bit (:64-71).  A channel no subframe wrote keeps count 0.
+     * Where the reference indexes out of bounds (a channel or parent number >= the number of subframes, a parent shorter
+     * than the difference, more samples than `stride`) the subframe is skipped / cut and BAD_FRAME raised. */
+    sub_view* v = (sub_view*)malloc(sizeof(sub_view) * (channels ? channels : 1));
+    const uint8_t* p = in + 4;
+    for (uint32_t c = 0; c < channels; c++) {
+        p = view_subframe(p, &v[c]);
+        counts[c] = 0;
+    }
+    int32_t* tmp = (int32_t*)malloc(4 * (size_t)65536);
+    for (uint32_t c = 0; c < channels; c++) /* :17-37 independent subframes first */
+        if (v[c].type == 0) {
+            if (v[c].channel >= channels || v[c].n > stride) {
+                raise_flag(flags, SELA_ORACLE_FLAG_BAD_FRAME);
+                continue;
+            }
+            decode_sub(&v[c], out + (size_t)v[c].channel * stride, flags);
+            counts[v[c].channel] = v[c].n;
+        }
+    for (uint32_t c = 0; c < channels; c++) /* :40-69 then dependent ones, in subframe order */
+        if (v[c].type == 1) {
+            if (v[c].channel >= channels || v[c].parent >= channels || v[c].n > stride || counts[v[c].parent] < v[c].n) {
+                raise_flag(flags, SELA_ORACLE_FLAG_BAD_FRAME);
+                continue;
+            }
+            decode_sub(&v[c], tmp, flags);
+            int32_t* dst = out + (size_t)v[c].channel * stride;
+            const int32_t* par = out + (size_t)v[c].parent * stride;
+            for (uint32_t i = 0; i < v[c].n; i++) /* :64-66 */
+                dst[i] = (int32_t)((uint32_t)par[i] - (uint32_t)tmp[i]);
+            counts[v[c].channel] = v[c].n;
+        }
+    free(tmp);
+    free(v);
+    return (size_t)(p - in);
+}
+
 size_t sela_oracle_frame_decode(const uint8_t* in, uint32_t channels, int16_t* pcm, uint32_t* flags)
 {
-    sub_view* v = (sub_view*)malloc(sizeof(sub_view) * channels);
-    const uint8_t* p = in + 4;
-    for (uint32_t c = 0; c < channels; c++)
-        p = view_subframe(p, &v[c]);
-    const uint32_t n = v[0].n;
-    int32_t* all = (int32_t*)calloc((size_t)channels * n, 4);
-    int32_t* tmp = (int32_t*)malloc(4 * (size_t)n + 4);
-    for (uint32_t c = 0; c < channels; c++) /* :17-37 independent subframes first */
-        if (v[c].type == 0 && v[c].channel < channels)
-            decode_sub(&v[c], all + (size_t)v[c].channel * n, flags);
-    for (uint32_t c = 0; c < channels; c++) /* :40-69 then dependent ones */
-        if (v[c].type == 1 && v[c].channel < channels && v[c].parent < channels) {
-            decode_sub(&v[c], tmp, flags);
-            int32_t* dst = all + (size_t)v[c].channel * n;
-            const int32_t* par = all + (size_t)v[c].parent * n;
-            for (uint32_t i = 0; i < n; i++)
-                dst[i] = (int32_t)((uint32_t)par[i] - (uint32_t)tmp[i]);
-        }
+    uint16_t n16;
+    memcpy(&n16, in + 4 + 7 + 4 * (size_t)(in[4 + 4] | (in[4 + 5] << 8)) + 3, 2); /* the first subframe's samplesPerChannel */
+    const uint32_t n = n16;
+    int32_t* all = (int32_t*)calloc((size_t)channels * (n ? n : 1), 4);
+    uint32_t* counts = (uint32_t*)calloc(channels ? channels : 1, 4);
+    const size_t used = sela_oracle_frame_decode_i32(in, channels, all, n, counts, flags);
     for (uint32_t i = 0; i < n; i++) /* truncation to 16 bits as in src/file/wav_file.cpp:248-251 */
         for (uint32_t c = 0; c < channels; c++)
             pcm[(size_t)i * channels + c] = (int16_t)(uint16_t)all[(size_t)c * n + i];
     free(all);
-    free(tmp);
-    free(v);
-    return (size_t)(p - in);
+    free(counts);
+    return used;
 }
 
 /* ---- batch drivers: the reference's static contiguous partition over T threads -------------

@@ -29,6 +29,7 @@ extern "C" {
 #define SELA_ORACLE_FLAG_COEF_OVERFLOW 2u /* |2^35*coef| >= 2^63 in the step-up output */
 #define SELA_ORACLE_FLAG_RICE_RANGE 4u   /* zig-zag value does not fit 32 bits */
 #define SELA_ORACLE_FLAG_RICE_OVERRUN 8u /* Rice decoder ran past the end of its words */
+#define SELA_ORACLE_FLAG_BAD_FRAME 32u   /* a subframe names a channel / parent that does not exist, or a parent shorter than itself */
 
 /* FP64 intermediates of one analysis, exposed so that GPU kernels can be compared stage by
  * stage (the reference keeps these private). */
@@ -57,7 +58,16 @@ void sela_oracle_rice_decode(const uint32_t* words, int nwords, int n, uint32_t 
 /* frame::FrameEncoder::process on interleaved int16 PCM -> on-disk frame bytes. Returns bytes. */
 size_t sela_oracle_frame_encode(const int16_t* pcm, uint32_t channels, uint32_t n, uint8_t* out, uint32_t* flags);
 
-/* frame::FrameDecoder::process from on-disk frame bytes -> interleaved int16. Returns bytes consumed. */
+/* The same on the reference's own value type: data::WavFrame = int32 samples per channel, any number of them
+ * (src/include/data/wav_frame.hpp:8-16).  planar = [channels][n]. */
+size_t sela_oracle_frame_encode_i32(const int32_t* planar, uint32_t channels, uint32_t n, uint8_t* out, uint32_t* flags);
+
+/* frame::FrameDecoder::process as the reference returns it: out[c][0 .. counts[c]) = WavFrame.samples[c], 32-bit,
+ * every subframe with its own samplesPerChannel; out is [channels][stride].  Returns bytes consumed. */
+size_t sela_oracle_frame_decode_i32(const uint8_t* in, uint32_t channels, int32_t* out, uint32_t stride, uint32_t* counts, uint32_t* flags);
+
+/* frame::FrameDecoder::process from on-disk frame bytes -> interleaved int16 (the first subframe's samplesPerChannel
+ * of them per channel). Returns bytes consumed. */
 size_t sela_oracle_frame_decode(const uint8_t* in, uint32_t channels, int16_t* pcm, uint32_t* flags);
 
 /* Batch drivers with the reference's static contiguous thread partition

@@ -15,7 +15,7 @@ OK = 0
 ERRORS = {-1: "ENODEV", -2: "EINVAL", -3: "ENOMEM", -4: "ECAPACITY", -5: "EFORMAT", -6: "ERANGE"}
 SAMPLES_PER_FRAME = 2048
 
-FLAG_Q_RANGE, FLAG_COEF_OVERFLOW, FLAG_RICE_RANGE, FLAG_RICE_OVERRUN, FLAG_WORDS_CAP, FLAG_BAD_FRAME, FLAG_INTERNAL = 1, 2, 4, 8, 16, 32, 64
+FLAG_Q_RANGE, FLAG_COEF_OVERFLOW, FLAG_RICE_RANGE, FLAG_RICE_OVERRUN, FLAG_WORDS_CAP, FLAG_BAD_FRAME, FLAG_INTERNAL, FLAG_SHORT_BLOCK = 1, 2, 4, 8, 16, 32, 64, 128
 
 # every symbol include/sela_hip.h declares
 EXPORTS = [
@@ -28,6 +28,8 @@ EXPORTS = [
     "sela_hip_host_alloc", "sela_hip_host_free", "sela_hip_decode_max_channels",
     "sela_hip_encode_begin", "sela_hip_encode_feed", "sela_hip_encode_end",
     "sela_hip_decode_begin", "sela_hip_decode_feed", "sela_hip_decode_end",
+    "sela_hip_encode_bound_bytes_n", "sela_hip_index_samples", "sela_hip_encode_i32", "sela_hip_decode_i32",
+    "sela_hip_lpc_encode_n", "sela_hip_lpc_decode_n",
 ]
 
 
@@ -107,6 +109,16 @@ def lib() -> C.CDLL:
     L.sela_hip_rice_encode.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.sela_hip_rice_decode.argtypes = [vp, vp, vp, vp, u32, vp]
     for name in ("sela_hip_lpc_encode", "sela_hip_lpc_decode", "sela_hip_rice_encode", "sela_hip_rice_decode"):
+        getattr(L, name).restype = C.c_int
+    L.sela_hip_encode_bound_bytes_n.argtypes = [u32, u32, u32]
+    L.sela_hip_encode_bound_bytes_n.restype = sz
+    L.sela_hip_index_samples.argtypes = [vp, vp, u32, u32, vp]
+    L.sela_hip_index_samples.restype = u32
+    L.sela_hip_encode_i32.argtypes = [vp, u32, u32, u32, vp, sz, vp]
+    L.sela_hip_decode_i32.argtypes = [vp, vp, u32, u32, vp, u32, vp]
+    L.sela_hip_lpc_encode_n.argtypes = [vp, u32, u32, vp, vp, vp]
+    L.sela_hip_lpc_decode_n.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    for name in ("sela_hip_encode_i32", "sela_hip_decode_i32", "sela_hip_lpc_encode_n", "sela_hip_lpc_decode_n"):
         getattr(L, name).restype = C.c_int
     L.sela_hip_debug_phase_buffer.argtypes = [C.c_void_p]
     L.sela_hip_debug_phase_buffer.restype = None

@@ -118,11 +118,12 @@ class Decoder:
 
 # ---- host-pointer API on numpy arrays (what the C++ host calls) --------------------------------------
 def encode_host(pcm: np.ndarray):
-    """pcm: int16 [n_frames, 2048, channels] -> (frames uint8[...], offsets uint64[n_frames+1])."""
+    """pcm: int16 [n_frames, n, channels] (n = 2048: the fast kernels; anything else in 1..65535: the any-length route)
+    -> (frames uint8[...], offsets uint64[n_frames+1])."""
     lib = capi.lib()
     p = np.ascontiguousarray(pcm, dtype=np.int16)
     n_frames, n, ch = p.shape
-    cap = max(2 * p.nbytes, 4096)
+    cap = max(2 * p.nbytes, 4096) if n == BLOCK else int(lib.sela_hip_encode_bound_bytes_n(n_frames, ch, n))
     frames = np.empty(cap, np.uint8)
     offs = np.zeros(n_frames + 1, np.uint64)
     capi.check(lib.sela_hip_encode(p.ctypes.data, n_frames, ch, n, frames.ctypes.data, cap, offs.ctypes.data))
@@ -130,13 +131,55 @@ def encode_host(pcm: np.ndarray):
 
 
 def decode_host(frames: np.ndarray, offsets: np.ndarray, channels: int) -> np.ndarray:
+    """-> int16 [n_frames, 2048, channels] for a stream of 2048-sample frames; for any other stream int16 [total samples,
+    channels], frame f's samples from index_samples()[0][f] on."""
     lib = capi.lib()
     fr = np.ascontiguousarray(frames, dtype=np.uint8)
     offs = np.ascontiguousarray(offsets, dtype=np.uint64)
     n_frames = len(offs) - 1
-    pcm = np.empty((n_frames, BLOCK, channels), np.int16)
+    sample_offsets, largest = index_samples(fr, offs, channels)
+    standard = largest == BLOCK and all(int(sample_offsets[f]) == f * BLOCK for f in range(n_frames + 1))
+    total = n_frames * BLOCK if standard or largest == 0 else int(sample_offsets[n_frames])
+    pcm = np.empty((max(total, 1), channels), np.int16)
     capi.check(lib.sela_hip_decode(fr.ctypes.data, offs.ctypes.data, n_frames, channels, pcm.ctypes.data))
-    return pcm
+    return pcm[:total].reshape(n_frames, BLOCK, channels) if standard or largest == 0 else pcm[:total]
+
+
+def index_samples(frames: np.ndarray, offsets: np.ndarray, channels: int):
+    """-> (sample_offsets uint64[n_frames+1], largest samplesPerChannel of the stream)."""
+    lib = capi.lib()
+    fr = np.ascontiguousarray(frames, dtype=np.uint8)
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n_frames = len(offs) - 1
+    so = np.zeros(n_frames + 1, np.uint64)
+    largest = lib.sela_hip_index_samples(fr.ctypes.data, offs.ctypes.data, n_frames, channels, so.ctypes.data)
+    return so, int(largest)
+
+
+def encode_i32(samples: np.ndarray):
+    """frame::FrameEncoder on data::WavFrame values: samples int32 [n_frames, channels, n] -> (frames uint8[...], offsets)."""
+    lib = capi.lib()
+    p = np.ascontiguousarray(samples, dtype=np.int32)
+    n_frames, ch, n = p.shape
+    cap = int(lib.sela_hip_encode_bound_bytes_n(n_frames, ch, n))
+    frames = np.empty(max(cap, 16), np.uint8)
+    offs = np.zeros(n_frames + 1, np.uint64)
+    capi.check(lib.sela_hip_encode_i32(p.ctypes.data, n_frames, ch, n, frames.ctypes.data, cap, offs.ctypes.data))
+    return frames[: int(offs[n_frames])].copy(), offs
+
+
+def decode_i32(frames: np.ndarray, offsets: np.ndarray, channels: int, stride=None):
+    """frame::FrameDecoder as it returns: -> list (per frame) of lists (per channel) of int32 arrays."""
+    lib = capi.lib()
+    fr = np.ascontiguousarray(frames, dtype=np.uint8)
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n_frames = len(offs) - 1
+    if stride is None:
+        stride = max(index_samples(fr, offs, channels)[1], 1)
+    out = np.zeros((n_frames, channels, stride), np.int32)
+    counts = np.zeros((n_frames, channels), np.uint32)
+    capi.check(lib.sela_hip_decode_i32(fr.ctypes.data, offs.ctypes.data, n_frames, channels, out.ctypes.data, stride, counts.ctypes.data))
+    return [[out[f, c, : int(counts[f, c])].copy() for c in range(channels)] for f in range(n_frames)]
 
 
 def index_frames(frames: np.ndarray, n_frames: int, channels: int) -> np.ndarray:
@@ -149,14 +192,43 @@ def index_frames(frames: np.ndarray, n_frames: int, channels: int) -> np.ndarray
 
 # ---- the stages on their own (sela_hip_lpc_* / sela_hip_rice_*: the reference's L1 classes, batched) -----------------------
 def lpc_encode(samples: np.ndarray):
-    """samples: int32 [n_blocks, 2048] -> (order int32[n], q int32[n, 100] (first order[i] entries valid), residues int32[n, 2048])."""
+    """samples: int32 [n_blocks, len] -> (order int32[n], q int32[n, 100] (first order[i] entries valid), residues int32[n, len]).
+    len = 2048 is sela_hip_lpc_encode (the frame kernels' analysis), any other length sela_hip_lpc_encode_n."""
     lib = capi.lib()
     s = np.ascontiguousarray(samples, dtype=np.int32)
     n = s.shape[0]
-    assert s.ndim == 2 and s.shape[1] == BLOCK
-    order, q, res = np.zeros(n, np.int32), np.zeros((n, 100), np.int32), np.zeros((n, BLOCK), np.int32)
-    capi.check(lib.sela_hip_lpc_encode(C.c_void_p(s.ctypes.data), n, C.c_void_p(order.ctypes.data), C.c_void_p(q.ctypes.data), C.c_void_p(res.ctypes.data)))
+    assert s.ndim == 2
+    length = s.shape[1]
+    order, q, res = np.zeros(n, np.int32), np.full((n, 100), 0x5A5A5A5A, np.int32), np.zeros((n, length), np.int32)
+    if length == BLOCK:
+        capi.check(lib.sela_hip_lpc_encode(C.c_void_p(s.ctypes.data), n, C.c_void_p(order.ctypes.data), C.c_void_p(q.ctypes.data), C.c_void_p(res.ctypes.data)))
+    else:
+        capi.check(lib.sela_hip_lpc_encode_n(C.c_void_p(s.ctypes.data), n, length, C.c_void_p(order.ctypes.data), C.c_void_p(q.ctypes.data), C.c_void_p(res.ctypes.data)))
     return order, q, res
+
+
+def lpc_encode_n(samples: np.ndarray):
+    """Always the any-length kernels (also for 2048)."""
+    lib = capi.lib()
+    s = np.ascontiguousarray(samples, dtype=np.int32)
+    n, length = s.shape
+    order, q, res = np.zeros(n, np.int32), np.full((n, 100), 0x5A5A5A5A, np.int32), np.zeros((n, length), np.int32)
+    capi.check(lib.sela_hip_lpc_encode_n(C.c_void_p(s.ctypes.data), n, length, C.c_void_p(order.ctypes.data), C.c_void_p(q.ctypes.data), C.c_void_p(res.ctypes.data)))
+    return order, q, res
+
+
+def lpc_decode_n(order: np.ndarray, q: np.ndarray, residues: np.ndarray, want_coefficients: bool = False):
+    """sela_hip_lpc_decode_n: residues int32 [n_blocks, len] of any length."""
+    lib = capi.lib()
+    o = np.ascontiguousarray(order, dtype=np.int32)
+    n = o.shape[0]
+    qq = np.ascontiguousarray(q, dtype=np.int32).reshape(n, 100)
+    r = np.ascontiguousarray(residues, dtype=np.int32).reshape(n, -1)
+    out = np.zeros_like(r)
+    coefs = np.zeros((n, 101), np.int64) if want_coefficients else None
+    capi.check(lib.sela_hip_lpc_decode_n(C.c_void_p(o.ctypes.data), C.c_void_p(qq.ctypes.data), C.c_void_p(r.ctypes.data), n, r.shape[1],
+                                         C.c_void_p(out.ctypes.data), C.c_void_p(coefs.ctypes.data) if coefs is not None else None))
+    return (out, coefs) if want_coefficients else out
 
 
 def lpc_decode(order: np.ndarray, q: np.ndarray, residues: np.ndarray, want_coefficients: bool = False):

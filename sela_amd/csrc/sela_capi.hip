@@ -42,6 +42,15 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles,
     uint8_t* frame_flags, int recurrence_form);
 int decode_waves(uint32_t channels);
+// the any-length / 32-bit route (sela_capi_generic.hip)
+void generic_release();
+size_t generic_encode_bound_bytes(uint32_t n_frames, uint32_t channels, uint32_t n);
+int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n, uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out);
+uint32_t generic_index_samples(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, uint64_t* sample_offsets, bool* all_standard);
+int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out, uint32_t stride,
+    uint32_t* counts_out, int16_t* pcm_out, const uint64_t* sample_offsets);
+int generic_lpc_encode(const int32_t* samples, uint32_t n_blocks, uint32_t n, int32_t* order_out, int32_t* q_out, int32_t* residues_out);
+int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* residues, uint32_t n_blocks, uint32_t n, int32_t* samples_out, int64_t* coefs_out);
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 uint32_t decode_max_channels();
 } // namespace sela
@@ -60,6 +69,13 @@ int fail_hip(hipError_t e, const char* where)
 {
     return fail(e == hipErrorOutOfMemory ? SELA_HIP_ENOMEM : SELA_HIP_ENODEV, std::string(where) + ": " + hipGetErrorString(e));
 }
+
+} // namespace
+namespace sela {
+int report_error(int code, const std::string& what) { return fail(code, what); }
+int report_hip_error(hipError_t e, const char* where) { return fail_hip(e, where); }
+}
+namespace {
 
 // ---- page-locked host memory (sela_hip_host_alloc) ---------------------------------------------------------
 // Copies from and to pageable memory go through the runtime's own staging and block the calling thread;
@@ -1029,11 +1045,16 @@ int sela_hip_init(int device)
     return SELA_HIP_OK;
 }
 
-void sela_hip_thread_release(void) { g_lease.give_back(); }
+void sela_hip_thread_release(void)
+{
+    g_lease.give_back();
+    sela::generic_release();
+}
 
 void sela_hip_shutdown(void)
 {
     g_lease.give_back();
+    sela::generic_release();
     std::vector<HostContext*> idle;
     {
         std::lock_guard<std::mutex> lock(park().mu);
@@ -1328,10 +1349,12 @@ int submit_small(bool encode, SmallCall& call)
 int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel, uint8_t* frames_out,
     size_t frames_cap, uint64_t* frame_offsets_out)
 {
-    if (samples_per_channel != SELA_HIP_SAMPLES_PER_FRAME)
-        return fail(SELA_HIP_EINVAL, "samples_per_channel must be 2048 (reference frame size)");
+    if (samples_per_channel == 0 || samples_per_channel > 65535)
+        return fail(SELA_HIP_EINVAL, "samples_per_channel must be 1 .. 65535 (the subframe's field is 16 bits wide)");
     if (channels == 0 || channels > 255 || !frame_offsets_out || (n_frames && (!pcm || !frames_out)))
         return fail(SELA_HIP_EINVAL, "bad argument");
+    if (samples_per_channel != SELA_HIP_SAMPLES_PER_FRAME) // not the shape the fast kernels are built for: the any-length route
+        return sela::generic_encode(pcm, true, n_frames, channels, samples_per_channel, frames_out, frames_cap, frame_offsets_out);
     if (n_frames == 0 || n_frames > kCoalesceFrames || (g_lease.held && g_lease.held->job_open)) // (a thread in the middle of a job of its own hears about that itself)
         return encode_now(pcm, n_frames, channels, frames_out, frames_cap, frame_offsets_out);
     SmallCall call;
@@ -1346,6 +1369,16 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
 {
     if (channels == 0 || channels > 255 || (n_frames && (!frames || !frame_offsets || !pcm_out)))
         return fail(SELA_HIP_EINVAL, "bad argument");
+    bool ordered = true;
+    for (uint32_t f = 0; f < n_frames && ordered; f++)
+        ordered = frame_offsets[f + 1] >= frame_offsets[f];
+    if (ordered && n_frames) { // a subframe that does not say 2048 sends the call down the any-length route
+        bool standard = true;
+        std::vector<uint64_t> sample_offsets((size_t)n_frames + 1);
+        const uint32_t largest = sela::generic_index_samples(frames, frame_offsets, n_frames, channels, sample_offsets.data(), &standard);
+        if (!standard && largest != 0)
+            return sela::generic_decode(frames, frame_offsets, n_frames, channels, nullptr, largest, nullptr, pcm_out, sample_offsets.data());
+    }
     if (n_frames == 0 || n_frames > kCoalesceFrames || (g_lease.held && g_lease.held->job_open))
         return decode_now(frames, frame_offsets, n_frames, channels, pcm_out);
     for (uint32_t f = 0; f < n_frames; f++) // (what the job would refuse is refused by the job, for this caller alone)
@@ -1357,6 +1390,77 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
     call.channels = channels, call.n_frames = n_frames;
     call.frames = frames, call.offsets_in = frame_offsets, call.pcm_out = pcm_out;
     return submit_small(false, call);
+}
+
+size_t sela_hip_encode_bound_bytes_n(uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel)
+{
+    if (samples_per_channel == SELA_HIP_SAMPLES_PER_FRAME)
+        return sela_hip_encode_bound_bytes(n_frames, channels);
+    return sela::generic_encode_bound_bytes(n_frames, channels, samples_per_channel);
+}
+
+uint32_t sela_hip_index_samples(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, uint64_t* sample_offsets)
+{
+    if (!frames || !frame_offsets || channels == 0) {
+        if (sample_offsets)
+            for (uint32_t f = 0; f <= n_frames; f++)
+                sample_offsets[f] = 0;
+        return 0;
+    }
+    for (uint32_t f = 0; f < n_frames; f++)
+        if (frame_offsets[f + 1] < frame_offsets[f])
+            return 0;
+    return sela::generic_index_samples(frames, frame_offsets, n_frames, channels, sample_offsets, nullptr);
+}
+
+int sela_hip_encode_i32(const int32_t* samples, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel, uint8_t* frames_out, size_t frames_cap,
+    uint64_t* frame_offsets_out)
+{
+    if (samples_per_channel == 0 || samples_per_channel > 65535)
+        return fail(SELA_HIP_EINVAL, "samples_per_channel must be 1 .. 65535 (the subframe's field is 16 bits wide)");
+    if (channels == 0 || channels > 255 || !frame_offsets_out || (n_frames && (!samples || !frames_out)))
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    return sela::generic_encode(samples, false, n_frames, channels, samples_per_channel, frames_out, frames_cap, frame_offsets_out);
+}
+
+int sela_hip_decode_i32(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out, uint32_t stride,
+    uint32_t* counts_out)
+{
+    if (channels == 0 || channels > 255 || (n_frames && (!frames || !frame_offsets || !samples_out || !counts_out)))
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    if (n_frames == 0)
+        return SELA_HIP_OK;
+    for (uint32_t f = 0; f < n_frames; f++)
+        if (frame_offsets[f + 1] < frame_offsets[f])
+            return fail(SELA_HIP_EFORMAT, "frame offsets must not decrease");
+    const uint32_t largest = sela::generic_index_samples(frames, frame_offsets, n_frames, channels, nullptr, nullptr);
+    if (largest > stride)
+        return fail(SELA_HIP_ECAPACITY, "stride is smaller than the largest samplesPerChannel of the stream (see sela_hip_index_samples)");
+    // (a stream the host walk cannot follow reports 0: the kernels find and report the malformed frame)
+    return sela::generic_decode(frames, frame_offsets, n_frames, channels, samples_out, stride, counts_out, nullptr, nullptr);
+}
+
+int sela_hip_lpc_encode_n(const int32_t* samples, uint32_t n_blocks, uint32_t samples_per_block, int32_t* order_out, int32_t* q_out, int32_t* residues_out)
+{
+    if (n_blocks && (!samples || !order_out || !q_out || !residues_out))
+        return fail(SELA_HIP_EINVAL, "null pointer");
+    if (samples_per_block == 0 || samples_per_block > (1u << 24))
+        return fail(SELA_HIP_EINVAL, "samples_per_block must be 1 .. 2^24");
+    if (n_blocks == 0)
+        return stage_device_ready();
+    return sela::generic_lpc_encode(samples, n_blocks, samples_per_block, order_out, q_out, residues_out);
+}
+
+int sela_hip_lpc_decode_n(const int32_t* order, const int32_t* q, const int32_t* residues, uint32_t n_blocks, uint32_t samples_per_block, int32_t* samples_out,
+    int64_t* coefs_out)
+{
+    if (n_blocks && (!order || !q || (samples_out && !residues) || (!samples_out && !coefs_out)))
+        return fail(SELA_HIP_EINVAL, "null pointer");
+    if (samples_per_block == 0 || samples_per_block > (1u << 24))
+        return fail(SELA_HIP_EINVAL, "samples_per_block must be 1 .. 2^24");
+    if (n_blocks == 0)
+        return stage_device_ready();
+    return sela::generic_lpc_decode(order, q, residues, n_blocks, samples_per_block, samples_out, coefs_out);
 }
 
 int sela_hip_lpc_encode(const int32_t* samples, uint32_t n_blocks, int32_t* order_out, int32_t* q_out, int32_t* residues_out)
@@ -1374,8 +1478,8 @@ int sela_hip_lpc_encode(const int32_t* samples, uint32_t n_blocks, int32_t* orde
     std::vector<int16_t> pcm((size_t)n_blocks * kBlk * 2);
     for (size_t i = 0; i < (size_t)n_blocks * kBlk; i++) {
         const int32_t s = samples[i];
-        if (s < -65535 || s > 65535)
-            return fail(SELA_HIP_EINVAL, "lpc_encode: samples must lie within 16-bit channels and their difference (|s| <= 65535)");
+        if (s < -65535 || s > 65535) // beyond 16-bit channels and their difference: not the fast kernels' input
+            return sela::generic_lpc_encode(samples, n_blocks, SELA_HIP_SAMPLES_PER_FRAME, order_out, q_out, residues_out);
         const int32_t left = s > 32767 ? 32767 : (s < -32768 ? -32768 : s);
         pcm[2 * i] = (int16_t)left;
         pcm[2 * i + 1] = (int16_t)(left - s);
@@ -1405,8 +1509,8 @@ int sela_hip_lpc_encode(const int32_t* samples, uint32_t n_blocks, int32_t* orde
     for (uint32_t b = 0; b < n_blocks; b++) {
         const sela_hip_trace& t = trace[(size_t)b * 3 + 2];
         order_out[b] = t.order;
-        for (int i = 0; i < t.order && i < SELA_MAX_LPC_ORDER; i++)
-            q_out[(size_t)b * SELA_MAX_LPC_ORDER + i] = t.q[i];
+        for (int i = 0; i < SELA_MAX_LPC_ORDER; i++)
+            q_out[(size_t)b * SELA_MAX_LPC_ORDER + i] = i < t.order ? t.q[i] : 0;
         flags |= t.flags;
     }
     if (flags & (SELA_HIP_FLAG_RICE_RANGE | SELA_HIP_FLAG_COEF_OVERFLOW))

@@ -1,0 +1,403 @@
+// sela_capi_generic.hip -- the host side of the any-length / 32-bit route (kernels: sela_generic.hip; declarations:
+// include/sela_hip.h "Blocks of any length" and "the frame classes' own value types").
+//
+// Plain synchronous calls on the calling thread's current device: copy in, kernels, copy out, in chunks of frames that keep
+// the device scratch bounded.  The scratch is one grow-only device allocation per thread (a frame at a time through
+// frame::FrameEncoder must not pay a hipMalloc / hipFree pair per call); sela_hip_thread_release() / sela_hip_shutdown() and
+// the thread's end give it back.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sela_device.h"
+#include "sela_generic.h"
+
+namespace sela {
+int report_error(int code, const std::string& what);      // sela_capi.hip: sets the thread's last error, returns code
+int report_hip_error(hipError_t e, const char* where);    // (ENOMEM for an allocation failure, ENODEV otherwise)
+}
+
+namespace {
+
+using sela::GenericMeta;
+using sela::GenericSubInfo;
+
+struct Arena { // one device allocation, handed out in aligned pieces for the length of a call
+    uint8_t* base = nullptr;
+    size_t cap = 0, used = 0;
+    int device = -1;
+    ~Arena() { release(); }
+    void release()
+    {
+        if (base) {
+            int before = -1;
+            (void)hipGetDevice(&before);
+            if (device >= 0 && before != device)
+                (void)hipSetDevice(device);
+            (void)hipFree(base);
+            if (before >= 0 && before != device)
+                (void)hipSetDevice(before);
+        }
+        base = nullptr, cap = used = 0, device = -1;
+    }
+    hipError_t reserve(size_t bytes)
+    {
+        int dev = -1;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess)
+            return e;
+        used = 0;
+        if (base && dev == device && bytes <= cap)
+            return hipSuccess;
+        release();
+        const size_t want = std::max<size_t>(bytes + (bytes >> 2), 1 << 20);
+        e = hipMalloc(reinterpret_cast<void**>(&base), want);
+        if (e != hipSuccess) {
+            base = nullptr;
+            return e;
+        }
+        cap = want, device = dev;
+        return hipSuccess;
+    }
+    template <typename T>
+    T* take(size_t count)
+    {
+        const size_t at = (used + 255) & ~(size_t)255;
+        used = at + std::max<size_t>(count, 1) * sizeof(T);
+        return reinterpret_cast<T*>(base + at);
+    }
+};
+thread_local Arena g_arena;
+
+constexpr size_t kPiece = 256; // what take() may add per piece
+constexpr size_t kChunkBudget = (size_t)768 << 20; // device scratch per chunk of frames
+
+int device_ready()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return sela::report_error(SELA_HIP_ENODEV, "no HIP device visible (the SELA MI355X path has no CPU fallback)");
+    return SELA_HIP_OK;
+}
+
+int flags_error(uint32_t flags, const char* who)
+{
+    if (flags & SELA_HIP_FLAG_SHORT_BLOCK)
+        return sela::report_error(SELA_HIP_ERANGE, std::string(who) + ": a block is not longer than its predictor order (the reference reads past its vector there, src/lpc/residue_generator.cpp:104-110)");
+    if (flags & SELA_HIP_FLAG_RICE_RANGE)
+        return sela::report_error(SELA_HIP_ERANGE, std::string(who) + ": a residue is beyond the reference's int32 zig-zag (|value| >= 2^30)");
+    if (flags & SELA_HIP_FLAG_COEF_OVERFLOW)
+        return sela::report_error(SELA_HIP_ERANGE, std::string(who) + ": a predictor coefficient left the int64 range");
+    if (flags & SELA_HIP_FLAG_WORDS_CAP)
+        return sela::report_error(SELA_HIP_ERANGE, std::string(who) + ": a Rice stream needs more words than a subframe's 16-bit count can say");
+    return SELA_HIP_OK;
+}
+
+} // namespace
+
+namespace sela {
+
+void generic_release() { g_arena.release(); }
+
+size_t generic_encode_bound_bytes(uint32_t n_frames, uint32_t channels, uint32_t n)
+{
+    // first-minimum k is no worse than k = 19: (u >> 19) + 20 bits per value, u < 2^31 (beyond: ERANGE); a subframe holds at most
+    // 65535 words (beyond: ERANGE)
+    const uint64_t res_words = std::min<uint64_t>(65535, ((uint64_t)n * (4095 + 20) + 31) / 32);
+    return (size_t)n_frames * (4 + (size_t)channels * (SELA_SUBFRAME_HEADER_BYTES + 4 * ((size_t)kCoefWordsCap + res_words)));
+}
+
+// input: int16 [n_frames][n][channels] (in16) or int32 [n_frames][channels][n]
+int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n, uint8_t* frames_out, size_t frames_cap,
+    uint64_t* frame_offsets_out)
+{
+    if (device_ready() != SELA_HIP_OK)
+        return SELA_HIP_ENODEV;
+    const uint32_t n_sig = channels == 2 ? 3u : channels;
+    const size_t in_frame_bytes = (size_t)n * channels * (in16 ? 2 : 4);
+    const size_t per_frame = (size_t)n_sig * n * 16 + (size_t)n_sig * (kMaxOrder * 4 + sizeof(GenericMeta) + 2 * kPiece) + in_frame_bytes + (size_t)channels * 12 + 8;
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
+    uint64_t base_bytes = 0;
+    frame_offsets_out[0] = 0;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const uint32_t cf = std::min(chunk, n_frames - f0);
+        const size_t blocks = (size_t)cf * n_sig, subs = (size_t)cf * channels;
+        const size_t fixed = blocks * n * 16 + blocks * (kMaxOrder * 4 + sizeof(GenericMeta)) + cf * in_frame_bytes + (subs + 1) * 12 + ((size_t)cf + 1) * 8 + 64 + 12 * kPiece;
+        hipError_t e = g_arena.reserve(fixed);
+        if (e != hipSuccess)
+            return report_hip_error(e, "generic encode: scratch");
+        void* d_in = g_arena.take<uint8_t>(cf * in_frame_bytes);
+        int32_t* d_sig = g_arena.take<int32_t>(blocks * n);
+        double* d_cen = g_arena.take<double>(blocks * n);
+        int32_t* d_res = g_arena.take<int32_t>(blocks * n);
+        int32_t* d_q = g_arena.take<int32_t>(blocks * kMaxOrder);
+        GenericMeta* d_meta = g_arena.take<GenericMeta>(blocks);
+        uint64_t* d_offsets = g_arena.take<uint64_t>((size_t)cf + 1);
+        uint64_t* d_word_base = g_arena.take<uint64_t>(subs + 1);
+        uint32_t* d_chosen = g_arena.take<uint32_t>(subs);
+        uint32_t* d_status = g_arena.take<uint32_t>(4);
+        e = hipMemcpy(d_in, static_cast<const uint8_t*>(input) + (size_t)f0 * in_frame_bytes, cf * in_frame_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(d_status, 0, 16, nullptr);
+        if (e == hipSuccess)
+            e = launch_generic_analyse(d_in, in16, cf, channels, n_sig, n, d_sig, d_cen, d_res, d_q, d_meta, nullptr);
+        if (e == hipSuccess)
+            e = launch_generic_plan(d_meta, cf, channels, n_sig, base_bytes, d_offsets, d_word_base, d_chosen, d_status, nullptr);
+        uint32_t status[4] = {};
+        uint64_t total_words = 0;
+        if (e == hipSuccess)
+            e = hipMemcpy(status, d_status, 16, hipMemcpyDeviceToHost); // (synchronises)
+        if (e == hipSuccess)
+            e = hipMemcpy(frame_offsets_out + f0, d_offsets, ((size_t)cf + 1) * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(&total_words, d_word_base + subs, 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return report_hip_error(e, "generic encode: analysis");
+        const int rc = flags_error(status[0], "encode");
+        if (rc != SELA_HIP_OK)
+            return rc;
+        const uint64_t chunk_bytes = frame_offsets_out[f0 + cf] - base_bytes;
+        if (frame_offsets_out[f0 + cf] > frames_cap)
+            return report_error(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes_n)");
+        // the second half's pieces live behind the first half's (which pack and assemble still read)
+        const size_t used_so_far = g_arena.used;
+        const size_t more = (size_t)total_words * 4 + chunk_bytes + 4 * kPiece;
+        if (used_so_far + more > g_arena.cap) { // (rare: a second allocation for this call only)
+            uint8_t* extra = nullptr;
+            e = hipMalloc(reinterpret_cast<void**>(&extra), more);
+            if (e != hipSuccess)
+                return report_hip_error(e, "generic encode: stream scratch");
+            uint32_t* d_words = reinterpret_cast<uint32_t*>(extra);
+            uint8_t* d_frames = extra + (((size_t)total_words * 4 + 255) & ~(size_t)255);
+            e = hipMemsetAsync(d_words, 0, (size_t)total_words * 4 + 4, nullptr);
+            if (e == hipSuccess)
+                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, d_offsets, base_bytes, d_frames, chunk_bytes, nullptr);
+            if (e == hipSuccess)
+                e = hipMemcpy(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost);
+            (void)hipFree(extra);
+        } else {
+            uint32_t* d_words = g_arena.take<uint32_t>((size_t)total_words + 1);
+            uint8_t* d_frames = g_arena.take<uint8_t>(chunk_bytes);
+            e = hipMemsetAsync(d_words, 0, (size_t)total_words * 4 + 4, nullptr);
+            if (e == hipSuccess)
+                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, d_offsets, base_bytes, d_frames, chunk_bytes, nullptr);
+            if (e == hipSuccess)
+                e = hipMemcpy(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess)
+            return report_hip_error(e, "generic encode: emit");
+        base_bytes += chunk_bytes;
+    }
+    return SELA_HIP_OK;
+}
+
+// Walk a stream's headers on the host: per frame the first subframe's samplesPerChannel (running total in sample_offsets, if
+// given), the largest samplesPerChannel of any subframe (returned; 0 when the walk falls off a frame), and whether every
+// subframe says exactly 2048.
+uint32_t generic_index_samples(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, uint64_t* sample_offsets,
+    bool* all_standard)
+{
+    uint32_t largest = 0;
+    bool standard = true, broken = false;
+    uint64_t total = 0;
+    for (uint32_t f = 0; f < n_frames; f++) {
+        if (sample_offsets)
+            sample_offsets[f] = total;
+        const uint8_t* fb = frames + frame_offsets[f];
+        const uint64_t fbytes = frame_offsets[f + 1] >= frame_offsets[f] ? frame_offsets[f + 1] - frame_offsets[f] : 0;
+        uint64_t p = 4;
+        uint32_t first = 0;
+        for (uint32_t c = 0; c < channels; c++) {
+            if (p + 12 > fbytes) {
+                broken = true;
+                break;
+            }
+            const uint64_t cw = (uint64_t)fb[p + 4] | ((uint64_t)fb[p + 5] << 8);
+            const uint64_t p2 = p + 7 + 4 * cw;
+            if (p2 + 5 > fbytes) {
+                broken = true;
+                break;
+            }
+            const uint64_t rw = (uint64_t)fb[p2 + 1] | ((uint64_t)fb[p2 + 2] << 8);
+            const uint32_t n = (uint32_t)fb[p2 + 3] | ((uint32_t)fb[p2 + 4] << 8);
+            if (c == 0)
+                first = n;
+            largest = std::max(largest, n);
+            standard = standard && n == SELA_HIP_SAMPLES_PER_FRAME;
+            p = p2 + 5 + 4 * rw;
+        }
+        total += first;
+    }
+    if (sample_offsets)
+        sample_offsets[n_frames] = total;
+    if (all_standard)
+        *all_standard = standard && !broken;
+    return broken ? 0 : largest;
+}
+
+// One of: samples_out + counts_out (32-bit, planar, stride), or pcm_out + sample_offsets (16-bit interleaved).
+int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out, uint32_t stride,
+    uint32_t* counts_out, int16_t* pcm_out, const uint64_t* sample_offsets)
+{
+    if (device_ready() != SELA_HIP_OK)
+        return SELA_HIP_ENODEV;
+    for (uint32_t f = 0; f < n_frames; f++)
+        if (frame_offsets[f + 1] < frame_offsets[f])
+            return report_error(SELA_HIP_EFORMAT, "frame offsets must not decrease");
+    if (stride == 0)
+        stride = 1;
+    const size_t per_frame = (size_t)channels * stride * 8 + (size_t)channels * (sizeof(GenericSubInfo) + 4) + 16 + (size_t)channels * stride * (pcm_out ? 2 : 0);
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const uint32_t cf = std::min(chunk, n_frames - f0);
+        const size_t subs = (size_t)cf * channels;
+        const uint64_t base_bytes = frame_offsets[f0], in_bytes = frame_offsets[f0 + cf] - base_bytes;
+        const uint64_t s0 = pcm_out ? sample_offsets[f0] : 0, chunk_samples = pcm_out ? sample_offsets[f0 + cf] - s0 : 0;
+        const size_t need = in_bytes + 8 + ((size_t)cf + 1) * 16 + subs * stride * 8 + subs * (sizeof(GenericSubInfo) + 4) + (size_t)chunk_samples * channels * 2 + 64
+            + 12 * kPiece;
+        hipError_t e = g_arena.reserve(need);
+        if (e != hipSuccess)
+            return report_hip_error(e, "generic decode: scratch");
+        uint8_t* d_frames = g_arena.take<uint8_t>(in_bytes + 8);
+        uint64_t* d_offsets = g_arena.take<uint64_t>((size_t)cf + 1);
+        int32_t* d_dec = g_arena.take<int32_t>(subs * stride);
+        int32_t* d_all = g_arena.take<int32_t>(subs * stride);
+        GenericSubInfo* d_info = g_arena.take<GenericSubInfo>(subs);
+        uint32_t* d_counts = g_arena.take<uint32_t>(subs);
+        uint32_t* d_status = g_arena.take<uint32_t>(4);
+        uint64_t* d_sample_offsets = pcm_out ? g_arena.take<uint64_t>((size_t)cf + 1) : nullptr;
+        int16_t* d_pcm = pcm_out ? g_arena.take<int16_t>((size_t)chunk_samples * channels) : nullptr;
+        e = hipMemcpy(d_frames, frames + base_bytes, in_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(d_offsets, frame_offsets + f0, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice);
+        std::vector<uint64_t> local;
+        if (e == hipSuccess && pcm_out) { // positions relative to the chunk's first sample
+            local.resize((size_t)cf + 1);
+            for (uint32_t i = 0; i <= cf; i++)
+                local[i] = sample_offsets[f0 + i] - s0;
+            e = hipMemcpy(d_sample_offsets, local.data(), local.size() * 8, hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess)
+            e = hipMemsetAsync(d_status, 0, 16, nullptr);
+        if (e == hipSuccess)
+            e = launch_generic_decode(d_frames, d_offsets, base_bytes, cf, channels, stride, d_dec, d_info, d_all, d_counts, d_sample_offsets, d_pcm, d_status, nullptr);
+        uint32_t status[4] = {};
+        if (e == hipSuccess)
+            e = hipMemcpy(status, d_status, 16, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return report_hip_error(e, "generic decode");
+        if (status[0] & SELA_HIP_FLAG_BAD_FRAME)
+            return report_error(SELA_HIP_EFORMAT, "malformed frame (sync word, sizes, an order above 100, a Rice parameter above 31, a channel or parent that does not exist, or channels of different lengths)");
+        if (status[0] & SELA_HIP_FLAG_RICE_OVERRUN)
+            return report_error(SELA_HIP_EFORMAT, "a Rice stream ended before all its values were read");
+        if (status[0] & SELA_HIP_FLAG_COEF_OVERFLOW)
+            return report_error(SELA_HIP_ERANGE, "decode: a predictor coefficient left the int64 range");
+        if (pcm_out) {
+            e = hipMemcpy(pcm_out + s0 * channels, d_pcm, (size_t)chunk_samples * channels * 2, hipMemcpyDeviceToHost);
+        } else {
+            e = hipMemcpy(counts_out + (size_t)f0 * channels, d_counts, subs * 4, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < subs && e == hipSuccess; i++) { // only what is valid crosses the link
+                const uint32_t cnt = counts_out[(size_t)f0 * channels + i];
+                if (cnt)
+                    e = hipMemcpy(samples_out + ((size_t)f0 * channels + i) * stride, d_all + i * stride, (size_t)cnt * 4, hipMemcpyDeviceToHost);
+            }
+        }
+        if (e != hipSuccess)
+            return report_hip_error(e, "generic decode: copy out");
+    }
+    return SELA_HIP_OK;
+}
+
+int generic_lpc_encode(const int32_t* samples, uint32_t n_blocks, uint32_t n, int32_t* order_out, int32_t* q_out, int32_t* residues_out)
+{
+    if (device_ready() != SELA_HIP_OK)
+        return SELA_HIP_ENODEV;
+    const size_t per_block = (size_t)n * 20 + kMaxOrder * 4 + sizeof(GenericMeta) + 16;
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_blocks, kChunkBudget / per_block));
+    std::vector<GenericMeta> meta;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk) {
+        const uint32_t cb = std::min(chunk, n_blocks - b0);
+        hipError_t e = g_arena.reserve((size_t)cb * per_block + 8 * kPiece);
+        if (e != hipSuccess)
+            return report_hip_error(e, "lpc_encode: scratch");
+        int32_t* d_in = g_arena.take<int32_t>((size_t)cb * n);
+        int32_t* d_sig = g_arena.take<int32_t>((size_t)cb * n);
+        double* d_cen = g_arena.take<double>((size_t)cb * n);
+        int32_t* d_res = g_arena.take<int32_t>((size_t)cb * n);
+        int32_t* d_q = g_arena.take<int32_t>((size_t)cb * kMaxOrder);
+        GenericMeta* d_meta = g_arena.take<GenericMeta>(cb);
+        e = hipMemcpy(d_in, samples + (size_t)b0 * n, (size_t)cb * n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) // a "frame" of one channel per block
+            e = launch_generic_analyse(d_in, false, cb, 1, 1, n, d_sig, d_cen, d_res, d_q, d_meta, nullptr);
+        meta.resize(cb);
+        if (e == hipSuccess)
+            e = hipMemcpy(meta.data(), d_meta, (size_t)cb * sizeof(GenericMeta), hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(q_out + (size_t)b0 * kMaxOrder, d_q, (size_t)cb * kMaxOrder * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(residues_out + (size_t)b0 * n, d_res, (size_t)cb * n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return report_hip_error(e, "lpc_encode");
+        uint32_t flags = 0;
+        for (uint32_t i = 0; i < cb; i++) {
+            order_out[b0 + i] = (int32_t)meta[i].order;
+            flags |= meta[i].flags;
+        }
+        // (a residue beyond the zig-zag's range or a long Rice stream is the Rice stage's business, not this one's)
+        const int rc = flags_error(flags & (SELA_HIP_FLAG_SHORT_BLOCK | SELA_HIP_FLAG_COEF_OVERFLOW), "lpc_encode");
+        if (rc != SELA_HIP_OK)
+            return rc;
+    }
+    return SELA_HIP_OK;
+}
+
+int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* residues, uint32_t n_blocks, uint32_t n, int32_t* samples_out, int64_t* coefs_out)
+{
+    if (device_ready() != SELA_HIP_OK)
+        return SELA_HIP_ENODEV;
+    constexpr size_t kCoefs = kMaxOrder + 1;
+    const size_t per_block = (size_t)n * 8 + kMaxOrder * 4 + 4 + kCoefs * 8;
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_blocks, kChunkBudget / per_block));
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk) {
+        const uint32_t cb = std::min(chunk, n_blocks - b0);
+        hipError_t e = g_arena.reserve((size_t)cb * per_block + 64 + 8 * kPiece);
+        if (e != hipSuccess)
+            return report_hip_error(e, "lpc_decode: scratch");
+        int32_t* d_order = g_arena.take<int32_t>(cb);
+        int32_t* d_q = g_arena.take<int32_t>((size_t)cb * kMaxOrder);
+        int32_t* d_res = samples_out ? g_arena.take<int32_t>((size_t)cb * n) : nullptr;
+        int32_t* d_out = samples_out ? g_arena.take<int32_t>((size_t)cb * n) : nullptr;
+        int64_t* d_coefs = coefs_out ? g_arena.take<int64_t>((size_t)cb * kCoefs) : nullptr;
+        uint32_t* d_status = g_arena.take<uint32_t>(4);
+        e = hipMemcpy(d_order, order + b0, (size_t)cb * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(d_q, q + (size_t)b0 * kMaxOrder, (size_t)cb * kMaxOrder * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && d_res)
+            e = hipMemcpy(d_res, residues + (size_t)b0 * n, (size_t)cb * n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(d_status, 0, 16, nullptr);
+        if (e == hipSuccess && d_coefs)
+            e = hipMemsetAsync(d_coefs, 0, (size_t)cb * kCoefs * 8, nullptr);
+        if (e == hipSuccess)
+            e = launch_generic_lpc_decode(d_order, d_q, d_res, cb, n, d_out, d_coefs, d_status, nullptr);
+        uint32_t status[4] = {};
+        if (e == hipSuccess)
+            e = hipMemcpy(status, d_status, 16, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && samples_out)
+            e = hipMemcpy(samples_out + (size_t)b0 * n, d_out, (size_t)cb * n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && coefs_out)
+            e = hipMemcpy(coefs_out + (size_t)b0 * kCoefs, d_coefs, (size_t)cb * kCoefs * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            return report_hip_error(e, "lpc_decode");
+        if (status[0] & SELA_HIP_FLAG_BAD_FRAME)
+            return report_error(SELA_HIP_EINVAL, "lpc_decode: order outside 0..100");
+        if (status[0] & SELA_HIP_FLAG_COEF_OVERFLOW)
+            return report_error(SELA_HIP_ERANGE, "lpc_decode: a predictor coefficient left the int64 range");
+    }
+    return SELA_HIP_OK;
+}
+
+} // namespace sela

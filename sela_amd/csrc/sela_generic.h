@@ -1,0 +1,33 @@
+// sela_generic.h -- what sela_generic.hip (the any-length / 32-bit route) shares with the C ABI (sela_capi.hip).
+#ifndef SELA_GENERIC_H_
+#define SELA_GENERIC_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sela {
+
+struct GenericMeta { // one per (frame, signal), written by k_generic_analyse
+    uint32_t order, coef_k, coef_words, res_k, res_words, flags;
+};
+struct GenericSubInfo { // one per (frame, subframe position), written by k_generic_decode
+    uint8_t channel, type, parent, ok;
+    uint32_t n;
+};
+
+size_t generic_encode_workspace_bytes(uint32_t n_frames, uint32_t channels, uint32_t n);
+hipError_t launch_generic_analyse(const void* d_input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, int32_t* d_sig, double* d_cen,
+    int32_t* d_res, int32_t* d_q, GenericMeta* d_meta, hipStream_t stream);
+hipError_t launch_generic_plan(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint64_t base_bytes, uint64_t* d_frame_offsets,
+    uint64_t* d_word_base, uint32_t* d_chosen, uint32_t* d_status, hipStream_t stream);
+hipError_t launch_generic_emit(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, const int32_t* d_res, const int32_t* d_q,
+    const uint32_t* d_chosen, const uint64_t* d_word_base, uint32_t* d_words /* zeroed */, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint8_t* d_frames,
+    uint64_t frames_cap, hipStream_t stream);
+hipError_t launch_generic_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint32_t n_frames, uint32_t channels, uint32_t stride,
+    int32_t* d_dec, GenericSubInfo* d_info, int32_t* d_all, uint32_t* d_counts, const uint64_t* d_sample_offsets, int16_t* d_pcm_out, uint32_t* d_status,
+    hipStream_t stream);
+hipError_t launch_generic_lpc_decode(const int32_t* d_order, const int32_t* d_q, const int32_t* d_residues, uint32_t n_blocks, uint32_t n, int32_t* d_samples,
+    int64_t* d_coefs, uint32_t* d_status, hipStream_t stream);
+
+} // namespace sela
+#endif

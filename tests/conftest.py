@@ -61,3 +61,16 @@ def file_digests():
 def album_digests():
     """BASELINE.json configs[3]: per-track .sela file / decoded PCM SHA-256s from the reference."""
     return _load_json("album_digests.json")
+
+
+@pytest.fixture(scope="session")
+def generic_digests():
+    """Frames of any length / 17-bit samples through the reference's frame classes (make_golden.py generic)."""
+    return _load_json("generic.json")
+
+
+@pytest.fixture(scope="session")
+def generic_kats():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "generic_kats.npz"))

@@ -6,7 +6,7 @@ which compiles the unmodified reference from /root/reference).  The fixtures are
 inputs and the reference's outputs.  Commit the resulting .npz / .json files; the GPU box
 and CI only ever read them.
 
-    python tests/golden/make_golden.py [kats] [configs] [files] [album]     (default: all four sections)
+    python tests/golden/make_golden.py [kats] [configs] [files] [album] [generic]     (default: all five sections)
 """
 import ctypes as C
 import hashlib
@@ -120,7 +120,9 @@ def album_digests(ref, threads=8):
 def main():
     ref = reference()
     assert ref is not None, "build oracle/_ref first: make -C oracle ref"
-    sections = set(sys.argv[1:]) or {"kats", "configs", "files", "album"}
+    sections = set(sys.argv[1:]) or {"kats", "configs", "files", "album", "generic"}
+    if "generic" in sections:
+        generic(ref)
     if "files" in sections:
         with open(os.path.join(HERE, "file_digests.json"), "w") as f:
             json.dump(file_digests(ref), f, indent=1, sort_keys=True)
@@ -131,6 +133,60 @@ def main():
         kats(ref)
     if "configs" in sections:
         config_digests(ref)
+
+
+def generic(ref):
+    """Frames of any length and 17-bit samples through the reference's frame classes (frame::FrameEncoder on a data::WavFrame,
+    frame::FrameDecoder on the result: oracle/ref_shim.cpp ref_frame_encode_i32 / ref_frame_decode_i32): per case the digests of
+    the input (regenerated by tests/generic_cases.py), of the frame bytes and of the decoded channels; the bytes themselves for
+    the short ones; and crafted frames (spliced subframes) with the reference's decoded channels."""
+    import generic_cases as gc
+
+    table, arrays = {}, {}
+    for label, n, kind, wide in gc.all_cases():
+        x = gc.case_input(n, kind, wide)
+        blob = ref.frame_encode_i32(x)
+        dec, used = ref.frame_decode_i32(blob, x.shape[0])
+        assert used == len(blob)
+        table[label] = {"n": n, "kind": kind, "wide": wide, "channels": int(x.shape[0]), "input_sha256": gc.sha(x),
+                        "frame_bytes": len(blob), "frame_sha256": hashlib.sha256(blob).hexdigest(), "decoded_sha256": gc.sha_channels(dec),
+                        "lossless": bool(all(np.array_equal(a, b) for a, b in zip(dec, x)))}
+        if n <= 2049:
+            arrays[f"{label}/bytes"] = np.frombuffer(blob, np.uint8)
+        print(label, table[label], flush=True)
+
+    # ---- crafted frames --------------------------------------------------------------------------------------------------------
+    a = ref.frame_encode_i32(gc.case_input(300, "three", True))     # three independent subframes of 300
+    b = ref.frame_encode_i32(gc.case_input(200, "three", False))    # ... and of 200
+    sa, sb = gc.subframes_of(a, 3), gc.subframes_of(b, 3)
+    crafted = {
+        # channels of different lengths: every subframe keeps its own samplesPerChannel (frame_decoder.cpp:24-25)
+        "mixed_lengths": (gc.join_frame([sa[0], gc.retag(sb[1], 1, 0, 1), sa[2]]), 3),
+        # a chain of dependent subframes, resolved in subframe order (:40-69): ch1 = ch0 - d1, ch2 = ch1 - d2
+        "dependent_chain": (gc.join_frame([sa[0], gc.retag(sa[1], 1, 1, 0), gc.retag(sa[2], 2, 1, 1)]), 3),
+        # the dependent subframe comes FIRST in the frame: independent ones are still decoded first (:17-37)
+        "dependent_first": (gc.join_frame([gc.retag(sa[1], 1, 1, 0), gc.retag(sa[0], 0, 0, 0), sa[2]]), 3),
+        # two subframes name the same channel: the later one wins; channel 2 stays empty
+        "same_channel_twice": (gc.join_frame([sa[0], gc.retag(sa[1], 0, 0, 0), gc.retag(sb[2], 1, 0, 1)]), 3),
+        # a parent longer than the difference (only the difference's length is produced)
+        "long_parent": (gc.join_frame([sa[0], gc.retag(sb[1], 1, 1, 0), sa[2]]), 3),
+        # a subframe type that is neither 0 nor 1 is skipped by both passes
+        "unknown_type": (gc.join_frame([sa[0], gc.retag(sa[1], 1, 7, 0), sa[2]]), 3),
+    }
+    names = []
+    for name, (blob, ch) in crafted.items():
+        dec, used = ref.frame_decode_i32(blob, ch)
+        assert used == len(blob)
+        names.append(name)
+        arrays[f"crafted/{name}/bytes"] = np.frombuffer(blob, np.uint8)
+        arrays[f"crafted/{name}/channels"] = np.int32(ch)
+        for c in range(ch):
+            arrays[f"crafted/{name}/decoded{c}"] = dec[c]
+        print("crafted", name, [len(d) for d in dec], flush=True)
+    arrays["crafted_names"] = np.array(names)
+    with open(os.path.join(HERE, "generic.json"), "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "generic_kats.npz"), **arrays)
 
 
 def kats(ref):

@@ -74,6 +74,12 @@ class Oracle:
         self._fdec = f("frame_decode")
         self._fdec.restype = C.c_size_t
         self._fdec.argtypes = [_u8p, C.c_uint32, _i16p] + flags
+        self._fenc32 = f("frame_encode_i32")
+        self._fenc32.restype = C.c_size_t
+        self._fenc32.argtypes = [_i32p, C.c_uint32, C.c_uint32, _u8p] + flags
+        self._fdec32 = f("frame_decode_i32")
+        self._fdec32.restype = C.c_size_t
+        self._fdec32.argtypes = [_u8p, C.c_uint32, _i32p, C.c_uint32, _u32p] + flags
         self._encmt = f("encode_frames_mt")
         self._encmt.restype = C.c_double
         self._encmt.argtypes = [_i16p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _u8p, _u64p]
@@ -148,6 +154,22 @@ class Oracle:
         pcm = np.zeros((n, channels), np.int16)
         used = self._fdec(b, channels, pcm, *self._fl())
         return pcm, used
+
+    def frame_encode_i32(self, planar):
+        """planar: int32 [channels, n] (data::WavFrame.samples) -> bytes of the on-disk frame."""
+        p = np.ascontiguousarray(planar, dtype=np.int32)
+        ch, n = p.shape
+        out = np.zeros(4 + ch * (12 + 4 * 128 + 16 * n + 256), np.uint8)
+        used = self._fenc32(p, ch, n, out, *self._fl())
+        return out[:used].tobytes()
+
+    def frame_decode_i32(self, blob, channels, stride=65535):
+        """-> (list of int32 arrays, one per channel, as FrameDecoder::process returns them; bytes consumed)."""
+        b = np.frombuffer(blob, dtype=np.uint8).copy()
+        out = np.zeros((channels, stride), np.int32)
+        counts = np.zeros(channels, np.uint32)
+        used = self._fdec32(b, channels, out, stride, counts, *self._fl())
+        return [out[c, : int(counts[c])].copy() for c in range(channels)], used
 
     # -- batch ------------------------------------------------------------------------------
     def encode_frames(self, pcm, threads=1):

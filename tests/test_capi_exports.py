@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header="sela_hip.h"):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sela_hip_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(sela_hip_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():

@@ -1,0 +1,191 @@
+"""GPU parity tests of round 5: the any-length / 32-bit route (sela_generic.hip through sela_hip_encode / sela_hip_decode with
+samples_per_channel != 2048, sela_hip_encode_i32 / sela_hip_decode_i32, sela_hip_lpc_*_n) against fixtures the unmodified
+reference wrote (tests/golden/generic.json, generic_kats.npz) and against the oracle -- bit-exact: frame bytes, offsets,
+decoded 32-bit channels."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import generic_cases as gc
+from oracle_lib import oracle
+from sela_amd.synth import synth_frames, synth_pcm
+from test_gpu_parity import gpu  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _one(offs):
+    return np.array([0, offs], np.uint64)
+
+
+@pytest.mark.parametrize("n", gc.LENGTHS)
+def test_generic_frames_against_the_reference_fixtures(gpu, generic_digests, generic_kats, n):  # noqa: F811
+    """n in {128, 1000, 2047, 2049, 4096, 65535} x {mono, stereo (difference wins / loses), three channels} x {16-bit, 17-bit}:
+    frame bytes and decoded int32 channels equal the reference's (digests; whole bytes for the short ones)."""
+    from sela_amd import codec
+
+    o = oracle()
+    for label, nn, kind, wide in gc.all_cases():
+        if nn != n:
+            continue
+        g = generic_digests[label]
+        x = gc.case_input(n, kind, wide)
+        assert gc.sha(x) == g["input_sha256"], label
+        frames, offs = codec.encode_i32(x[None])
+        blob = frames.tobytes()
+        if hashlib.sha256(blob).hexdigest() != g["frame_sha256"]:  # say where, with the oracle's help
+            want = o.frame_encode_i32(x)
+            first = next((i for i, (a, b) in enumerate(zip(blob, want)) if a != b), min(len(blob), len(want)))
+            pytest.fail(f"{label}: frame bytes differ from the reference's at byte {first} ({len(blob)} vs {len(want)} bytes)")
+        assert int(offs[1]) == g["frame_bytes"], label
+        if f"{label}/bytes" in generic_kats:
+            assert blob == generic_kats[f"{label}/bytes"].tobytes(), label
+        dec = codec.decode_i32(frames, offs, x.shape[0])[0]
+        assert gc.sha_channels(dec) == g["decoded_sha256"], label
+        assert all(np.array_equal(a, b) for a, b in zip(dec, x)) == g["lossless"], label
+        if not wide:  # the int16 entry points: the same frame, the same samples
+            pcm = np.ascontiguousarray(x.T.astype(np.int16))[None]
+            f16, o16 = codec.encode_host(pcm)
+            assert f16.tobytes() == blob and int(o16[1]) == len(blob), label
+            back = codec.decode_host(frames, offs, x.shape[0])
+            assert back.shape == (n, x.shape[0]) and np.array_equal(back, pcm[0]), label
+        else:  # 17-bit samples through the 16-bit writer: truncated like src/file/wav_file.cpp:248-251
+            back = codec.decode_host(frames, offs, x.shape[0])
+            assert np.array_equal(back, x.T.astype(np.uint32).astype(np.uint16).view(np.int16)), label
+
+
+def test_crafted_frames_decode_like_the_reference(gpu, generic_kats):  # noqa: F811
+    """Subframes spliced by hand: channels of different lengths, a chain of dependent subframes, a dependent subframe ahead of
+    its parent, one channel named twice, a long parent, an unknown subframe type -- FrameDecoder's answer, channel by channel."""
+    from sela_amd import capi, codec
+
+    for name in generic_kats["crafted_names"]:
+        blob = generic_kats[f"crafted/{name}/bytes"]
+        ch = int(generic_kats[f"crafted/{name}/channels"])
+        dec = codec.decode_i32(blob, _one(len(blob)), ch)[0]
+        lengths = []
+        for c in range(ch):
+            want = generic_kats[f"crafted/{name}/decoded{c}"]
+            assert np.array_equal(dec[c], want), (name, c)
+            lengths.append(len(want))
+        if len(set(lengths)) > 1:  # no interleaved PCM exists for channels of different lengths
+            with pytest.raises(capi.SelaHipError) as err:
+                codec.decode_host(blob, _one(len(blob)), ch)
+            assert err.value.code == -5, name
+        else:
+            back = codec.decode_host(blob, _one(len(blob)), ch)
+            want = np.stack([generic_kats[f"crafted/{name}/decoded{c}"] for c in range(ch)], axis=1)
+            assert np.array_equal(back, want.astype(np.uint32).astype(np.uint16).view(np.int16)), name
+
+
+def test_batches_of_odd_frames_and_mixed_streams(gpu):  # noqa: F811
+    """Many frames per call (offsets, chunking), and ONE stream whose frames have different lengths, 2048 among them."""
+    from sela_amd import codec
+
+    o = oracle()
+    blobs, pcms = [], []
+    for n, ch, nf, track in ((1000, 2, 37, 3), (2047, 1, 9, 4), (2049, 3, 5, 5), (4096, 2, 11, 6)):
+        pcm = synth_pcm(n * nf, ch, track).reshape(nf, n, ch)
+        frames, offs = codec.encode_host(pcm)
+        want = [o.frame_encode(pcm[f]) for f in range(nf)]
+        assert frames.tobytes() == b"".join(want), (n, ch)
+        assert offs.tolist() == np.concatenate([[0], np.cumsum([len(w) for w in want])]).tolist(), (n, ch)
+        back = codec.decode_host(frames, offs, ch)
+        assert np.array_equal(back, pcm.reshape(-1, ch)), (n, ch)
+        planar = np.ascontiguousarray(pcm.transpose(0, 2, 1)).astype(np.int32)
+        f32, o32 = codec.encode_i32(planar)
+        assert f32.tobytes() == frames.tobytes() and np.array_equal(o32, offs)
+        if ch == 2:
+            blobs += want
+            pcms += [pcm[f] for f in range(nf)]
+    # a stereo stream of 1000-, 4096- and 2048-sample frames, interleaved
+    std = synth_frames(6, 2, 9)
+    blobs += [o.frame_encode(std[f]) for f in range(6)]
+    pcms += [std[f] for f in range(6)]
+    order = np.random.default_rng(0).permutation(len(blobs))
+    stream = b"".join(blobs[i] for i in order)
+    offs = np.concatenate([[0], np.cumsum([len(blobs[i]) for i in order])]).astype(np.uint64)
+    so, largest = codec.index_samples(np.frombuffer(stream, np.uint8), offs, 2)
+    assert largest == 4096 and so.tolist() == np.concatenate([[0], np.cumsum([len(pcms[i]) for i in order])]).tolist()
+    back = codec.decode_host(np.frombuffer(stream, np.uint8), offs, 2)
+    assert np.array_equal(back, np.concatenate([pcms[i] for i in order]))
+    dec = codec.decode_i32(np.frombuffer(stream, np.uint8), offs, 2)
+    for j, i in enumerate(order):
+        assert np.array_equal(np.stack(dec[j], axis=1), pcms[i].astype(np.int32)), j
+
+
+def test_2048_through_the_generic_route_equals_the_fast_kernels(gpu, kats):  # noqa: F811
+    """The same frames through both routes: bytes and samples identical (stereo with both decisions, mono, the KAT blocks)."""
+    from sela_amd import codec
+
+    for pcm in (synth_frames(24, 2, 0), synth_frames(7, 1, 2), synth_frames(5, 3, 4)):
+        fast, fo = codec.encode_host(pcm)
+        planar = np.ascontiguousarray(pcm.transpose(0, 2, 1)).astype(np.int32)
+        gen, go = codec.encode_i32(planar)
+        assert gen.tobytes() == fast.tobytes() and np.array_equal(go, fo)
+        dec = codec.decode_i32(fast, fo, pcm.shape[2])
+        for f in range(pcm.shape[0]):
+            assert np.array_equal(np.stack(dec[f], axis=1), pcm[f].astype(np.int32)), f
+    names = [str(n) for n in kats["blk_names"]]
+    blocks = np.stack([kats[f"blk/{n}/samples"] for n in names]).astype(np.int32)  # (diff_extreme is 17-bit)
+    gen, go = codec.encode_i32(blocks[:, None, :])
+    o = oracle()
+    assert gen.tobytes() == b"".join(o.frame_encode_i32(b[None]) for b in blocks)
+
+
+def test_what_the_reference_cannot_answer_is_refused(gpu):  # noqa: F811
+    """A block not longer than its own order (the reference reads past its vector), lengths the u16 field cannot say,
+    a stride too small, residues beyond the int32 zig-zag."""
+    from sela_amd import capi, codec
+
+    rng = np.random.default_rng(2)
+    noise = rng.integers(-20000, 20000, (1, 1, 40)).astype(np.int32)  # white noise: the order comes out above 40
+    assert oracle().lpc_analyze(noise[0, 0])[0] >= 40
+    with pytest.raises(capi.SelaHipError) as err:
+        codec.encode_i32(noise)
+    assert err.value.code == -6
+    for bad in (0, 65536):
+        lib = capi.lib()
+        buf = np.zeros(16, np.int16)
+        out = np.zeros(4096, np.uint8)
+        offs = np.zeros(2, np.uint64)
+        assert lib.sela_hip_encode(buf.ctypes.data, 1, 1, bad, out.ctypes.data, out.nbytes, offs.ctypes.data) == -2
+    x = gc.case_input(1000, "mono", False)
+    frames, offs = codec.encode_i32(x[None])
+    with pytest.raises(capi.SelaHipError) as err:
+        codec.decode_i32(frames, offs, 1, stride=999)
+    assert err.value.code == -4
+    wild = (rng.integers(-(1 << 31), 1 << 31, (1, 1, 500))).astype(np.int32)  # full-range int32: residues overflow the zig-zag
+    with pytest.raises(capi.SelaHipError) as err:
+        codec.encode_i32(wild)
+    assert err.value.code == -6
+    # a short frame that IS longer than its order: a constant block has order 1
+    flat = np.full((1, 1, 2), 5, np.int32)
+    frames, offs = codec.encode_i32(flat)
+    assert frames.tobytes() == oracle().frame_encode_i32(flat[0])
+
+
+def test_lpc_stages_of_any_length(gpu):  # noqa: F811
+    """lpc::ResidueGenerator / SampleGenerator on vectors of any length and any 32-bit value, against the oracle."""
+    from sela_amd import codec
+
+    o = oracle()
+    rng = np.random.default_rng(8)
+    for n, amp in ((101, 3000), (500, 32767), (2048, 1 << 20), (4096, 65535), (10000, 1 << 22)):
+        t = np.arange(n)
+        blocks = np.stack([np.clip(np.round(amp * 0.6 * np.sin(t * (0.01 + 0.003 * b)) + rng.normal(0, amp * 0.02, n)), -amp, amp) for b in range(6)]).astype(np.int32)
+        order, q, res = codec.lpc_encode_n(blocks)
+        for b in range(len(blocks)):
+            wo, wq, wr = o.lpc_analyze(blocks[b])
+            assert order[b] == wo and np.array_equal(q[b, :wo], wq) and not q[b, wo:].any() and np.array_equal(res[b], wr), (n, b)
+        back, coefs = codec.lpc_decode_n(order, q, res, want_coefficients=True)
+        for b in range(len(blocks)):
+            assert np.array_equal(back[b], o.lpc_synth(int(order[b]), q[b, : order[b]], res[b])), (n, b)
+            assert np.array_equal(coefs[b, : order[b] + 1], o.lpc_coeffs(int(order[b]), q[b, : order[b]])), (n, b)
+    # the 2048 entry with samples beyond 17 bits goes the same way, and zeroes q beyond the order
+    big = (rng.integers(-(1 << 19), 1 << 19, (3, 2048))).astype(np.int32)
+    order, q, res = codec.lpc_encode(big)
+    for b in range(3):
+        wo, wq, wr = o.lpc_analyze(big[b])
+        assert order[b] == wo and np.array_equal(q[b, :wo], wq) and not q[b, wo:].any() and np.array_equal(res[b], wr)
