@@ -316,8 +316,8 @@ class Bench:
         if getattr(args, "priorities", None):
             self.lib.sela_hip_debug_priorities(int(args.priorities.split(":")[0], 16))
         self.exchange = torch.cuda.Stream() if self.dist is not None else None
-        self.n_lanes = max(1, args.lanes)
-        self.lanes_forced = "--lanes" in sys.argv
+        self.lanes_forced = args.lanes is not None  # (also --lanes=N and abbreviations: argparse's own answer)
+        self.n_lanes = max(1, args.lanes if self.lanes_forced else 2)
 
     def barrier(self):
         if self.dist is not None:
@@ -889,7 +889,7 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=3, help="steps per measurement of the album block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2, help="batches in flight: independent encode->decode chains on their own HIP streams")
+    ap.add_argument("--lanes", type=int, default=None, help="(default 2) batches in flight: independent encode->decode chains on their own HIP streams")
     ap.add_argument("--encode-teams", type=int, default=-1, choices=[-1, 0, 8, 16],
                     help="experiments only: force the encoder's block kernel (0: k_encode_blocks, 8 / 16: k_encode_teams); -1: the library's own choice by launch size")
     ap.add_argument("--priorities", type=str, default=None,

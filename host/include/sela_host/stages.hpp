@@ -41,8 +41,9 @@ public:
 
 namespace lpc {
 
-// src/include/lpc.hpp:73-85.  dequantizeReflectionCoefficients() is a table lookup on the device and leaves nothing to look
-// at on the host (reflectionCoefficients stays empty); generatelinearPredictionCoefficients() fills the Q35 predictor.
+// src/include/lpc.hpp:73-85.  dequantizeReflectionCoefficients() fills reflectionCoefficients from the reference's tables (three
+// lookups per coefficient; the device looks the same tables up for itself); generatelinearPredictionCoefficients() fills the
+// Q35 predictor on the device.
 class LinearPredictor {
 public:
     uint8_t optimalLpcOrder = 1;
@@ -54,7 +55,7 @@ public:
         : optimalLpcOrder(optimalLpcOrder), quantizedReflectionCoefficients(std::move(quantizedReflectionCoefficients))
     {
     }
-    void dequantizeReflectionCoefficients() {}
+    void dequantizeReflectionCoefficients();      // src/lpc/linear_predictor.cpp:16-28
     void generatelinearPredictionCoefficients(); // src/lpc/linear_predictor.cpp:30-61
 };
 
@@ -64,7 +65,7 @@ class ResidueGenerator {
 
 public:
     explicit ResidueGenerator(const data::LpcDecodedData& data) : samples(data.samples), bitsPerSample(data.bitsPerSample) {}
-    data::LpcEncodedData process(); // src/lpc/residue_generator.cpp:121-134 (blocks of 2048 samples: what the file path produces)
+    data::LpcEncodedData process(); // src/lpc/residue_generator.cpp:121-134 (any number of samples; order < samples)
 };
 
 class SampleGenerator {

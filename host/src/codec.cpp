@@ -12,6 +12,7 @@
 #include <mutex>
 #include <thread>
 
+#include "sela_format.h"
 #include "sela_hip.h"
 #include "sela_host/fileio.hpp"
 
@@ -221,6 +222,32 @@ void streamDecode(Fetch fetch, file::SelaFile& sela, size_t payload, sela_host::
     drain(pcm.data(), pcm.size());
 }
 
+// A stream whose frames do not all say 2048 samples: the reference's encoder never writes one, its decoder takes one
+// (every subframe brings its own samplesPerChannel, src/frame/frame_decoder.cpp:24-25; file::WavFile sizes its header by the
+// frames it gets, src/file/wav_file.cpp:9-14).  The streaming jobs are the fast path for 2048 everywhere; such a stream goes,
+// whole, through sela_hip_decode's any-length route instead.  sela.frameBytes holds the whole payload.  Returns false for a
+// stream that is an ordinary one (the caller's first error stands).
+bool decodeOddStream(file::SelaFile& sela, size_t payload, sela_host::PinnedBuffer<int16_t>& pcm)
+{
+    const uint32_t channels = sela.selaHeader.channels;
+    const size_t plausible = std::min<size_t>(sela.selaHeader.numFrames, payload / (4 + 12 * (size_t)channels));
+    sela.frameOffsets.assign(plausible + 1, 0);
+    const uint32_t found = sela_hip_index_frames(sela.frameBytes.data(), payload, (uint32_t)plausible, channels, sela.frameOffsets.data());
+    sela.frameOffsets.resize((size_t)found + 1);
+    std::vector<uint64_t> sampleOffsets((size_t)found + 1);
+    const uint32_t largest = sela_hip_index_samples(sela.frameBytes.data(), sela.frameOffsets.data(), found, channels, sampleOffsets.data());
+    bool ordinary = largest == kBlock;
+    for (uint32_t f = 0; ordinary && f <= found; f++)
+        ordinary = sampleOffsets[f] == (uint64_t)f * kBlock;
+    if (ordinary || largest == 0)
+        return false;
+    pcm.resize((size_t)sampleOffsets[found] * channels);
+    if (sela_hip_decode(sela.frameBytes.data(), sela.frameOffsets.data(), found, channels, pcm.data()) != SELA_HIP_OK)
+        gpuFailure("Decoder");
+    sela.frameBytes.resize((size_t)sela.frameOffsets.back());
+    return true;
+}
+
 // fetch() of a file that is read with the calling thread's own ifstream reads, kPieceBytes at a time
 struct StreamFetcher {
     std::ifstream& in;
@@ -340,7 +367,15 @@ file::WavFile Decoder::process()
 {
     const size_t payload = selaFile.readHeader(ifStream);
     sela_host::PinnedBuffer<int16_t> pcm;
-    streamDecode(StreamFetcher{ ifStream, selaFile }, selaFile, payload, pcm, [](const int16_t*, size_t) {});
+    try {
+        streamDecode(StreamFetcher{ ifStream, selaFile }, selaFile, payload, pcm, [](const int16_t*, size_t) {});
+    } catch (const data::Exception&) { // frames that do not say 2048?  (decodeOddStream)
+        ifStream.clear();
+        ifStream.seekg(SELA_FILE_HEADER_BYTES, std::ios::beg);
+        selaFile.frameBytes.resize(payload);
+        if (!readExact(ifStream, selaFile.frameBytes.data(), payload) || !decodeOddStream(selaFile, payload, pcm))
+            throw;
+    }
     file::WavFile out(selaFile.selaHeader.sampleRate, (uint16_t)selaFile.selaHeader.channels, std::move(pcm));
     if (demuxFrames)
         out.demuxSamples();
@@ -385,12 +420,24 @@ size_t decodeFile(std::ifstream& in, std::ofstream& out)
     file::WavFile::writeHeader(out, sela.selaHeader.sampleRate, (uint16_t)channels, 16, (uint32_t)(announced * kBlock * channels * 2));
     sela_host::PinnedBuffer<int16_t> pcm;
     size_t written = 0;
-    streamDecode(StreamFetcher{ in, sela }, sela, payload, pcm, [&](const int16_t* p, size_t done) {
-        if (done > written) {
-            out.write(reinterpret_cast<const char*>(p + written), (std::streamsize)((done - written) * 2));
-            written = done;
-        }
-    });
+    try {
+        streamDecode(StreamFetcher{ in, sela }, sela, payload, pcm, [&](const int16_t* p, size_t done) {
+            if (done > written) {
+                out.write(reinterpret_cast<const char*>(p + written), (std::streamsize)((done - written) * 2));
+                written = done;
+            }
+        });
+    } catch (const data::Exception&) { // frames that do not say 2048?  (decodeOddStream)
+        in.clear();
+        in.seekg(SELA_FILE_HEADER_BYTES, std::ios::beg);
+        sela.frameBytes.resize(payload);
+        if (!readExact(in, sela.frameBytes.data(), payload) || !decodeOddStream(sela, payload, pcm))
+            throw;
+        out.seekp(0, std::ios::beg);
+        file::WavFile::writeHeader(out, sela.selaHeader.sampleRate, (uint16_t)channels, 16, (uint32_t)(pcm.size() * 2));
+        out.write(reinterpret_cast<const char*>(pcm.data()), (std::streamsize)(pcm.size() * 2));
+        return sela.frameCount();
+    }
     const size_t frames = sela.frameCount();
     if (frames != announced) { // the stream ended early (bad sync word): the header sizes follow what was decoded
         out.seekp(0, std::ios::beg);
@@ -666,13 +713,28 @@ size_t decodeFile(const std::string& inPath, const std::string& outPath)
     sela_host::PinnedBuffer<int16_t> pcm;
     sela_host::ReadAhead ahead(in, sela.frameBytes.data(), 15, info.payload, kIoSubBytes, kIoSubBytes);
     sela_host::WriteBehind behind(out, 44, kIoSubBytes, info.announced * frameBytes);
-    streamDecode(
-        [&](size_t have, size_t payload) {
-            const size_t upTo = std::min(payload, have + kIoSubBytes);
-            ahead.need(upTo);
-            return upTo;
-        },
-        sela, info.payload, pcm, [&](const int16_t* p, size_t done) { behind.drain(p, done * 2); });
+    try {
+        streamDecode(
+            [&](size_t have, size_t payload) {
+                const size_t upTo = std::min(payload, have + kIoSubBytes);
+                ahead.need(upTo);
+                return upTo;
+            },
+            sela, info.payload, pcm, [&](const int16_t* p, size_t done) { behind.drain(p, done * 2); });
+    } catch (const data::Exception&) { // frames that do not say 2048?  (decodeOddStream)
+        ahead.need(info.payload);
+        ahead.finish();
+        behind.quiesce();
+        if (!decodeOddStream(sela, info.payload, pcm))
+            throw;
+        const size_t bytes = pcm.size() * 2;
+        wavHeaderBytes(header, info.header.sampleRate, (uint16_t)channels, 16, (uint32_t)bytes);
+        out.writeAt(header, 44, 0);
+        if (bytes)
+            out.writeAt(pcm.data(), bytes, 44);
+        out.truncate(44 + bytes);
+        return sela.frameCount();
+    }
     ahead.finish();
     const size_t frames = sela.frameCount(), decodedBytes = frames * frameBytes;
     behind.finish(&decodedBytes);

@@ -2,6 +2,7 @@
 // FrameEncoder / FrameDecoder entry points on top of libsela_hip.so.
 #include "sela_host/frame.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -97,26 +98,51 @@ data::SelaFrame FrameEncoder::process()
     const size_t channels = wavFrame.samples.size();
     if (channels == 0 || channels > 255)
         throw data::Exception("FrameEncoder: a frame needs 1..255 channels");
-    std::vector<int16_t> pcm(kBlock * channels);
+    // The reference takes a data::WavFrame as it is: int32 samples, as many per channel as the vectors hold
+    // (src/frame/frame_encoder.cpp:11-102 never looks at a length; only its WAV reader cuts 2048-sample frames).  The shape that
+    // reader produces -- 2048 samples within 16 bits -- goes to the fast kernels (and is coalesced with other threads' frames);
+    // anything else to the any-length kernels (sela_hip_encode_i32).  What stays refused: channels of different lengths (the
+    // reference's stereo difference indexes the shorter one out of bounds, :22-24), more than 65535 samples (the subframe's
+    // u16 field) and a block not longer than its own predictor order (the reference reads past its vector; SELA_HIP_ERANGE).
+    const size_t n = wavFrame.samples[0].size();
+    bool narrow = n == kBlock;
     for (size_t c = 0; c < channels; c++) {
-        if (wavFrame.samples[c].size() != kBlock)
-            throw data::Exception("FrameEncoder: the MI355X path codes whole 2048-sample frames only");
-        for (size_t i = 0; i < kBlock; i++) {
-            const int32_t v = wavFrame.samples[c][i];
-            if (v < INT16_MIN || v > INT16_MAX)
-                throw data::Exception("FrameEncoder: sample outside the 16-bit range");
-            pcm[i * channels + c] = (int16_t)v;
-        }
+        if (wavFrame.samples[c].size() != n)
+            throw data::Exception("FrameEncoder: the channels of a frame must have one length");
+        for (size_t i = 0; narrow && i < n; i++)
+            narrow = wavFrame.samples[c][i] >= INT16_MIN && wavFrame.samples[c][i] <= INT16_MAX;
     }
-    std::vector<uint8_t> bytes(sela_hip_encode_bound_bytes(1, (uint32_t)channels));
+    if (n == 0 || n > 65535)
+        throw data::Exception("FrameEncoder: a channel holds 1..65535 samples (the subframe's count is 16 bits wide)");
     uint64_t offsets[2] = { 0, 0 };
-    if (sela_hip_encode(pcm.data(), 1, (uint32_t)channels, (uint32_t)kBlock, bytes.data(), bytes.size(), offsets) != SELA_HIP_OK)
+    std::vector<uint8_t> bytes;
+    int rc;
+    if (narrow) {
+        std::vector<int16_t> pcm(kBlock * channels);
+        for (size_t c = 0; c < channels; c++)
+            for (size_t i = 0; i < kBlock; i++)
+                pcm[i * channels + c] = (int16_t)wavFrame.samples[c][i];
+        bytes.resize(sela_hip_encode_bound_bytes(1, (uint32_t)channels));
+        rc = sela_hip_encode(pcm.data(), 1, (uint32_t)channels, (uint32_t)kBlock, bytes.data(), bytes.size(), offsets);
+    } else {
+        std::vector<int32_t> planar(n * channels);
+        for (size_t c = 0; c < channels; c++)
+            std::memcpy(planar.data() + c * n, wavFrame.samples[c].data(), n * sizeof(int32_t));
+        bytes.resize(sela_hip_encode_bound_bytes_n(1, (uint32_t)channels, (uint32_t)n));
+        rc = sela_hip_encode_i32(planar.data(), 1, (uint32_t)channels, (uint32_t)n, bytes.data(), bytes.size(), offsets);
+    }
+    if (rc != SELA_HIP_OK)
         throw data::Exception(std::string("FrameEncoder: ") + sela_hip_last_error());
     data::SelaFrame frame(wavFrame.bitsPerSample);
     parseFrame(bytes.data(), (size_t)offsets[1], (uint8_t)channels, wavFrame.bitsPerSample, frame);
     return frame;
 }
 
+// frame::FrameDecoder::process returns what the subframes hold: every channel as long as its subframe says and the samples as
+// the 32-bit values the synthesis produces (src/frame/frame_decoder.cpp:24-25,48-49,64-71; only file::WavFile::writeToFile
+// narrows to 16 bits).  That is sela_hip_decode_i32, the any-length kernels -- for every frame, also the 2048-sample ones: the
+// fast decode kernels store int16 (what the WAV writer keeps), which would truncate what a hand-made stream can hold.  Whole
+// files and batches (sela::Decoder, decodeFile, decodeBatch ...) go through the fast kernels; this class is the exact one.
 data::WavFrame FrameDecoder::process()
 {
     const size_t channels = selaFrame.subFrames.size();
@@ -125,13 +151,16 @@ data::WavFrame FrameDecoder::process()
     std::vector<uint8_t> bytes;
     appendFrame(selaFrame, bytes);
     const uint64_t offsets[2] = { 0, bytes.size() };
-    std::vector<int16_t> pcm(kBlock * channels);
-    if (sela_hip_decode(bytes.data(), offsets, 1, (uint32_t)channels, pcm.data()) != SELA_HIP_OK)
+    uint32_t stride = 1;
+    for (const data::SelaSubFrame& s : selaFrame.subFrames)
+        stride = std::max<uint32_t>(stride, s.samplesPerChannel);
+    std::vector<int32_t> planar((size_t)stride * channels);
+    std::vector<uint32_t> counts(channels, 0);
+    if (sela_hip_decode_i32(bytes.data(), offsets, 1, (uint32_t)channels, planar.data(), stride, counts.data()) != SELA_HIP_OK)
         throw data::Exception(std::string("FrameDecoder: ") + sela_hip_last_error());
-    std::vector<std::vector<int32_t>> samples(channels, std::vector<int32_t>(kBlock));
-    for (size_t i = 0; i < kBlock; i++)
-        for (size_t c = 0; c < channels; c++)
-            samples[c][i] = pcm[i * channels + c];
+    std::vector<std::vector<int32_t>> samples(channels);
+    for (size_t c = 0; c < channels; c++)
+        samples[c].assign(planar.begin() + (ptrdiff_t)(c * stride), planar.begin() + (ptrdiff_t)(c * stride + counts[c]));
     return data::WavFrame(selaFrame.bitsPerSample, std::move(samples));
 }
 

@@ -298,15 +298,69 @@ int main(int argc, char** argv)
                 data::RiceEncodedData coefWords = rice::RiceEncoder(data::RiceDecodedData(std::vector<int32_t>(encoded.quantizedReflectionCoefficients))).process();
                 CHECK(coefWords.optimumRiceParam == coded.subFrames[0].reflectionCoefficientRiceParam && coefWords.encodedData == coded.subFrames[0].encodedReflectionCoefficients);
             }
-            // mono + a sample outside 16 bits is rejected loudly
-            std::vector<int32_t> wide(2048, 40000);
-            bool threw = false;
-            try {
-                frame::FrameEncoder(data::WavFrame(16, { wide })).process();
-            } catch (const data::Exception&) {
-                threw = true;
+            // what the reference's classes take beyond its CLI's shape: samples beyond 16 bits, any length (round 5: the any-length
+            // kernels behind the same classes).  A 17-bit mono frame, a 1000-sample stereo frame whose difference wins, a
+            // 5000-sample three-channel frame: each comes back exactly, channel lengths and all.
+            {
+                std::vector<int32_t> wide(2048);
+                for (int i = 0; i < 2048; i++)
+                    wide[i] = 40000 + (int32_t)(20000 * std::sin(i * 0.01)) + (i * 7919) % 13;
+                data::SelaFrame f = frame::FrameEncoder(data::WavFrame(16, { wide })).process();
+                CHECK(f.subFrames.size() == 1 && f.subFrames[0].samplesPerChannel == 2048);
+                data::WavFrame back = frame::FrameDecoder(f).process();
+                CHECK(back.samples.size() == 1 && back.samples[0] == wide);
+
+                std::vector<int32_t> left(1000), right(1000);
+                for (int i = 0; i < 1000; i++) {
+                    left[i] = (int32_t)(12000 * std::sin(i * 0.05) + 3000 * std::sin(i * 0.31)) + (i * 104729) % 7;
+                    right[i] = left[i] - (i % 3);
+                }
+                f = frame::FrameEncoder(data::WavFrame(16, { left, right })).process();
+                CHECK(f.subFrames.size() == 2 && f.subFrames[1].subFrameType == 1 && f.subFrames[1].samplesPerChannel == 1000);
+                back = frame::FrameDecoder(f).process();
+                CHECK(back.samples.size() == 2 && back.samples[0] == left && back.samples[1] == right);
+
+                std::vector<std::vector<int32_t>> three(3, std::vector<int32_t>(5000));
+                for (int c = 0; c < 3; c++)
+                    for (int i = 0; i < 5000; i++)
+                        three[c][i] = (int32_t)((60000 - 9000 * c) * std::sin(i * (0.003 + 0.002 * c))) + (i * (31 + c)) % 17;
+                f = frame::FrameEncoder(data::WavFrame(24, three)).process();
+                CHECK(f.subFrames.size() == 3 && f.subFrames[2].samplesPerChannel == 5000 && f.subFrames[2].subFrameType == 0);
+                back = frame::FrameDecoder(f).process();
+                CHECK(back.samples == three && back.bitsPerSample == 24);
+
+                // the stages on a vector of another length
+                data::LpcDecodedData block((uint8_t)16, std::vector<int32_t>(three[1]));
+                data::LpcEncodedData enc = lpc::ResidueGenerator(block).process();
+                CHECK(enc.residues.size() == 5000 && enc.optimalLpcOrder >= 1 && enc.quantizedReflectionCoefficients.size() == enc.optimalLpcOrder);
+                CHECK(lpc::SampleGenerator(enc).process().samples == three[1]);
+                lpc::LinearPredictor predictor(enc.quantizedReflectionCoefficients, enc.optimalLpcOrder);
+                predictor.dequantizeReflectionCoefficients();
+                CHECK(predictor.reflectionCoefficients.size() == std::max<size_t>(1, enc.optimalLpcOrder > 1 ? enc.optimalLpcOrder : 1));
+                CHECK(enc.optimalLpcOrder <= 1 || (predictor.reflectionCoefficients[0] >= -1.0 && predictor.reflectionCoefficients[0] <= 1.0));
+
+                // channels of different lengths, and a block shorter than its order, stay refused (undefined in the reference)
+                bool threw = false;
+                try {
+                    frame::FrameEncoder(data::WavFrame(16, { left, wide })).process();
+                } catch (const data::Exception&) {
+                    threw = true;
+                }
+                CHECK(threw);
+                std::vector<int32_t> noise(30);
+                uint32_t x = 99u;
+                for (int32_t& v : noise) {
+                    x = x * 1664525u + 1013904223u;
+                    v = (int32_t)(x >> 17) - 16384;
+                }
+                threw = false;
+                try {
+                    frame::FrameEncoder(data::WavFrame(16, { noise })).process();
+                } catch (const data::Exception&) {
+                    threw = true;
+                }
+                CHECK(threw);
             }
-            CHECK(threw);
         } catch (const data::Exception& e) {
             std::fprintf(stderr, "FAIL exception: %s\n", e.exceptionMessage.c_str());
             failures++;

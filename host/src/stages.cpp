@@ -1,8 +1,10 @@
 // stages.cpp -- see stages.hpp.
 #include "sela_host/stages.hpp"
 
+#include <algorithm>
 #include <string>
 
+#include "sela_format.h"
 #include "sela_hip.h"
 
 namespace {
@@ -62,13 +64,39 @@ void LinearPredictor::generatelinearPredictionCoefficients()
     linearPredictionCoefficients.assign(a.begin(), a.begin() + order + 1);
 }
 
+// src/lpc/linear_predictor.cpp:16-28: order <= 1 -> [0.0]; else the three tables (include/sela_tables.inc, the reference's
+// data), indexed with q + 64.  (Host arithmetic there is none: three lookups per coefficient.  An index outside the tables --
+// undefined in the reference -- is clamped like the kernels clamp it.)
+void LinearPredictor::dequantizeReflectionCoefficients()
+{
+    reflectionCoefficients.clear();
+    if (optimalLpcOrder <= 1) {
+        reflectionCoefficients.push_back(0.0);
+        return;
+    }
+    if (quantizedReflectionCoefficients.size() < (size_t)optimalLpcOrder)
+        throw data::Exception("LinearPredictor: fewer coefficients than the order");
+    auto at = [](int32_t q) { return (size_t)std::min(127, std::max(0, (int)std::min<int64_t>(std::max<int64_t>((int64_t)q + 64, -1), 128))); };
+    reflectionCoefficients.reserve(optimalLpcOrder);
+    reflectionCoefficients.push_back(SELA_DEQUANT_FIRST[at(quantizedReflectionCoefficients[0])]);
+    reflectionCoefficients.push_back(SELA_DEQUANT_SECOND[at(quantizedReflectionCoefficients[1])]);
+    for (size_t i = 2; i < (size_t)optimalLpcOrder; i++)
+        reflectionCoefficients.push_back(SELA_DEQUANT_HIGHER[at(quantizedReflectionCoefficients[i])]);
+}
+
+// (any number of samples of any 32-bit value, like the reference's class: 2048 samples go to the frame kernels' analysis,
+// other lengths to the any-length kernels; a block not longer than the order its analysis picks is refused -- the reference
+// reads past its vector there, src/lpc/residue_generator.cpp:104-110)
 data::LpcEncodedData ResidueGenerator::process()
 {
-    if (samples.size() != kBlock)
-        throw data::Exception("ResidueGenerator: a block is 2048 samples");
+    const size_t n = samples.size();
+    if (n == 0 || n > ((size_t)1 << 24))
+        throw data::Exception("ResidueGenerator: 1 .. 2^24 samples");
     int32_t order = 0;
-    std::vector<int32_t> q(kMaxOrder, 0), residues(kBlock);
-    if (sela_hip_lpc_encode(samples.data(), 1, &order, q.data(), residues.data()) != SELA_HIP_OK)
+    std::vector<int32_t> q(kMaxOrder, 0), residues(n);
+    const int rc = n == kBlock ? sela_hip_lpc_encode(samples.data(), 1, &order, q.data(), residues.data())
+                               : sela_hip_lpc_encode_n(samples.data(), 1, (uint32_t)n, &order, q.data(), residues.data());
+    if (rc != SELA_HIP_OK)
         stageFailure("ResidueGenerator");
     q.resize((size_t)order);
     return data::LpcEncodedData((uint8_t)order, bitsPerSample, std::move(q), std::move(residues));
@@ -76,15 +104,18 @@ data::LpcEncodedData ResidueGenerator::process()
 
 data::LpcDecodedData SampleGenerator::process()
 {
-    if (residues.size() != kBlock)
-        throw data::Exception("SampleGenerator: a block is 2048 residues");
+    const size_t n = residues.size();
+    if (n == 0 || n > ((size_t)1 << 24))
+        throw data::Exception("SampleGenerator: 1 .. 2^24 residues");
     const int32_t order = linearPredictor.optimalLpcOrder;
     if ((size_t)order > kMaxOrder || linearPredictor.quantizedReflectionCoefficients.size() < (size_t)order)
         throw data::Exception("SampleGenerator: order beyond 100 or fewer coefficients than the order");
-    std::vector<int32_t> q(kMaxOrder, 0), out(kBlock);
+    std::vector<int32_t> q(kMaxOrder, 0), out(n);
     for (int32_t i = 0; i < order; i++)
         q[(size_t)i] = linearPredictor.quantizedReflectionCoefficients[(size_t)i];
-    if (sela_hip_lpc_decode(&order, q.data(), residues.data(), 1, out.data(), nullptr) != SELA_HIP_OK)
+    const int rc = n == kBlock ? sela_hip_lpc_decode(&order, q.data(), residues.data(), 1, out.data(), nullptr)
+                               : sela_hip_lpc_decode_n(&order, q.data(), residues.data(), 1, (uint32_t)n, out.data(), nullptr);
+    if (rc != SELA_HIP_OK)
         stageFailure("SampleGenerator");
     return data::LpcDecodedData(bitsPerSample, std::move(out));
 }

@@ -151,14 +151,18 @@ void Decoder::processFrames(std::vector<data::WavFrame>& decodedWavFrames)
         appendFrame(selaFile.selaFrames[f], bytes);
     }
     offsets[frames] = bytes.size();
-    std::vector<int16_t> pcm((size_t)frames * kSamplesPerFrame * channels);
+    // frames say their own length (2048 from the reference's encoder; anything in a hand-made stream, src/frame/frame_decoder.cpp:24-25)
+    std::vector<uint64_t> at(frames + 1);
+    (void)sela_hip_index_samples(bytes.data(), offsets.data(), frames, channels, at.data());
+    std::vector<int16_t> pcm((size_t)at[frames] * channels + 1);
     if (sela_hip_decode(bytes.data(), offsets.data(), frames, channels, pcm.data()) != SELA_HIP_OK)
         throw data::Exception(std::string(sela_hip_last_error()));
     decodedWavFrames.reserve(frames);
     for (uint32_t f = 0; f < frames; f++) {
-        std::vector<std::vector<int32_t> > samples(channels, std::vector<int32_t>(kSamplesPerFrame));
-        const int16_t* p = pcm.data() + (size_t)f * kSamplesPerFrame * channels;
-        for (size_t i = 0; i < kSamplesPerFrame; i++)
+        const size_t n = (size_t)(at[f + 1] - at[f]);
+        std::vector<std::vector<int32_t> > samples(channels, std::vector<int32_t>(n));
+        const int16_t* p = pcm.data() + (size_t)at[f] * channels;
+        for (size_t i = 0; i < n; i++)
             for (uint32_t c = 0; c < channels; c++)
                 samples[c][i] = p[i * channels + c];
         decodedWavFrames.push_back(data::WavFrame((uint8_t)selaFile.selaHeader.bitsPerSample, std::move(samples)));

@@ -82,22 +82,35 @@ class CallCoalescer {
         for (const SmallCall* c : batch)
             total += c->n_frames;
         std::vector<uint64_t> offsets(total + 1, 0);
-        void *in = nullptr, *out = nullptr;
+        struct Staging { // the page-locked buffers go back to the pool however this function is left (a std::string or an error
+            void* p = nullptr; // assignment below may throw: submit() catches, the buffers must not leak)
+            ~Staging()
+            {
+                if (p)
+                    Backend::give(p);
+            }
+            operator void*() const { return p; }
+            Staging& operator=(void* q)
+            {
+                p = q;
+                return *this;
+            }
+        } in, out;
         int rc = SELA_HIP_OK;
         bool oom = false;
         if (encode) {
             const size_t cap = Backend::encode_bound_bytes((uint32_t)total, channels);
             in = Backend::take(total * frame_pcm);
             out = Backend::take(cap);
-            if (!in || !out) {
+            if (!in.p || !out.p) {
                 rc = SELA_HIP_ENOMEM, oom = true;
             } else {
                 size_t at = 0;
                 for (const SmallCall* c : batch) {
-                    std::memcpy(static_cast<uint8_t*>(in) + at * frame_pcm, c->pcm, c->n_frames * frame_pcm);
+                    std::memcpy(static_cast<uint8_t*>(in.p) + at * frame_pcm, c->pcm, c->n_frames * frame_pcm);
                     at += c->n_frames;
                 }
-                rc = Backend::encode_now(static_cast<const int16_t*>(in), (uint32_t)total, channels, static_cast<uint8_t*>(out), cap, offsets.data());
+                rc = Backend::encode_now(static_cast<const int16_t*>(in.p), (uint32_t)total, channels, static_cast<uint8_t*>(out.p), cap, offsets.data());
             }
             const std::string msg = rc == SELA_HIP_OK ? std::string() : (oom ? std::string("no page-locked memory for a coalesced batch") : Backend::last_error());
             size_t at = 0;
@@ -108,7 +121,7 @@ class CallCoalescer {
                 } else if (bytes > c->frames_cap) {
                     c->rc = SELA_HIP_ECAPACITY, c->error = "frames_out too small (see sela_hip_encode_bound_bytes)";
                 } else {
-                    std::memcpy(c->frames_out, static_cast<const uint8_t*>(out) + base, (size_t)bytes);
+                    std::memcpy(c->frames_out, static_cast<const uint8_t*>(out.p) + base, (size_t)bytes);
                     for (uint32_t f = 0; f <= c->n_frames; f++)
                         c->offsets_out[f] = offsets[at + f] - base;
                 }
@@ -120,20 +133,20 @@ class CallCoalescer {
                 bytes += (size_t)(c->offsets_in[c->n_frames] - c->offsets_in[0] + 3) & ~(size_t)3;
             in = Backend::take(bytes + 4);
             out = Backend::take(total * frame_pcm);
-            if (!in || !out) {
+            if (!in.p || !out.p) {
                 rc = SELA_HIP_ENOMEM, oom = true;
             } else {
                 size_t at = 0, pos = 0;
                 for (const SmallCall* c : batch) {
                     const uint64_t first = c->offsets_in[0], len = c->offsets_in[c->n_frames] - first;
-                    std::memcpy(static_cast<uint8_t*>(in) + pos, c->frames + first, (size_t)len);
+                    std::memcpy(static_cast<uint8_t*>(in.p) + pos, c->frames + first, (size_t)len);
                     for (uint32_t f = 0; f < c->n_frames; f++)
                         offsets[at + f] = pos + (c->offsets_in[f] - first);
                     at += c->n_frames;
                     pos += ((size_t)len + 3) & ~(size_t)3; // (frames are whole words: every call's first frame stays aligned)
                     offsets[at] = pos; // (the padding, if a malformed frame left any, belongs to the call's last frame)
                 }
-                rc = Backend::decode_now(static_cast<const uint8_t*>(in), offsets.data(), (uint32_t)total, channels, static_cast<int16_t*>(out));
+                rc = Backend::decode_now(static_cast<const uint8_t*>(in.p), offsets.data(), (uint32_t)total, channels, static_cast<int16_t*>(out.p));
             }
             if (rc == SELA_HIP_EFORMAT) {
                 // somebody's malformed frame must not fail its neighbours' calls: everyone on their own
@@ -146,15 +159,11 @@ class CallCoalescer {
                     if (rc != SELA_HIP_OK)
                         c->rc = rc, c->error = msg;
                     else
-                        std::memcpy(c->pcm_out, static_cast<const uint8_t*>(out) + at * frame_pcm, c->n_frames * frame_pcm);
+                        std::memcpy(c->pcm_out, static_cast<const uint8_t*>(out.p) + at * frame_pcm, c->n_frames * frame_pcm);
                     at += c->n_frames;
                 }
             }
         }
-        if (in)
-            Backend::give(in);
-        if (out)
-            Backend::give(out);
     }
 
 public:

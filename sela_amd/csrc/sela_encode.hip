@@ -2124,6 +2124,9 @@ __global__ __launch_bounds__(64) void k_stage_rice_encode(const int32_t* __restr
             best_bits = bits, best_k = (uint32_t)k;
     }
     uint32_t flags = __any(wide) ? (uint32_t)SELA_HIP_FLAG_RICE_RANGE : 0u;
+    // requiredInts = ceil((float)bits / 32) is what the reference reports AND writes (rice_encoder.cpp:37,63-70): above 2^24
+    // bits the float drops low bits of the count, and a count that rounds DOWN across a multiple of 32 leaves the stream's
+    // last bits unwritten there.  Same here: `words` is the reference's number, and no codeword bit lands beyond it.
     const uint32_t words = best_bits < (1ull << 31) ? words_for_bits(best_bits) : 0xFFFFFFFFu;
     if (words > cap)
         flags |= SELA_HIP_FLAG_WORDS_CAP;
@@ -2135,14 +2138,26 @@ __global__ __launch_bounds__(64) void k_stage_rice_encode(const int32_t* __restr
     }
     if (flags)
         return;
+    const bool clipped = ((best_bits + 31) >> 5) > (uint64_t)words; // (only ever beyond 2^24 bits)
     uint32_t base = 0;
     for (uint64_t i0 = 0; i0 < n; i0 += 64) {
         const bool valid = i0 + lane < n;
         const uint32_t u = valid ? zigzag32(v[i0 + lane]) : 0u;
         const uint32_t len = valid ? (u >> best_k) + 1 + best_k : 0u;
         const uint32_t before = wave_exclusive_scan(len, lane);
-        if (valid)
-            (void)put_codeword(out, base + before, u, best_k);
+        if (valid) {
+            const uint32_t at = base + before;
+            if (!clipped || (uint64_t)at + len <= 32ull * words) {
+                (void)put_codeword(out, at, u, best_k);
+            } else { // the codeword that straddles (or lies beyond) the reference's last word: bit by bit, the rest dropped
+                const uint32_t ones = u >> best_k;
+                for (uint32_t b = 0; b < len && (uint64_t)at + b < 32ull * words; b++) {
+                    const uint32_t bit = b < ones ? 1u : (b == ones ? 0u : (u >> (best_k - 1 - (b - ones - 1))) & 1u);
+                    if (bit)
+                        atomicOr(&out[(at + b) >> 5], 1u << ((at + b) & 31));
+                }
+            }
+        }
         base += (uint32_t)__builtin_amdgcn_readlane((int)(before + len), 63);
     }
 }

@@ -68,3 +68,44 @@ def retag(sub: bytearray, channel: int, type_: int, parent: int) -> bytearray:
     s = bytearray(sub)
     s[0], s[1], s[2] = channel, type_, parent
     return s
+
+
+# ---- a hand-made .sela FILE whose frames have different lengths (stereo; every length <= 5000: the reference's stereo WAV
+#      writer keeps a 10000-sample buffer, src/file/wav_file.cpp:245-255) --------------------------------------------------
+ODD_FILE_LENGTHS = (2048, 2048, 1000, 1000, 3000, 2048, 777, 3000)
+
+
+def odd_file_bytes(frame_encode):
+    """frame_encode(pcm int16 [n, 2]) -> frame bytes; returns (the .sela file's bytes, the PCM a decoder must write)."""
+    import struct
+
+    frames, pcms, at = [], [], 5000
+    src = synth_pcm(at + sum(ODD_FILE_LENGTHS), 2, 57)
+    for n in ODD_FILE_LENGTHS:
+        pcm = np.ascontiguousarray(src[at:at + n])
+        at += n
+        frames.append(frame_encode(pcm))
+        pcms.append(pcm)
+    header = b"SeLa" + struct.pack("<IHBI", 44100, 16, 2, len(frames))
+    return header + b"".join(frames), np.concatenate(pcms)
+
+
+# ---- a Rice stream of more than 2^24 bits whose count the reference's float rounds DOWN across a word ------------------------
+def long_rice_stream():
+    """int32 values whose best-k bit count is = 1 (mod 32) and above 2^24: ceil((float)bits / 32) is one word short of the
+    stream (src/rice/rice_encoder.cpp:37,63), and the reference's last word is simply not written."""
+    rng = np.random.default_rng(24)
+    v = rng.integers(-(1 << 13), 1 << 13, 1_250_000).astype(np.int32)
+
+    def plan(vals):
+        u = np.where(vals < 0, -2 * vals.astype(np.int64) - 1, 2 * vals.astype(np.int64))
+        bits = [int((u >> k).sum()) + len(vals) * (1 + k) for k in range(20)]
+        k = int(np.argmin(bits))
+        return k, bits[k]
+
+    for _ in range(64):
+        k, bits = plan(v)
+        if bits > (1 << 24) and bits % 32 == 1:
+            return v, k, bits
+        v = np.append(v, np.int32(0))  # one more codeword of 1 + k bits
+    raise AssertionError("no such stream found")

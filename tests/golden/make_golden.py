@@ -184,6 +184,23 @@ def generic(ref):
             arrays[f"crafted/{name}/decoded{c}"] = dec[c]
         print("crafted", name, [len(d) for d in dec], flush=True)
     arrays["crafted_names"] = np.array(names)
+
+    # ---- a hand-made file with frames of different lengths through the reference's own decoder + WAV writer -------------------
+    lib = ref.lib
+    lib.ref_decode_file.argtypes = [C.c_char_p, C.c_char_p]
+    lib.ref_decode_file.restype = C.c_int
+    blob, pcm = gc.odd_file_bytes(ref.frame_encode)
+    with tempfile.TemporaryDirectory() as tmp:
+        sela, wav = os.path.join(tmp, "odd.sela"), os.path.join(tmp, "odd.wav")
+        with open(sela, "wb") as f:
+            f.write(blob)
+        assert lib.ref_decode_file(sela.encode(), wav.encode()) == 0
+        wsha, wsize = sha_file(wav)
+        with open(wav, "rb") as f:
+            assert f.read()[44:] == pcm.tobytes()
+    table["odd_file"] = {"sela_sha256": hashlib.sha256(blob).hexdigest(), "sela_bytes": len(blob), "decoded_wav_sha256": wsha,
+                         "decoded_wav_bytes": wsize, "frame_lengths": list(gc.ODD_FILE_LENGTHS)}
+    print("odd_file", table["odd_file"], flush=True)
     with open(os.path.join(HERE, "generic.json"), "w") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "generic_kats.npz"), **arrays)

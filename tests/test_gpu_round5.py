@@ -189,3 +189,42 @@ def test_lpc_stages_of_any_length(gpu):  # noqa: F811
     for b in range(3):
         wo, wq, wr = o.lpc_analyze(big[b])
         assert order[b] == wo and np.array_equal(q[b, :wo], wq) and not q[b, wo:].any() and np.array_equal(res[b], wr)
+
+
+def test_a_file_with_frames_of_other_lengths_decodes_like_the_reference(gpu, tmp_path, generic_digests):  # noqa: F811
+    """A hand-made .sela file (frames of 2048, 1000, 3000, 777 samples, stereo) through `sela_mi355x -d`, the reference's
+    unchanged main.cpp on this host (object path: sela::Decoder::process + WavFile::writeToFile) and the reference's classes
+    bound to the library: the WAV file the reference's own decoder writes (digest made by make_golden.py)."""
+    import os
+    import subprocess
+
+    g = generic_digests["odd_file"]
+    blob, pcm = gc.odd_file_bytes(oracle().frame_encode)
+    assert hashlib.sha256(blob).hexdigest() == g["sela_sha256"] and len(blob) == g["sela_bytes"]
+    sela = tmp_path / "odd.sela"
+    sela.write_bytes(blob)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools = [os.path.join(root, "host", "sela_mi355x")]
+    on_host = os.path.join(root, "oracle", "_ref", "sela_ref_main_on_host")
+    bound = os.path.join(root, "oracle", "_ref", "sela_ref_bound")
+    tools += [t for t in (on_host, bound) if os.path.exists(t)]
+    for i, exe in enumerate(tools):
+        wav = tmp_path / f"odd{i}.wav"
+        out = subprocess.run([exe, "-d", str(sela), str(wav)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        data = wav.read_bytes()
+        assert len(data) == g["decoded_wav_bytes"] and hashlib.sha256(data).hexdigest() == g["decoded_wav_sha256"], exe
+        assert data[44:] == pcm.tobytes()
+
+
+def test_rice_stage_cuts_a_stream_beyond_2_24_bits_like_the_reference(gpu):  # noqa: F811
+    """sela_hip_rice_encode on a stream whose float-rounded word count is one short: the reference's k, count and
+    words -- nothing written past them (the stream behind it in the same call is intact)."""
+    from sela_amd import codec
+
+    v, k, bits = gc.long_rice_stream()
+    tail = np.array([0, -1, 1, -2, 2, 100, -100, 5], np.int32)
+    (k0, w0), (k1, w1) = codec.rice_encode([v, tail])
+    ko, wo = oracle().rice_encode(v)
+    assert k0 == ko == k and len(w0) == (bits + 31) // 32 - 1 and np.array_equal(w0, wo)
+    assert k1 == 5 and [hex(x) for x in w1] == ["0xc8c10800", "0x538fc4f"]

@@ -60,3 +60,15 @@ def test_oracle_against_the_reference_on_odd_shapes():
                 assert ua == ub == len(a)
                 for u, v in zip(da, db):
                     assert np.array_equal(u, v), (n, ch, amp)
+
+
+def test_a_rice_stream_beyond_2_24_bits_is_cut_like_the_reference():
+    """ceil((float)bits / 32) is one word short for this stream (src/rice/rice_encoder.cpp:37,63): the oracle returns the
+    reference's words, where oracle/_ref exists compared with the real thing."""
+    v, k, bits = gc.long_rice_stream()
+    ko, wo = oracle().rice_encode(v)
+    assert ko == k and len(wo) == (bits + 31) // 32 - 1
+    ref = reference()
+    if ref is not None:
+        kr, wr = ref.rice_encode(v)
+        assert kr == ko and np.array_equal(wr, wo)
