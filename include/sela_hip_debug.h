@@ -40,9 +40,15 @@ int sela_hip_debug_encode_kernel(uint32_t n_frames, uint32_t channels);
  * writes the group's bytes -- no plan / assemble kernels) on device pointers.  Same bytes; bench.py --encode-fused times it
  * beside the default. */
 void sela_hip_debug_encode_fused(int enable);
-/* Debug hook (measurements only; device-wide): the wave priorities (s_setprio 0..3) of k_encode_teams' waves in the four quarters
- * of their work, one byte each from the low end (0x00010203: falling from 3 to 0; default 0: none -- DESIGN.md section 9). */
+/* Debug hooks (measurements and tests; process-wide): the wave priorities (s_setprio 0..3) of the encode kernels' waves in the four
+ * quarters of their work, one byte each from the low end (0x00010203: falling from 3 to 0; 0: none).  By default the library
+ * decides per device-pointer launch: the falling schedule when no other stream has library work pending on the device, none
+ * otherwise (sela_capi.hip, "does a device-pointer launch have the device to itself?").  sela_hip_debug_priorities() fixes the
+ * schedule for every launch, sela_hip_debug_priorities_adaptive() goes back to the default; sela_hip_debug_launches_alone()
+ * counts the launches that were given the falling schedule by that default. */
 void sela_hip_debug_priorities(uint32_t team_quarters);
+void sela_hip_debug_priorities_adaptive(void);
+int sela_hip_debug_launches_alone(void);
 /* Debug hook (process-wide): 1 = write the slots of BOTH candidates for an exactly-stereo frame's second channel (the channel
  * itself and the difference signal), as rounds 1-3 did; 0 (default) = the candidate that knows it has lost does not write
  * its slot (sela_encode_tail.inc).  Same bytes either way, which is what the tests check; the difference is HBM traffic. */
@@ -61,6 +67,14 @@ void sela_hip_debug_decode_recurrence(int form);
 /* Debug hook: how many per-thread contexts (streams, events, staging buffers) this process has CREATED so far -- threads
  * that take over a parked one (sela_hip.h, sela_hip_thread_release) do not count. */
 int sela_hip_debug_contexts_created(void);
+
+/* Debug hook (tests): which form of the residue filter (sela_encode_tail.inc: one pass of FP64 taps / two passes / the plain
+ * 64-bit loop) the blocks of the LAST device-pointer encode that used this workspace took -- counts_out[0..2], over all
+ * n_frames * signals blocks (the losing stereo candidate included); forms_out (or NULL): the form of every block, 0 / 1 / 2,
+ * [n_frames * signals].  The forms are chosen per block from its predictor and its
+ * loudest sample; the product kernels leave the choice in two spare bits of their per-block records, which this reads back.
+ * Synchronises the device.  Returns SELA_HIP_OK or an error code. */
+int sela_hip_debug_block_forms(const void* d_workspace, uint32_t n_frames, uint32_t channels, uint32_t* counts_out, uint8_t* forms_out);
 
 #ifdef __cplusplus
 }

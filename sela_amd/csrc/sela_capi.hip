@@ -26,12 +26,11 @@
 namespace sela {
 size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced);
-hipError_t set_team_priorities(uint32_t quarters);
 void set_keep_both_candidates(int on);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
     hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override, int team_lanes,
-    int32_t* d_trace_residues = nullptr);
+    int32_t* d_trace_residues = nullptr, uint32_t priorities = 0);
 hipError_t launch_stage_rice_encode(const int32_t* d_values, const uint64_t* d_value_offsets, uint32_t n_streams, uint32_t* d_k, uint32_t* d_word_counts,
     uint32_t* d_words, const uint64_t* d_word_offsets, uint32_t* d_status, hipStream_t stream);
 hipError_t launch_stage_lpc_decode(const int32_t* d_order, const int32_t* d_q, const int32_t* d_residues, uint32_t n_blocks, int32_t* d_samples,
@@ -974,6 +973,82 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
     return SELA_HIP_OK;
 }
 
+
+// ---- does a device-pointer launch have the device to itself? ------------------------------------------------------------------
+// The encode kernels take a schedule of wave priorities that FALLS with a wave's progress (sela_encode.hip, the note on
+// priorities): on its own a launch of one fill finishes 7 % sooner with it, beside another stream's kernels the same schedule
+// starves the neighbour and costs 6 %.  Whether there is a neighbour the library can tell for its own launches: every
+// device-pointer call leaves an event on its stream, and a call looks at the events of the OTHER streams -- one still pending
+// means that stream's kernels will run beside this launch's.  (Decided when the launch is queued; work the library does not
+// know of is not seen: then the schedule is merely not the best one.  Events, not the streams themselves, are kept: a caller
+// may destroy its stream.)
+struct Flights {
+    struct Entry {
+        hipStream_t stream;
+        hipEvent_t done;
+    };
+    std::mutex mu;
+    std::vector<Entry> entries[64]; // by device
+    bool others_pending(int dev, hipStream_t stream)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Entry& e : entries[dev])
+            if (e.stream != stream && hipEventQuery(e.done) == hipErrorNotReady)
+                return true;
+        return false;
+    }
+    void note(int dev, hipStream_t stream)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        std::vector<Entry>& v = entries[dev];
+        Entry* mine = nullptr;
+        for (Entry& e : v)
+            if (e.stream == stream)
+                mine = &e;
+        if (!mine && v.size() >= 16) // streams come and go: an entry whose work is done is as good as a new one
+            for (Entry& e : v)
+                if (hipEventQuery(e.done) != hipErrorNotReady) {
+                    mine = &e;
+                    mine->stream = stream;
+                    break;
+                }
+        if (!mine) {
+            if (v.size() >= 64)
+                return; // (not tracked: at worst a launch is taken to be alone)
+            Entry e{ stream, nullptr };
+            if (hipEventCreateWithFlags(&e.done, hipEventDisableTiming) != hipSuccess)
+                return;
+            v.push_back(e);
+            mine = &v.back();
+        }
+        (void)hipEventRecord(mine->done, stream);
+    }
+};
+Flights& flights()
+{
+    static Flights* f = new Flights; // (never destroyed: events outlive the statics' teardown)
+    return *f;
+}
+std::atomic<int64_t> g_forced_priorities{ -1 }; // debug (sela_hip_debug_priorities): a fixed schedule for every launch; -1: by the neighbours
+std::atomic<int> g_launches_alone{ 0 };         // debug: launches that were given the falling schedule
+constexpr uint32_t kFallingPriorities = 0x00010203u; // 3, 2, 1, 0 by quarters of a wave's work (least significant byte first)
+
+uint32_t launch_priorities(hipStream_t stream, int& dev)
+{
+    dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        dev = -1;
+        return 0;
+    }
+    const int64_t forced = g_forced_priorities.load(std::memory_order_relaxed);
+    if (forced >= 0)
+        return (uint32_t)forced;
+    if (flights().others_pending(dev, stream))
+        return 0;
+    g_launches_alone.fetch_add(1, std::memory_order_relaxed);
+    return kFallingPriorities;
+}
+
 } // namespace
 
 // ---- the stages on their own (sela_hip.h): plain synchronous calls, device buffers of their own -----------------------------
@@ -1088,7 +1163,29 @@ void sela_hip_debug_force_plain_fir(int enable) { g_force_plain_fir = enable & 3
 void sela_hip_debug_mean_workers(int self_blocks) { g_self_blocks = self_blocks; }
 void sela_hip_debug_encode_teams(int lanes) { g_team_lanes = lanes; }
 void sela_hip_debug_encode_fused(int enable) { g_fused_device = enable != 0; }
-void sela_hip_debug_priorities(uint32_t team_quarters) { (void)sela::set_team_priorities(team_quarters); }
+void sela_hip_debug_priorities(uint32_t team_quarters) { g_forced_priorities.store((int64_t)team_quarters, std::memory_order_relaxed); }
+void sela_hip_debug_priorities_adaptive(void) { g_forced_priorities.store(-1, std::memory_order_relaxed); }
+int sela_hip_debug_launches_alone(void) { return g_launches_alone.load(std::memory_order_relaxed); }
+int sela_hip_debug_block_forms(const void* d_workspace, uint32_t n_frames, uint32_t channels, uint32_t* counts_out, uint8_t* forms_out)
+{
+    if (!d_workspace || !counts_out || channels == 0)
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    counts_out[0] = counts_out[1] = counts_out[2] = 0;
+    const size_t blocks = (size_t)n_frames * sela_hip_signals_per_frame(channels);
+    std::vector<sela::BlockMeta> meta(blocks);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && blocks) // (the records open the workspace, launch_encode)
+        e = hipMemcpy(meta.data(), reinterpret_cast<const void*>(((uintptr_t)d_workspace + 255) & ~(uintptr_t)255), blocks * sizeof(sela::BlockMeta), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return fail_hip(e, "block forms");
+    for (size_t b = 0; b < blocks; b++) {
+        const uint32_t form = (meta[b].flags & sela::kBlockFormPlain) ? 2 : ((meta[b].flags & sela::kBlockFormTwoPass) ? 1 : 0);
+        counts_out[form]++;
+        if (forms_out)
+            forms_out[b] = (uint8_t)form;
+    }
+    return SELA_HIP_OK;
+}
 void sela_hip_debug_keep_both_candidates(int on) { sela::set_keep_both_candidates(on); }
 int sela_hip_debug_encode_kernel(uint32_t n_frames, uint32_t channels) { return sela::encode_team_lanes(n_frames, channels, g_team_lanes); }
 
@@ -1141,10 +1238,15 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
     const bool use_fused = g_fused_device && !d_trace && !g_phase_cycles;
     if (use_fused)
         g_timing.recorded = ev ? 1 : 0;
+    int dev = -1;
+    const uint32_t priorities = launch_priorities(static_cast<hipStream_t>(stream), dev);
     hipError_t e = sela::launch_encode(d_pcm, n_frames, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace,
-        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, use_fused ? &fused : nullptr, g_force_plain_fir, g_self_blocks, g_team_lanes);
+        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, use_fused ? &fused : nullptr, g_force_plain_fir, g_self_blocks, g_team_lanes, nullptr,
+        priorities);
     if (e != hipSuccess)
         return fail_hip(e, "encode launch");
+    if (dev >= 0 && n_frames)
+        flights().note(dev, static_cast<hipStream_t>(stream));
     return SELA_HIP_OK;
 }
 
@@ -1167,6 +1269,9 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
         static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_recurrence_form);
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
+    int dev = -1;
+    if (n_frames && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64)
+        flights().note(dev, static_cast<hipStream_t>(stream));
     return SELA_HIP_OK;
 }
 

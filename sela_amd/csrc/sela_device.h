@@ -35,6 +35,11 @@ struct BlockMeta {
     uint16_t res_words;
 };
 static_assert(sizeof(BlockMeta) == 8, "BlockMeta is read as one 8-byte word");
+// In BlockMeta::flags only (never in d_status: frame_words masks them): which form of the residue filter the block took
+// (sela_encode_tail.inc) -- neither bit: one pass of FP64 taps.  They reuse the bits of two flags an encoder block never
+// raises (RICE_OVERRUN is the decoder's, SHORT_BLOCK the any-length route's).  Read by sela_hip_debug_block_forms (tests).
+constexpr uint32_t kBlockFormTwoPass = SELA_HIP_FLAG_RICE_OVERRUN, kBlockFormPlain = SELA_HIP_FLAG_SHORT_BLOCK;
+constexpr uint32_t kBlockFormBits = kBlockFormTwoPass | kBlockFormPlain;
 
 // What the host pipeline hands an encode launch (launch_encode): where the launch reports to the host, where the
 // job's stream position lives, and -- when the PCM is still in page-locked host memory -- where to fetch it from.

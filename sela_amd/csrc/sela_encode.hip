@@ -711,6 +711,7 @@ struct FuseArgs {
     uint64_t tag;            // process nonce << 32 | ticket (see launch_encode): what marks a cell as written by THIS launch
     uint64_t* sizes_pub;     // [blocks]: the stereo candidates' sizes (sela_encode_tail.inc), sizes_tag | words; or null
     uint64_t sizes_tag;      // 20 bits of the nonce << 44 | ticket << 12
+    uint32_t priorities;     // wave priorities by quarters of a wave's work (0: none), see k_encode_teams' note on priorities
 };
 
 __device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t channels, uint32_t& choice, uint32_t& flags)
@@ -722,13 +723,13 @@ __device__ __forceinline__ uint32_t frame_words(const BlockMeta* m, uint32_t cha
         if (c == 1 && channels == 2) { // exactly-stereo only, src/frame/frame_encoder.cpp:18
             const BlockMeta d = m[2];
             const uint32_t dsz = (uint32_t)d.coef_words + d.res_words, asz = (uint32_t)b.coef_words + b.res_words;
-            flags |= d.flags;
+            flags |= d.flags & ~kBlockFormBits;
             if (dsz < asz) { // strict <, src/frame/frame_encoder.cpp:64
                 choice = 1;
                 b = d;
             }
         }
-        flags |= b.flags;
+        flags |= b.flags & ~kBlockFormBits;
         words += (uint32_t)b.coef_words + b.res_words;
     }
     return words;
@@ -1068,7 +1069,6 @@ __device__ __attribute__((noinline)) void finish_group(const FuseArgs& fa, uint3
 
 // The priorities (s_setprio) of a wave of k_encode_teams in the four quarters of its work, one byte each from the low end;
 // sela_hip_debug_priorities sets them (device-wide, measurements).  Default: none -- see the note at the autocorrelation's loop.
-__device__ uint32_t g_team_priorities = 0;
 
 // kFused: the host pipeline's one-launch form (await_frame, finish_group); compiled out of the device-pointer path's kernel
 template <int kMode, bool kFused>
@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // (the hook of k_encode_teams' note on priorities, for a launch of at most one fill of this kernel: 2 and 1 through the
         // autocorrelation, 1 through the Schur recursion, 0 behind it.  1000 frames on their own: 0.158 -> 0.148 ms; off by default
         // for the same reason -- beside another stream's kernels it costs what it gains here)
-        const bool falling = n_workers == 0 && g_team_priorities != 0;
+        const bool falling = !kFused && n_workers == 0 && fa.priorities != 0; // (the host pipeline runs beside its stagers and copies: never alone)
 #pragma unroll 1
         for (int k = 0; k < kBlock / kRingHalf; k++) {
             if (falling && k == 0)
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // Column j of gen[0]/gen[1] lives in lane j (j < 64) and lane j - 64 of a second register.
     // Stage i reads gen1[j+1] (old) -> a one-lane shift; all columns update from old values.
     double k_lo = 0.0, k_hi = 0.0; // k[lane], k[lane + 64]
-    if (n_workers == 0 && g_team_priorities != 0)
+    if (!kFused && n_workers == 0 && fa.priorities != 0)
         __builtin_amdgcn_s_setprio(1);
     else
         __builtin_amdgcn_s_setprio(2); // latency-bound (100 dependent stages, one division each)
@@ -1612,7 +1612,7 @@ template <int kMode, int P>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_encode_teams(
     const int16_t* __restrict__ pcm, uint32_t n_frames, uint32_t channels, uint32_t n_sig, BlockMeta* __restrict__ meta,
     uint32_t* __restrict__ slots, sela_hip_trace* __restrict__ trace, int force_plain_fir, uint64_t* __restrict__ phase_cycles,
-    uint64_t* __restrict__ sizes_pub, uint64_t sizes_tag)
+    uint64_t* __restrict__ sizes_pub, uint64_t sizes_tag, uint32_t team_priorities)
 {
     using Plan = TeamPlan<P>;
     constexpr int B = Plan::B, G = Plan::G, kPer = Plan::kPer, kMeanPer = Plan::kMeanPer, kChunk = Plan::kChunk, kRing = Plan::kRing;
@@ -1660,7 +1660,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         team_load_raw<kMeanPer>(fp, channels, sig, kTeamMeanChunk + mine, raw_a);
         team_load_raw<kMeanPer>(fp, channels, sig, 2 * kTeamMeanChunk + mine, raw_b);
         double sum = 0.0;
-        const uint32_t quarter_priorities = g_team_priorities;
+        const uint32_t quarter_priorities = team_priorities;
         set_wave_priority((int)(quarter_priorities & 0xFF)); // (see the note on priorities at the autocorrelation's loop)
 #pragma unroll 1
         for (int c = 0; c < kChunks; c++) {
@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             pos_stage += kChunk;
             pos_stage = pos_stage >= (uint32_t)kRing ? 0u : pos_stage;
         };
-        // Priorities (g_team_priorities; off by default).  The SIMD's arbiter serves the OLDEST of its waves first, at equal
+        // Priorities (team_priorities, a launch argument; 0 = none).  The SIMD's arbiter serves the OLDEST of its waves first, at equal
         // priority: of three waves that start together, the first keeps nearly the whole SIMD to itself, finishes after 0.51 M
         // cycles and leaves the last one to walk its second half alone, at a lone wave's issue rate, until 0.96 M
         // (tools/ramp_profile.py: a launch that fills the device once takes as long as that last wave).  With a priority that
@@ -1745,9 +1745,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll 1
         for (int c = 0; c < kChunks; c++) { // (the PCM of a chunk is fetched two chunks ahead)
             if (c == kPrio2From)
-                set_wave_priority((int)((g_team_priorities >> 8) & 0xFF));
+                set_wave_priority((int)((team_priorities >> 8) & 0xFF));
             if (c == kPrio1From)
-                set_wave_priority((int)((g_team_priorities >> 16) & 0xFF));
+                set_wave_priority((int)((team_priorities >> 16) & 0xFF));
             if (c + 1 < kChunks)
                 stage_next(raw_a); // chunk c + 1
 #pragma unroll
@@ -1896,7 +1896,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const int lane = lane_now;
         const uint32_t block_id = frame * n_sig + sig;
         if (4 * (bb + 1) > B) // (the last three quarters of the tails: the wave is through most of its work -- lowest priority)
-            set_wave_priority((int)((g_team_priorities >> 24) & 0xFF));
+            set_wave_priority((int)((team_priorities >> 24) & 0xFF));
         const int8_t* const q_mine = q_all + bb * Plan::kQStride;
         const int order = (uint8_t)q_mine[100];
         int32_t q_lo = q_mine[lane], q_hi = lane < kMaxOrder - 64 ? q_mine[64 + lane] : 0;
@@ -2263,7 +2263,6 @@ static int team_lanes_for(size_t blocks)
 static std::atomic<int> g_keep_both_candidates{0};
 void set_keep_both_candidates(int on) { g_keep_both_candidates.store(on, std::memory_order_relaxed); }
 
-hipError_t set_team_priorities(uint32_t quarters) { return hipMemcpyToSymbol(HIP_SYMBOL(g_team_priorities), &quarters, sizeof(quarters)); }
 
 int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced)
 {
@@ -2275,7 +2274,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     hipStream_t stream, hipEvent_t* ev /* 4 events or nullptr */, uint64_t* d_phase_cycles,
     const EncodeHostLink* link /* the host pipeline's one-launch form; nullptr: three kernels */,
     int force_plain_fir, int self_blocks_override, int team_lanes /* -1: by launch size; 0: k_encode_blocks; 8, 16: k_encode_teams<P> */,
-    int32_t* d_trace_residues /* with d_trace and team_lanes 0: every block's residues, [block][2048]; or nullptr */)
+    int32_t* d_trace_residues /* with d_trace and team_lanes 0: every block's residues, [block][2048]; or nullptr */,
+    uint32_t priorities /* wave priorities by quarters of a wave's work, e.g. 0x00010203 falling; 0: none (the caller knows whether the launch has the device to itself) */)
 {
     const uint32_t n_sig = sela_hip_signals_per_frame(channels);
     const size_t blocks = (size_t)n_frames * n_sig;
@@ -2378,6 +2378,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         sizes_pub = nullptr;
     fa.sizes_pub = sizes_pub;
     fa.sizes_tag = sizes_tag;
+    fa.priorities = priorities;
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     // Which kernel analyses the blocks: k_encode_teams (several blocks side by side in a wave: fewer instructions per block,
@@ -2395,7 +2396,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         const uint32_t per_wave = 64u / (uint32_t)teams;
         const uint32_t waves = ((n_frames + per_wave - 1) / per_wave + 7) / 8 * 8 * n_sig;
 #define SELA_LAUNCH_TEAMS(MODE, LANES) \
-    hipLaunchKernelGGL((k_encode_teams<MODE, LANES>), dim3(waves), wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, force_plain_fir, d_phase_cycles, sizes_pub, sizes_tag)
+    hipLaunchKernelGGL((k_encode_teams<MODE, LANES>), dim3(waves), wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, d_trace, force_plain_fir, d_phase_cycles, sizes_pub, sizes_tag, priorities)
         if (teams == 8) {
             if (d_phase_cycles)
                 SELA_LAUNCH_TEAMS(2, 8);

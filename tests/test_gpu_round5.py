@@ -228,3 +228,71 @@ def test_rice_stage_cuts_a_stream_beyond_2_24_bits_like_the_reference(gpu):  # n
     ko, wo = oracle().rice_encode(v)
     assert k0 == ko == k and len(w0) == (bits + 31) // 32 - 1 and np.array_equal(w0, wo)
     assert k1 == 5 and [hex(x) for x in w1] == ["0xc8c10800", "0x538fc4f"]
+
+
+def test_wide_differential_corpus_against_the_reference(gpu):  # noqa: F811
+    """33,400 stereo frames = 100,200 analysed blocks (tests/corpus.py: AR(2..32) noise at many levels, |k| hovering at 0.05,
+    clipped and faded tones, DC steps, silence <-> full scale inside a block, 17-bit differences, loud and smooth polyphony)
+    through all three encode kernels and the decoder against the UNMODIFIED reference (oracle/_ref/libsela_ref.so on all host
+    threads; the oracle where that library is absent): frame bytes, offsets, decoded PCM.  And which form of the residue
+    filter every block took, unforced, read back from the product kernels' per-block records: equal to the documented rule
+    evaluated on the oracle's predictor for a sample of blocks; one pass and two passes both occur (the plain loop does not:
+    no 16-bit input was found that gets a predictor past 2^39 through the reference's quantiser -- it is reached by the
+    forced-form tests of round 4 and by the trace builds)."""
+    import ctypes as C
+    import os
+    import time
+
+    import corpus
+    from oracle_lib import reference
+    from sela_amd import capi, codec
+
+    t0 = time.time()
+    pcm = corpus.build()
+    n = pcm.shape[0]
+    ref = reference() or oracle()
+    threads = os.cpu_count() or 8
+    want, want_offs, _ = ref.encode_frames(pcm, threads=threads)
+    want_dec, _ = ref.decode_frames(want, want_offs, 2, threads=threads)
+    t1 = time.time()
+    lib = capi.lib()
+    enc = codec.Encoder(n, 2)
+    enc.frames = gpu.empty(int(lib.sela_hip_encode_bound_bytes(n, 2)), dtype=gpu.uint8, device="cuda")
+    enc.capacity = enc.frames.numel()
+    d_pcm = gpu.from_numpy(pcm).cuda()
+    o = oracle()
+    seen = np.zeros(3, np.int64)
+    try:
+        for teams in (-1, 0, 16, 8):
+            lib.sela_hip_debug_encode_teams(teams)
+            out = enc.encode(d_pcm)
+            gpu.cuda.synchronize()
+            frames, offs = out.to_host()
+            assert np.array_equal(offs, want_offs), teams
+            assert np.array_equal(frames, want), teams
+            counts = (C.c_uint32 * 3)()
+            forms = np.zeros(n * 3, np.uint8)
+            assert lib.sela_hip_debug_block_forms(enc.workspace.data_ptr(), n, 2, counts, forms.ctypes.data) == 0
+            seen += np.array(list(counts))
+            assert counts[0] > 0 and counts[1] > 0 and sum(counts) == 3 * n, (teams, list(counts))
+            if teams == -1:
+                picked = list(counts)
+                rng = np.random.default_rng(5)
+                sample = set(rng.integers(0, n, 400).tolist()) | set((np.nonzero(forms.reshape(n, 3).any(axis=1))[0][:200]).tolist())
+                for f in sorted(sample):
+                    l, r = pcm[f, :, 0].astype(np.int32), pcm[f, :, 1].astype(np.int32)
+                    for sig, s in enumerate((l, r, l - r)):
+                        order, q = o.lpc_analyze(s)[:2]
+                        a = o.lpc_coeffs(order, q)
+                        assert forms[3 * f + sig] == corpus.expected_form(a, order, s), (f, sig)
+    finally:
+        lib.sela_hip_debug_encode_teams(-1)
+    dec = codec.Decoder(n, 2)
+    back = dec.decode(out.frames, out.offsets, n)
+    gpu.cuda.synchronize()
+    dec.check()
+    assert np.array_equal(back.cpu().numpy(), want_dec)
+    lossy = int((want_dec != pcm).reshape(n, -1).any(axis=1).sum())
+    print(f"\ncorpus: {n} stereo frames, {3 * n} blocks; reference {'libsela_ref.so' if ref.is_reference else 'oracle'} on {threads} threads "
+          f"{t1 - t0:.1f} s (with generation); forms by the library's own kernel choice (one pass, two passes, plain) = {picked}; "
+          f"frames the reference's own decoder does not return exactly: {lossy}; whole test {time.time() - t0:.1f} s")
