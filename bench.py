@@ -608,8 +608,12 @@ def run_chain(bench: Bench, job: ChainJob, steps: int, warmup: int, min_total_s=
 
 
 def lanes_block(job: ChainJob, m, samples, steps):
+    forced = getattr(job.b.args, "priorities", None)
     return {"in_flight": len(job.lanes), "stream_renewals": getattr(job, "stream_renewals", 0),
             "ms_per_step_one_lane": m["serial_s"] * 1e3, "value_one_lane": samples / m["serial_s"] / 1e6,
+            "wave_priorities": ("forced " + forced) if forced else "by the library: an encode launch gets the falling schedule when no other stream has library work pending "
+                                                                   "(the strictly serial leg), none beside a neighbour (the lanes)",
+            "launches_given_the_falling_schedule": int(job.b.lib.sela_hip_debug_launches_alone()),
             "what": "consecutive batches are independent encode->decode chains on alternating HIP streams; one lane = strictly serial"}
 
 
@@ -963,6 +967,8 @@ def main():
             base["bit_exact_vs_gpu"] = bool(np.array_equal(blob, g_frames) and np.array_equal(offs, g_offsets) and np.array_equal(dec, g_back))
             result["cpu_baseline"] = base
             assert base["bit_exact_vs_gpu"], "GPU output differs from the CPU reference"
+            if bench.world == 1:
+                result["any_length"] = any_length_leg(np)
     if bench.dist is not None:
         bench.dist.barrier()
         bench.dist.destroy_process_group()

@@ -68,6 +68,12 @@ void sela_hip_debug_decode_recurrence(int form);
  * that take over a parked one (sela_hip.h, sela_hip_thread_release) do not count. */
 int sela_hip_debug_contexts_created(void);
 
+/* Debug hook (tests; process-wide): while on, a device-pointer encode with a d_trace pointer runs the PRODUCT kernels plus a few
+ * instructions (their kMode 3 instantiations, not the trace builds) and leaves, instead of traces, two 64-bit words per block at
+ * d_trace -- uint64 [n_frames * signals][2]: a position-keyed hash of the block's normalised autocorrelation ac[0..100] and
+ * one of its reflection coefficients k[0..99], as bit patterns (sela_encode.hip, hash_term; tests/test_gpu_round5.py folds
+ * the oracle's trace the same way).  The FP64 contract checked on the kernels that are timed. */
+void sela_hip_debug_encode_hashes(int on);
 /* Debug hook (tests): which form of the residue filter (sela_encode_tail.inc: one pass of FP64 taps / two passes / the plain
  * 64-bit loop) the blocks of the LAST device-pointer encode that used this workspace took -- counts_out[0..2], over all
  * n_frames * signals blocks (the losing stereo candidate included); forms_out (or NULL): the form of every block, 0 / 1 / 2,

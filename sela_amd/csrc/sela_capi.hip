@@ -27,6 +27,7 @@ namespace sela {
 size_t encode_workspace_bytes(uint32_t n_frames, uint32_t channels);
 int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced);
 void set_keep_both_candidates(int on);
+void set_encode_hashes(int on);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
     hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override, int team_lanes,
@@ -1187,6 +1188,7 @@ int sela_hip_debug_block_forms(const void* d_workspace, uint32_t n_frames, uint3
     return SELA_HIP_OK;
 }
 void sela_hip_debug_keep_both_candidates(int on) { sela::set_keep_both_candidates(on); }
+void sela_hip_debug_encode_hashes(int on) { sela::set_encode_hashes(on); }
 int sela_hip_debug_encode_kernel(uint32_t n_frames, uint32_t channels) { return sela::encode_team_lanes(n_frames, channels, g_team_lanes); }
 
 void sela_hip_debug_stage_wait(int naps) { g_stage_wait_naps = naps; }

@@ -228,6 +228,10 @@ uint32_t generic_index_samples(const uint8_t* frames, const uint64_t* frame_offs
             largest = std::max(largest, n);
             standard = standard && n == SELA_HIP_SAMPLES_PER_FRAME;
             p = p2 + 5 + 4 * rw;
+            if (p > fbytes) {
+                broken = true;
+                break;
+            }
         }
         total += first;
     }

@@ -742,6 +742,31 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
     return v;
 }
 
+// ---- kMode 3: the analysis' FP64 intermediates folded into two 64-bit words per block --------------------------------------
+// The trace builds (kMode 1) write mean, ac[0..100] and k[0..99] of every block and cost registers the product kernels do not
+// have to spare, so they are instantiations of their own; this mode is the product kernel plus a handful of instructions behind
+// the normalisation and the Schur recursion: hash(ac) = XOR_i mix(bits(ac[i]), i), hash(k) likewise, written to
+// hashes[2 block], hashes[2 block + 1] (the launch's d_trace pointer, reinterpreted).  The tests fold the oracle's trace the
+// same way: one wrong bit in one of the 201 doubles changes the word.  NaNs (degenerate blocks) count as one canonical NaN.
+__device__ __forceinline__ uint64_t hash_term(double v, int i)
+{
+    uint64_t x = v != v ? 0x7FF8000000000000ull : __builtin_bit_cast(uint64_t, v);
+    x ^= 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+template <int kLanes> // XOR over aligned groups of kLanes lanes (every lane of a group gets the result)
+__device__ __forceinline__ uint64_t lanes_xor(uint64_t v)
+{
+#pragma unroll
+    for (int d = kLanes / 2; d >= 1; d >>= 1)
+        v ^= (uint64_t)__shfl_xor((unsigned long long)v, d, 64);
+    return v;
+}
+
 // The on-disk bytes of one frame (src/file/sela_file.cpp:115-135), by one wave.  Frame sizes are multiples of 4
 // and the stream base is 4-byte aligned, so everything is written as aligned u32.  Within a subframe the 7 header
 // bytes push the coefficient words 3 bytes off word alignment (funnel shift below); the 5 bytes of the residue
@@ -1059,7 +1084,7 @@ __device__ __attribute__((noinline)) void finish_group(const FuseArgs& fa, uint3
         (void)group_arrive(fa.groups_done, fa.tag, n_groups);
 }
 
-// kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts
+// kMode: 0 = product, 1 = also write the analysis trace, 2 = also write per-phase cycle counts, 3 = product + two hash words per block (hash_term)
 // (debug hook sela_hip_debug_phase_buffer; 16 uint64 per block).
 #define SELA_STAMP(n)                 \
     do {                              \
@@ -1379,6 +1404,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         k_lo = sm->k[lane];
         k_hi = lane < kMaxOrder - 64 ? sm->k[lane + 64] : 0.0;
         wave_sync(); // (sm->k is overwritten with the dequantised coefficients below)
+    }
+    if (kMode == 3) { // (hash_term: the product kernel + these lines)
+        uint64_t h_ac = hash_term(sm->ac[lane], lane) ^ (lane + 64 <= kMaxOrder ? hash_term(sm->ac[lane + 64], lane + 64) : 0ull);
+        uint64_t h_k = hash_term(k_lo, lane) ^ (lane < kMaxOrder - 64 ? hash_term(k_hi, lane + 64) : 0ull);
+        h_ac = lanes_xor<64>(h_ac);
+        h_k = lanes_xor<64>(h_k);
+        if (lane == 0) {
+            uint64_t* const hp = reinterpret_cast<uint64_t*>(trace) + 2 * (size_t)block_id;
+            hp[0] = h_ac;
+            hp[1] = h_k;
+        }
     }
 
     {
@@ -1780,6 +1816,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (G * p + g <= kMaxOrder)
                 tr->ac[G * p + g] = acc[g];
     }
+    if (kMode == 3) { // (hash_term: the product kernel + these lines and their like behind the Schur recursion)
+        uint64_t h = 0;
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            h ^= G * p + g <= kMaxOrder ? hash_term(acc[g], G * p + g) : 0ull;
+        h = lanes_xor<P>(h);
+        if (team_live && p == 0)
+            reinterpret_cast<uint64_t*>(trace)[2 * ((size_t)my_frame * n_sig + sig)] = h;
+    }
 
     // ---- Schur recursion (src/lpc/residue_generator.cpp:47-68), always 100 stages ------------------------------------------
     // Lane p holds columns j = G p + r of gen0 / gen1.  Stage i reads gen1[j + 1] (old): the next register, and for the
@@ -1876,6 +1921,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             tr->k[lane] = k_lo;
             if (lane < 36)
                 tr->k[lane + 64] = k_hi;
+        }
+        if (kMode == 3) {
+            uint64_t h = hash_term(k_lo, lane) ^ (lane < kMaxOrder - 64 ? hash_term(k_hi, lane + 64) : 0ull);
+            h = lanes_xor<64>(h);
+            if (lane == 0)
+                reinterpret_cast<uint64_t*>(trace)[2 * ((size_t)frame * n_sig + sig) + 1] = h;
         }
     }
     wave_sync();
@@ -2262,6 +2313,10 @@ static int team_lanes_for(size_t blocks)
 // the traffic and for the tests, which check that the bytes do not depend on it
 static std::atomic<int> g_keep_both_candidates{0};
 void set_keep_both_candidates(int on) { g_keep_both_candidates.store(on, std::memory_order_relaxed); }
+// debug (sela_hip_debug_encode_hashes): a launch with a d_trace pointer takes the kMode 3 instantiations and leaves two 64-bit
+// words per block there (hash_term) instead of a trace
+static std::atomic<int> g_encode_hashes{0};
+void set_encode_hashes(int on) { g_encode_hashes.store(on, std::memory_order_relaxed); }
 
 
 int encode_team_lanes(uint32_t n_frames, uint32_t channels, int forced)
@@ -2386,6 +2441,7 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     // and for the host pipeline's one-launch form.
     if (d_trace_residues && (!d_trace || team_lanes != 0))
         return hipErrorInvalidValue;
+    const bool hashes = d_trace && !d_trace_residues && !d_phase_cycles && !link && g_encode_hashes.load(std::memory_order_relaxed);
     int teams = 0;
     if (!link) {
         teams = team_lanes >= 0 ? team_lanes : (d_phase_cycles ? 0 : team_lanes_for(blocks));
@@ -2400,6 +2456,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         if (teams == 8) {
             if (d_phase_cycles)
                 SELA_LAUNCH_TEAMS(2, 8);
+            else if (hashes)
+                SELA_LAUNCH_TEAMS(3, 8);
             else if (d_trace)
                 SELA_LAUNCH_TEAMS(1, 8);
             else
@@ -2407,6 +2465,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         } else {
             if (d_phase_cycles)
                 SELA_LAUNCH_TEAMS(2, 16);
+            else if (hashes)
+                SELA_LAUNCH_TEAMS(3, 16);
             else if (d_trace)
                 SELA_LAUNCH_TEAMS(1, 16);
             else
@@ -2416,6 +2476,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     } else
     if (d_phase_cycles)
         hipLaunchKernelGGL((k_encode_blocks<2, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
+    else if (hashes)
+        hipLaunchKernelGGL((k_encode_blocks<3, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     else if (d_trace)
         hipLaunchKernelGGL((k_encode_blocks<1, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     else if (link)

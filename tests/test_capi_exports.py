@@ -66,3 +66,44 @@ def test_no_gpu_means_loud_failure():
     with pytest.raises(capi.SelaHipError) as e:
         codec.encode_host(np.zeros((1, 2048, 2), np.int16))
     assert e.value.code == -1  # ENODEV: no CPU fallback
+
+
+def test_index_samples_and_the_any_length_bound_need_no_gpu(generic_kats, kats):
+    """sela_hip_index_samples walks a stream's headers on the host: frames of different lengths, a frame whose channels
+    disagree (the first subframe's count stands for the frame), a stream the walk falls off."""
+    import numpy as np
+
+    from sela_amd import codec
+
+    lib = capi.lib()
+    a = generic_kats["n128_stereo_diff_i16/bytes"]
+    b = generic_kats["n1000_stereo_indep_i17/bytes"]
+    c = kats["frame/stereo_same_sine/bytes"]
+    stream = np.concatenate([a, b, c, a])
+    offs = np.cumsum([0, len(a), len(b), len(c), len(a)]).astype(np.uint64)
+    so, largest = codec.index_samples(stream, offs, 2)
+    assert largest == 2048 and so.tolist() == [0, 128, 1128, 3176, 3304]
+    mixed = generic_kats["crafted/mixed_lengths/bytes"]
+    so, largest = codec.index_samples(mixed, np.array([0, len(mixed)], np.uint64), 3)
+    assert largest == 300 and so.tolist() == [0, 300]
+    so, largest = codec.index_samples(a, np.array([0, len(a) - 7], np.uint64), 2)
+    assert largest == 0  # (a frame cut short: the walk runs off its end; the decode calls report EFORMAT)
+    assert lib.sela_hip_encode_bound_bytes_n(3, 2, 2048) == lib.sela_hip_encode_bound_bytes(3, 2)
+    for n, ch in ((1, 1), (128, 2), (1000, 3), (65535, 2)):
+        bound = lib.sela_hip_encode_bound_bytes_n(1, ch, n)
+        assert bound >= 4 + ch * (12 + 4 * min(65535, n)) and bound <= 4 + ch * (12 + 4 * (32 + 65535))
+
+
+def test_no_gpu_means_loud_failure_on_the_any_length_route_too():
+    import numpy as np
+
+    lib = capi.lib()
+    if lib.sela_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from sela_amd import codec
+
+    for call in (lambda: codec.encode_host(np.zeros((1, 1000, 2), np.int16)), lambda: codec.encode_i32(np.zeros((1, 2, 300), np.int32)),
+                 lambda: codec.lpc_encode_n(np.zeros((1, 500), np.int32)), lambda: codec.lpc_decode_n(np.ones(1, np.int32), np.zeros((1, 100), np.int32), np.zeros((1, 500), np.int32))):
+        with pytest.raises(capi.SelaHipError) as e:
+            call()
+        assert e.value.code == -1 and "no CPU fallback" in str(e.value)

@@ -296,3 +296,57 @@ def test_wide_differential_corpus_against_the_reference(gpu):  # noqa: F811
     print(f"\ncorpus: {n} stereo frames, {3 * n} blocks; reference {'libsela_ref.so' if ref.is_reference else 'oracle'} on {threads} threads "
           f"{t1 - t0:.1f} s (with generation); forms by the library's own kernel choice (one pass, two passes, plain) = {picked}; "
           f"frames the reference's own decoder does not return exactly: {lossy}; whole test {time.time() - t0:.1f} s")
+
+
+def _fold(values):
+    """hash_term of sela_encode.hip over an array of doubles, position-keyed, XOR-ed."""
+    v = np.asarray(values, dtype=np.float64).copy()
+    v[np.isnan(v)] = np.float64("nan")
+    x = v.view(np.uint64).copy()
+    x[np.isnan(v)] = np.uint64(0x7FF8000000000000)
+    with np.errstate(over="ignore"):
+        x ^= np.uint64(0x9E3779B97F4A7C15) * (np.arange(len(x), dtype=np.uint64) + np.uint64(1))
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return int(np.bitwise_xor.reduce(x))
+
+
+@pytest.mark.parametrize("teams", [16, 8, 0], ids=["k_encode_teams<.,16>", "k_encode_teams<.,8>", "k_encode_blocks<.,false>"])
+def test_fp64_intermediates_of_the_product_kernels_by_hash(gpu, kats, teams):  # noqa: F811
+    """The normalised autocorrelation ac[0..100] and the reflection coefficients k[0..99] of the kernels that are TIMED --
+    k_encode_teams<0,16>, <0,8>, k_encode_blocks<0,false> plus the few instructions that fold them (their kMode 3
+    instantiations; round 4 checked these doubles on the trace builds only) -- as two 64-bit hashes per block against the
+    oracle's trace folded the same way: the KAT blocks, the corner blocks (NaN paths), stereo and three-channel frames."""
+    from sela_amd import capi, codec
+    from test_gpu_parity import _kat_block_frames
+    from test_gpu_round4 import _hard_blocks
+
+    lib = capi.lib()
+    o = oracle()
+    _, mono = _kat_block_frames(kats)
+    lib.sela_hip_debug_encode_teams(teams)
+    lib.sela_hip_debug_encode_hashes(1)
+    try:
+        for pcm in (mono, _hard_blocks(), synth_frames(27, 2, 3), synth_frames(5, 3, 4)):
+            nf, _, ch = pcm.shape
+            n_sig = 3 if ch == 2 else ch
+            enc = codec.Encoder(nf, ch, with_trace=True)  # (the trace buffer is more than the 16 bytes per block used here)
+            enc.trace.zero_()
+            out = enc.encode(gpu.from_numpy(np.ascontiguousarray(pcm)).cuda())
+            gpu.cuda.synchronize()
+            frames, offs = out.to_host()
+            want, want_offs, _ = o.encode_frames(pcm, threads=4)
+            assert np.array_equal(frames, want) and np.array_equal(offs, want_offs)
+            got = enc.trace[: nf * n_sig * 16].cpu().numpy().view(np.uint64).reshape(nf * n_sig, 2)
+            for f in range(nf):
+                for sig in range(n_sig):
+                    s = (pcm[f, :, 0].astype(np.int32) - pcm[f, :, 1]) if (ch == 2 and sig == 2) else pcm[f, :, sig].astype(np.int32)
+                    tr = o.lpc_analyze(s, with_trace=True)[4]
+                    assert int(got[f * n_sig + sig, 0]) == _fold(list(tr.ac)), (teams, f, sig, "ac")
+                    assert int(got[f * n_sig + sig, 1]) == _fold(list(tr.k)), (teams, f, sig, "k")
+    finally:
+        lib.sela_hip_debug_encode_hashes(0)
+        lib.sela_hip_debug_encode_teams(-1)
