@@ -241,9 +241,10 @@ bool decodeOddStream(file::SelaFile& sela, size_t payload, sela_host::PinnedBuff
         ordinary = sampleOffsets[f] == (uint64_t)f * kBlock;
     if (ordinary || largest == 0)
         return false;
-    pcm.resize((size_t)sampleOffsets[found] * channels);
+    pcm.resize(std::max<size_t>((size_t)sampleOffsets[found], (size_t)found * kBlock) * channels); // (sela_hip.h: the fast kernels are tried first)
     if (sela_hip_decode(sela.frameBytes.data(), sela.frameOffsets.data(), found, channels, pcm.data()) != SELA_HIP_OK)
         gpuFailure("Decoder");
+    pcm.resize((size_t)sampleOffsets[found] * channels);
     sela.frameBytes.resize((size_t)sela.frameOffsets.back());
     return true;
 }
@@ -563,9 +564,20 @@ std::vector<file::WavFile> decodeBatch(const std::vector<file::SelaFile>& selas)
         runOnDevices(pieces, devs, [&](size_t, const std::vector<Piece>& mine) {
             for (const Piece& p : mine) { // decoded samples land in their track's buffer: nothing to stitch
                 const file::SelaFile& sela = selas[members[p.track]];
-                if (sela_hip_decode(sela.frameBytes.data(), sela.frameOffsets.data() + p.first, (uint32_t)p.n, channels,
-                        pcm[p.track].data() + p.first * kBlock * channels)
-                    != SELA_HIP_OK)
+                // (a job, not sela_hip_decode: the samples of a piece have their place in the track's buffer, 2048 per frame --
+                // the one-shot call would take a stream with frames of another length down the any-length route and lay them
+                // out by their own lengths; the batch verbs serve the shape files have, and a job refuses anything else)
+                sela_hip_job* job = nullptr;
+                int rc = sela_hip_decode_begin(&job, channels, (uint32_t)p.n, pcm[p.track].data() + p.first * kBlock * channels);
+                if (rc == SELA_HIP_OK) {
+                    rc = sela_hip_decode_feed(job, sela.frameBytes.data(), sela.frameOffsets.data() + p.first, (uint32_t)p.n, nullptr);
+                    const std::string why = rc != SELA_HIP_OK ? sela_hip_last_error() : "";
+                    const int rcEnd = sela_hip_decode_end(job, nullptr);
+                    if (rc != SELA_HIP_OK)
+                        throw data::Exception("decodeBatch: " + why);
+                    rc = rcEnd;
+                }
+                if (rc != SELA_HIP_OK)
                     gpuFailure("decodeBatch");
             }
         });

@@ -140,7 +140,7 @@ def decode_host(frames: np.ndarray, offsets: np.ndarray, channels: int) -> np.nd
     sample_offsets, largest = index_samples(fr, offs, channels)
     standard = largest == BLOCK and all(int(sample_offsets[f]) == f * BLOCK for f in range(n_frames + 1))
     total = n_frames * BLOCK if standard or largest == 0 else int(sample_offsets[n_frames])
-    pcm = np.empty((max(total, 1), channels), np.int16)
+    pcm = np.empty((max(total, n_frames * BLOCK, 1), channels), np.int16)  # (the fast kernels are tried first: sela_hip.h)
     capi.check(lib.sela_hip_decode(fr.ctypes.data, offs.ctypes.data, n_frames, channels, pcm.ctypes.data))
     return pcm[:total].reshape(n_frames, BLOCK, channels) if standard or largest == 0 else pcm[:total]
 

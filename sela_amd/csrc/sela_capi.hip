@@ -1472,20 +1472,10 @@ int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, ui
     return submit_small(true, call);
 }
 
-int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm_out)
+namespace {
+// the fast route: 2048 samples per channel and frame
+int decode_standard(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm_out)
 {
-    if (channels == 0 || channels > 255 || (n_frames && (!frames || !frame_offsets || !pcm_out)))
-        return fail(SELA_HIP_EINVAL, "bad argument");
-    bool ordered = true;
-    for (uint32_t f = 0; f < n_frames && ordered; f++)
-        ordered = frame_offsets[f + 1] >= frame_offsets[f];
-    if (ordered && n_frames) { // a subframe that does not say 2048 sends the call down the any-length route
-        bool standard = true;
-        std::vector<uint64_t> sample_offsets((size_t)n_frames + 1);
-        const uint32_t largest = sela::generic_index_samples(frames, frame_offsets, n_frames, channels, sample_offsets.data(), &standard);
-        if (!standard && largest != 0)
-            return sela::generic_decode(frames, frame_offsets, n_frames, channels, nullptr, largest, nullptr, pcm_out, sample_offsets.data());
-    }
     if (n_frames == 0 || n_frames > kCoalesceFrames || (g_lease.held && g_lease.held->job_open))
         return decode_now(frames, frame_offsets, n_frames, channels, pcm_out);
     for (uint32_t f = 0; f < n_frames; f++) // (what the job would refuse is refused by the job, for this caller alone)
@@ -1497,6 +1487,31 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
     call.channels = channels, call.n_frames = n_frames;
     call.frames = frames, call.offsets_in = frame_offsets, call.pcm_out = pcm_out;
     return submit_small(false, call);
+}
+} // namespace
+
+int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm_out)
+{
+    if (channels == 0 || channels > 255 || (n_frames && (!frames || !frame_offsets || !pcm_out)))
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    // The fast kernels first, unasked: a stream of 2048-sample frames -- every stream an encoder writes -- pays nothing for the
+    // other kind (a walk over the headers in host memory is a cache miss or two per frame: 0.1 ms and more for a 3-minute
+    // track, a tenth of the whole call).  They refuse a subframe that does not say 2048 (SELA_HIP_EFORMAT, nothing written
+    // beyond [n_frames][2048][channels], which is why pcm_out must hold that much, sela_hip.h); only then are the headers
+    // walked, and a stream that turns out to be of the other kind goes, whole, down the any-length route.
+    const int rc = decode_standard(frames, frame_offsets, n_frames, channels, pcm_out);
+    if (rc != SELA_HIP_EFORMAT || n_frames == 0)
+        return rc;
+    const std::string first_error = sela_hip_last_error();
+    for (uint32_t f = 0; f < n_frames; f++)
+        if (frame_offsets[f + 1] < frame_offsets[f])
+            return rc;
+    bool standard = true;
+    std::vector<uint64_t> sample_offsets((size_t)n_frames + 1);
+    const uint32_t largest = sela::generic_index_samples(frames, frame_offsets, n_frames, channels, sample_offsets.data(), &standard);
+    if (standard || largest == 0)
+        return fail(rc, first_error); // (malformed in the ordinary sense)
+    return sela::generic_decode(frames, frame_offsets, n_frames, channels, nullptr, largest, nullptr, pcm_out, sample_offsets.data());
 }
 
 size_t sela_hip_encode_bound_bytes_n(uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel)
