@@ -882,6 +882,45 @@ def kernel_blocks(bench: Bench, k_enc, k_dec, n0: int, sela_bytes0: int, counter
     }
 
 
+def any_length_leg(np):
+    """The any-length / 32-bit route (sela_generic.hip behind sela_hip_encode / sela_hip_decode with samples_per_channel != 2048
+    and sela_hip_encode_i32 / sela_hip_decode_i32), host pointers in and out, on frames the fast kernels do not take: not tuned,
+    not part of `value` -- the line says what the route costs and that its bytes are the oracle's (the checker, as in
+    cpu_baseline)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import oracle
+    from sela_amd import codec
+    from sela_amd.synth import synth_pcm
+
+    out = {"what": "host pointers in and out, synchronous, the any-length kernels (one wave per block, untuned); checked against the oracle"}
+    o = oracle()
+    for label, n, nf in (("stereo_4096_samples", 4096, 64), ("stereo_1000_samples", 1000, 256)):
+        pcm = synth_pcm(n * nf, 2, 21).reshape(nf, n, 2)
+        codec.encode_host(pcm[:2])  # (the thread's scratch)
+        t0 = time.perf_counter()
+        frames, offs = codec.encode_host(pcm)
+        t1 = time.perf_counter()
+        back = codec.decode_host(frames, offs, 2)
+        t2 = time.perf_counter()
+        want = b"".join(o.frame_encode(pcm[f]) for f in range(nf))
+        ok = frames.tobytes() == want and bool(np.array_equal(back, pcm.reshape(-1, 2)))
+        assert ok, "the any-length route differs from the oracle"
+        out[label] = {"frames": nf, "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3, "encode_msps": n * nf / (t1 - t0) / 1e6,
+                      "decode_msps": n * nf / (t2 - t1) / 1e6, "bit_exact_vs_oracle": ok}
+    wide = np.clip(2 * synth_pcm(2048 * 32, 2, 22).astype(np.int32).reshape(32, 2048, 2).transpose(0, 2, 1) + 1, -65535, 65535)
+    wide = np.ascontiguousarray(wide)
+    t0 = time.perf_counter()
+    frames, offs = codec.encode_i32(wide)
+    t1 = time.perf_counter()
+    dec = codec.decode_i32(frames, offs, 2)
+    t2 = time.perf_counter()
+    ok = frames.tobytes() == b"".join(o.frame_encode_i32(np.ascontiguousarray(wide[f])) for f in range(32))
+    assert ok, "the 32-bit route differs from the oracle"
+    out["stereo_2048_samples_17_bit"] = {"frames": 32, "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t2 - t1) * 1e3, "bit_exact_vs_oracle": ok,
+                                         "lossless": bool(all(np.array_equal(np.stack(dec[f]), wide[f]) for f in range(32)))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

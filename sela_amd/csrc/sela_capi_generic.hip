@@ -1,8 +1,10 @@
 // sela_capi_generic.hip -- the host side of the any-length / 32-bit route (kernels: sela_generic.hip; declarations:
 // include/sela_hip.h "Blocks of any length" and "the frame classes' own value types").
 //
-// Plain synchronous calls on the calling thread's current device: copy in, kernels, copy out, in chunks of frames that keep
-// the device scratch bounded.  The scratch is one grow-only device allocation per thread (a frame at a time through
+// Plain synchronous calls on the calling thread's current device and the calling thread's OWN stream (hipStreamPerThread:
+// threads that code a frame at a time through the frame classes run side by side on the device instead of taking turns on
+// the default stream): copy in, kernels, copy out, in chunks of frames that keep the device scratch bounded, with as few
+// waits for the device as the data flow allows (an encode: two; a decode: two).  The scratch is one grow-only device allocation per thread (a frame at a time through
 // frame::FrameEncoder must not pay a hipMalloc / hipFree pair per call); sela_hip_thread_release() / sela_hip_shutdown() and
 // the thread's end give it back.
 #include <hip/hip_runtime.h>
@@ -122,6 +124,7 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
     uint64_t base_bytes = 0;
     frame_offsets_out[0] = 0;
+    const hipStream_t st = hipStreamPerThread;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const uint32_t cf = std::min(chunk, n_frames - f0);
         const size_t blocks = (size_t)cf * n_sig, subs = (size_t)cf * channels;
@@ -135,27 +138,30 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
         int32_t* d_res = g_arena.take<int32_t>(blocks * n);
         int32_t* d_q = g_arena.take<int32_t>(blocks * kMaxOrder);
         GenericMeta* d_meta = g_arena.take<GenericMeta>(blocks);
-        uint64_t* d_offsets = g_arena.take<uint64_t>((size_t)cf + 1);
+        // what the host reads back after the plan, in one piece: status (4 x u32) | total words | frame offsets
+        uint64_t* d_head = g_arena.take<uint64_t>(3 + (size_t)cf + 1);
+        uint32_t* d_status = reinterpret_cast<uint32_t*>(d_head);
+        uint64_t* d_offsets = d_head + 3;
         uint64_t* d_word_base = g_arena.take<uint64_t>(subs + 1);
         uint32_t* d_chosen = g_arena.take<uint32_t>(subs);
-        uint32_t* d_status = g_arena.take<uint32_t>(4);
-        e = hipMemcpy(d_in, static_cast<const uint8_t*>(input) + (size_t)f0 * in_frame_bytes, cf * in_frame_bytes, hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(d_in, static_cast<const uint8_t*>(input) + (size_t)f0 * in_frame_bytes, cf * in_frame_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
-            e = hipMemsetAsync(d_status, 0, 16, nullptr);
+            e = hipMemsetAsync(d_head, 0, 24, st);
         if (e == hipSuccess)
-            e = launch_generic_analyse(d_in, in16, cf, channels, n_sig, n, d_sig, d_cen, d_res, d_q, d_meta, nullptr);
+            e = launch_generic_analyse(d_in, in16, cf, channels, n_sig, n, d_sig, d_cen, d_res, d_q, d_meta, st);
         if (e == hipSuccess)
-            e = launch_generic_plan(d_meta, cf, channels, n_sig, base_bytes, d_offsets, d_word_base, d_chosen, d_status, nullptr);
-        uint32_t status[4] = {};
-        uint64_t total_words = 0;
+            e = launch_generic_plan(d_meta, cf, channels, n_sig, base_bytes, d_offsets, d_word_base, d_chosen, d_status, d_head + 2, st);
+        std::vector<uint64_t> head(3 + (size_t)cf + 1);
         if (e == hipSuccess)
-            e = hipMemcpy(status, d_status, 16, hipMemcpyDeviceToHost); // (synchronises)
+            e = hipMemcpyAsync(head.data(), d_head, head.size() * 8, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess)
-            e = hipMemcpy(frame_offsets_out + f0, d_offsets, ((size_t)cf + 1) * 8, hipMemcpyDeviceToHost);
-        if (e == hipSuccess)
-            e = hipMemcpy(&total_words, d_word_base + subs, 8, hipMemcpyDeviceToHost);
+            e = hipStreamSynchronize(st);
         if (e != hipSuccess)
             return report_hip_error(e, "generic encode: analysis");
+        uint32_t status[4];
+        std::memcpy(status, head.data(), 16);
+        const uint64_t total_words = head[2];
+        std::memcpy(frame_offsets_out + f0, head.data() + 3, ((size_t)cf + 1) * 8);
         const int rc = flags_error(status[0], "encode");
         if (rc != SELA_HIP_OK)
             return rc;
@@ -172,20 +178,24 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
                 return report_hip_error(e, "generic encode: stream scratch");
             uint32_t* d_words = reinterpret_cast<uint32_t*>(extra);
             uint8_t* d_frames = extra + (((size_t)total_words * 4 + 255) & ~(size_t)255);
-            e = hipMemsetAsync(d_words, 0, (size_t)total_words * 4 + 4, nullptr);
+            e = hipMemsetAsync(d_words, 0, (size_t)total_words * 4 + 4, st);
             if (e == hipSuccess)
-                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, d_offsets, base_bytes, d_frames, chunk_bytes, nullptr);
+                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, d_offsets, base_bytes, d_frames, chunk_bytes, st);
             if (e == hipSuccess)
-                e = hipMemcpy(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost);
+                e = hipMemcpyAsync(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(st);
             (void)hipFree(extra);
         } else {
             uint32_t* d_words = g_arena.take<uint32_t>((size_t)total_words + 1);
             uint8_t* d_frames = g_arena.take<uint8_t>(chunk_bytes);
-            e = hipMemsetAsync(d_words, 0, (size_t)total_words * 4 + 4, nullptr);
+            e = hipMemsetAsync(d_words, 0, (size_t)total_words * 4 + 4, st);
             if (e == hipSuccess)
-                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, d_offsets, base_bytes, d_frames, chunk_bytes, nullptr);
+                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, d_offsets, base_bytes, d_frames, chunk_bytes, st);
             if (e == hipSuccess)
-                e = hipMemcpy(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost);
+                e = hipMemcpyAsync(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(st);
         }
         if (e != hipSuccess)
             return report_hip_error(e, "generic encode: emit");
@@ -255,6 +265,7 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
         stride = 1;
     const size_t per_frame = (size_t)channels * stride * 8 + (size_t)channels * (sizeof(GenericSubInfo) + 4) + 16 + (size_t)channels * stride * (pcm_out ? 2 : 0);
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
+    const hipStream_t st = hipStreamPerThread;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const uint32_t cf = std::min(chunk, n_frames - f0);
         const size_t subs = (size_t)cf * channels;
@@ -270,29 +281,34 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
         int32_t* d_dec = g_arena.take<int32_t>(subs * stride);
         int32_t* d_all = g_arena.take<int32_t>(subs * stride);
         GenericSubInfo* d_info = g_arena.take<GenericSubInfo>(subs);
-        uint32_t* d_counts = g_arena.take<uint32_t>(subs);
-        uint32_t* d_status = g_arena.take<uint32_t>(4);
+        // what the host reads back first, in one piece: status (4 x u32) | a count per (frame, channel)
+        uint32_t* d_tail = g_arena.take<uint32_t>(4 + subs);
+        uint32_t* d_status = d_tail;
+        uint32_t* d_counts = d_tail + 4;
         uint64_t* d_sample_offsets = pcm_out ? g_arena.take<uint64_t>((size_t)cf + 1) : nullptr;
         int16_t* d_pcm = pcm_out ? g_arena.take<int16_t>((size_t)chunk_samples * channels) : nullptr;
-        e = hipMemcpy(d_frames, frames + base_bytes, in_bytes, hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(d_frames, frames + base_bytes, in_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
-            e = hipMemcpy(d_offsets, frame_offsets + f0, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice);
+            e = hipMemcpyAsync(d_offsets, frame_offsets + f0, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice, st);
         std::vector<uint64_t> local;
         if (e == hipSuccess && pcm_out) { // positions relative to the chunk's first sample
             local.resize((size_t)cf + 1);
             for (uint32_t i = 0; i <= cf; i++)
                 local[i] = sample_offsets[f0 + i] - s0;
-            e = hipMemcpy(d_sample_offsets, local.data(), local.size() * 8, hipMemcpyHostToDevice);
+            e = hipMemcpyAsync(d_sample_offsets, local.data(), local.size() * 8, hipMemcpyHostToDevice, st);
         }
         if (e == hipSuccess)
-            e = hipMemsetAsync(d_status, 0, 16, nullptr);
+            e = hipMemsetAsync(d_tail, 0, (4 + subs) * 4, st);
         if (e == hipSuccess)
-            e = launch_generic_decode(d_frames, d_offsets, base_bytes, cf, channels, stride, d_dec, d_info, d_all, d_counts, d_sample_offsets, d_pcm, d_status, nullptr);
-        uint32_t status[4] = {};
+            e = launch_generic_decode(d_frames, d_offsets, base_bytes, cf, channels, stride, d_dec, d_info, d_all, d_counts, d_sample_offsets, d_pcm, d_status, st);
+        std::vector<uint32_t> tail(4 + subs);
         if (e == hipSuccess)
-            e = hipMemcpy(status, d_status, 16, hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(tail.data(), d_tail, tail.size() * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
         if (e != hipSuccess)
             return report_hip_error(e, "generic decode");
+        const uint32_t* const status = tail.data();
         if (status[0] & SELA_HIP_FLAG_BAD_FRAME)
             return report_error(SELA_HIP_EFORMAT, "malformed frame (sync word, sizes, an order above 100, a Rice parameter above 31, a channel or parent that does not exist, or channels of different lengths)");
         if (status[0] & SELA_HIP_FLAG_RICE_OVERRUN)
@@ -300,15 +316,15 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
         if (status[0] & SELA_HIP_FLAG_COEF_OVERFLOW)
             return report_error(SELA_HIP_ERANGE, "decode: a predictor coefficient left the int64 range");
         if (pcm_out) {
-            e = hipMemcpy(pcm_out + s0 * channels, d_pcm, (size_t)chunk_samples * channels * 2, hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(pcm_out + s0 * channels, d_pcm, (size_t)chunk_samples * channels * 2, hipMemcpyDeviceToHost, st);
         } else {
-            e = hipMemcpy(counts_out + (size_t)f0 * channels, d_counts, subs * 4, hipMemcpyDeviceToHost);
-            for (size_t i = 0; i < subs && e == hipSuccess; i++) { // only what is valid crosses the link
-                const uint32_t cnt = counts_out[(size_t)f0 * channels + i];
-                if (cnt)
-                    e = hipMemcpy(samples_out + ((size_t)f0 * channels + i) * stride, d_all + i * stride, (size_t)cnt * 4, hipMemcpyDeviceToHost);
-            }
+            std::memcpy(counts_out + (size_t)f0 * channels, tail.data() + 4, subs * 4);
+            // samples_out and the device's channel-major array have one layout ([frame][channel][stride]): ONE copy (a copy per
+            // channel cost 13 us each: 7 ms for 256 stereo frames).  What lies behind a channel's count is not defined.
+            e = hipMemcpyAsync(samples_out + (size_t)f0 * channels * stride, d_all, subs * stride * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         }
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
         if (e != hipSuccess)
             return report_hip_error(e, "generic decode: copy out");
     }

@@ -19,7 +19,7 @@ size_t generic_encode_workspace_bytes(uint32_t n_frames, uint32_t channels, uint
 hipError_t launch_generic_analyse(const void* d_input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, int32_t* d_sig, double* d_cen,
     int32_t* d_res, int32_t* d_q, GenericMeta* d_meta, hipStream_t stream);
 hipError_t launch_generic_plan(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint64_t base_bytes, uint64_t* d_frame_offsets,
-    uint64_t* d_word_base, uint32_t* d_chosen, uint32_t* d_status, hipStream_t stream);
+    uint64_t* d_word_base, uint32_t* d_chosen, uint32_t* d_status, uint64_t* d_total_words, hipStream_t stream);
 hipError_t launch_generic_emit(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, const int32_t* d_res, const int32_t* d_q,
     const uint32_t* d_chosen, const uint64_t* d_word_base, uint32_t* d_words /* zeroed */, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint8_t* d_frames,
     uint64_t frames_cap, hipStream_t stream);

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__
 constexpr int kPlanThreads = 256;
 __global__ __launch_bounds__(kPlanThreads) void k_generic_plan(const GenericMeta* __restrict__ meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig,
     uint64_t base_bytes, uint64_t* __restrict__ frame_offsets /* [n_frames + 1], absolute */, uint64_t* __restrict__ word_base /* [n_frames * channels + 1] */,
-    uint32_t* __restrict__ chosen /* [n_frames * channels]: signal index */, uint32_t* __restrict__ status)
+    uint32_t* __restrict__ chosen /* [n_frames * channels]: signal index */, uint32_t* __restrict__ status, uint64_t* __restrict__ total_words_out)
 {
     __shared__ uint64_t part_bytes[kPlanThreads], part_words[kPlanThreads];
     __shared__ uint32_t part_flags[kPlanThreads];
@@ -364,6 +364,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_generic_plan(const GenericMeta
         }
         frame_offsets[n_frames] = base_bytes + run_b;
         word_base[(size_t)n_frames * channels] = run_w;
+        *total_words_out = run_w;
         atomicOr(&status[0], fl);
     }
     __syncthreads();
@@ -441,50 +442,121 @@ __global__ __launch_bounds__(kAsmThreads) void k_generic_assemble(const GenericM
 
 // ---- decode: one wave per subframe -------------------------------------------------------------------------------------------
 // src/frame/frame_decoder.cpp:19-36 / :42-61 for one subframe: rice::RiceDecoder on the coefficients (n = order) and on the
-// residues (n = samplesPerChannel) -- the serial parse of src/rice/rice_decoder.cpp:21-52, wave-uniform -- and
+// residues (n = samplesPerChannel) -- src/rice/rice_decoder.cpp:21-52: the codewords' lengths walked serially, wave-uniform, the
+// remainder fields fetched by all lanes at once (RiceScan below) -- and
 // lpc::SampleGenerator (src/lpc/sample_generator.cpp:11-39) in transposed form: lane l carries the part of sample i + 1 + l's
 // prediction that is already known, P[l] = sum a[i + 1 + l - i'] s[i'] over the samples i' <= i; a new sample adds a[l + 1] s[i]
 // to every lane after the lanes have moved down by one.  (Integer arithmetic mod 2^64: the order of the additions is free.)
-struct BitReader {
-    const uint8_t* base; // the frame
-    uint64_t end;        // the stream's own end (bits from the frame's first byte; a whole number of bytes)
-    bool overrun;
-    __device__ __forceinline__ uint32_t byte_or_zero(uint64_t byte_index) const { return 8 * byte_index < end ? base[byte_index] : 0u; }
-    // the 32 stream bits from position p on, the first one in bit 0; zeros beyond the stream's end
-    __device__ __forceinline__ uint32_t peek32(uint64_t p) const
+// The parse is serial only in the codewords' LENGTHS.  RiceScan walks those, wave-uniform, on a 64-bit register window that is
+// refilled word by word from a lane-held buffer of the frame's next 64 aligned words (one coalesced load per 2048 bits, no
+// load on the chain); each lane keeps the start and the unary count of ONE codeword of a chunk of 64, and then all lanes
+// fetch their remainder fields at once.  Bits at or beyond the stream's end read as zero (a stream that ends early raises
+// RICE_OVERRUN), exactly as the byte-wise reader of the first version did.
+struct RiceScan {
+    const uint32_t* words; // the frame's aligned words
+    uint32_t n_words;
+    uint64_t end;          // the stream's end, in bits from the frame's first byte
+    uint64_t pos;          // bit position of the window's first bit
+    uint64_t cur;          // the next `avail` bits of the stream, LSB first
+    uint32_t avail, wpos;  // wpos: the next word to append
+    uint32_t buf, wbase;   // lane l holds word wbase + l (masked to the stream)
+    int lane;
+
+    __device__ __forceinline__ uint32_t masked_word(uint32_t w) const
     {
-        const uint64_t at = p >> 3;
-        uint64_t w = 0;
-#pragma unroll
-        for (int i = 0; i < 5; i++)
-            w |= (uint64_t)byte_or_zero(at + i) << (8 * i);
-        return (uint32_t)(w >> (p & 7));
+        const uint64_t first = 32ull * w;
+        if (w >= n_words || first >= end)
+            return 0u;
+        const uint32_t v = words[w];
+        return first + 32 > end ? v & ((1u << (uint32_t)(end - first)) - 1u) : v;
+    }
+    __device__ __forceinline__ void load_buf(uint32_t base)
+    {
+        wbase = base;
+        buf = masked_word(base + (uint32_t)lane);
+    }
+    __device__ __forceinline__ void refill()
+    {
+        while (avail <= 32) {
+            if (wpos - wbase >= 64u)
+                load_buf(wpos);
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)buf, (int)(wpos - wbase));
+            cur |= (uint64_t)w << avail;
+            avail += 32;
+            wpos++;
+        }
+    }
+    __device__ __forceinline__ void start(const uint32_t* frame_words, uint32_t frame_word_count, uint64_t first_bit, uint64_t end_bit, int lane_)
+    {
+        words = frame_words, n_words = frame_word_count, end = end_bit, lane = lane_;
+        pos = first_bit;
+        wpos = (uint32_t)(first_bit >> 5);
+        load_buf(wpos);
+        cur = 0, avail = 0;
+        refill();
+        const uint32_t skip = (uint32_t)first_bit & 31; // the stream starts inside its first aligned word
+        cur >>= skip, avail -= skip;
+        refill();
+    }
+    __device__ __forceinline__ void consume(uint32_t n) // n <= 32
+    {
+        cur >>= n;
+        avail -= n;
+        pos += n;
+        refill();
+    }
+    // one codeword: where it starts and how many ones it has; the window moves past its k remainder bits
+    __device__ __forceinline__ void next(uint32_t k, uint64_t& at, uint32_t& ones)
+    {
+        at = pos;
+        ones = 0;
+        for (;;) {
+            const uint32_t low = (uint32_t)cur;
+            const uint32_t t = low == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~low);
+            ones += t;
+            consume(t);
+            if (t < 32)
+                break; // (beyond the stream's end everything is zero: the run ends there at the latest)
+        }
+        consume(1 + k);
     }
 };
 
-__device__ inline int32_t rice_next(BitReader& br, uint64_t& pos, uint32_t k)
+// the k bits at bit position p of the frame, the first one the most significant (src/rice/rice_decoder.cpp:37-40); bits at or
+// beyond `end` are zero.  Per lane (every lane its own position).
+__device__ __forceinline__ uint32_t remainder_bits(const uint8_t* base, uint64_t p, uint64_t end, uint32_t k)
 {
-    uint32_t ones = 0;
-    for (;;) { // up to a word of ones at a time; beyond the stream's end everything reads as zero, so this ends
-        const uint32_t w = br.peek32(pos);
-        const uint32_t t = w == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~w);
-        ones += t;
-        pos += t;
-        if (t < 32)
-            break;
+    if (k == 0)
+        return 0u;
+    const uint64_t at = p >> 3;
+    uint64_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+        w |= (uint64_t)(8 * (at + i) < end ? base[at + i] : 0u) << (8 * i);
+    uint32_t v = (uint32_t)(w >> (p & 7));
+    if (p + 32 > end) // (the stream ends inside these 32 bits; its end is a whole number of bytes, so only bytes were masked above)
+        v &= p >= end ? 0u : (uint32_t)(((uint64_t)1 << (end - p)) - 1);
+    return __brev(v) >> (32 - k);
+}
+
+// up to 64 values of a stream, value i0 + lane in each lane (lanes beyond `count` get 0)
+__device__ inline int32_t rice_chunk(RiceScan& sc, const uint8_t* base, uint32_t k, uint32_t count, bool& overrun)
+{
+    uint64_t my_at = 0;
+    uint32_t my_ones = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        uint64_t at;
+        uint32_t ones;
+        sc.next(k, at, ones);
+        if ((uint32_t)sc.lane == i)
+            my_at = at, my_ones = ones;
     }
-    if (pos >= br.end)
-        br.overrun = true;
-    pos++; // the terminator
-    uint32_t rem = 0;
-    if (k) {
-        rem = __brev(br.peek32(pos)) >> (32 - k); // k bits, the first one the most significant (src/rice/rice_decoder.cpp:37-40)
-        if (pos + k > br.end)
-            br.overrun = true;
-    }
-    pos += k;
-    const uint32_t u = (ones << k) | rem; // (uint32 arithmetic: src/rice/rice_decoder.cpp:35)
-    return (int32_t)((u >> 1) ^ (0u - (u & 1u)));
+    const bool live = (uint32_t)sc.lane < count;
+    const uint64_t field = my_at + my_ones + 1;
+    overrun |= live && field + k > sc.end;
+    const uint32_t rem = live ? remainder_bits(base, field, sc.end, k) : 0u;
+    const uint32_t u = (my_ones << k) | rem; // (uint32 arithmetic: src/rice/rice_decoder.cpp:35)
+    return live ? (int32_t)((u >> 1) ^ (0u - (u & 1u))) : 0;
 }
 
 __global__ __launch_bounds__(64) void k_generic_decode(const uint8_t* __restrict__ frames, const uint64_t* __restrict__ frame_offsets, uint64_t base_bytes,
@@ -538,15 +610,19 @@ __global__ __launch_bounds__(64) void k_generic_decode(const uint8_t* __restrict
         return;
     }
     si.n = n, si.ok = 1;
-    BitReader br;
-    br.base = fb, br.overrun = false;
+    const uint32_t* const fw = reinterpret_cast<const uint32_t*>(fb); // (frames are whole words at word-aligned offsets)
+    const uint32_t n_fw = (uint32_t)(fbytes >> 2);
+    bool overrun = false;
+    RiceScan sc;
     // ---- the coefficients ----
-    uint64_t pos = 8 * (p + 7);
-    br.end = pos + 32ull * cw;
-    for (uint32_t i = 0; i < order; i++) {
-        const int32_t v = rice_next(br, pos, ck);
-        if (lane == 0)
-            q_lds[i] = v;
+    {
+        const uint64_t first = 8 * (p + 7);
+        sc.start(fw, n_fw, first, first + 32ull * cw, lane);
+        for (uint32_t i0 = 0; i0 < order; i0 += 64) {
+            const int32_t v = rice_chunk(sc, fb, ck, order - i0 < 64u ? order - i0 : 64u, overrun);
+            if (i0 + lane < order)
+                q_lds[i0 + lane] = v;
+        }
     }
     wave_sync();
     {
@@ -560,26 +636,39 @@ __global__ __launch_bounds__(64) void k_generic_decode(const uint8_t* __restrict
     // lane l: a[l + 1], a[l + 65] (0 beyond the order)
     const uint64_t a_lo = (uint32_t)lane + 1 <= order ? (uint64_t)a_lds[lane + 1] : 0;
     const uint64_t a_hi = (uint32_t)lane + 65 <= order ? (uint64_t)a_lds[lane + 65] : 0;
-    // ---- residues -> samples ----
-    pos = 8 * (p + 12 + 4 * (uint64_t)cw);
-    br.end = pos + 32ull * rw;
+    // ---- residues -> samples, 64 at a time ----
+    {
+        const uint64_t first = 8 * (p + 12 + 4 * (uint64_t)cw);
+        sc.start(fw, n_fw, first, first + 32ull * rw, lane);
+    }
     int32_t* const out = dec_ws + (size_t)sub * stride;
     uint64_t p_lo = 0, p_hi = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const int32_t res = rice_next(br, pos, rk);
-        const uint64_t sum = read_first_lane(p_lo);
-        const uint64_t temp = ((uint64_t)1 << (SELA_Q_SHIFT - 1)) - sum;
-        const int32_t smp = (int32_t)((uint32_t)res - (uint32_t)(int32_t)((int64_t)temp >> SELA_Q_SHIFT));
-        if (lane == 0)
-            out[i] = smp;
-        const uint64_t carry = read_first_lane(p_hi);
-        // lane l <- lane l + 1
-        const uint32_t nlo = (uint32_t)wave_shl1((int)(uint32_t)carry, (int)(uint32_t)p_lo);
-        const uint32_t nhi = (uint32_t)wave_shl1((int)(uint32_t)(carry >> 32), (int)(uint32_t)(p_lo >> 32));
-        p_lo = (((uint64_t)nhi << 32) | nlo) + a_lo * (uint64_t)(int64_t)smp;
-        p_hi = wave_shl1_zero(p_hi) + a_hi * (uint64_t)(int64_t)smp;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t cnt = n - i0 < 64u ? n - i0 : 64u;
+        const int32_t mine = rice_chunk(sc, fb, rk, cnt, overrun);
+        int32_t made = 0;
+        for (uint32_t l = 0; l < cnt; l++) {
+            const int32_t res = __builtin_amdgcn_readlane(mine, (int)l);
+            const uint64_t sum = read_first_lane(p_lo);
+            const uint64_t temp = ((uint64_t)1 << (SELA_Q_SHIFT - 1)) - sum;
+            const int32_t smp = (int32_t)((uint32_t)res - (uint32_t)(int32_t)((int64_t)temp >> SELA_Q_SHIFT));
+            if ((uint32_t)lane == l)
+                made = smp;
+            if (order > 64) { // two registers: lags 1..64 and 65..100
+                const uint64_t carry = read_first_lane(p_hi);
+                // lane l <- lane l + 1
+                const uint32_t nlo = (uint32_t)wave_shl1((int)(uint32_t)carry, (int)(uint32_t)p_lo);
+                const uint32_t nhi = (uint32_t)wave_shl1((int)(uint32_t)(carry >> 32), (int)(uint32_t)(p_lo >> 32));
+                p_lo = (((uint64_t)nhi << 32) | nlo) + a_lo * (uint64_t)(int64_t)smp;
+                p_hi = wave_shl1_zero(p_hi) + a_hi * (uint64_t)(int64_t)smp;
+            } else {
+                p_lo = wave_shl1_zero(p_lo) + a_lo * (uint64_t)(int64_t)smp;
+            }
+        }
+        if (i0 + lane < n)
+            out[i0 + lane] = made;
     }
-    if (br.overrun)
+    if (__any(overrun))
         flags |= SELA_HIP_FLAG_RICE_OVERRUN;
     flags = wave_or(flags);
     if (lane == 0) {
@@ -739,10 +828,10 @@ hipError_t launch_generic_analyse(const void* d_input, bool in16, uint32_t n_fra
 }
 
 hipError_t launch_generic_plan(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint64_t base_bytes, uint64_t* d_frame_offsets,
-    uint64_t* d_word_base, uint32_t* d_chosen, uint32_t* d_status, hipStream_t stream)
+    uint64_t* d_word_base, uint32_t* d_chosen, uint32_t* d_status, uint64_t* d_total_words, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_generic_plan, dim3(1), dim3(kPlanThreads), 0, stream, d_meta, n_frames, channels, n_sig, base_bytes, d_frame_offsets, d_word_base, d_chosen,
-        d_status);
+        d_status, d_total_words);
     return hipGetLastError();
 }
 
