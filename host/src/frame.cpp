@@ -143,6 +143,8 @@ data::SelaFrame FrameEncoder::process()
 // narrows to 16 bits).  That is sela_hip_decode_i32, the any-length kernels -- for every frame, also the 2048-sample ones: the
 // fast decode kernels store int16 (what the WAV writer keeps), which would truncate what a hand-made stream can hold.  Whole
 // files and batches (sela::Decoder, decodeFile, decodeBatch ...) go through the fast kernels; this class is the exact one.
+bool FrameDecoder::sixteenBitFastPath = false;
+
 data::WavFrame FrameDecoder::process()
 {
     const size_t channels = selaFrame.subFrames.size();
@@ -151,6 +153,21 @@ data::WavFrame FrameDecoder::process()
     std::vector<uint8_t> bytes;
     appendFrame(selaFrame, bytes);
     const uint64_t offsets[2] = { 0, bytes.size() };
+    if (sixteenBitFastPath && selaFrame.bitsPerSample <= 16) {
+        bool standard = true;
+        for (const data::SelaSubFrame& s : selaFrame.subFrames)
+            standard = standard && s.samplesPerChannel == kBlock;
+        if (standard) { // (the caller's promise: what comes out fits 16 bits)
+            std::vector<int16_t> pcm(kBlock * channels);
+            if (sela_hip_decode(bytes.data(), offsets, 1, (uint32_t)channels, pcm.data()) != SELA_HIP_OK)
+                throw data::Exception(std::string("FrameDecoder: ") + sela_hip_last_error());
+            std::vector<std::vector<int32_t>> samples(channels, std::vector<int32_t>(kBlock));
+            for (size_t i = 0; i < kBlock; i++)
+                for (size_t c = 0; c < channels; c++)
+                    samples[c][i] = pcm[i * channels + c];
+            return data::WavFrame(selaFrame.bitsPerSample, std::move(samples));
+        }
+    }
     uint32_t stride = 1;
     for (const data::SelaSubFrame& s : selaFrame.subFrames)
         stride = std::max<uint32_t>(stride, s.samplesPerChannel);

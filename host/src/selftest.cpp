@@ -452,6 +452,12 @@ int main(int argc, char** argv)
                     coded[i] = frame::FrameEncoder(in[i]).process();
                     frame::appendFrame(coded[i], alone[i]);
                 }
+                // (twice: the decoder class on its exact route -- one device call per frame, every thread its own stream -- and
+                // on the coalesced fast kernels, FrameDecoder::sixteenBitFastPath)
+                for (int mode = 0; mode < 2; mode++) {
+                frame::FrameDecoder::sixteenBitFastPath = mode == 1;
+                for (auto& bytes : together)
+                    bytes.clear();
                 std::vector<int> bad(threads, 0), threw(threads, 0);
                 std::vector<std::thread> pool;
                 for (int t = 0; t < threads; t++)
@@ -472,6 +478,7 @@ int main(int argc, char** argv)
                     });
                 for (std::thread& th : pool)
                     th.join();
+                frame::FrameDecoder::sixteenBitFastPath = false;
                 size_t differing = 0, notLossless = 0, exceptions = 0;
                 for (size_t i = 0; i < in.size(); i++)
                     differing += together[i] != alone[i];
@@ -480,6 +487,7 @@ int main(int argc, char** argv)
                 CHECK(differing == 0);
                 CHECK(notLossless == 0);
                 CHECK(exceptions == 1 && threw[5] == 1); // the broken frame's caller, nobody else
+                }
             }
             // the player on the same file: every frame of the decoded file, in order, as packets of one frame; a sink that
             // fails in the middle surfaces as the reference's kind of exception, and the next job runs as if nothing had happened

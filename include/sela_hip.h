@@ -178,8 +178,10 @@ uint32_t sela_hip_index_samples(const uint8_t* frames, const uint64_t* frame_off
  * truncates to 16 bits).  Always the any-length kernels; results identical to the calls above wherever both apply.
  *   samples      [n_frames][channels][samples_per_channel] (planar per frame: WavFrame.samples[c][i]), 1 .. 65535 per channel.
  *   samples_out  [n_frames][channels][stride]: channel c of frame f at ((f * channels) + c) * stride, counts_out[f * channels + c]
- *                of them valid (0 for a channel no subframe of the frame names); stride >= the largest samplesPerChannel in the
- *                stream (sela_hip_index_samples() returns it) or SELA_HIP_ECAPACITY.
+ *                of them valid (0 for a channel no subframe of the frame names; what lies behind a channel's count is not
+ *                defined); stride >= the largest samplesPerChannel in the stream (sela_hip_index_samples() returns it) or
+ *                SELA_HIP_ECAPACITY.  The calls run on the calling thread's own stream (hipStreamPerThread) and return when
+ *                the result is in host memory.
  * Errors as above; values whose int32 zig-zag overflows in the reference (|residue| >= 2^30) and Rice streams beyond the u16
  * word count of a subframe are SELA_HIP_ERANGE. */
 int sela_hip_encode_i32(const int32_t* samples, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel,
