@@ -350,3 +350,49 @@ def test_fp64_intermediates_of_the_product_kernels_by_hash(gpu, kats, teams):  #
     finally:
         lib.sela_hip_debug_encode_hashes(0)
         lib.sela_hip_debug_encode_teams(-1)
+
+
+def test_wave_priorities_follow_the_neighbours(gpu):  # noqa: F811
+    """An encode launch takes the falling wave-priority schedule exactly when no OTHER stream has library work pending
+    (sela_capi.hip, Flights): alone on its stream -- every launch; queued behind a 20,000-frame encode that another stream
+    still runs -- none; and the bytes do not depend on it (forced on, forced off, by the library)."""
+    from sela_amd import capi, codec
+
+    lib = capi.lib()
+    pcm = gpu.from_numpy(synth_frames(600, 2, 6)).cuda()
+    big = gpu.from_numpy(np.tile(synth_frames(500, 2, 7), (40, 1, 1))).cuda()
+    enc_a, enc_b = codec.Encoder(600, 2), codec.Encoder(20000, 2)
+    want = None
+    for forced in (0x00010203, 0, None):
+        if forced is None:
+            lib.sela_hip_debug_priorities_adaptive()
+        else:
+            lib.sela_hip_debug_priorities(forced)
+        out = enc_a.encode(pcm)
+        gpu.cuda.synchronize()
+        frames, offs = out.to_host()
+        if want is None:
+            want = (frames.copy(), offs.copy())
+            ref, ref_offs, _ = oracle().encode_frames(pcm.cpu().numpy(), threads=8)
+            assert np.array_equal(frames, ref) and np.array_equal(offs, ref_offs)
+        assert np.array_equal(frames, want[0]) and np.array_equal(offs, want[1]), forced
+    gpu.cuda.synchronize()
+    before = lib.sela_hip_debug_launches_alone()
+    for _ in range(5):  # one stream, nothing else in flight: every launch is alone
+        enc_a.encode(pcm)
+    gpu.cuda.synchronize()
+    assert lib.sela_hip_debug_launches_alone() - before == 5
+    s1, s2 = gpu.cuda.Stream(), gpu.cuda.Stream()
+    gpu.cuda.synchronize()
+    before = lib.sela_hip_debug_launches_alone()
+    with gpu.cuda.stream(s1):
+        enc_b.encode(big)  # (several milliseconds of work: alone when it was queued)
+    with gpu.cuda.stream(s2):
+        for _ in range(3):
+            enc_a.encode(pcm)  # queued while the other stream's launch is pending: a neighbour
+    gpu.cuda.synchronize()
+    assert lib.sela_hip_debug_launches_alone() - before == 1
+    out = enc_a.encode(pcm)
+    gpu.cuda.synchronize()
+    frames, offs = out.to_host()
+    assert np.array_equal(frames, want[0]) and np.array_equal(offs, want[1])
