@@ -22,7 +22,10 @@ class RiceEncoder {
 
 public:
     explicit RiceEncoder(const data::RiceDecodedData& decodedData) : input(decodedData.decodedData) {}
-    data::RiceEncodedData process(); // src/rice/rice_encoder.cpp:73-81
+    // src/rice/rice_encoder.cpp:73-81.  LIMITS: |value| < 2^30 (the reference's int32 zig-zag overflows beyond: data::Exception);
+    // a stream of more than 2^24 bits comes back with the word count the reference's float arithmetic gives it (:37,63), its
+    // last bits unwritten like the reference's.
+    data::RiceEncodedData process();
 };
 
 class RiceDecoder {
@@ -65,7 +68,11 @@ class ResidueGenerator {
 
 public:
     explicit ResidueGenerator(const data::LpcDecodedData& data) : samples(data.samples), bitsPerSample(data.bitsPerSample) {}
-    data::LpcEncodedData process(); // src/lpc/residue_generator.cpp:121-134 (any number of samples; order < samples)
+    // src/lpc/residue_generator.cpp:121-134.  Any number of samples (1 .. 2^24) of any 32-bit value.  LIMITS: a block must be
+    // longer than the order its own analysis picks -- the reference reads past its vector otherwise (:104-110) -- else
+    // data::Exception; a residue Rice stream too long for a frame's slot is not this stage's business (the residues are
+    // returned whatever their size).
+    data::LpcEncodedData process();
 };
 
 class SampleGenerator {
