@@ -43,7 +43,8 @@ void sela_hip_debug_encode_fused(int enable);
 /* Debug hooks (measurements and tests; process-wide): the wave priorities (s_setprio 0..3) of the encode kernels' waves in the four
  * quarters of their work, one byte each from the low end (0x00010203: falling from 3 to 0; 0: none).  By default the library
  * decides per device-pointer launch: the falling schedule when no other stream has library work pending on the device, none
- * otherwise (sela_capi.hip, "does a device-pointer launch have the device to itself?").  sela_hip_debug_priorities() fixes the
+ * otherwise (sela_capi.hip, "does a device-pointer launch have the device to itself?"); a decode launch that is alone raises
+ * the subframes of orders above 60 through their synthesis likewise (any non-zero forced schedule switches that on, 0 off).  sela_hip_debug_priorities() fixes the
  * schedule for every launch, sela_hip_debug_priorities_adaptive() goes back to the default; sela_hip_debug_launches_alone()
  * counts the launches that were given the falling schedule by that default. */
 void sela_hip_debug_priorities(uint32_t team_quarters);

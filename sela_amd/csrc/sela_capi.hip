@@ -40,7 +40,7 @@ hipError_t launch_stage_rice_decode(const uint32_t* d_words, const uint64_t* d_w
     uint32_t n_streams, int32_t* d_values, uint32_t* d_status, hipStream_t stream);
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev, uint64_t* d_phase_cycles,
-    uint8_t* frame_flags, int recurrence_form);
+    uint8_t* frame_flags, int recurrence_form, uint32_t synth_priorities = 0);
 int decode_waves(uint32_t channels);
 // the any-length / 32-bit route (sela_capi_generic.hip)
 void generic_release();
@@ -1033,6 +1033,7 @@ Flights& flights()
 std::atomic<int64_t> g_forced_priorities{ -1 }; // debug (sela_hip_debug_priorities): a fixed schedule for every launch; -1: by the neighbours
 std::atomic<int> g_launches_alone{ 0 };         // debug: launches that were given the falling schedule
 constexpr uint32_t kFallingPriorities = 0x00010203u; // 3, 2, 1, 0 by quarters of a wave's work (least significant byte first)
+constexpr uint32_t kHeavySubframesFirst = 0x00010000u; // the decoder: orders above 60 at priority 1 through their synthesis (launch_decode)
 
 uint32_t launch_priorities(hipStream_t stream, int& dev)
 {
@@ -1267,12 +1268,20 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
         return fail(SELA_HIP_ECAPACITY, "workspace smaller than sela_hip_decode_workspace_bytes()");
     hipEvent_t* ev = n_frames ? g_timing.events() : nullptr;
     g_timing.recorded = ev ? 1 : 0;
+    // (the decoder's counterpart of the encoder's schedule: a launch that has the device to itself raises its heavy subframes)
+    int dev = -1;
+    uint32_t synth_priorities = 0;
+    if (n_frames && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        const int64_t forced = g_forced_priorities.load(std::memory_order_relaxed);
+        synth_priorities = forced >= 0 ? (forced ? kHeavySubframesFirst : 0u) : (flights().others_pending(dev, static_cast<hipStream_t>(stream)) ? 0u : kHeavySubframesFirst);
+    } else {
+        dev = -1;
+    }
     hipError_t e = sela::launch_decode(d_frames, d_frame_offsets, n_frames, channels, d_pcm_out, d_status, d_workspace,
-        static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_recurrence_form);
+        static_cast<hipStream_t>(stream), ev, g_phase_cycles, nullptr, g_recurrence_form, synth_priorities);
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
-    int dev = -1;
-    if (n_frames && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64)
+    if (dev >= 0)
         flights().note(dev, static_cast<hipStream_t>(stream));
     return SELA_HIP_OK;
 }

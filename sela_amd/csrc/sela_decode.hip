@@ -787,7 +787,8 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) __attribute__((amdgpu_waves_per_
     const uint64_t* __restrict__ frame_offsets, uint32_t n_frames, uint32_t channels, int16_t* __restrict__ pcm_out,
     uint32_t* __restrict__ status, int32_t* __restrict__ ws_residues, uint64_t* __restrict__ phase_cycles,
     uint8_t* __restrict__ frame_flags /* or null: one byte per (frame, wave), written only when not zero */,
-    uint32_t vec_shift_from /* frames from this one on run the synthesis with the shift on the vector side (synth_steps) */)
+    uint32_t vec_shift_from /* frames from this one on run the synthesis with the shift on the vector side (synth_steps) */,
+    uint32_t synth_priorities /* s_setprio through the synthesis by the subframe's order class: byte 0 orders <= 48, 1 <= 60, 2 above; 0: none */)
 {
     long long stamp[10];
     for (int i = 0; i < 10; i++)
@@ -871,10 +872,14 @@ __global__ __launch_bounds__(kDecMaxWaves * 64) __attribute__((amdgpu_waves_per_
         const bool fits24 = build_synth_table(tables->a, tables->tab, (int)order, lane);
         if (kProf)
             stamp[7] = clock64();
+        if (synth_priorities)
+            set_wave_priority((int)((synth_priorities >> (order <= 48 ? 0 : (order <= 60 ? 8 : 16))) & 0xFF));
         if (vec_shift)
             synthesize_by_order<true>(order, gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
         else
             synthesize_by_order<false>(order, gw, nw, hd.rk, sl->pos, ws_c, tables->tab, fits24, lane);
+        if (synth_priorities)
+            __builtin_amdgcn_s_setprio(0);
         if (kProf)
             stamp[8] = clock64();
         if (lane == 0)
@@ -1260,7 +1265,12 @@ hipError_t launch_stage_rice_decode(const uint32_t* d_words, const uint64_t* d_w
 hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint32_t n_frames, uint32_t channels,
     int16_t* d_pcm_out, uint32_t* d_status, void* d_workspace, hipStream_t stream, hipEvent_t* ev /* 2 events or nullptr */,
     uint64_t* d_phase_cycles, uint8_t* frame_flags /* null: flags go to d_status, which is zeroed here */,
-    int recurrence_form /* -1: by launch size (vec_shift_from_for); 0 / 1: every frame in the scalar- / vector-shift form (tests) */)
+    int recurrence_form /* -1: by launch size (vec_shift_from_for); 0 / 1: every frame in the scalar- / vector-shift form (tests) */,
+    uint32_t synth_priorities /* s_setprio through the synthesis by order class (k_decode_frames); 0: none.  A launch that has the
+                                 device to itself raises the subframes of orders above 60 -- two registers per lane, 1.6 x the
+                                 synthesis work, 31 % of the bench track's subframes -- so that they do not finish last:
+                                 k_decode_frames 0.247 -> 0.240 ms at 3875 frames, one lane +1.1 %; beside another stream's
+                                 kernels the same costs 0.4 %, so the caller passes 0 there */)
 {
     hipError_t err = frame_flags ? hipSuccess : hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
     if (err != hipSuccess || n_frames == 0)
@@ -1296,14 +1306,15 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
     }
     const uint32_t from = recurrence_form >= 0 ? (recurrence_form ? 0u : n_frames)
                                                 : vec_shift_from_for(n_frames, n_waves, resident_frames(reinterpret_cast<const void*>(k_decode_frames<false>), n_waves, lds));
+    const uint32_t synth_prio = synth_priorities;
     if (ev)
         (void)hipEventRecord(ev[0], stream);
     if (d_phase_cycles)
         hipLaunchKernelGGL(k_decode_frames<true>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
-            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags, from);
+            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags, from, synth_prio);
     else
         hipLaunchKernelGGL(k_decode_frames<false>, dim3(n_frames), dim3(n_waves * 64), lds, stream, d_frames, d_frame_offsets, n_frames, channels,
-            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags, from);
+            d_pcm_out, d_status, ws, d_phase_cycles, frame_flags, from, synth_prio);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
     return hipGetLastError();
