@@ -1007,6 +1007,8 @@ def main():
             result["cpu_baseline"] = base
             assert base["bit_exact_vs_gpu"], "GPU output differs from the CPU reference"
             if bench.world == 1:
+                # (still the cpu_baseline leg -- the only place bench.py touches oracle/: the any-length route is timed and then
+                # checked against the oracle's bytes, like the headline against the reference's)
                 result["any_length"] = any_length_leg(np)
     if bench.dist is not None:
         bench.dist.barrier()
