@@ -396,3 +396,54 @@ def test_wave_priorities_follow_the_neighbours(gpu):  # noqa: F811
     gpu.cuda.synchronize()
     frames, offs = out.to_host()
     assert np.array_equal(frames, want[0]) and np.array_equal(offs, want[1])
+
+
+def test_random_shapes_against_the_oracle(gpu):  # noqa: F811
+    """300 frames of random shape -- 1 .. 6000 samples, 1 .. 6 channels, amplitudes from 1 to 2^20, silent and constant
+    channels, near-copies (difference coding), lengths around the analysis' landmarks (63 .. 65, 100 .. 102, 127 .. 129) --
+    through sela_hip_encode_i32 / sela_hip_decode_i32 against the oracle; a frame with a block not longer than its own order
+    must be refused with SELA_HIP_ERANGE, exactly those."""
+    from sela_amd import capi, codec
+
+    o = oracle()
+    rng = np.random.default_rng(77)
+    landmarks = [1, 2, 3, 31, 63, 64, 65, 100, 101, 102, 103, 127, 128, 129, 2047, 2048, 2049]
+    refused = coded = 0
+    for trial in range(300):
+        n = int(rng.choice(landmarks)) if trial % 3 == 0 else int(rng.integers(1, 6001))
+        ch = int(rng.integers(1, 7))
+        amp = int(2 ** rng.uniform(0, 20))
+        t = np.arange(n)
+        x = np.zeros((ch, n), np.int64)
+        for c in range(ch):
+            kind = rng.integers(0, 6)
+            if kind == 0:
+                x[c] = 0
+            elif kind == 1:
+                x[c] = rng.integers(-amp, amp + 1)
+            elif kind == 2:
+                x[c] = rng.integers(-amp, amp + 1, n)
+            else:
+                x[c] = np.round(amp * 0.7 * np.sin(t * rng.uniform(0.001, 1.5) + rng.uniform(0, 6)) + rng.normal(0, amp * rng.choice([0.0, 0.01, 0.2]), n))
+        if ch == 2 and rng.random() < 0.5:
+            x[1] = x[0] - rng.integers(-2, 3, n)
+        x = np.clip(x, -(1 << 20), 1 << 20).astype(np.int32)
+        # the orders of every block the frame encoder analyses (the difference signal of a stereo frame included)
+        signals = [x[c] for c in range(ch)] + ([(x[0] - x[1]).astype(np.int32)] if ch == 2 else [])
+        short = any(o.lpc_analyze(s)[0] >= n for s in signals)
+        if short:
+            with pytest.raises(capi.SelaHipError) as err:
+                codec.encode_i32(x[None])
+            assert err.value.code == -6, (trial, n, ch)
+            refused += 1
+            continue
+        frames, offs = codec.encode_i32(x[None])
+        want = o.frame_encode_i32(x)
+        assert frames.tobytes() == want, (trial, n, ch, amp)
+        dec = codec.decode_i32(frames, offs, ch)[0]
+        ref_dec, used = o.frame_decode_i32(want, ch)
+        assert used == len(want)
+        for c in range(ch):
+            assert np.array_equal(dec[c], ref_dec[c]), (trial, n, ch, c)
+        coded += 1
+    assert refused >= 5 and coded >= 200, (refused, coded)
