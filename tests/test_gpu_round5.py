@@ -447,3 +447,57 @@ def test_random_shapes_against_the_oracle(gpu):  # noqa: F811
             assert np.array_equal(dec[c], ref_dec[c]), (trial, n, ch, c)
         coded += 1
     assert refused >= 5 and coded >= 200, (refused, coded)
+
+
+def test_hostile_streams_through_the_any_length_decoder(gpu):  # noqa: F811
+    """Frames no encoder wrote: random words as Rice streams, random parameters, orders and lengths, coefficient values far
+    outside the dequantisation tables (clamped, like the oracle clamps them).  Where the oracle reads past a stream's end or
+    a predictor coefficient leaves int64 the call must fail (EFORMAT / ERANGE); everywhere else every sample must be the
+    oracle's -- wrap-around arithmetic, 32-bit results."""
+    import ctypes as C
+    import struct
+
+    from sela_amd import capi, codec
+
+    o = oracle()
+    rng = np.random.default_rng(99)
+    same = failed = 0
+    for trial in range(250):
+        ch = int(rng.integers(1, 4))
+        subs = []
+        n_frame = int(rng.integers(1, 700))
+        roomy = rng.random() < 0.7  # (most frames get streams long enough for their values; the rest run dry)
+        for c in range(ch):
+            order = int(rng.integers(0, 101))
+            ck = int(rng.integers(0, 12))
+            rk = int(rng.integers(0, 20))
+            n = n_frame if rng.random() < 0.8 else int(rng.integers(1, 700))
+            cwords = (order * (ck + 3)) // 32 + 2 + int(rng.integers(0, 4)) if roomy else int(rng.integers(0, 40))
+            rwords = (n * (rk + 3)) // 32 + 8 + int(rng.integers(0, 8)) if roomy else int(rng.integers(1, 1 + (n * (rk + 3)) // 32 + 8))
+            dense = rng.random() < 0.5  # sparse words = short unary runs, so that most streams do hold their values
+            mk = (lambda m: (rng.integers(0, 1 << 32, m, dtype=np.uint64) & rng.integers(0, 1 << 32, m, dtype=np.uint64)
+                             & (rng.integers(0, 1 << 32, m, dtype=np.uint64) if not dense else np.uint64(0xFFFFFFFF))).astype(np.uint32))
+            cw, rw = mk(cwords), mk(rwords)
+            typ = 1 if (c > 0 and rng.random() < 0.3) else 0
+            parent = int(rng.integers(0, c)) if typ else c
+            subs.append(struct.pack("<BBBBHB", c, typ, parent, ck, cwords, order) + cw.tobytes() + struct.pack("<BHH", rk, rwords, n) + rw.tobytes())
+        blob = bytes.fromhex("00ff55aa") + b"".join(subs)
+        fl = C.c_uint32(0)
+        b = np.frombuffer(blob, np.uint8).copy()
+        out = np.zeros((ch, 700), np.int32)
+        counts = np.zeros(ch, np.uint32)
+        used = o._fdec32(b, ch, out, 700, counts, C.byref(fl))
+        assert used == len(blob)
+        bad = fl.value & (8 | 2 | 32)  # RICE_OVERRUN, COEF_OVERFLOW, BAD_FRAME
+        offs = np.array([0, len(blob)], np.uint64)
+        if bad:
+            with pytest.raises(capi.SelaHipError) as err:
+                codec.decode_i32(b, offs, ch)
+            assert err.value.code in (-5, -6), (trial, hex(fl.value))
+            failed += 1
+        else:
+            dec = codec.decode_i32(b, offs, ch)[0]
+            for c in range(ch):
+                assert np.array_equal(dec[c], out[c, : int(counts[c])]), (trial, c, hex(fl.value))
+            same += 1
+    assert same >= 60 and failed >= 60, (same, failed)
