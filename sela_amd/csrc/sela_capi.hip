@@ -1431,6 +1431,11 @@ struct HipBackend {
     {
         return ::decode_now(frames, offsets, n_frames, channels, pcm_out);
     }
+    static int decode_i32_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out, uint32_t stride,
+        uint32_t* counts_out)
+    {
+        return sela::generic_decode(frames, offsets, n_frames, channels, samples_out, stride, counts_out, nullptr, nullptr);
+    }
     static size_t encode_bound_bytes(uint32_t n_frames, uint32_t channels) { return sela_hip_encode_bound_bytes(n_frames, channels); }
     static void* take(size_t bytes) { return pool().take(bytes); }
     static void give(void* p) { pool().give(p); }
@@ -1443,21 +1448,21 @@ typedef sela::CallCoalescer<HipBackend> Coalescer;
 
 // One coalescer per device and direction: calls for different GPUs (one thread per GPU, each coding frame by frame) can never
 // share a batch, so they do not wait for each other's leaders either.
-Coalescer* coalescer(bool encode, int device)
+Coalescer* coalescer(Coalescer::Kind kind, int device)
 {
     static std::mutex mu;
-    static Coalescer* table[2][64] = {};
+    static Coalescer* table[3][64] = {};
     const int d = device >= 0 && device < 64 ? device : 0;
     std::lock_guard<std::mutex> lock(mu);
-    Coalescer*& c = table[encode ? 1 : 0][d];
+    Coalescer*& c = table[(int)kind][d];
     if (!c)
-        c = new Coalescer(encode); // (never destroyed: calls may outlive the statics)
+        c = new Coalescer(kind); // (never destroyed: calls may outlive the statics)
     return c;
 }
 
-int submit_small(bool encode, SmallCall& call)
+int submit_small(Coalescer::Kind kind, SmallCall& call)
 {
-    const int rc = coalescer(encode, call.device)->submit(call);
+    const int rc = coalescer(kind, call.device)->submit(call);
     return rc == SELA_HIP_OK ? SELA_HIP_OK : fail(rc, call.error);
 }
 } // namespace
@@ -1478,7 +1483,7 @@ int sela_hip_encode(const int16_t* pcm, uint32_t n_frames, uint32_t channels, ui
         return encode_now(pcm, n_frames, channels, frames_out, frames_cap, frame_offsets_out); // (reports the missing device)
     call.channels = channels, call.n_frames = n_frames;
     call.pcm = pcm, call.frames_out = frames_out, call.frames_cap = frames_cap, call.offsets_out = frame_offsets_out;
-    return submit_small(true, call);
+    return submit_small(Coalescer::kEncode, call);
 }
 
 namespace {
@@ -1495,7 +1500,7 @@ int decode_standard(const uint8_t* frames, const uint64_t* frame_offsets, uint32
         return decode_now(frames, frame_offsets, n_frames, channels, pcm_out);
     call.channels = channels, call.n_frames = n_frames;
     call.frames = frames, call.offsets_in = frame_offsets, call.pcm_out = pcm_out;
-    return submit_small(false, call);
+    return submit_small(Coalescer::kDecode, call);
 }
 } // namespace
 
@@ -1568,7 +1573,14 @@ int sela_hip_decode_i32(const uint8_t* frames, const uint64_t* frame_offsets, ui
     if (largest > stride)
         return fail(SELA_HIP_ECAPACITY, "stride is smaller than the largest samplesPerChannel of the stream (see sela_hip_index_samples)");
     // (a stream the host walk cannot follow reports 0: the kernels find and report the malformed frame)
-    return sela::generic_decode(frames, frame_offsets, n_frames, channels, samples_out, stride, counts_out, nullptr, nullptr);
+    // Small calls from many threads -- the reference's thread loop over frame::FrameDecoder -- go to the device together, like
+    // the one-shot calls of the fast path (sela_coalescer.h): every call its own rows, its own error.
+    SmallCall call;
+    if (n_frames > kCoalesceFrames || hipGetDevice(&call.device) != hipSuccess)
+        return sela::generic_decode(frames, frame_offsets, n_frames, channels, samples_out, stride, counts_out, nullptr, nullptr);
+    call.channels = channels, call.n_frames = n_frames;
+    call.frames = frames, call.offsets_in = frame_offsets, call.samples_out = samples_out, call.stride = stride, call.counts_out = counts_out;
+    return submit_small(Coalescer::kDecode32, call);
 }
 
 int sela_hip_lpc_encode_n(const int32_t* samples, uint32_t n_blocks, uint32_t samples_per_block, int32_t* order_out, int32_t* q_out, int32_t* residues_out)

@@ -7,6 +7,8 @@
 //   struct Backend {
 //       static int encode_now(const int16_t* pcm, uint32_t n_frames, uint32_t channels, uint8_t* frames_out, size_t frames_cap, uint64_t* offsets_out);
 //       static int decode_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm_out);
+//       static int decode_i32_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out,
+//                                 uint32_t stride, uint32_t* counts_out);   // sela_hip_decode_i32: [frame][channel][stride] + a count per row
 //       static size_t encode_bound_bytes(uint32_t n_frames, uint32_t channels);
 //       static void* take(size_t bytes);  static void give(void* p);      // staging memory of a batch
 //       static std::string last_error();                                  // of the calling thread's last *_now
@@ -49,6 +51,9 @@ struct SmallCall {
     const uint8_t* frames = nullptr; // decode
     const uint64_t* offsets_in = nullptr;
     int16_t* pcm_out = nullptr;
+    int32_t* samples_out = nullptr; // decode to 32-bit channels (sela_hip_decode_i32): [n_frames][channels][stride], counts_out[n_frames * channels]
+    uint32_t stride = 0;
+    uint32_t* counts_out = nullptr;
     int rc = SELA_HIP_OK;
     std::string error;
     bool done = false, lead = false;
@@ -56,7 +61,12 @@ struct SmallCall {
 
 template <class Backend>
 class CallCoalescer {
-    const bool encode;
+public:
+    enum Kind { kDecode = 0, kEncode = 1, kDecode32 = 2 };
+
+private:
+    const Kind kind;
+    const bool encode; // (kind == kEncode)
     std::mutex mu;
     std::condition_variable cv;
     std::deque<SmallCall*> queue;
@@ -67,7 +77,8 @@ class CallCoalescer {
     void run_one(SmallCall& c)
     {
         c.rc = encode ? Backend::encode_now(c.pcm, c.n_frames, c.channels, c.frames_out, c.frames_cap, c.offsets_out)
-                      : Backend::decode_now(c.frames, c.offsets_in, c.n_frames, c.channels, c.pcm_out);
+            : kind == kDecode32 ? Backend::decode_i32_now(c.frames, c.offsets_in, c.n_frames, c.channels, c.samples_out, c.stride, c.counts_out)
+                                : Backend::decode_now(c.frames, c.offsets_in, c.n_frames, c.channels, c.pcm_out);
         if (c.rc != SELA_HIP_OK)
             c.error = Backend::last_error();
     }
@@ -127,6 +138,57 @@ class CallCoalescer {
                 }
                 at += c->n_frames;
             }
+        } else if (kind == kDecode32) {
+            // frames of any shape to 32-bit channels: one job with the widest caller's stride, every call handed its own rows
+            size_t bytes = 0;
+            uint32_t stride = 1;
+            for (const SmallCall* c : batch) {
+                bytes += (size_t)(c->offsets_in[c->n_frames] - c->offsets_in[0] + 3) & ~(size_t)3;
+                stride = c->stride > stride ? c->stride : stride;
+            }
+            const size_t rows = total * channels;
+            in = Backend::take(bytes + 4);
+            out = Backend::take(rows * stride * sizeof(int32_t) + rows * sizeof(uint32_t));
+            if (!in.p || !out.p) {
+                rc = SELA_HIP_ENOMEM, oom = true;
+            } else {
+                int32_t* const samples = static_cast<int32_t*>(out.p);
+                uint32_t* const counts = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(out.p) + rows * stride * sizeof(int32_t));
+                size_t at = 0, pos = 0;
+                for (const SmallCall* c : batch) {
+                    const uint64_t first = c->offsets_in[0], len = c->offsets_in[c->n_frames] - first;
+                    std::memcpy(static_cast<uint8_t*>(in.p) + pos, c->frames + first, (size_t)len);
+                    for (uint32_t f = 0; f < c->n_frames; f++)
+                        offsets[at + f] = pos + (c->offsets_in[f] - first);
+                    at += c->n_frames;
+                    pos += ((size_t)len + 3) & ~(size_t)3;
+                    offsets[at] = pos;
+                }
+                rc = Backend::decode_i32_now(static_cast<const uint8_t*>(in.p), offsets.data(), (uint32_t)total, channels, samples, stride, counts);
+                if (rc == SELA_HIP_OK) {
+                    at = 0;
+                    for (SmallCall* c : batch) {
+                        for (size_t r = 0; r < (size_t)c->n_frames * channels && c->rc == SELA_HIP_OK; r++) {
+                            const uint32_t cnt = counts[at * channels + r];
+                            if (cnt > c->stride) {
+                                c->rc = SELA_HIP_ECAPACITY, c->error = "stride is smaller than a channel of the frame";
+                                break;
+                            }
+                            c->counts_out[r] = cnt;
+                            std::memcpy(c->samples_out + r * c->stride, samples + (at * channels + r) * stride, (size_t)cnt * sizeof(int32_t));
+                        }
+                        at += c->n_frames;
+                    }
+                }
+            }
+            if (rc == SELA_HIP_EFORMAT || rc == SELA_HIP_ERANGE || rc == SELA_HIP_ECAPACITY) {
+                for (SmallCall* c : batch) // somebody's frame must not fail its neighbours' calls: everyone on their own
+                    run_one(*c);
+            } else if (rc != SELA_HIP_OK) {
+                const std::string msg = oom ? std::string("no page-locked memory for a coalesced batch") : Backend::last_error();
+                for (SmallCall* c : batch)
+                    c->rc = rc, c->error = msg;
+            }
         } else {
             size_t bytes = 0;
             for (const SmallCall* c : batch)
@@ -167,7 +229,8 @@ class CallCoalescer {
     }
 
 public:
-    explicit CallCoalescer(bool enc) : encode(enc) {}
+    explicit CallCoalescer(bool enc) : kind(enc ? kEncode : kDecode), encode(enc) {}
+    explicit CallCoalescer(Kind k) : kind(k), encode(k == kEncode) {}
 
     int submit(SmallCall& call)
     {

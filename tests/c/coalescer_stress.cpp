@@ -59,6 +59,32 @@ struct StubBackend {
         std::this_thread::sleep_for(std::chrono::microseconds(30));
         return SELA_HIP_OK;
     }
+    // "decoding to 32-bit channels": channel c of a frame gets 100 + 10 c samples, all the frame's first sample + c
+    static int decode_i32_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int32_t* samples, uint32_t stride,
+        uint32_t* counts)
+    {
+        g_jobs++, g_frames += (int)n_frames;
+        for (uint32_t f = 0; f < n_frames; f++) {
+            uint32_t first;
+            std::memcpy(&first, frames + offsets[f], 4);
+            if ((int16_t)(uint16_t)first == -32768) {
+                t_error = "malformed frame";
+                return SELA_HIP_EFORMAT;
+            }
+            for (uint32_t c = 0; c < channels; c++) {
+                const uint32_t cnt = 100 + 10 * c;
+                if (cnt > stride) {
+                    t_error = "stride too small";
+                    return SELA_HIP_ECAPACITY;
+                }
+                counts[f * channels + c] = cnt;
+                for (uint32_t i = 0; i < cnt; i++)
+                    samples[((size_t)f * channels + c) * stride + i] = (int32_t)(int16_t)(uint16_t)first + (int32_t)c;
+            }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(30));
+        return SELA_HIP_OK;
+    }
     static void* take(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
     static void give(void* p) { std::free(p); }
     static std::string last_error() { return t_error; }
@@ -67,7 +93,7 @@ struct StubBackend {
 
 typedef sela::CallCoalescer<StubBackend> Coalescer;
 
-int worker(Coalescer& enc, Coalescer& dec, int id, int rounds, std::atomic<int>& failures)
+int worker(Coalescer& enc, Coalescer& dec, Coalescer& dec32, int id, int rounds, std::atomic<int>& failures)
 {
     std::mt19937 rng(1000 + id);
     for (int r = 0; r < rounds; r++) {
@@ -114,6 +140,28 @@ int worker(Coalescer& enc, Coalescer& dec, int id, int rounds, std::atomic<int>&
         const int rd = dec.submit(d);
         if (bad ? rd != SELA_HIP_EFORMAT : (rd != SELA_HIP_OK || back != pcm))
             failures++, std::fprintf(stderr, "thread %d round %d: decode rc %d (bad frame: %d)\n", id, r, rd, (int)bad);
+        // the same frames to 32-bit channels, every caller with a stride of its own; every 17th call with one that is too small
+        const bool narrow = !bad && r % 17 == 3;
+        const uint32_t stride = narrow ? 50u : 128u + (uint32_t)(id % 5) * 7u;
+        std::vector<int32_t> wide((size_t)n * channels * stride, -7);
+        std::vector<uint32_t> counts((size_t)n * channels, 999);
+        sela::SmallCall w;
+        w.device = e.device, w.channels = channels, w.n_frames = n;
+        w.frames = bytes.data(), w.offsets_in = offsets.data(), w.samples_out = wide.data(), w.stride = stride, w.counts_out = counts.data();
+        const int rw = dec32.submit(w);
+        if (bad ? rw != SELA_HIP_EFORMAT : (narrow ? rw != SELA_HIP_ECAPACITY : rw != SELA_HIP_OK)) {
+            failures++, std::fprintf(stderr, "thread %d round %d: decode32 rc %d (bad %d narrow %d)\n", id, r, rw, (int)bad, (int)narrow);
+        } else if (!bad && !narrow) {
+            for (uint32_t f = 0; f < n; f++)
+                for (uint32_t c = 0; c < channels; c++) {
+                    const size_t row = (size_t)f * channels + c;
+                    bool ok = counts[row] == 100 + 10 * c;
+                    for (uint32_t i = 0; ok && i < counts[row]; i++)
+                        ok = wide[row * stride + i] == (int32_t)pcm[(size_t)f * kFrame * channels] + (int32_t)c;
+                    if (!ok)
+                        failures++, std::fprintf(stderr, "thread %d round %d: decode32 row %zu came back as somebody else's\n", id, r, row);
+                }
+        }
     }
     return 0;
 }
@@ -123,11 +171,11 @@ int worker(Coalescer& enc, Coalescer& dec, int id, int rounds, std::atomic<int>&
 int main(int argc, char** argv)
 {
     const int threads = argc > 1 ? std::atoi(argv[1]) : 16, rounds = argc > 2 ? std::atoi(argv[2]) : 120;
-    Coalescer enc(true), dec(false);
+    Coalescer enc(true), dec(false), dec32(Coalescer::kDecode32);
     std::atomic<int> failures{ 0 };
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; t++)
-        pool.emplace_back(worker, std::ref(enc), std::ref(dec), t, rounds, std::ref(failures));
+        pool.emplace_back(worker, std::ref(enc), std::ref(dec), std::ref(dec32), t, rounds, std::ref(failures));
     for (std::thread& t : pool)
         t.join();
     std::printf("%d threads x %d rounds: %d device jobs for %d frames, %d batches led, %d failures\n", threads, rounds, g_jobs.load(), g_frames.load(),
