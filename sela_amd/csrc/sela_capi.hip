@@ -44,6 +44,7 @@ hipError_t launch_decode(const uint8_t* d_frames, const uint64_t* d_frame_offset
 int decode_waves(uint32_t channels);
 // the any-length / 32-bit route (sela_capi_generic.hip)
 void generic_release();
+void generic_shutdown();
 size_t generic_encode_bound_bytes(uint32_t n_frames, uint32_t channels, uint32_t n);
 int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n, uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out);
 uint32_t generic_index_samples(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, uint64_t* sample_offsets, bool* all_standard);
@@ -1131,7 +1132,7 @@ void sela_hip_thread_release(void)
 void sela_hip_shutdown(void)
 {
     g_lease.give_back();
-    sela::generic_release();
+    sela::generic_shutdown();
     std::vector<HostContext*> idle;
     {
         std::lock_guard<std::mutex> lock(park().mu);

@@ -1,7 +1,7 @@
 // sela_capi_generic.hip -- the host side of the any-length / 32-bit route (kernels: sela_generic.hip; declarations:
 // include/sela_hip.h "Blocks of any length" and "the frame classes' own value types").
 //
-// Plain synchronous calls on the calling thread's current device and the calling thread's OWN stream (hipStreamPerThread:
+// Plain synchronous calls on the calling thread's current device and a stream of the calling thread's own (GenericContext below:
 // threads that code a frame at a time through the frame classes run side by side on the device instead of taking turns on
 // the default stream): copy in, kernels, copy out, in chunks of frames that keep the device scratch bounded, with as few
 // waits for the device as the data flow allows (an encode: two; a decode: two).  The scratch is one grow-only device allocation per thread (a frame at a time through
@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,38 +31,25 @@ using sela::GenericSubInfo;
 struct Arena { // one device allocation, handed out in aligned pieces for the length of a call
     uint8_t* base = nullptr;
     size_t cap = 0, used = 0;
-    int device = -1;
-    ~Arena() { release(); }
     void release()
     {
-        if (base) {
-            int before = -1;
-            (void)hipGetDevice(&before);
-            if (device >= 0 && before != device)
-                (void)hipSetDevice(device);
+        if (base)
             (void)hipFree(base);
-            if (before >= 0 && before != device)
-                (void)hipSetDevice(before);
-        }
-        base = nullptr, cap = used = 0, device = -1;
+        base = nullptr, cap = used = 0;
     }
     hipError_t reserve(size_t bytes)
     {
-        int dev = -1;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess)
-            return e;
         used = 0;
-        if (base && dev == device && bytes <= cap)
+        if (base && bytes <= cap)
             return hipSuccess;
         release();
         const size_t want = std::max<size_t>(bytes + (bytes >> 2), 1 << 20);
-        e = hipMalloc(reinterpret_cast<void**>(&base), want);
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), want);
         if (e != hipSuccess) {
             base = nullptr;
             return e;
         }
-        cap = want, device = dev;
+        cap = want;
         return hipSuccess;
     }
     template <typename T>
@@ -72,7 +60,89 @@ struct Arena { // one device allocation, handed out in aligned pieces for the le
         return reinterpret_cast<T*>(base + at);
     }
 };
-thread_local Arena g_arena;
+
+// What a calling thread needs on a device: scratch and a stream of its own (threads that code a frame at a time through the
+// frame classes run side by side on the device instead of taking turns on the default stream).  Leased like the fast path's
+// contexts (sela_capi.hip): a thread that ends -- programs start threads per job -- parks its set for the next thread on
+// that device instead of paying a stream and an allocation again; sela_hip_shutdown() frees the parked ones.
+struct GenericContext {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    Arena arena;
+    void destroy()
+    {
+        int before = -1;
+        (void)hipGetDevice(&before);
+        if (device >= 0 && before != device)
+            (void)hipSetDevice(device);
+        arena.release();
+        if (stream)
+            (void)hipStreamDestroy(stream);
+        stream = nullptr;
+        if (before >= 0 && before != device)
+            (void)hipSetDevice(before);
+    }
+};
+struct ContextPark {
+    std::mutex mu;
+    std::vector<GenericContext*> idle;
+};
+ContextPark& park()
+{
+    static ContextPark* p = new ContextPark; // (never destroyed: threads may end after the statics)
+    return *p;
+}
+constexpr size_t kParked = 64;
+struct Lease {
+    GenericContext* held = nullptr;
+    ~Lease() { give_back(); }
+    void give_back()
+    {
+        if (!held)
+            return;
+        GenericContext* c = held;
+        held = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(park().mu);
+            if (park().idle.size() < kParked) {
+                park().idle.push_back(c);
+                return;
+            }
+        }
+        c->destroy();
+        delete c;
+    }
+    // the calling thread's context on its current device (null + an error code when the runtime refuses)
+    GenericContext* get(hipError_t& err)
+    {
+        int dev = -1;
+        err = hipGetDevice(&dev);
+        if (err != hipSuccess)
+            return nullptr;
+        if (held && held->device == dev)
+            return held;
+        give_back();
+        {
+            std::lock_guard<std::mutex> lock(park().mu);
+            for (size_t i = 0; i < park().idle.size(); i++)
+                if (park().idle[i]->device == dev) {
+                    held = park().idle[i];
+                    park().idle.erase(park().idle.begin() + (ptrdiff_t)i);
+                    return held;
+                }
+        }
+        GenericContext* c = new GenericContext;
+        c->device = dev;
+        err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (err != hipSuccess) {
+            delete c;
+            return nullptr;
+        }
+        held = c;
+        return held;
+    }
+};
+thread_local Lease g_lease;
 
 constexpr size_t kPiece = 256; // what take() may add per piece
 constexpr size_t kChunkBudget = (size_t)768 << 20; // device scratch per chunk of frames
@@ -102,7 +172,20 @@ int flags_error(uint32_t flags, const char* who)
 
 namespace sela {
 
-void generic_release() { g_arena.release(); }
+void generic_release() { g_lease.give_back(); }
+void generic_shutdown()
+{
+    g_lease.give_back();
+    std::vector<GenericContext*> idle;
+    {
+        std::lock_guard<std::mutex> lock(park().mu);
+        idle.swap(park().idle);
+    }
+    for (GenericContext* c : idle) {
+        c->destroy();
+        delete c;
+    }
+}
 
 size_t generic_encode_bound_bytes(uint32_t n_frames, uint32_t channels, uint32_t n)
 {
@@ -118,13 +201,18 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
 {
     if (device_ready() != SELA_HIP_OK)
         return SELA_HIP_ENODEV;
+    hipError_t ctx_err = hipSuccess;
+    GenericContext* const ctx = g_lease.get(ctx_err);
+    if (!ctx)
+        return report_hip_error(ctx_err, "the calling thread's scratch and stream");
+    Arena& g_arena = ctx->arena;
     const uint32_t n_sig = channels == 2 ? 3u : channels;
     const size_t in_frame_bytes = (size_t)n * channels * (in16 ? 2 : 4);
     const size_t per_frame = (size_t)n_sig * n * 16 + (size_t)n_sig * (kMaxOrder * 4 + sizeof(GenericMeta) + 2 * kPiece) + in_frame_bytes + (size_t)channels * 12 + 8;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
     uint64_t base_bytes = 0;
     frame_offsets_out[0] = 0;
-    const hipStream_t st = hipStreamPerThread;
+    const hipStream_t st = ctx->stream;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const uint32_t cf = std::min(chunk, n_frames - f0);
         const size_t blocks = (size_t)cf * n_sig, subs = (size_t)cf * channels;
@@ -258,6 +346,11 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
 {
     if (device_ready() != SELA_HIP_OK)
         return SELA_HIP_ENODEV;
+    hipError_t ctx_err = hipSuccess;
+    GenericContext* const ctx = g_lease.get(ctx_err);
+    if (!ctx)
+        return report_hip_error(ctx_err, "the calling thread's scratch and stream");
+    Arena& g_arena = ctx->arena;
     for (uint32_t f = 0; f < n_frames; f++)
         if (frame_offsets[f + 1] < frame_offsets[f])
             return report_error(SELA_HIP_EFORMAT, "frame offsets must not decrease");
@@ -265,7 +358,7 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
         stride = 1;
     const size_t per_frame = (size_t)channels * stride * 8 + (size_t)channels * (sizeof(GenericSubInfo) + 4) + 16 + (size_t)channels * stride * (pcm_out ? 2 : 0);
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
-    const hipStream_t st = hipStreamPerThread;
+    const hipStream_t st = ctx->stream;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const uint32_t cf = std::min(chunk, n_frames - f0);
         const size_t subs = (size_t)cf * channels;
@@ -335,6 +428,11 @@ int generic_lpc_encode(const int32_t* samples, uint32_t n_blocks, uint32_t n, in
 {
     if (device_ready() != SELA_HIP_OK)
         return SELA_HIP_ENODEV;
+    hipError_t ctx_err = hipSuccess;
+    GenericContext* const ctx = g_lease.get(ctx_err);
+    if (!ctx)
+        return report_hip_error(ctx_err, "the calling thread's scratch and stream");
+    Arena& g_arena = ctx->arena;
     const size_t per_block = (size_t)n * 20 + kMaxOrder * 4 + sizeof(GenericMeta) + 16;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_blocks, kChunkBudget / per_block));
     std::vector<GenericMeta> meta;
@@ -378,6 +476,11 @@ int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* re
 {
     if (device_ready() != SELA_HIP_OK)
         return SELA_HIP_ENODEV;
+    hipError_t ctx_err = hipSuccess;
+    GenericContext* const ctx = g_lease.get(ctx_err);
+    if (!ctx)
+        return report_hip_error(ctx_err, "the calling thread's scratch and stream");
+    Arena& g_arena = ctx->arena;
     constexpr size_t kCoefs = kMaxOrder + 1;
     const size_t per_block = (size_t)n * 8 + kMaxOrder * 4 + 4 + kCoefs * 8;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_blocks, kChunkBudget / per_block));
