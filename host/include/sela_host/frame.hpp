@@ -28,15 +28,10 @@ class FrameDecoder {
 public:
     explicit FrameDecoder(const data::SelaFrame& frame) : selaFrame(frame) {}
     // The reference's answer: every channel as long as its subframe says, the samples as the 32-bit values the synthesis
-    // produces (src/frame/frame_decoder.cpp:24-25,64-71) -- the any-length kernels (sela_hip_decode_i32; calls from many
-    // threads are coalesced into device batches like the encoder's).
+    // produces (src/frame/frame_decoder.cpp:24-25,64-71) -- sela_hip_decode_i32: the fast kernels' parse and synthesis for the
+    // 2048-sample subframes an encoder writes, the any-length kernel for the rest; calls from many threads are coalesced into
+    // device batches like the encoder's.
     data::WavFrame process();
-    // For callers that know what they decode (frames of 2048 samples of at most 16 bits: every frame an encoder writes)
-    // and run the reference's thread loop over this class: true sends such frames through the FAST decode kernels -- two to
-    // five times the frames per second of the exact route, whose kernels are a lone wave per subframe -- which keep the low
-    // 16 bits of a sample, as the WAV writer does (src/file/wav_file.cpp:248-251).  A frame of any other shape still takes
-    // the exact route.  Off by default: the class answers like the reference's.
-    static bool sixteenBitFastPath;
 };
 
 // On-disk bytes of one frame (layout of the reference's src/file/sela_file.cpp:115-135) -> object.

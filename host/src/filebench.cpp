@@ -79,7 +79,6 @@ int main(int argc, char** argv)
         // sela_filebench frames <threads> <frames per thread>: the reference's own fan-out (src/sela/encoder.cpp:58-73: T threads,
         // each constructing a frame::FrameEncoder per frame of its share) on the host classes, then the decoders the same way
         const int threads = std::max(1, std::atoi(argv[2])), per = argc > 3 ? std::max(1, std::atoi(argv[3])) : 16;
-        frame::FrameDecoder::sixteenBitFastPath = argc > 4 && std::string(argv[4]) == "fast"; // frames T N fast: the decoder class on the coalesced fast kernels
         using clock = std::chrono::steady_clock;
         std::vector<data::WavFrame> in;
         uint32_t x = 2463534242u;

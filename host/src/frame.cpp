@@ -140,11 +140,9 @@ data::SelaFrame FrameEncoder::process()
 
 // frame::FrameDecoder::process returns what the subframes hold: every channel as long as its subframe says and the samples as
 // the 32-bit values the synthesis produces (src/frame/frame_decoder.cpp:24-25,48-49,64-71; only file::WavFile::writeToFile
-// narrows to 16 bits).  That is sela_hip_decode_i32, the any-length kernels -- for every frame, also the 2048-sample ones: the
-// fast decode kernels store int16 (what the WAV writer keeps), which would truncate what a hand-made stream can hold.  Whole
-// files and batches (sela::Decoder, decodeFile, decodeBatch ...) go through the fast kernels; this class is the exact one.
-bool FrameDecoder::sixteenBitFastPath = false;
-
+// narrows to 16 bits).  That is sela_hip_decode_i32: a frame of 2048-sample subframes -- every frame an encoder writes -- runs
+// the fast kernels' parse and synthesis with the samples kept in 32 bits (k_decode_subframes32), any other frame the
+// any-length kernel; calls from many threads are coalesced into device batches like the encoder's.
 data::WavFrame FrameDecoder::process()
 {
     const size_t channels = selaFrame.subFrames.size();
@@ -153,21 +151,6 @@ data::WavFrame FrameDecoder::process()
     std::vector<uint8_t> bytes;
     appendFrame(selaFrame, bytes);
     const uint64_t offsets[2] = { 0, bytes.size() };
-    if (sixteenBitFastPath && selaFrame.bitsPerSample <= 16) {
-        bool standard = true;
-        for (const data::SelaSubFrame& s : selaFrame.subFrames)
-            standard = standard && s.samplesPerChannel == kBlock;
-        if (standard) { // (the caller's promise: what comes out fits 16 bits)
-            std::vector<int16_t> pcm(kBlock * channels);
-            if (sela_hip_decode(bytes.data(), offsets, 1, (uint32_t)channels, pcm.data()) != SELA_HIP_OK)
-                throw data::Exception(std::string("FrameDecoder: ") + sela_hip_last_error());
-            std::vector<std::vector<int32_t>> samples(channels, std::vector<int32_t>(kBlock));
-            for (size_t i = 0; i < kBlock; i++)
-                for (size_t c = 0; c < channels; c++)
-                    samples[c][i] = pcm[i * channels + c];
-            return data::WavFrame(selaFrame.bitsPerSample, std::move(samples));
-        }
-    }
     uint32_t stride = 1;
     for (const data::SelaSubFrame& s : selaFrame.subFrames)
         stride = std::max<uint32_t>(stride, s.samplesPerChannel);

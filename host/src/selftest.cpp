@@ -452,10 +452,7 @@ int main(int argc, char** argv)
                     coded[i] = frame::FrameEncoder(in[i]).process();
                     frame::appendFrame(coded[i], alone[i]);
                 }
-                // (twice: the decoder class on its exact route -- one device call per frame, every thread its own stream -- and
-                // on the coalesced fast kernels, FrameDecoder::sixteenBitFastPath)
-                for (int mode = 0; mode < 2; mode++) {
-                frame::FrameDecoder::sixteenBitFastPath = mode == 1;
+                for (int pass = 0; pass < 2; pass++) { // (twice: the second pass meets parked contexts and warm coalescers)
                 for (auto& bytes : together)
                     bytes.clear();
                 std::vector<int> bad(threads, 0), threw(threads, 0);
@@ -478,7 +475,6 @@ int main(int argc, char** argv)
                     });
                 for (std::thread& th : pool)
                     th.join();
-                frame::FrameDecoder::sixteenBitFastPath = false;
                 size_t differing = 0, notLossless = 0, exceptions = 0;
                 for (size_t i = 0; i < in.size(); i++)
                     differing += together[i] != alone[i];

@@ -175,13 +175,16 @@ uint32_t sela_hip_index_samples(const uint8_t* frames, const uint64_t* frame_off
  * frame::FrameEncoder(const data::WavFrame&).process() and frame::FrameDecoder(const data::SelaFrame&).process()
  * (src/include/frame.hpp:8-24) on what they really take and return: data::WavFrame = int32 samples per channel
  * (src/include/data/wav_frame.hpp:8-16), nothing narrowed (src/frame/frame_decoder.cpp:64-71; only file::WavFile::writeToFile
- * truncates to 16 bits).  Always the any-length kernels; results identical to the calls above wherever both apply.
+ * truncates to 16 bits).  The encoder always runs the any-length kernels; the decoder offers its subframes to the fast kernels'
+ * parse and synthesis first (k_decode_subframes32: subframes of 2048 samples that fit the parser's plan -- every stream an
+ * encoder writes -- with the samples kept in 32 bits) and runs the any-length kernel on a chunk of frames in which anything
+ * else turns up.  Results identical to the calls above wherever both apply.
  *   samples      [n_frames][channels][samples_per_channel] (planar per frame: WavFrame.samples[c][i]), 1 .. 65535 per channel.
  *   samples_out  [n_frames][channels][stride]: channel c of frame f at ((f * channels) + c) * stride, counts_out[f * channels + c]
  *                of them valid (0 for a channel no subframe of the frame names; what lies behind a channel's count is not
  *                defined); stride >= the largest samplesPerChannel in the stream (sela_hip_index_samples() returns it) or
- *                SELA_HIP_ECAPACITY.  The calls run on the calling thread's own stream (hipStreamPerThread) and return when
- *                the result is in host memory.
+ *                SELA_HIP_ECAPACITY.  The calls run on a stream of the calling thread's own (leased, not the default stream)
+ *                and return when the result is in host memory; after an error the outputs' contents are not defined.
  * Errors as above; values whose int32 zig-zag overflows in the reference (|residue| >= 2^30) and Rice streams beyond the u16
  * word count of a subframe are SELA_HIP_ERANGE. */
 int sela_hip_encode_i32(const int32_t* samples, uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel,

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -31,6 +32,7 @@ using sela::GenericSubInfo;
 struct Arena { // one device allocation, handed out in aligned pieces for the length of a call
     uint8_t* base = nullptr;
     size_t cap = 0, used = 0;
+    bool fits() const { return used <= cap; } // (asked after the pieces are taken: the callers' size estimates are checked, not trusted)
     void release()
     {
         if (base)
@@ -144,6 +146,9 @@ struct Lease {
 };
 thread_local Lease g_lease;
 
+std::atomic<int> g_standard_first_mode{-1}; // sela_hip_debug_standard_first
+std::atomic<int> g_standard_chunks{0};
+
 constexpr size_t kPiece = 256; // what take() may add per piece
 constexpr size_t kChunkBudget = (size_t)768 << 20; // device scratch per chunk of frames
 
@@ -232,6 +237,8 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
         uint64_t* d_offsets = d_head + 3;
         uint64_t* d_word_base = g_arena.take<uint64_t>(subs + 1);
         uint32_t* d_chosen = g_arena.take<uint32_t>(subs);
+        if (!g_arena.fits())
+            return report_error(SELA_HIP_ENOMEM, "generic encode: internal scratch estimate too small");
         e = hipMemcpyAsync(d_in, static_cast<const uint8_t*>(input) + (size_t)f0 * in_frame_bytes, cf * in_frame_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
             e = hipMemsetAsync(d_head, 0, 24, st);
@@ -341,8 +348,11 @@ uint32_t generic_index_samples(const uint8_t* frames, const uint64_t* frame_offs
 }
 
 // One of: samples_out + counts_out (32-bit, planar, stride), or pcm_out + sample_offsets (16-bit interleaved).
+// standard_first: the chunk's subframes are first offered to k_decode_subframes32 (the fast kernels' parse and synthesis with
+// 32-bit samples, for subframes of 2048 samples: every stream an encoder writes); a chunk in which that kernel leaves anything
+// alone is decoded again by k_generic_decode.
 int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out, uint32_t stride,
-    uint32_t* counts_out, int16_t* pcm_out, const uint64_t* sample_offsets)
+    uint32_t* counts_out, int16_t* pcm_out, const uint64_t* sample_offsets, bool standard_first)
 {
     if (device_ready() != SELA_HIP_OK)
         return SELA_HIP_ENODEV;
@@ -380,6 +390,8 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
         uint32_t* d_counts = d_tail + 4;
         uint64_t* d_sample_offsets = pcm_out ? g_arena.take<uint64_t>((size_t)cf + 1) : nullptr;
         int16_t* d_pcm = pcm_out ? g_arena.take<int16_t>((size_t)chunk_samples * channels) : nullptr;
+        if (!g_arena.fits())
+            return report_error(SELA_HIP_ENOMEM, "generic decode: internal scratch estimate too small");
         e = hipMemcpyAsync(d_frames, frames + base_bytes, in_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
             e = hipMemcpyAsync(d_offsets, frame_offsets + f0, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice, st);
@@ -390,17 +402,38 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
                 local[i] = sample_offsets[f0 + i] - s0;
             e = hipMemcpyAsync(d_sample_offsets, local.data(), local.size() * 8, hipMemcpyHostToDevice, st);
         }
-        if (e == hipSuccess)
-            e = hipMemsetAsync(d_tail, 0, (4 + subs) * 4, st);
-        if (e == hipSuccess)
-            e = launch_generic_decode(d_frames, d_offsets, base_bytes, cf, channels, stride, d_dec, d_info, d_all, d_counts, d_sample_offsets, d_pcm, d_status, st);
         std::vector<uint32_t> tail(4 + subs);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(tail.data(), d_tail, tail.size() * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(st);
-        if (e != hipSuccess)
-            return report_hip_error(e, "generic decode");
+        const int mode = g_standard_first_mode.load(std::memory_order_relaxed);
+        const bool offer = (mode < 0 ? standard_first : mode != 0) && stride >= SELA_HIP_SAMPLES_PER_FRAME;
+        // A small chunk's samples travel with the status, one wait for the device instead of two (a call of one frame -- the
+        // frame classes' kind -- is mostly waits); what they are worth is known when both have arrived.
+        const size_t out_bytes = pcm_out ? (size_t)chunk_samples * channels * 2 : subs * stride * sizeof(int32_t);
+        const bool eager = out_bytes <= ((size_t)4 << 20);
+        auto copy_out = [&]() {
+            // samples_out and the device's channel-major array have one layout ([frame][channel][stride]): ONE copy (a copy per
+            // channel cost 13 us each: 7 ms for 256 stereo frames).  What lies behind a channel's count is not defined.
+            return pcm_out ? hipMemcpyAsync(pcm_out + s0 * channels, d_pcm, out_bytes, hipMemcpyDeviceToHost, st)
+                           : hipMemcpyAsync(samples_out + (size_t)f0 * channels * stride, d_all, out_bytes, hipMemcpyDeviceToHost, st);
+        };
+        for (int attempt = offer ? 0 : 1; attempt < 2; attempt++) {
+            if (e == hipSuccess)
+                e = hipMemsetAsync(d_tail, 0, (4 + subs) * 4, st);
+            if (e == hipSuccess)
+                e = launch_generic_decode(d_frames, d_offsets, base_bytes, cf, channels, stride, d_dec, d_info, d_all, d_counts, d_sample_offsets, d_pcm, d_status,
+                    attempt == 0, st);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(tail.data(), d_tail, tail.size() * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && eager)
+                e = copy_out();
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(st);
+            if (e != hipSuccess)
+                return report_hip_error(e, "generic decode");
+            if (attempt == 0 && tail[2] == 0) { // (every subframe was of the standard kind and came out clean)
+                g_standard_chunks.fetch_add(1, std::memory_order_relaxed);
+                break;
+            }
+        }
         const uint32_t* const status = tail.data();
         if (status[0] & SELA_HIP_FLAG_BAD_FRAME)
             return report_error(SELA_HIP_EFORMAT, "malformed frame (sync word, sizes, an order above 100, a Rice parameter above 31, a channel or parent that does not exist, or channels of different lengths)");
@@ -408,16 +441,13 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
             return report_error(SELA_HIP_EFORMAT, "a Rice stream ended before all its values were read");
         if (status[0] & SELA_HIP_FLAG_COEF_OVERFLOW)
             return report_error(SELA_HIP_ERANGE, "decode: a predictor coefficient left the int64 range");
-        if (pcm_out) {
-            e = hipMemcpyAsync(pcm_out + s0 * channels, d_pcm, (size_t)chunk_samples * channels * 2, hipMemcpyDeviceToHost, st);
-        } else {
+        if (!pcm_out)
             std::memcpy(counts_out + (size_t)f0 * channels, tail.data() + 4, subs * 4);
-            // samples_out and the device's channel-major array have one layout ([frame][channel][stride]): ONE copy (a copy per
-            // channel cost 13 us each: 7 ms for 256 stereo frames).  What lies behind a channel's count is not defined.
-            e = hipMemcpyAsync(samples_out + (size_t)f0 * channels * stride, d_all, subs * stride * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (!eager) {
+            e = copy_out();
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(st);
         }
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(st);
         if (e != hipSuccess)
             return report_hip_error(e, "generic decode: copy out");
     }
@@ -436,6 +466,7 @@ int generic_lpc_encode(const int32_t* samples, uint32_t n_blocks, uint32_t n, in
     const size_t per_block = (size_t)n * 20 + kMaxOrder * 4 + sizeof(GenericMeta) + 16;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_blocks, kChunkBudget / per_block));
     std::vector<GenericMeta> meta;
+    const hipStream_t st = ctx->stream;
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk) {
         const uint32_t cb = std::min(chunk, n_blocks - b0);
         hipError_t e = g_arena.reserve((size_t)cb * per_block + 8 * kPiece);
@@ -447,16 +478,20 @@ int generic_lpc_encode(const int32_t* samples, uint32_t n_blocks, uint32_t n, in
         int32_t* d_res = g_arena.take<int32_t>((size_t)cb * n);
         int32_t* d_q = g_arena.take<int32_t>((size_t)cb * kMaxOrder);
         GenericMeta* d_meta = g_arena.take<GenericMeta>(cb);
-        e = hipMemcpy(d_in, samples + (size_t)b0 * n, (size_t)cb * n * 4, hipMemcpyHostToDevice);
+        if (!g_arena.fits())
+            return report_error(SELA_HIP_ENOMEM, "lpc_encode: internal scratch estimate too small");
+        e = hipMemcpyAsync(d_in, samples + (size_t)b0 * n, (size_t)cb * n * 4, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) // a "frame" of one channel per block
-            e = launch_generic_analyse(d_in, false, cb, 1, 1, n, d_sig, d_cen, d_res, d_q, d_meta, nullptr);
+            e = launch_generic_analyse(d_in, false, cb, 1, 1, n, d_sig, d_cen, d_res, d_q, d_meta, st);
         meta.resize(cb);
         if (e == hipSuccess)
-            e = hipMemcpy(meta.data(), d_meta, (size_t)cb * sizeof(GenericMeta), hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(meta.data(), d_meta, (size_t)cb * sizeof(GenericMeta), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess)
-            e = hipMemcpy(q_out + (size_t)b0 * kMaxOrder, d_q, (size_t)cb * kMaxOrder * 4, hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(q_out + (size_t)b0 * kMaxOrder, d_q, (size_t)cb * kMaxOrder * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess)
-            e = hipMemcpy(residues_out + (size_t)b0 * n, d_res, (size_t)cb * n * 4, hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(residues_out + (size_t)b0 * n, d_res, (size_t)cb * n * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
         if (e != hipSuccess)
             return report_hip_error(e, "lpc_encode");
         uint32_t flags = 0;
@@ -482,6 +517,7 @@ int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* re
         return report_hip_error(ctx_err, "the calling thread's scratch and stream");
     Arena& g_arena = ctx->arena;
     constexpr size_t kCoefs = kMaxOrder + 1;
+    const hipStream_t st = ctx->stream;
     const size_t per_block = (size_t)n * 8 + kMaxOrder * 4 + 4 + kCoefs * 8;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_blocks, kChunkBudget / per_block));
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += chunk) {
@@ -495,24 +531,28 @@ int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* re
         int32_t* d_out = samples_out ? g_arena.take<int32_t>((size_t)cb * n) : nullptr;
         int64_t* d_coefs = coefs_out ? g_arena.take<int64_t>((size_t)cb * kCoefs) : nullptr;
         uint32_t* d_status = g_arena.take<uint32_t>(4);
-        e = hipMemcpy(d_order, order + b0, (size_t)cb * 4, hipMemcpyHostToDevice);
+        if (!g_arena.fits())
+            return report_error(SELA_HIP_ENOMEM, "lpc_decode: internal scratch estimate too small");
+        e = hipMemcpyAsync(d_order, order + b0, (size_t)cb * 4, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
-            e = hipMemcpy(d_q, q + (size_t)b0 * kMaxOrder, (size_t)cb * kMaxOrder * 4, hipMemcpyHostToDevice);
+            e = hipMemcpyAsync(d_q, q + (size_t)b0 * kMaxOrder, (size_t)cb * kMaxOrder * 4, hipMemcpyHostToDevice, st);
         if (e == hipSuccess && d_res)
-            e = hipMemcpy(d_res, residues + (size_t)b0 * n, (size_t)cb * n * 4, hipMemcpyHostToDevice);
+            e = hipMemcpyAsync(d_res, residues + (size_t)b0 * n, (size_t)cb * n * 4, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
-            e = hipMemsetAsync(d_status, 0, 16, nullptr);
+            e = hipMemsetAsync(d_status, 0, 16, st);
         if (e == hipSuccess && d_coefs)
-            e = hipMemsetAsync(d_coefs, 0, (size_t)cb * kCoefs * 8, nullptr);
+            e = hipMemsetAsync(d_coefs, 0, (size_t)cb * kCoefs * 8, st);
         if (e == hipSuccess)
-            e = launch_generic_lpc_decode(d_order, d_q, d_res, cb, n, d_out, d_coefs, d_status, nullptr);
+            e = launch_generic_lpc_decode(d_order, d_q, d_res, cb, n, d_out, d_coefs, d_status, st);
         uint32_t status[4] = {};
         if (e == hipSuccess)
-            e = hipMemcpy(status, d_status, 16, hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && samples_out)
-            e = hipMemcpy(samples_out + (size_t)b0 * n, d_out, (size_t)cb * n * 4, hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(samples_out + (size_t)b0 * n, d_out, (size_t)cb * n * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && coefs_out)
-            e = hipMemcpy(coefs_out + (size_t)b0 * kCoefs, d_coefs, (size_t)cb * kCoefs * 8, hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(coefs_out + (size_t)b0 * kCoefs, d_coefs, (size_t)cb * kCoefs * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
         if (e != hipSuccess)
             return report_hip_error(e, "lpc_decode");
         if (status[0] & SELA_HIP_FLAG_BAD_FRAME)
@@ -524,3 +564,8 @@ int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* re
 }
 
 } // namespace sela
+
+extern "C" {
+void sela_hip_debug_standard_first(int mode) { g_standard_first_mode.store(mode, std::memory_order_relaxed); }
+int sela_hip_debug_standard_chunks(void) { return g_standard_chunks.load(std::memory_order_relaxed); }
+}

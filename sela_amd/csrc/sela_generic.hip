@@ -850,12 +850,17 @@ hipError_t launch_generic_emit(const GenericMeta* d_meta, uint32_t n_frames, uin
 
 hipError_t launch_generic_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint32_t n_frames, uint32_t channels, uint32_t stride,
     int32_t* d_dec, GenericSubInfo* d_info, int32_t* d_all, uint32_t* d_counts, const uint64_t* d_sample_offsets, int16_t* d_pcm_out, uint32_t* d_status,
-    hipStream_t stream)
+    bool standard_first, hipStream_t stream)
 {
     const uint32_t subs = n_frames * channels;
     if (subs == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_generic_decode, dim3(subs), dim3(64), 0, stream, d_frames, d_frame_offsets, base_bytes, n_frames, channels, stride, d_dec, d_info, d_status);
+    if (standard_first) {
+        const hipError_t e = launch_decode_subframes32(d_frames, d_frame_offsets, base_bytes, n_frames, channels, stride, d_dec, d_info, d_status, stream);
+        if (e != hipSuccess)
+            return e;
+    } else
+        hipLaunchKernelGGL(k_generic_decode, dim3(subs), dim3(64), 0, stream, d_frames, d_frame_offsets, base_bytes, n_frames, channels, stride, d_dec, d_info, d_status);
     if (d_pcm_out)
         hipLaunchKernelGGL(k_generic_combine<true>, dim3(n_frames), dim3(kCombineThreads), 0, stream, d_dec, d_info, n_frames, channels, stride, d_all, d_counts,
             d_sample_offsets, d_pcm_out, d_status);

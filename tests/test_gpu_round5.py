@@ -501,3 +501,190 @@ def test_hostile_streams_through_the_any_length_decoder(gpu):  # noqa: F811
                 assert np.array_equal(dec[c], out[c, : int(counts[c])]), (trial, c, hex(fl.value))
             same += 1
     assert same >= 60 and failed >= 60, (same, failed)
+
+
+def _subframe_words(blob, ch):
+    """aligned words (coefficient words + 2 + residue words) of every subframe of one frame"""
+    import struct
+
+    out, p = [], 4
+    for _ in range(ch):
+        cw = struct.unpack_from("<H", blob, p + 4)[0]
+        rw = struct.unpack_from("<H", blob, p + 7 + 4 * cw + 1)[0]
+        out.append(cw + 2 + rw)
+        p += 12 + 4 * (cw + rw)
+    return out
+
+
+def _both_decoders(blob, offs, ch):
+    """decode_i32 with the standard kernel offered and with the any-length kernel alone -> (offered, alone, chunks the standard
+    kernel decoded)."""
+    from sela_amd import capi, codec
+
+    lib = capi.lib()
+    try:
+        lib.sela_hip_debug_standard_first(1)
+        before = lib.sela_hip_debug_standard_chunks()
+        offered = codec.decode_i32(blob, offs, ch)
+        took = lib.sela_hip_debug_standard_chunks() - before
+        lib.sela_hip_debug_standard_first(0)
+        alone = codec.decode_i32(blob, offs, ch)
+    finally:
+        lib.sela_hip_debug_standard_first(-1)
+    return offered, alone, took
+
+
+def test_standard_subframes_come_out_as_32_bit_samples_on_the_fast_parse_and_synthesis(gpu, kats):  # noqa: F811
+    """sela_hip_decode_i32 (frame::FrameDecoder behind it) on 2048-sample frames: k_decode_subframes32 must give the oracle's 32-bit
+    samples -- an encoder's frames (stereo with both decisions, mono, three channels; one call of many frames and calls of one),
+    frames of samples far beyond 16 bits, and the KAT blocks -- and so must the any-length kernel on the same bytes."""
+    from sela_amd import codec
+
+    o = oracle()
+    for pcm in (synth_frames(40, 2, 0), synth_frames(7, 1, 2), synth_frames(5, 3, 4)):
+        ch = pcm.shape[2]
+        frames, offs = codec.encode_host(pcm)
+        offered, alone, took = _both_decoders(frames, offs, ch)
+        assert took == 1
+        for f in range(pcm.shape[0]):
+            for c in range(ch):
+                assert np.array_equal(offered[f][c], pcm[f, :, c].astype(np.int32)), (f, c)
+                assert np.array_equal(alone[f][c], offered[f][c]), (f, c)
+        one = codec.decode_i32(frames[int(offs[3]):int(offs[4])], _one(int(offs[4] - offs[3])), ch)[0]  # (the library's own choice)
+        assert np.array_equal(np.stack(one, axis=1), pcm[3].astype(np.int32))
+    # samples no WAV file holds: 21-bit tones and noise, a 32-bit frame API's business
+    rng = np.random.default_rng(5)
+    t = np.arange(2048)
+    wide = np.stack([
+        np.round((1 << 20) * 0.9 * np.sin(t * 0.01) + rng.normal(0, 3000, 2048)),
+        np.round((1 << 19) * np.sin(t * 0.31 + 1) + rng.normal(0, 10, 2048)),
+        rng.integers(-(1 << 20), 1 << 20, 2048).astype(np.float64),
+    ]).astype(np.int32)
+    taken = 0
+    for chans in (wide[:1], wide[1:2], wide[:2], wide):
+        frames, offs = codec.encode_i32(chans[None])
+        want = o.frame_encode_i32(chans)
+        assert frames.tobytes() == want
+        ref_dec, used = o.frame_decode_i32(want, len(chans))
+        offered, alone, took = _both_decoders(frames, offs, len(chans))
+        # the standard kernel takes a frame whose subframes all fit the parser's plan (1072 aligned words; the uniform 21-bit
+        # noise of the third channel does not)
+        assert took == int(all(w <= 1072 for w in _subframe_words(want, len(chans)))) and used == len(want), (len(chans), _subframe_words(want, len(chans)))
+        taken += took
+        for c in range(len(chans)):
+            assert np.array_equal(offered[0][c], ref_dec[c]) and np.array_equal(alone[0][c], ref_dec[c]), c
+    assert taken >= 2
+    names = [str(n) for n in kats["blk_names"]]
+    blocks = np.stack([kats[f"blk/{n}/samples"] for n in names]).astype(np.int32)  # (diff_extreme is 17-bit)
+    frames, offs = codec.encode_i32(blocks[:, None, :])
+    taken = 0
+    for i, name in enumerate(names):  # (a call per block: the standard kernel takes a chunk whole or not at all)
+        blob = frames[int(offs[i]):int(offs[i + 1])]
+        ref_dec, _ = o.frame_decode_i32(blob.tobytes(), 1)
+        offered, alone, took = _both_decoders(blob, _one(len(blob)), 1)
+        assert took == int(_subframe_words(blob.tobytes(), 1)[0] <= 1072), name
+        taken += took
+        assert np.array_equal(offered[0][0], ref_dec[0]) and np.array_equal(alone[0][0], ref_dec[0]), name
+    assert taken >= len(names) // 2
+
+
+def test_what_the_standard_kernel_leaves_alone_is_decoded_by_the_any_length_kernel(gpu):  # noqa: F811
+    """A chunk with anything the standard kernel does not take -- a frame of another length among 2048-sample ones, a Rice stream
+    beyond the parser's plan (incompressible full-scale noise), a subframe type the reference ignores -- is decoded again,
+    whole, by the any-length kernel: same answer as with that kernel alone, and the standard kernel's count stays."""
+    import struct
+
+    from sela_amd import codec
+
+    o = oracle()
+    std = synth_frames(6, 2, 9)
+    blobs = [o.frame_encode(std[f]) for f in range(6)]
+    odd = synth_pcm(1000 * 2, 2, 3).reshape(2, 1000, 2)
+    blobs.insert(3, o.frame_encode(odd[0]))
+    stream = np.frombuffer(b"".join(blobs), np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(b) for b in blobs])]).astype(np.uint64)
+    offered, alone, took = _both_decoders(stream, offs, 2)
+    assert took == 0
+    for f in range(len(blobs)):
+        ref_dec, _ = o.frame_decode_i32(blobs[f], 2)
+        for c in range(2):
+            assert np.array_equal(offered[f][c], ref_dec[c]) and np.array_equal(alone[f][c], ref_dec[c]), (f, c)
+    # beyond the plan: more than 1072 aligned words in one subframe
+    noise = np.random.default_rng(2).integers(-(1 << 19), 1 << 19, (1, 2, 2048)).astype(np.int32)
+    frames, fo = codec.encode_i32(noise)
+    assert max(_subframe_words(frames.tobytes(), 2)) > 1072
+    offered, alone, took = _both_decoders(frames, fo, 2)
+    assert took == 0
+    ref_dec, _ = o.frame_decode_i32(frames.tobytes(), 2)
+    for c in range(2):
+        assert np.array_equal(offered[0][c], ref_dec[c]) and np.array_equal(alone[0][c], ref_dec[c])
+    # a subframe of a type the reference's two passes both skip (src/frame/frame_decoder.cpp:17-69): its channel stays empty
+    blob = bytearray(blobs[0])
+    second = 4 + 12 + 4 * (struct.unpack_from("<H", blob, 8)[0] + struct.unpack_from("<H", blob, 4 + 7 + 4 * struct.unpack_from("<H", blob, 8)[0] + 1)[0])
+    assert blob[second] == 1  # (the second subframe's channel byte)
+    blob[second + 1] = 7
+    b = np.frombuffer(bytes(blob), np.uint8)
+    ref_dec, used = o.frame_decode_i32(bytes(blob), 2)
+    offered, alone, took = _both_decoders(b, _one(len(blob)), 2)
+    assert took == 0 and used == len(blob)
+    for c in range(2):
+        assert np.array_equal(offered[0][c], ref_dec[c]) and np.array_equal(alone[0][c], ref_dec[c]), c
+
+
+def test_hostile_2048_sample_frames_through_both_decoders(gpu):  # noqa: F811
+    """Frames of 2048 samples no encoder wrote (random words as Rice streams, random parameters and orders, coefficient values
+    outside the tables): whatever the standard kernel takes must be the oracle's wrap-around arithmetic in 32 bits, whatever it
+    leaves alone the any-length kernel's answer; failures (a stream that runs dry, a coefficient beyond int64) fail both ways."""
+    import ctypes as C
+    import struct
+
+    from sela_amd import capi, codec
+
+    o = oracle()
+    rng = np.random.default_rng(123)
+    same = failed = taken = 0
+    for trial in range(160):
+        ch = int(rng.integers(1, 4))
+        subs = []
+        roomy = rng.random() < 0.75
+        for c in range(ch):
+            order = int(rng.integers(0, 101))
+            ck = int(rng.integers(0, 10))
+            rk = int(rng.integers(0, 14))
+            n = 2048
+            cwords = (order * (ck + 3)) // 32 + 2 + int(rng.integers(0, 4)) if roomy else int(rng.integers(0, 40))
+            rwords = min(1040 - cwords, (n * (rk + 3)) // 32 + 8 + int(rng.integers(0, 8))) if roomy else int(rng.integers(1, 900))
+            dense = rng.random() < 0.3
+            mk = (lambda m: (rng.integers(0, 1 << 32, m, dtype=np.uint64) & rng.integers(0, 1 << 32, m, dtype=np.uint64)
+                             & (rng.integers(0, 1 << 32, m, dtype=np.uint64) if not dense else np.uint64(0xFFFFFFFF))).astype(np.uint32))
+            cw, rw = mk(cwords), mk(rwords)
+            typ = 1 if (c > 0 and rng.random() < 0.3) else 0
+            parent = int(rng.integers(0, c)) if typ else c
+            subs.append(struct.pack("<BBBBHB", c, typ, parent, ck, cwords, order) + cw.tobytes() + struct.pack("<BHH", rk, rwords, n) + rw.tobytes())
+        blob = bytes.fromhex("00ff55aa") + b"".join(subs)
+        fl = C.c_uint32(0)
+        b = np.frombuffer(blob, np.uint8).copy()
+        out = np.zeros((ch, 2048), np.int32)
+        counts = np.zeros(ch, np.uint32)
+        used = o._fdec32(b, ch, out, 2048, counts, C.byref(fl))
+        assert used == len(blob)
+        bad = fl.value & (8 | 2 | 32)  # RICE_OVERRUN, COEF_OVERFLOW, BAD_FRAME
+        offs = np.array([0, len(blob)], np.uint64)
+        if bad:
+            for mode in (1, 0):
+                capi.lib().sela_hip_debug_standard_first(mode)
+                try:
+                    with pytest.raises(capi.SelaHipError) as err:
+                        codec.decode_i32(b, offs, ch)
+                finally:
+                    capi.lib().sela_hip_debug_standard_first(-1)
+                assert err.value.code in (-5, -6), (trial, mode, hex(fl.value))
+            failed += 1
+        else:
+            offered, alone, took = _both_decoders(b, offs, ch)
+            taken += took
+            for c in range(ch):
+                assert np.array_equal(offered[0][c], out[c, : int(counts[c])]), (trial, c, took, hex(fl.value))
+                assert np.array_equal(alone[0][c], out[c, : int(counts[c])]), (trial, c, hex(fl.value))
+            same += 1
+    assert same >= 40 and failed >= 20 and taken >= 20, (same, failed, taken)

@@ -13,11 +13,26 @@ for CFG in "" "--lanes 1" "--priorities 0" "--priorities 0 --lanes 1" "--priorit
 done > "$OUT/headline_variants.txt" 2>&1
 SELA_SWEEP_HOST=0 python tools/sweep.py > "$OUT/sweep.txt" 2>&1
 [ -x tools/tmp/chain_ubench_bin ] && tools/tmp/chain_ubench_bin > "$OUT/chain_ubench.txt" 2>&1
-# the any-length route: calls and kernels
-python tools/generic_probe.py 2>&1 | grep -v amdgpu.ids > "$OUT/generic_route.txt"
-(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/gp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gp -o gp -- python "$ROOT/tools/generic_probe.py" > /tmp/gp.log 2>&1; find /tmp/gp -name "*kernel_stats.csv" -exec cp {} "$OUT/generic_kernel_stats.csv" \;)
-# the frame classes from many threads: the decoder class on its exact route and on the coalesced fast kernels
-{ for T in 1 4 16 64; do host/sela_filebench frames $T 16; done; for T in 1 4 16 64; do host/sela_filebench frames $T 16 fast; done; } > "$OUT/frame_classes_fanout.txt" 2>&1
+# the any-length route: calls (small batches, ONE frame, large batches) and kernels, launch by launch
+python tools/generic_probe.py big 2>&1 | grep -v amdgpu.ids > "$OUT/generic_route.txt"
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/gp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gp -o gp -- python "$ROOT/tools/generic_probe.py" big > /tmp/gp.log 2>&1
+ find /tmp/gp -name "*kernel_stats.csv" -exec cp {} "$OUT/generic_kernel_stats.csv" \;
+ find /tmp/gp -name "*kernel_trace.csv" -exec cp {} /tmp/gp_trace.csv \;)
+python - /tmp/gp_trace.csv > "$OUT/generic_launches.txt" <<'PY'
+import collections, csv, sys
+groups = collections.OrderedDict()  # (kernel, workgroups) in order of first launch -> durations
+for r in csv.DictReader(open(sys.argv[1])):
+    name = r["Kernel_Name"].split("(")[0]
+    if "sela" not in name:
+        continue
+    grid = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
+    groups.setdefault((name, grid), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("# tools/generic_probe.py big under rocprofv3 --kernel-trace: the route's kernels by launch size (workgroups = blocks, subframes or frames)")
+for (name, grid), d in groups.items():
+    print(f"{name:48s} workgroups {grid:7d}  launches {len(d):3d}  min {min(d):10.1f} us  mean {sum(d)/len(d):10.1f} us")
+PY
+# the frame classes from many threads (the reference's own loop, src/sela/encoder.cpp:58-73), three times
+{ for R in 1 2 3; do for T in 1 4 16 64; do host/sela_filebench frames $T 16; done; done; } > "$OUT/frame_classes_fanout.txt" 2>&1
 # the differential corpus (its printed summary)
 python -m pytest tests/test_gpu_round5.py -q -s -k corpus 2>&1 | grep -v amdgpu.ids | tail -6 > "$OUT/corpus.txt"
 # the default line with these profiles in place
@@ -26,7 +41,7 @@ cp "$OUT"/kernel_stats.csv "$OUT"/traffic.json "$OUT"/traffic_calibration.json "
 python bench.py > "$OUT/bench.log" 2>&1
 tail -1 "$OUT/bench.log" > "$OUT/bench_line.json"
 ls -la "$OUT"
-cat "$OUT/headline_variants.txt" "$OUT/generic_route.txt" "$OUT/frame_classes_fanout.txt" "$OUT/corpus.txt"
+cat "$OUT/headline_variants.txt" "$OUT/generic_route.txt" "$OUT/generic_launches.txt" "$OUT/frame_classes_fanout.txt" "$OUT/corpus.txt"
 grep -v amdgpu.ids "$OUT/valu_counters.txt"
 python -c "import json; d=json.load(open('$OUT/traffic.json')); print(json.dumps({k:{kk:vv for kk,vv in v.items() if 'calibrated' in kk or kk=='launches'} for k,v in d.items() if k!='_calibration'}, indent=0))"
 head -8 "$OUT/kernel_stats.csv"

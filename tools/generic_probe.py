@@ -33,3 +33,14 @@ for n, nf in ((1000, 256), (2048, 32), (4096, 64), (65535, 4)):
     one_d, _ = timed(lambda: codec.decode_i32(f1, o1, 2))
     print(f"n {n:6d} x {nf:4d} stereo frames: encode_i32 {e_ms:8.3f} ms  decode_i32 {d32_ms:8.3f} ms  sela_hip_decode (fast kernels tried first) {d16_ms:8.3f} ms"
           f"   ONE frame: encode {one_e:6.3f} ms decode {one_d:6.3f} ms   = {n * nf / e_ms / 1e3:7.1f} / {n * nf / d32_ms / 1e3:7.1f} M samples/s")
+
+# Large batches (argument "big"): what the route sustains when the device is full -- host pointers in and out (pageable), so
+# the call times include the copies; the kernels' own durations come from running this under rocprofv3 --kernel-trace --stats.
+if "big" in sys.argv[1:]:
+    for n, nf in ((1000, 8000), (2048, 3875), (4096, 2000)):
+        pcm = synth_pcm(n * nf, 2, 23).reshape(nf, n, 2)
+        planar = np.ascontiguousarray(pcm.transpose(0, 2, 1)).astype(np.int32)
+        e_ms, (frames, offs) = timed(lambda: codec.encode_i32(planar), reps=2)
+        d32_ms, dec = timed(lambda: codec.decode_i32(frames, offs, 2), reps=2)
+        print(f"big: n {n:6d} x {nf:5d} stereo frames: encode_i32 {e_ms:8.3f} ms  decode_i32 {d32_ms:8.3f} ms   = {n * nf / e_ms / 1e3:7.1f} / "
+              f"{n * nf / d32_ms / 1e3:7.1f} M samples/s (copies from and to pageable host memory included)")
