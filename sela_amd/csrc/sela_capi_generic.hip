@@ -213,7 +213,7 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
     Arena& g_arena = ctx->arena;
     const uint32_t n_sig = channels == 2 ? 3u : channels;
     const size_t in_frame_bytes = (size_t)n * channels * (in16 ? 2 : 4);
-    const size_t per_frame = (size_t)n_sig * n * 16 + (size_t)n_sig * (kMaxOrder * 4 + sizeof(GenericMeta) + 2 * kPiece) + in_frame_bytes + (size_t)channels * 12 + 8;
+    const size_t per_frame = (size_t)n_sig * n * 8 + (size_t)n_sig * (kMaxOrder * 4 + sizeof(GenericMeta) + 2 * kPiece) + in_frame_bytes + (size_t)channels * 12 + 8;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
     uint64_t base_bytes = 0;
     frame_offsets_out[0] = 0;
@@ -221,13 +221,12 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
     for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const uint32_t cf = std::min(chunk, n_frames - f0);
         const size_t blocks = (size_t)cf * n_sig, subs = (size_t)cf * channels;
-        const size_t fixed = blocks * n * 16 + blocks * (kMaxOrder * 4 + sizeof(GenericMeta)) + cf * in_frame_bytes + (subs + 1) * 12 + ((size_t)cf + 1) * 8 + 64 + 12 * kPiece;
+        const size_t fixed = blocks * n * 8 + blocks * (kMaxOrder * 4 + sizeof(GenericMeta)) + cf * in_frame_bytes + (subs + 1) * 12 + ((size_t)cf + 1) * 8 + 64 + 12 * kPiece;
         hipError_t e = g_arena.reserve(fixed);
         if (e != hipSuccess)
             return report_hip_error(e, "generic encode: scratch");
         void* d_in = g_arena.take<uint8_t>(cf * in_frame_bytes);
         int32_t* d_sig = g_arena.take<int32_t>(blocks * n);
-        double* d_cen = g_arena.take<double>(blocks * n);
         int32_t* d_res = g_arena.take<int32_t>(blocks * n);
         int32_t* d_q = g_arena.take<int32_t>(blocks * kMaxOrder);
         GenericMeta* d_meta = g_arena.take<GenericMeta>(blocks);
@@ -243,7 +242,7 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
         if (e == hipSuccess)
             e = hipMemsetAsync(d_head, 0, 24, st);
         if (e == hipSuccess)
-            e = launch_generic_analyse(d_in, in16, cf, channels, n_sig, n, d_sig, d_cen, d_res, d_q, d_meta, st);
+            e = launch_generic_analyse(d_in, in16, cf, channels, n_sig, n, d_sig, d_res, d_q, d_meta, st);
         if (e == hipSuccess)
             e = launch_generic_plan(d_meta, cf, channels, n_sig, base_bytes, d_offsets, d_word_base, d_chosen, d_status, d_head + 2, st);
         std::vector<uint64_t> head(3 + (size_t)cf + 1);
@@ -463,7 +462,7 @@ int generic_lpc_encode(const int32_t* samples, uint32_t n_blocks, uint32_t n, in
     if (!ctx)
         return report_hip_error(ctx_err, "the calling thread's scratch and stream");
     Arena& g_arena = ctx->arena;
-    const size_t per_block = (size_t)n * 20 + kMaxOrder * 4 + sizeof(GenericMeta) + 16;
+    const size_t per_block = (size_t)n * 12 + kMaxOrder * 4 + sizeof(GenericMeta) + 16;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_blocks, kChunkBudget / per_block));
     std::vector<GenericMeta> meta;
     const hipStream_t st = ctx->stream;
@@ -474,7 +473,6 @@ int generic_lpc_encode(const int32_t* samples, uint32_t n_blocks, uint32_t n, in
             return report_hip_error(e, "lpc_encode: scratch");
         int32_t* d_in = g_arena.take<int32_t>((size_t)cb * n);
         int32_t* d_sig = g_arena.take<int32_t>((size_t)cb * n);
-        double* d_cen = g_arena.take<double>((size_t)cb * n);
         int32_t* d_res = g_arena.take<int32_t>((size_t)cb * n);
         int32_t* d_q = g_arena.take<int32_t>((size_t)cb * kMaxOrder);
         GenericMeta* d_meta = g_arena.take<GenericMeta>(cb);
@@ -482,7 +480,7 @@ int generic_lpc_encode(const int32_t* samples, uint32_t n_blocks, uint32_t n, in
             return report_error(SELA_HIP_ENOMEM, "lpc_encode: internal scratch estimate too small");
         e = hipMemcpyAsync(d_in, samples + (size_t)b0 * n, (size_t)cb * n * 4, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) // a "frame" of one channel per block
-            e = launch_generic_analyse(d_in, false, cb, 1, 1, n, d_sig, d_cen, d_res, d_q, d_meta, st);
+            e = launch_generic_analyse(d_in, false, cb, 1, 1, n, d_sig, d_res, d_q, d_meta, st);
         meta.resize(cb);
         if (e == hipSuccess)
             e = hipMemcpyAsync(meta.data(), d_meta, (size_t)cb * sizeof(GenericMeta), hipMemcpyDeviceToHost, st);

@@ -16,7 +16,7 @@ struct GenericSubInfo { // one per (frame, subframe position), written by k_gene
 };
 
 size_t generic_encode_workspace_bytes(uint32_t n_frames, uint32_t channels, uint32_t n);
-hipError_t launch_generic_analyse(const void* d_input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, int32_t* d_sig, double* d_cen,
+hipError_t launch_generic_analyse(const void* d_input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, int32_t* d_sig,
     int32_t* d_res, int32_t* d_q, GenericMeta* d_meta, hipStream_t stream);
 hipError_t launch_generic_plan(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint64_t base_bytes, uint64_t* d_frame_offsets,
     uint64_t* d_word_base, uint32_t* d_chosen, uint32_t* d_status, uint64_t* d_total_words, hipStream_t stream);

@@ -42,8 +42,8 @@ __device__ __forceinline__ int32_t trunc_to_i32(double v)
     return (int32_t)v;
 }
 
-// OR the low `nbits` (1..32) of v into a zeroed word buffer in global memory at bit position pos
-__device__ __forceinline__ void or_bits_global(uint32_t* buf, uint64_t pos, uint32_t v, uint32_t nbits)
+// OR the low `nbits` (1..32) of v into a zeroed word buffer (global memory or LDS) at bit position pos
+__device__ __forceinline__ void or_bits(uint32_t* buf, uint64_t pos, uint32_t v, uint32_t nbits)
 {
     const uint64_t w = pos >> 5;
     const uint32_t sh = (uint32_t)pos & 31;
@@ -53,51 +53,63 @@ __device__ __forceinline__ void or_bits_global(uint32_t* buf, uint64_t pos, uint
 }
 
 // one Golomb-Rice codeword (src/rice/rice_encoder.cpp:41-53): u >> k ones, a zero, the low k bits MSB first
-__device__ inline void put_codeword_global(uint32_t* buf, uint64_t pos, uint32_t u, uint32_t k)
+__device__ inline void put_codeword(uint32_t* buf, uint64_t pos, uint32_t u, uint32_t k)
 {
     uint32_t ones = u >> k;
     const uint32_t rem = k ? __brev(u << (32 - k)) : 0u;
     while (ones >= 32) {
-        or_bits_global(buf, pos, 0xFFFFFFFFu, 32);
+        or_bits(buf, pos, 0xFFFFFFFFu, 32);
         pos += 32;
         ones -= 32;
     }
-    or_bits_global(buf, pos, (1u << ones) - 1u, ones + 1); // the ones and their terminator (a zero: nothing to OR)
+    or_bits(buf, pos, (1u << ones) - 1u, ones + 1); // the ones and their terminator (a zero: nothing to OR)
     pos += ones + 1;
     if (k)
-        or_bits_global(buf, pos, rem, k);
+        or_bits(buf, pos, rem, k);
 }
 
 // rice::RiceEncoder::calculateOptimumRiceParam (src/rice/rice_encoder.cpp:20-33) for values v[0..n) of one stream: all 20
 // candidates, the first minimum.  `wide`: a value whose int32 zig-zag overflows (undefined in the reference).
 __device__ inline void rice_plan_stream(const int32_t* v, uint32_t n, int lane, uint32_t& best_k, uint64_t& best_bits, bool& wide)
 {
-    uint64_t sum[SELA_MAX_RICE_PARAM];
-#pragma unroll
-    for (int k = 0; k < SELA_MAX_RICE_PARAM; k++)
-        sum[k] = 0;
-    bool w = false;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const int32_t x = v[i];
-        w |= (x >= (1 << 30)) || (x < -(1 << 30));
-        const uint32_t u = zigzag32(x);
-#pragma unroll
-        for (int k = 0; k < SELA_MAX_RICE_PARAM; k++)
-            sum[k] += u >> k;
-    }
+    // (the twenty candidates in two halves, a pass over the values each, one reduction at a time: with all twenty sums and their
+    // reductions in flight at once the kernel needed 180 registers -- two waves per SIMD)
+    constexpr int kHalf = SELA_MAX_RICE_PARAM / 2;
     best_k = 0;
     best_bits = ~0ull;
+    bool w = false;
+#pragma unroll 1
+    for (int k0 = 0; k0 < SELA_MAX_RICE_PARAM; k0 += kHalf) {
+        uint64_t sum[kHalf];
 #pragma unroll
-    for (int k = 0; k < SELA_MAX_RICE_PARAM; k++) {
-        const uint64_t bits = wave_sum_wrap(sum[k]) + (uint64_t)n * (uint64_t)(1 + k);
-        if (bits < best_bits) // strict: the FIRST minimum
-            best_bits = bits, best_k = (uint32_t)k;
+        for (int k = 0; k < kHalf; k++)
+            sum[k] = 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const int32_t x = v[i];
+            w |= (x >= (1 << 30)) || (x < -(1 << 30));
+            const uint32_t u = zigzag32(x) >> k0;
+#pragma unroll
+            for (int k = 0; k < kHalf; k++)
+                sum[k] += u >> k;
+        }
+#pragma unroll
+        for (int k = 0; k < kHalf; k++) {
+            const uint64_t bits = wave_sum_wrap(sum[k]) + (uint64_t)n * (uint64_t)(1 + k0 + k);
+            if (bits < best_bits) // strict: the FIRST minimum
+                best_bits = bits, best_k = (uint32_t)(k0 + k);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     wide = __any(w);
 }
 
-// pack the stream v[0..n) with parameter k into zeroed words
-__device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k, uint32_t* out, int lane)
+// pack the stream v[0..n) with parameter k into zeroed words.  The 64 codewords of a round are OR-ed together in an LDS window
+// (`win`, kPackWindow words) and go out as whole words: plain stores, but for the round's first and last word, which the
+// rounds before and behind it share (an atomic OR each; first version: every codeword piece an atomic OR in global memory,
+// 0.85 ms of a 3.6 ms encode at 3875 stereo frames).  A round longer than the window (unary runs of thousands of bits) goes
+// piece by piece as before.
+constexpr uint32_t kPackWindow = 512; // words: 16,384 bits for 64 codewords
+__device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k, uint32_t* out, int lane, uint32_t* win)
 {
     uint64_t base = 0;
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
@@ -113,11 +125,31 @@ __device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k
             if (lane >= d)
                 incl += ((uint64_t)hi << 32) | lo;
         }
-        if (valid)
-            put_codeword_global(out, base + incl - len, u, k);
         const uint32_t tlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)incl, 63);
         const uint32_t thi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(incl >> 32), 63);
-        base += ((uint64_t)thi << 32) | tlo;
+        const uint64_t total = ((uint64_t)thi << 32) | tlo; // the round's bits (wave-uniform)
+        const uint64_t first_word = base >> 5, span = ((base + total + 31) >> 5) - first_word;
+        if (span <= kPackWindow) {
+            for (uint32_t w = lane; w < (uint32_t)span; w += 64)
+                win[w] = 0;
+            wave_sync();
+            if (valid)
+                put_codeword(win, (base & 31) + incl - len, u, k);
+            wave_sync();
+            for (uint32_t w = lane; w < (uint32_t)span; w += 64) {
+                const uint32_t x = win[w];
+                if (x == 0)
+                    continue; // (the words are zeroed)
+                if (w == 0 || w + 1 == (uint32_t)span)
+                    atomicOr(&out[first_word + w], x);
+                else
+                    out[first_word + w] = x;
+            }
+            wave_sync();
+        } else if (valid) {
+            put_codeword(out, base + incl - len, u, k);
+        }
+        base += total;
     }
 }
 
@@ -132,7 +164,7 @@ __device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k
 // then both Rice plans (rice_encoder.cpp:20-33, 37).
 template <bool kIn16>
 __global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__ input, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n,
-    int32_t* __restrict__ sig_ws, double* __restrict__ cen_ws, int32_t* __restrict__ res_ws, int32_t* __restrict__ q_ws, GenericMeta* __restrict__ meta)
+    int32_t* __restrict__ sig_ws, int32_t* __restrict__ res_ws, int32_t* __restrict__ q_ws, GenericMeta* __restrict__ meta)
 {
     __shared__ double g0[128], g1[128], kk[128];
     __shared__ int64_t a_lds[kMaxOrder + 1];
@@ -143,7 +175,6 @@ __global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__
     const int lane = threadIdx.x;
     const uint32_t f = b / n_sig, sg = b % n_sig;
     int32_t* const s = sig_ws + (size_t)b * n;
-    double* const cen = cen_ws + (size_t)b * n;
     int32_t* const r = res_ws + (size_t)b * n;
     uint32_t flags = 0;
 
@@ -165,32 +196,43 @@ __global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__
             s[j] = v;
         }
         const double x = valid ? (double)v / SELA_SAMPLE_SCALE : 0.0;
-        if (valid)
-            cen[j] = x;
         const int cnt = n - j0 < 64u ? (int)(n - j0) : 64;
         for (int l = 0; l < cnt; l++)
             sum += read_lane(x, l);
     }
     const double mean = sum / (double)n;
-    for (uint32_t j = lane; j < n; j += 64)
-        cen[j] = cen[j] - mean;
-    __threadfence(); // the other lanes' s[] and cen[] are read below
+    __threadfence(); // the other lanes' s[] is read below
 
     // ---- autocorrelation: lags lane and lane + 64 ---------------------------------------------------------------------------
+    // In registers: w_lo / w_hi hold c[j - lane] / c[j - 64 - lane] (c = x - mean; zero before the block: a product with it adds
+    // +-0, which leaves an accumulator as it is -- c is finite).  A step moves both windows up one lane (DPP), feeds lane 0 with the
+    // new sample (a scalar, read from the lane that loaded it) and with what leaves the first window, and adds c[j] * window: every
+    // accumulator sees its products in the reference's order.  64 samples per load, no memory access inside a round.
+    // (First version: c[] in global scratch, three loads per step -- 4.6 ms of analysis for 3875 stereo frames, this form 1.4.)
     double acc_lo = 0.0, acc_hi = 0.0;
     {
-        const uint32_t lag_lo = (uint32_t)lane, lag_hi = (uint32_t)lane + 64;
-        const bool has_hi = lag_hi <= (uint32_t)kMaxOrder;
-#pragma unroll 4
-        for (uint32_t j = 0; j < n; j++) {
-            const double cj = cen[j];
-            if (j >= lag_lo) {
-                const double p = cj * cen[j - lag_lo];
-                acc_lo += p;
-            }
-            if (has_hi && j >= lag_hi) {
-                const double p = cj * cen[j - lag_hi];
-                acc_hi += p;
+        double w_lo = 0.0, w_hi = 0.0;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+            const bool valid = j0 + lane < n;
+            const double c_mine = valid ? (double)s[j0 + lane] / SELA_SAMPLE_SCALE - mean : 0.0;
+            auto step = [&](int t) {
+                const double cj = read_lane(c_mine, t);
+                const double leaving = read_lane(w_lo, 63);
+                w_lo = wave_shr1(cj, w_lo);
+                w_hi = wave_shr1(leaving, w_hi);
+                const double p_lo = cj * w_lo;
+                const double p_hi = cj * w_hi;
+                acc_lo += p_lo;
+                acc_hi += p_hi;
+            };
+            if (n - j0 >= 64u) {
+#pragma unroll
+                for (int t = 0; t < 64; t++)
+                    step(t);
+            } else {
+                const int cnt = (int)(n - j0);
+                for (int t = 0; t < cnt; t++)
+                    step(t);
             }
         }
     }
@@ -279,12 +321,29 @@ __global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__
     // ---- residues (:98-119): r[0] = s[0]; r[i] = s[i] - (int32)((2^34 + sum_{j=1..min(i,order)} a[j] s[i-j]) >> 35) ----------
     if ((uint32_t)order >= n)
         flags |= SELA_HIP_FLAG_SHORT_BLOCK; // the reference's warm-up loop reads samples[1 .. order] (:104-110): past its vector
-    for (uint32_t i = lane; i < n; i += 64) {
-        uint64_t temp = (uint64_t)1 << (SELA_Q_SHIFT - 1);
-        const uint32_t taps = i < (uint32_t)order ? i : (uint32_t)order;
-        for (uint32_t j = 1; j <= taps; j++)
-            temp += (uint64_t)a_lds[j] * (uint64_t)(int64_t)s[i - j];
-        r[i] = (int32_t)((uint32_t)s[i] - (uint32_t)(int32_t)((int64_t)temp >> SELA_Q_SHIFT));
+    // In registers as well: a round's 64 samples, the 64 before them and the 64 before those; tap j wants sample i - j = the
+    // value j lanes down, so a window starts as the round's own samples and moves up one lane per tap, lane 0 fed from the
+    // rounds before (zero before the block: a tap that reaches there adds 0, which is what "taps = min(i, order)" means).
+    {
+        const uint32_t o = (uint32_t)order;
+        int32_t before1 = 0, before2 = 0; // samples i0 - 64 + lane, i0 - 128 + lane
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const bool valid = i0 + lane < n;
+            const int32_t mine = valid ? s[i0 + lane] : 0;
+            uint64_t temp = (uint64_t)1 << (SELA_Q_SHIFT - 1);
+            int32_t win = mine;
+#pragma unroll 4
+            for (uint32_t j = 1; j <= o; j++) {
+                // lane 0's tap j is sample i0 - j: lane 64 - j of the round before, lane 128 - j of the one before that
+                const int32_t feed = j <= 64u ? __builtin_amdgcn_readlane(before1, (int)(64u - j)) : __builtin_amdgcn_readlane(before2, (int)(128u - j));
+                win = __builtin_amdgcn_update_dpp(feed, win, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                temp += (uint64_t)a_lds[j] * (uint64_t)(int64_t)win;
+            }
+            if (valid)
+                r[i0 + lane] = (int32_t)((uint32_t)mine - (uint32_t)(int32_t)((int64_t)temp >> SELA_Q_SHIFT));
+            before2 = before1;
+            before1 = mine;
+        }
     }
     __threadfence();
 
@@ -392,9 +451,10 @@ __global__ __launch_bounds__(64) void k_generic_pack(const GenericMeta* __restri
     const GenericMeta m = meta[b];
     if (m.flags & (SELA_HIP_FLAG_WORDS_CAP | SELA_HIP_FLAG_RICE_RANGE))
         return;
+    __shared__ uint32_t win[kPackWindow];
     uint32_t* const out = words + word_base[sub];
-    rice_pack_stream(q_ws + b * kMaxOrder, m.order, m.coef_k, out, lane);
-    rice_pack_stream(res_ws + b * n, n, m.res_k, out + m.coef_words, lane);
+    rice_pack_stream(q_ws + b * kMaxOrder, m.order, m.coef_k, out, lane, win);
+    rice_pack_stream(res_ws + b * n, n, m.res_k, out + m.coef_words, lane, win);
 }
 
 // ---- assemble: the on-disk bytes (src/file/sela_file.cpp:115-135), one workgroup per subframe -------------------------------
@@ -811,19 +871,19 @@ __global__ __launch_bounds__(64) void k_generic_lpc_decode(const int32_t* __rest
 size_t generic_encode_workspace_bytes(uint32_t n_frames, uint32_t channels, uint32_t n)
 {
     const size_t n_sig = channels == 2 ? 3 : channels, blocks = (size_t)n_frames * n_sig;
-    return blocks * n * (4 + 8 + 4) + blocks * kMaxOrder * 4 + blocks * sizeof(GenericMeta) + ((size_t)n_frames * channels + 1) * (8 + 4) + 1024;
+    return blocks * n * (4 + 4) + blocks * kMaxOrder * 4 + blocks * sizeof(GenericMeta) + ((size_t)n_frames * channels + 1) * (8 + 4) + 1024;
 }
 
-hipError_t launch_generic_analyse(const void* d_input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, int32_t* d_sig, double* d_cen,
+hipError_t launch_generic_analyse(const void* d_input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, int32_t* d_sig,
     int32_t* d_res, int32_t* d_q, GenericMeta* d_meta, hipStream_t stream)
 {
     const uint32_t blocks = n_frames * n_sig;
     if (blocks == 0)
         return hipSuccess;
     if (in16)
-        hipLaunchKernelGGL(k_generic_analyse<true>, dim3(blocks), dim3(64), 0, stream, d_input, n_frames, channels, n_sig, n, d_sig, d_cen, d_res, d_q, d_meta);
+        hipLaunchKernelGGL(k_generic_analyse<true>, dim3(blocks), dim3(64), 0, stream, d_input, n_frames, channels, n_sig, n, d_sig, d_res, d_q, d_meta);
     else
-        hipLaunchKernelGGL(k_generic_analyse<false>, dim3(blocks), dim3(64), 0, stream, d_input, n_frames, channels, n_sig, n, d_sig, d_cen, d_res, d_q, d_meta);
+        hipLaunchKernelGGL(k_generic_analyse<false>, dim3(blocks), dim3(64), 0, stream, d_input, n_frames, channels, n_sig, n, d_sig, d_res, d_q, d_meta);
     return hipGetLastError();
 }
 
