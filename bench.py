@@ -884,7 +884,7 @@ def kernel_blocks(bench: Bench, k_enc, k_dec, n0: int, sela_bytes0: int, counter
 
 def any_length_leg(np):
     """The any-length / 32-bit route (sela_generic.hip behind sela_hip_encode / sela_hip_decode with samples_per_channel != 2048
-    and sela_hip_encode_i32 / sela_hip_decode_i32), host pointers in and out, on frames the fast kernels do not take: not tuned,
+    and sela_hip_encode_i32 / sela_hip_decode_i32), host pointers in and out, on frames the fast kernels do not take: lightly tuned,
     not part of `value` -- the line says what the route costs and that its bytes are the oracle's (the checker, as in
     cpu_baseline)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -893,7 +893,7 @@ def any_length_leg(np):
     from sela_amd.synth import synth_pcm
 
     out = {"what": "host pointers in and out, synchronous calls, best of 3 (the first call of a kind also loads its kernels and grows the thread's "
-                   "scratch); the any-length kernels (one wave per block, untuned), and for the 2048-sample 17-bit frames' decode the fast parse and "
+                   "scratch); the any-length kernels (one wave per block), and for the 2048-sample 17-bit frames' decode the fast parse and "
                    "synthesis with 32-bit samples (k_decode_subframes32); checked against the oracle"}
     o = oracle()
 

@@ -152,7 +152,7 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
  * frames.  So:
  *   sela_hip_encode() takes any samples_per_channel in 1 .. 65535 (pcm = [n_frames][samples_per_channel][channels]); other
  *     than 2048 goes through the any-length kernels (sela_generic.hip: the same arithmetic with a run-time length, one wave
- *     per block, not tuned).  frames_out needs sela_hip_encode_bound_bytes_n().  A block that is not longer than the
+ *     per block).  frames_out needs sela_hip_encode_bound_bytes_n().  A block that is not longer than the
  *     predictor order its own analysis picks makes the reference read past its vector (residue_generator.cpp:104-110):
  *     SELA_HIP_ERANGE.
  *   sela_hip_decode() takes a stream whose frames say anything in 0 .. 65535: when one says something other than 2048 the
