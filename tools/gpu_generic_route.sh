@@ -1,4 +1,5 @@
 #!/bin/bash
+# (one gpurun call) tests/test_gpu_round5.py, then tools/generic_probe.py big alone and under rocprofv3, launch by launch
 cd "$GRAFT_REPO_ROOT" || exit 1
 ROOT="$GRAFT_REPO_ROOT"
 OUT="$ROOT/gpurun_out/r05"; mkdir -p "$OUT"

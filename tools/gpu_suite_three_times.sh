@@ -1,4 +1,5 @@
 #!/bin/bash
+# (one gpurun call) the GPU suite three times over -- flaky tests show -- then smoke() and bench.py the way the driver runs it
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r05
 for i in 1 2 3; do
