@@ -643,7 +643,9 @@ def test_hostile_2048_sample_frames_through_both_decoders(gpu):  # noqa: F811
     o = oracle()
     rng = np.random.default_rng(123)
     same = failed = taken = 0
-    for trial in range(160):
+    import os
+    trials = int(os.environ.get("SELA_HOSTILE_TRIALS", "160"))  # (a long soak: SELA_HOSTILE_TRIALS=5000)
+    for trial in range(trials):
         ch = int(rng.integers(1, 4))
         subs = []
         roomy = rng.random() < 0.75
