@@ -82,13 +82,16 @@ void sela_hip_debug_encode_hashes(int on);
  * loudest sample; the product kernels leave the choice in two spare bits of their per-block records, which this reads back.
  * Synchronises the device.  Returns SELA_HIP_OK or an error code. */
 int sela_hip_debug_block_forms(const void* d_workspace, uint32_t n_frames, uint32_t channels, uint32_t* counts_out, uint8_t* forms_out);
-/* Debug hook (tests; process-wide): sela_hip_decode_i32 -- frame::FrameDecoder behind it -- offers its subframes to
- * k_decode_subframes32 first (the fast kernels' parse and synthesis with 32-bit samples, for subframes of 2048 samples that fit
- * the parser's plan) and decodes again on the any-length kernel when that kernel left anything alone.  0: never offer,
- * 1: always offer, -1: the library's choice (offer when the host's walk over the headers found only 2048-sample subframes).
- * sela_hip_debug_standard_chunks(): how many chunks of frames the standard kernel has decoded, alone, so far. */
+/* Debug hook (tests; process-wide): the any-length decoder (sela_hip_decode_i32 -- frame::FrameDecoder behind it -- and
+ * sela_hip_decode on streams that are not 2048 samples per frame) offers its subframes to k_decode_subframes32 first (the fast
+ * decoder's lane-parallel parse and tuned synthesis with 32-bit samples: one piece for 2048-sample subframes that fit the
+ * parser's plan, segments for everything else) and decodes again on the serial kernel k_generic_decode when that kernel left
+ * anything alone.  -1 / 1: the product; 0: never offer (the serial kernel alone); 2: offer, but every subframe by segments.
+ * sela_hip_debug_standard_chunks(): how many chunks of frames the fast kernel has decoded, alone, so far;
+ * sela_hip_debug_segment_subframes(): how many subframes of those chunks it parsed by segments. */
 void sela_hip_debug_standard_first(int mode);
 int sela_hip_debug_standard_chunks(void);
+long long sela_hip_debug_segment_subframes(void);
 
 #ifdef __cplusplus
 }

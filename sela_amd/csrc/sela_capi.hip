@@ -49,7 +49,7 @@ size_t generic_encode_bound_bytes(uint32_t n_frames, uint32_t channels, uint32_t
 int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n, uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out);
 uint32_t generic_index_samples(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, uint64_t* sample_offsets, bool* all_standard);
 int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out, uint32_t stride,
-    uint32_t* counts_out, int16_t* pcm_out, const uint64_t* sample_offsets, bool standard_first);
+    uint32_t* counts_out, int16_t* pcm_out, const uint64_t* sample_offsets);
 int generic_lpc_encode(const int32_t* samples, uint32_t n_blocks, uint32_t n, int32_t* order_out, int32_t* q_out, int32_t* residues_out);
 int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* residues, uint32_t n_blocks, uint32_t n, int32_t* samples_out, int64_t* coefs_out);
 size_t decode_workspace_bytes(uint32_t n_frames, uint32_t channels);
@@ -1435,8 +1435,7 @@ struct HipBackend {
     static int decode_i32_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out, uint32_t stride,
         uint32_t* counts_out)
     {
-        // (a batch of frame::FrameDecoder calls: nearly always an encoder's frames -- the standard kernel first)
-        return sela::generic_decode(frames, offsets, n_frames, channels, samples_out, stride, counts_out, nullptr, nullptr, true);
+        return sela::generic_decode(frames, offsets, n_frames, channels, samples_out, stride, counts_out, nullptr, nullptr);
     }
     static size_t encode_bound_bytes(uint32_t n_frames, uint32_t channels) { return sela_hip_encode_bound_bytes(n_frames, channels); }
     static void* take(size_t bytes) { return pool().take(bytes); }
@@ -1531,7 +1530,7 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
     const uint32_t largest = sela::generic_index_samples(frames, frame_offsets, n_frames, channels, sample_offsets.data(), &standard);
     if (standard || largest == 0)
         return fail(rc, first_error); // (malformed in the ordinary sense)
-    return sela::generic_decode(frames, frame_offsets, n_frames, channels, nullptr, largest, nullptr, pcm_out, sample_offsets.data(), false);
+    return sela::generic_decode(frames, frame_offsets, n_frames, channels, nullptr, largest, nullptr, pcm_out, sample_offsets.data());
 }
 
 size_t sela_hip_encode_bound_bytes_n(uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel)
@@ -1575,8 +1574,7 @@ int sela_hip_decode_i32(const uint8_t* frames, const uint64_t* frame_offsets, ui
     for (uint32_t f = 0; f < n_frames; f++)
         if (frame_offsets[f + 1] < frame_offsets[f])
             return fail(SELA_HIP_EFORMAT, "frame offsets must not decrease");
-    bool standard = false; // every subframe says 2048 samples: the standard kernel is tried first (sela_capi_generic.hip)
-    const uint32_t largest = sela::generic_index_samples(frames, frame_offsets, n_frames, channels, nullptr, &standard);
+    const uint32_t largest = sela::generic_index_samples(frames, frame_offsets, n_frames, channels, nullptr, nullptr);
     if (largest > stride)
         return fail(SELA_HIP_ECAPACITY, "stride is smaller than the largest samplesPerChannel of the stream (see sela_hip_index_samples)");
     // (a stream the host walk cannot follow reports 0: the kernels find and report the malformed frame)
@@ -1584,7 +1582,7 @@ int sela_hip_decode_i32(const uint8_t* frames, const uint64_t* frame_offsets, ui
     // the one-shot calls of the fast path (sela_coalescer.h): every call its own rows, its own error.
     SmallCall call;
     if (n_frames > kCoalesceFrames || hipGetDevice(&call.device) != hipSuccess)
-        return sela::generic_decode(frames, frame_offsets, n_frames, channels, samples_out, stride, counts_out, nullptr, nullptr, standard);
+        return sela::generic_decode(frames, frame_offsets, n_frames, channels, samples_out, stride, counts_out, nullptr, nullptr);
     call.channels = channels, call.n_frames = n_frames;
     call.frames = frames, call.offsets_in = frame_offsets, call.samples_out = samples_out, call.stride = stride, call.counts_out = counts_out;
     return submit_small(Coalescer::kDecode32, call);

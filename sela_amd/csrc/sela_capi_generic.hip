@@ -148,6 +148,7 @@ thread_local Lease g_lease;
 
 std::atomic<int> g_standard_first_mode{-1}; // sela_hip_debug_standard_first
 std::atomic<int> g_standard_chunks{0};
+std::atomic<long long> g_segment_subframes{0}; // subframes k_decode_subframes32 parsed by segments (sela_hip_debug_segment_subframes)
 
 constexpr size_t kPiece = 256; // what take() may add per piece
 constexpr size_t kChunkBudget = (size_t)768 << 20; // device scratch per chunk of frames
@@ -347,11 +348,12 @@ uint32_t generic_index_samples(const uint8_t* frames, const uint64_t* frame_offs
 }
 
 // One of: samples_out + counts_out (32-bit, planar, stride), or pcm_out + sample_offsets (16-bit interleaved).
-// standard_first: the chunk's subframes are first offered to k_decode_subframes32 (the fast kernels' parse and synthesis with
-// 32-bit samples, for subframes of 2048 samples: every stream an encoder writes); a chunk in which that kernel leaves anything
-// alone is decoded again by k_generic_decode.
+// Every chunk's subframes are first offered to k_decode_subframes32 (the fast decoder's lane-parallel parse and tuned synthesis
+// with 32-bit samples, any length); a chunk in which that kernel leaves anything alone -- a frame that is not whole words at
+// an aligned place, a malformed header, a stream that runs dry, coefficients outside the tables -- is decoded again by
+// k_generic_decode, which reproduces what the reference does with such streams (or reports them).
 int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out, uint32_t stride,
-    uint32_t* counts_out, int16_t* pcm_out, const uint64_t* sample_offsets, bool standard_first)
+    uint32_t* counts_out, int16_t* pcm_out, const uint64_t* sample_offsets)
 {
     if (device_ready() != SELA_HIP_OK)
         return SELA_HIP_ENODEV;
@@ -402,8 +404,8 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
             e = hipMemcpyAsync(d_sample_offsets, local.data(), local.size() * 8, hipMemcpyHostToDevice, st);
         }
         std::vector<uint32_t> tail(4 + subs);
-        const int mode = g_standard_first_mode.load(std::memory_order_relaxed);
-        const bool offer = (mode < 0 ? standard_first : mode != 0) && stride >= SELA_HIP_SAMPLES_PER_FRAME;
+        const int mode = g_standard_first_mode.load(std::memory_order_relaxed); // -1: the product; 0: the serial kernel alone; 1: as -1; 2: offered, every subframe by segments
+        const bool offer = mode != 0, standard_path = mode != 2;
         // A small chunk's samples travel with the status, one wait for the device instead of two (a call of one frame -- the
         // frame classes' kind -- is mostly waits); what they are worth is known when both have arrived.
         const size_t out_bytes = pcm_out ? (size_t)chunk_samples * channels * 2 : subs * stride * sizeof(int32_t);
@@ -419,7 +421,7 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
                 e = hipMemsetAsync(d_tail, 0, (4 + subs) * 4, st);
             if (e == hipSuccess)
                 e = launch_generic_decode(d_frames, d_offsets, base_bytes, cf, channels, stride, d_dec, d_info, d_all, d_counts, d_sample_offsets, d_pcm, d_status,
-                    attempt == 0, st);
+                    attempt == 0, standard_path, st);
             if (e == hipSuccess)
                 e = hipMemcpyAsync(tail.data(), d_tail, tail.size() * 4, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess && eager)
@@ -428,8 +430,9 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
                 e = hipStreamSynchronize(st);
             if (e != hipSuccess)
                 return report_hip_error(e, "generic decode");
-            if (attempt == 0 && tail[2] == 0) { // (every subframe was of the standard kind and came out clean)
+            if (attempt == 0 && tail[2] == 0) { // (the fast kernel took every subframe and every one came out clean)
                 g_standard_chunks.fetch_add(1, std::memory_order_relaxed);
+                g_segment_subframes.fetch_add(tail[3], std::memory_order_relaxed);
                 break;
             }
         }
@@ -541,7 +544,7 @@ int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* re
         if (e == hipSuccess && d_coefs)
             e = hipMemsetAsync(d_coefs, 0, (size_t)cb * kCoefs * 8, st);
         if (e == hipSuccess)
-            e = launch_generic_lpc_decode(d_order, d_q, d_res, cb, n, d_out, d_coefs, d_status, st);
+            e = launch_lpc_decode_any(d_order, d_q, d_res, cb, n, d_out, d_coefs, d_status, st);
         uint32_t status[4] = {};
         if (e == hipSuccess)
             e = hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, st);
@@ -566,4 +569,5 @@ int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* re
 extern "C" {
 void sela_hip_debug_standard_first(int mode) { g_standard_first_mode.store(mode, std::memory_order_relaxed); }
 int sela_hip_debug_standard_chunks(void) { return g_standard_chunks.load(std::memory_order_relaxed); }
+long long sela_hip_debug_segment_subframes(void) { return g_segment_subframes.load(std::memory_order_relaxed); }
 }

@@ -501,6 +501,7 @@ __global__ __launch_bounds__(64) void k_stage_lpc_decode(const int32_t* __restri
         const bool fits24 = build_synth_table(tables->a, tables->tab, (int)order, lane);
         SynthOut<true> out32;
         out32.samples = samples_out + (size_t)b * kBlock;
+        out32.n = (uint32_t)kBlock;
         synthesize_by_order<false, true>(order, nullptr, 0, 0, nullptr, residues + (size_t)b * kBlock, tables->tab, fits24, lane, out32);
     }
     flags = wave_or(flags);

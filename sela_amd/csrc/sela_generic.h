@@ -23,15 +23,16 @@ hipError_t launch_generic_plan(const GenericMeta* d_meta, uint32_t n_frames, uin
 hipError_t launch_generic_emit(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, const int32_t* d_res, const int32_t* d_q,
     const uint32_t* d_chosen, const uint64_t* d_word_base, uint32_t* d_words /* zeroed */, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint8_t* d_frames,
     uint64_t frames_cap, hipStream_t stream);
-// standard_first: the subframes go to k_decode_subframes32 (sela_decode.hip: the fast kernels' parse and synthesis, for subframes
-// of 2048 samples) instead of k_generic_decode; d_status[2] then counts the subframes that kernel left alone -- not zero: run
-// the launch again without standard_first.
+// fast_first: the subframes go to k_decode_subframes32 (sela_decode32.hip: the fast decoder's lane-parallel parse and tuned
+// synthesis, any length) instead of k_generic_decode (the serial walk); d_status[2] then counts the subframes that kernel left
+// alone -- not zero: run the launch again without fast_first -- and d_status[3] those it parsed by segments (standard_path:
+// 2048-sample subframes that fit the parser's plan take the frame kernel's own one-piece parse; off only in tests).
 hipError_t launch_generic_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint32_t n_frames, uint32_t channels, uint32_t stride,
     int32_t* d_dec, GenericSubInfo* d_info, int32_t* d_all, uint32_t* d_counts, const uint64_t* d_sample_offsets, int16_t* d_pcm_out, uint32_t* d_status,
-    bool standard_first, hipStream_t stream);
+    bool fast_first, bool standard_path, hipStream_t stream);
 hipError_t launch_decode_subframes32(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint32_t n_frames, uint32_t channels,
-    uint32_t stride, int32_t* d_dec, GenericSubInfo* d_info, uint32_t* d_status, hipStream_t stream);
-hipError_t launch_generic_lpc_decode(const int32_t* d_order, const int32_t* d_q, const int32_t* d_residues, uint32_t n_blocks, uint32_t n, int32_t* d_samples,
+    uint32_t stride, int32_t* d_dec, GenericSubInfo* d_info, uint32_t* d_status, bool standard_path, hipStream_t stream);
+hipError_t launch_lpc_decode_any(const int32_t* d_order, const int32_t* d_q, const int32_t* d_residues, uint32_t n_blocks, uint32_t n, int32_t* d_samples,
     int64_t* d_coefs, uint32_t* d_status, hipStream_t stream);
 
 } // namespace sela

@@ -810,63 +810,6 @@ __global__ __launch_bounds__(kCombineThreads) void k_generic_combine(const int32
     }
 }
 
-// ---- lpc::SampleGenerator on its own for any length (src/lpc/sample_generator.cpp:11-39), one wave per block -------------------
-__global__ __launch_bounds__(64) void k_generic_lpc_decode(const int32_t* __restrict__ order_in, const int32_t* __restrict__ q_in, const int32_t* __restrict__ residues,
-    uint32_t n_blocks, uint32_t n, int32_t* __restrict__ samples_out, int64_t* __restrict__ coefs_out, uint32_t* __restrict__ status)
-{
-    __shared__ int64_t a_lds[kMaxOrder + 1];
-    const uint32_t b = blockIdx.x;
-    if (b >= n_blocks)
-        return;
-    const int lane = threadIdx.x;
-    uint32_t flags = 0;
-    const int32_t o = order_in[b];
-    if (o < 0 || o > kMaxOrder) {
-        if (lane == 0)
-            atomicOr(&status[0], (uint32_t)SELA_HIP_FLAG_BAD_FRAME);
-        return;
-    }
-    const uint32_t order = (uint32_t)o;
-    const int32_t q_lo = (uint32_t)lane < order ? q_in[(size_t)b * kMaxOrder + lane] : 0;
-    const int32_t q_hi = (uint32_t)lane + 64 < order ? q_in[(size_t)b * kMaxOrder + lane + 64] : 0;
-    const double k_lo = (uint32_t)lane < order ? (order <= 1 ? 0.0 : dequant(lane, q_lo, flags)) : 0.0;
-    const double k_hi = (uint32_t)lane + 64 < order ? dequant(lane + 64, q_hi, flags) : 0.0;
-    step_up_regs(k_lo, k_hi, a_lds, (int)order, lane, flags);
-    if (coefs_out)
-        for (uint32_t i = lane; i <= order; i += kWave)
-            coefs_out[(size_t)b * (kMaxOrder + 1) + i] = a_lds[i];
-    if (samples_out) {
-        const uint64_t a_lo = (uint32_t)lane + 1 <= order ? (uint64_t)a_lds[lane + 1] : 0;
-        const uint64_t a_hi = (uint32_t)lane + 65 <= order ? (uint64_t)a_lds[lane + 65] : 0;
-        const int32_t* const r = residues + (size_t)b * n;
-        int32_t* const out = samples_out + (size_t)b * n;
-        uint64_t p_lo = 0, p_hi = 0;
-        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-            const int32_t mine = i0 + lane < n ? r[i0 + lane] : 0;
-            int32_t made = 0;
-            const int cnt = n - i0 < 64u ? (int)(n - i0) : 64;
-            for (int l = 0; l < cnt; l++) {
-                const int32_t res = __builtin_amdgcn_readlane(mine, l);
-                const uint64_t sum = read_first_lane(p_lo);
-                const uint64_t temp = ((uint64_t)1 << (SELA_Q_SHIFT - 1)) - sum;
-                const int32_t smp = (int32_t)((uint32_t)res - (uint32_t)(int32_t)((int64_t)temp >> SELA_Q_SHIFT));
-                if (lane == l)
-                    made = smp;
-                const uint64_t carry = read_first_lane(p_hi);
-                const uint32_t nlo = (uint32_t)wave_shl1((int)(uint32_t)carry, (int)(uint32_t)p_lo);
-                const uint32_t nhi = (uint32_t)wave_shl1((int)(uint32_t)(carry >> 32), (int)(uint32_t)(p_lo >> 32));
-                p_lo = (((uint64_t)nhi << 32) | nlo) + a_lo * (uint64_t)(int64_t)smp;
-                p_hi = wave_shl1_zero(p_hi) + a_hi * (uint64_t)(int64_t)smp;
-            }
-            if (i0 + lane < n)
-                out[i0 + lane] = made;
-        }
-    }
-    flags = wave_or(flags);
-    if (lane == 0 && flags)
-        atomicOr(&status[0], flags);
-}
-
 // ---- launchers --------------------------------------------------------------------------------------------------------------
 size_t generic_encode_workspace_bytes(uint32_t n_frames, uint32_t channels, uint32_t n)
 {
@@ -910,13 +853,13 @@ hipError_t launch_generic_emit(const GenericMeta* d_meta, uint32_t n_frames, uin
 
 hipError_t launch_generic_decode(const uint8_t* d_frames, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint32_t n_frames, uint32_t channels, uint32_t stride,
     int32_t* d_dec, GenericSubInfo* d_info, int32_t* d_all, uint32_t* d_counts, const uint64_t* d_sample_offsets, int16_t* d_pcm_out, uint32_t* d_status,
-    bool standard_first, hipStream_t stream)
+    bool fast_first, bool standard_path, hipStream_t stream)
 {
     const uint32_t subs = n_frames * channels;
     if (subs == 0)
         return hipSuccess;
-    if (standard_first) {
-        const hipError_t e = launch_decode_subframes32(d_frames, d_frame_offsets, base_bytes, n_frames, channels, stride, d_dec, d_info, d_status, stream);
+    if (fast_first) {
+        const hipError_t e = launch_decode_subframes32(d_frames, d_frame_offsets, base_bytes, n_frames, channels, stride, d_dec, d_info, d_status, standard_path, stream);
         if (e != hipSuccess)
             return e;
     } else
@@ -927,14 +870,6 @@ hipError_t launch_generic_decode(const uint8_t* d_frames, const uint64_t* d_fram
     else
         hipLaunchKernelGGL(k_generic_combine<false>, dim3(n_frames), dim3(kCombineThreads), 0, stream, d_dec, d_info, n_frames, channels, stride, d_all, d_counts,
             d_sample_offsets, d_pcm_out, d_status);
-    return hipGetLastError();
-}
-
-hipError_t launch_generic_lpc_decode(const int32_t* d_order, const int32_t* d_q, const int32_t* d_residues, uint32_t n_blocks, uint32_t n, int32_t* d_samples,
-    int64_t* d_coefs, uint32_t* d_status, hipStream_t stream)
-{
-    if (n_blocks)
-        hipLaunchKernelGGL(k_generic_lpc_decode, dim3(n_blocks), dim3(64), 0, stream, d_order, d_q, d_residues, n_blocks, n, d_samples, d_coefs, d_status);
     return hipGetLastError();
 }
 
