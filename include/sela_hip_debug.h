@@ -92,6 +92,10 @@ int sela_hip_debug_block_forms(const void* d_workspace, uint32_t n_frames, uint3
 void sela_hip_debug_standard_first(int mode);
 int sela_hip_debug_standard_chunks(void);
 long long sela_hip_debug_segment_subframes(void);
+/* Debug hook (tests; process-wide): the any-length encoder's residue filter runs in FP64 wherever that is exact for the block
+ * (2^34 + sum |a[j]| x max |sample| < 2^53) and on 64-bit wrap-around taps otherwise; on != 0 sends every block down the
+ * wrap-around taps. */
+void sela_hip_debug_generic_wrap_taps(int on);
 
 #ifdef __cplusplus
 }

@@ -570,4 +570,5 @@ extern "C" {
 void sela_hip_debug_standard_first(int mode) { g_standard_first_mode.store(mode, std::memory_order_relaxed); }
 int sela_hip_debug_standard_chunks(void) { return g_standard_chunks.load(std::memory_order_relaxed); }
 long long sela_hip_debug_segment_subframes(void) { return g_segment_subframes.load(std::memory_order_relaxed); }
+void sela_hip_debug_generic_wrap_taps(int on) { sela::set_generic_wrap_taps(on); }
 }

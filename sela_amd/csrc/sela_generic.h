@@ -9,7 +9,9 @@ namespace sela {
 
 struct GenericMeta { // one per (frame, signal), written by k_generic_analyse
     uint32_t order, coef_k, coef_words, res_k, res_words, flags;
+    uint32_t form; // which form of the residue filter the block took: 0 FP64 taps (exact by its bound), 1 the 64-bit wrap-around taps
 };
+void set_generic_wrap_taps(int on); // tests: every block on the wrap-around taps
 struct GenericSubInfo { // one per (frame, subframe position), written by k_generic_decode
     uint8_t channel, type, parent, ok;
     uint32_t n;

@@ -16,6 +16,8 @@
 // (independent subframes first, then dependent ones in subframe order: src/frame/frame_decoder.cpp:17-69).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "sela_device.h"
 #include "sela_generic.h"
 
@@ -66,41 +68,6 @@ __device__ inline void put_codeword(uint32_t* buf, uint64_t pos, uint32_t u, uin
     pos += ones + 1;
     if (k)
         or_bits(buf, pos, rem, k);
-}
-
-// rice::RiceEncoder::calculateOptimumRiceParam (src/rice/rice_encoder.cpp:20-33) for values v[0..n) of one stream: all 20
-// candidates, the first minimum.  `wide`: a value whose int32 zig-zag overflows (undefined in the reference).
-__device__ inline void rice_plan_stream(const int32_t* v, uint32_t n, int lane, uint32_t& best_k, uint64_t& best_bits, bool& wide)
-{
-    // (the twenty candidates in two halves, a pass over the values each, one reduction at a time: with all twenty sums and their
-    // reductions in flight at once the kernel needed 180 registers -- two waves per SIMD)
-    constexpr int kHalf = SELA_MAX_RICE_PARAM / 2;
-    best_k = 0;
-    best_bits = ~0ull;
-    bool w = false;
-#pragma unroll 1
-    for (int k0 = 0; k0 < SELA_MAX_RICE_PARAM; k0 += kHalf) {
-        uint64_t sum[kHalf];
-#pragma unroll
-        for (int k = 0; k < kHalf; k++)
-            sum[k] = 0;
-        for (uint32_t i = lane; i < n; i += 64) {
-            const int32_t x = v[i];
-            w |= (x >= (1 << 30)) || (x < -(1 << 30));
-            const uint32_t u = zigzag32(x) >> k0;
-#pragma unroll
-            for (int k = 0; k < kHalf; k++)
-                sum[k] += u >> k;
-        }
-#pragma unroll
-        for (int k = 0; k < kHalf; k++) {
-            const uint64_t bits = wave_sum_wrap(sum[k]) + (uint64_t)n * (uint64_t)(1 + k0 + k);
-            if (bits < best_bits) // strict: the FIRST minimum
-                best_bits = bits, best_k = (uint32_t)(k0 + k);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    wide = __any(w);
 }
 
 // pack the stream v[0..n) with parameter k into zeroed words.  The 64 codewords of a round are OR-ed together in an LDS window
@@ -158,17 +125,129 @@ __device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k
 // ---- analysis: one wave per (frame, signal) -------------------------------------------------------------------------------
 // lpc::ResidueGenerator::process (src/lpc/residue_generator.cpp:121-134) as written, with samples.size() = n:
 //   x[j] = s[j] / 32767 (:12-18);  mean = (sequential sum) / n (:27-30);  ac[lag] = sequential sum over j = lag .. n-1 of
-//   (x[j] - mean) * (x[j - lag] - mean), lag = 0..100 -- a lane per lag (two for lanes 0..36), all lanes walking j upwards
-//   together, so every accumulator sees the reference's order of additions (:33-38);  Schur (:47-68);  order (:70-78);
-//   quantise (:80-96);  dequantise + step-up (linear_predictor.cpp:16-61);  residues, a sample per lane (:98-119);
-// then both Rice plans (rice_encoder.cpp:20-33, 37).
-template <bool kIn16>
-__global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__ input, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n,
-    int32_t* __restrict__ sig_ws, int32_t* __restrict__ res_ws, int32_t* __restrict__ q_ws, GenericMeta* __restrict__ meta)
+//   (x[j] - mean) * (x[j - lag] - mean), lag = 0..100 (:33-38);  Schur (:47-68);  order (:70-78);  quantise (:80-96);
+//   dequantise + step-up (linear_predictor.cpp:16-61);  residues (:98-119);  then both Rice plans (rice_encoder.cpp:20-33, 37).
+//
+// Round 6: the loops of the fast kernels (sela_encode.hip) with the length a run-time value -- the first version walked
+// every chain through v_readlane and moved its windows by DPP, 45 k vector instructions for a block of 2048 samples.
+//   mean            a chunk of 64 quotients goes to LDS and comes back by same-address reads: one v_add_f64 per sample.
+//   autocorrelation lane L owns lags 2L and 2L + 1 (51 lanes): its two window values are c[j - 2L] and the one before, so a
+//                   step needs ONE new value per lane -- from a ring of 256 centred samples in LDS (+ 64 mirrored behind its
+//                   end: the 64 reads of a chunk have compile-time offsets) -- the wave-uniform c[j] as a scalar operand
+//                   (v_readlane of the register that holds the chunk), two multiplies and two adds: every product rounded
+//                   before it is added, every accumulator in ascending j.
+//   Schur           in registers: lane L holds columns 2L, 2L + 1 of gen0 / gen1; gen1[j + 1] of the odd column is the next
+//                   lane's register (one DPP move of 64 bits per stage).
+//   residues        2048 samples at a time, lane L owning 32 CONSECUTIVE samples and sliding a statically addressed window of
+//                   32 registers over its history (one new LDS word and 32 multiply-adds per tap) -- in FP64 (v_fma_f64, full
+//                   rate) where that is exact: 2^34 + sum |a[j]| x max |s| < 2^53 bounds every partial sum of integers, in any
+//                   order.  A block beyond that bound (21-bit noise with a long predictor; nothing 16-bit) takes the 64-bit
+//                   wrap-around taps in a window that moves one lane per tap, as the first version did for every block.
+//   Rice parameter  by convexity (rice_plan_convex), not by all twenty sums.
+constexpr int kGenPad = 128;                                   // "no sample" / the samples before a stretch of 2048, in front of it
+constexpr int kGenStretch = 2048;                              // samples per pass of the residue filter
+constexpr int kGenPerLane = kGenStretch / kWave;               // 32
+constexpr int kGenSBufWords = (kGenPad + kGenStretch) / 32 * 33; // index i stored at i + i / 32: 32-word strides fall on different banks
+constexpr int kGenRing = 256, kGenMirror = 64;
+
+struct AnalyseLds {
+    union {
+        struct {
+            double ring[kGenRing + kGenMirror];
+            double chunk[64];
+        } ac;
+        int32_t st[kGenSBufWords];
+    };
+    double kk[104];   // reflection coefficients, then the dequantised ones
+    int64_t a[104];   // Q35 predictor
+    double af[104];   // the same as doubles (FP64 taps)
+    int32_t q[128];
+};
+
+typedef const volatile __attribute__((address_space(3))) double* LdsDoubles; // (volatile: the reads stay ds_read_b64, 2 LDS cycles each)
+
+// x = s / 32767 (src/lpc/residue_generator.cpp:12-18): q0 = s * RN(1/32767), one residual fma, one correction fma equal the
+// correctly rounded quotient for every |s| <= 70000 (exhaustive check: tests/test_host_logic.py); anything larger divides.
+__device__ __forceinline__ double scale_any(int32_t v, bool small /* wave-uniform: every lane's |v| <= 70000 */)
 {
-    __shared__ double g0[128], g1[128], kk[128];
-    __shared__ int64_t a_lds[kMaxOrder + 1];
-    __shared__ int32_t q_lds[kMaxOrder];
+    if (small) {
+        constexpr double r = 1.0 / SELA_SAMPLE_SCALE;
+        const double x = (double)v;
+        const double q0 = x * r;
+        const double e = __builtin_fma(-SELA_SAMPLE_SCALE, q0, x);
+        return __builtin_fma(e, r, q0);
+    }
+    return (double)v / SELA_SAMPLE_SCALE;
+}
+
+// Taps j0 + JJ + 1 .. j0 + 32 of the residue filter in FP64 (the window of sela_encode.hip's fir_taps_f64): tap j uses
+// win[(t - j) mod 32] = s[32 lane + t - j] and loads the one new element s[32 lane - j].
+template <int JJ>
+__device__ __forceinline__ void gen_taps_f64(int j0, int order, int lane, const int32_t* sT, const double* a_f, double (&win)[kGenPerLane], double (&acc)[kGenPerLane])
+{
+    const int j = j0 + JJ + 1;
+    if (j > order)
+        return;
+    const double aj = read_first_lane(a_f[j]);
+    const int e = kGenPad + 32 * lane - j;
+    win[(32 - JJ - 1) & 31] = (double)sT[e + (e >> 5)];
+#pragma unroll
+    for (int t = 0; t < kGenPerLane; t++)
+        acc[t] = __builtin_fma(aj, win[(t - JJ - 1) & 31], acc[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (JJ < 31)
+        gen_taps_f64<JJ + 1>(j0, order, lane, sT, a_f, win, acc);
+}
+
+// rice::RiceEncoder::calculateOptimumRiceParam (src/rice/rice_encoder.cpp:20-33) for the values load(0 .. n): the FIRST k in
+// [0, 20) that minimises bits(k) = sum(u >> k) + n (1 + k).  The reference evaluates all 20 candidates; the same answer needs
+// a few of them because bits() is convex in k (the argument of rice_plan, sela_encode.hip): the first minimum is the smallest
+// k with T(k) - T(k + 1) <= n, found by walking from a guess near log2(mean u).  Exact 64-bit sums.  t0 = T(0) = sum of the
+// zig-zagged values.
+template <typename Load>
+__device__ __forceinline__ void rice_plan_convex(Load load, uint32_t n, int lane, uint64_t t0, uint32_t& best_k, uint64_t& best_bits)
+{
+    constexpr uint32_t kLast = SELA_MAX_RICE_PARAM - 1;
+    auto T = [&](uint32_t k) -> uint64_t {
+        uint64_t part = 0;
+        for (uint32_t i = lane; i < n; i += 64)
+            part += zigzag32(load(i)) >> k;
+        return wave_sum_wrap(part);
+    };
+    const uint64_t mean = n ? t0 / n : 0;
+    uint32_t k = mean ? 63u - (uint32_t)__clzll(mean) : 0u;
+    k = k > kLast - 1 ? kLast - 1 : k;
+    uint64_t ta = k ? T(k) : t0;
+    uint64_t tb = T(k + 1);
+    if (ta - tb <= n) { // bits(k + 1) >= bits(k): the first minimum is at or below k
+        while (k > 0) {
+            const uint64_t tc = k != 1 ? T(k - 1) : t0;
+            if (tc - ta > n)
+                break;
+            k--;
+            tb = ta;
+            ta = tc;
+        }
+    } else { // still descending: move up
+        for (;;) {
+            k++;
+            ta = tb;
+            if (k == kLast)
+                break;
+            tb = T(k + 1);
+            if (ta - tb <= n)
+                break;
+        }
+    }
+    best_k = k;
+    best_bits = ta + (uint64_t)n * (1 + k);
+}
+
+template <bool kIn16>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_generic_analyse(const void* __restrict__ input, uint32_t n_frames, uint32_t channels,
+    uint32_t n_sig, uint32_t n, int32_t* __restrict__ sig_ws, int32_t* __restrict__ res_ws, int32_t* __restrict__ q_ws, GenericMeta* __restrict__ meta, uint32_t force_wrap_taps /* tests: every block on the 64-bit wrap-around taps */)
+{
+    __shared__ __attribute__((aligned(16))) AnalyseLds lds;
     const uint32_t b = blockIdx.x;
     if (b >= n_frames * n_sig)
         return;
@@ -179,111 +258,129 @@ __global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__
     uint32_t flags = 0;
 
     // ---- the signal: a channel, or channel 0 - channel 1 of an exactly-stereo frame (src/frame/frame_encoder.cpp:18-24);
-    //      x = s / 32767 and its sequential sum --------------------------------------------------------------------------------
-    double sum = 0.0;
-    for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool valid = j < n;
-        int32_t v = 0;
-        if (valid) {
-            if (kIn16) {
-                const int16_t* pcm = static_cast<const int16_t*>(input) + (size_t)f * n * channels;
-                v = sg < channels ? (int32_t)pcm[(size_t)j * channels + sg] : (int32_t)pcm[(size_t)j * channels] - (int32_t)pcm[(size_t)j * channels + 1];
-            } else {
-                const int32_t* pl = static_cast<const int32_t*>(input) + (size_t)f * channels * n;
-                v = sg < channels ? pl[(size_t)sg * n + j] : (int32_t)((uint32_t)pl[j] - (uint32_t)pl[(size_t)n + j]);
-            }
-            s[j] = v;
+    //      x = s / 32767 and its sequential sum (:27-29) ---------------------------------------------------------------------
+    auto load_sample = [&](uint32_t j) -> int32_t {
+        if (kIn16) {
+            const int16_t* pcm = static_cast<const int16_t*>(input) + (size_t)f * n * channels;
+            return sg < channels ? (int32_t)pcm[(size_t)j * channels + sg] : (int32_t)pcm[(size_t)j * channels] - (int32_t)pcm[(size_t)j * channels + 1];
         }
-        const double x = valid ? (double)v / SELA_SAMPLE_SCALE : 0.0;
-        const int cnt = n - j0 < 64u ? (int)(n - j0) : 64;
-        for (int l = 0; l < cnt; l++)
-            sum += read_lane(x, l);
-    }
-    const double mean = sum / (double)n;
-    __threadfence(); // the other lanes' s[] is read below
-
-    // ---- autocorrelation: lags lane and lane + 64 ---------------------------------------------------------------------------
-    // In registers: w_lo / w_hi hold c[j - lane] / c[j - 64 - lane] (c = x - mean; zero before the block: a product with it adds
-    // +-0, which leaves an accumulator as it is -- c is finite).  A step moves both windows up one lane (DPP), feeds lane 0 with the
-    // new sample (a scalar, read from the lane that loaded it) and with what leaves the first window, and adds c[j] * window: every
-    // accumulator sees its products in the reference's order.  64 samples per load, no memory access inside a round.
-    // (First version: c[] in global scratch, three loads per step -- 4.6 ms of analysis for 3875 stereo frames, this form 1.4.)
-    double acc_lo = 0.0, acc_hi = 0.0;
+        const int32_t* pl = static_cast<const int32_t*>(input) + (size_t)f * channels * n;
+        return sg < channels ? pl[(size_t)sg * n + j] : (int32_t)((uint32_t)pl[j] - (uint32_t)pl[(size_t)n + j]);
+    };
+    double sum = 0.0;
+    uint32_t mag_lane = 0; // the largest |sample| of this lane
     {
-        double w_lo = 0.0, w_hi = 0.0;
+        int32_t v_next = (uint32_t)lane < n ? load_sample(lane) : 0;
         for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-            const bool valid = j0 + lane < n;
-            const double c_mine = valid ? (double)s[j0 + lane] / SELA_SAMPLE_SCALE - mean : 0.0;
-            auto step = [&](int t) {
-                const double cj = read_lane(c_mine, t);
-                const double leaving = read_lane(w_lo, 63);
-                w_lo = wave_shr1(cj, w_lo);
-                w_hi = wave_shr1(leaving, w_hi);
-                const double p_lo = cj * w_lo;
-                const double p_hi = cj * w_hi;
-                acc_lo += p_lo;
-                acc_hi += p_hi;
-            };
+            const uint32_t j = j0 + lane;
+            const bool valid = j < n;
+            const int32_t v = v_next;
+            if (j0 + 64 < n)
+                v_next = j + 64 < n ? load_sample(j + 64) : 0;
+            if (valid)
+                s[j] = v;
+            const uint32_t mag = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+            mag_lane = max(mag_lane, mag);
+            const double x = valid ? scale_any(v, !__any(mag > 70000u)) : 0.0;
+            lds.ac.chunk[lane] = x;
+            wave_sync();
+            const LdsDoubles ch = (LdsDoubles)lds.ac.chunk;
             if (n - j0 >= 64u) {
 #pragma unroll
-                for (int t = 0; t < 64; t++)
-                    step(t);
+                for (int l = 0; l < 64; l++)
+                    sum += ch[l];
             } else {
                 const int cnt = (int)(n - j0);
-                for (int t = 0; t < cnt; t++)
-                    step(t);
+                for (int l = 0; l < cnt; l++)
+                    sum += ch[l];
             }
+            wave_sync();
         }
     }
-    const double ac0 = read_lane(acc_lo, 0);
-    // normalise (:41-44): ac[i] /= ac[0] for i >= 1; ac[0] = 1.0
-    const double ac_lo = lane == 0 ? 1.0 : acc_lo / ac0;
-    const double ac_hi = acc_hi / ac0;
+    const double mean = sum / (double)n;
+    const uint32_t s_mag = wave_max_u32(mag_lane);
+    const bool small_samples = s_mag <= 70000u;
+    // the other lanes' s[] is read below: the stores have left the CU, nothing older is served from its vector cache
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
-    // ---- Schur recursion (:47-68), always 100 stages ------------------------------------------------------------------------
-    // gen0 = gen1 = ac[1..100]
-    if (lane >= 1)
-        g0[lane - 1] = g1[lane - 1] = ac_lo;
-    if (lane + 64 <= kMaxOrder)
-        g0[lane + 63] = g1[lane + 63] = ac_hi;
-    wave_sync();
-    double err = 1.0;
+    // ---- autocorrelation (:33-38): lags 2 lane and 2 lane + 1 ---------------------------------------------------------------
+    double acc_e = 0.0, acc_o = 0.0;
     {
-        const double k0 = -g1[0] / err;
-        err += g1[0] * k0;
+        for (int i = lane; i < kGenRing + kGenMirror; i += 64)
+            lds.ac.ring[i] = 0.0; // c before the block: a product with it adds +-0, which leaves an accumulator as it is
+        wave_sync();
+        double B = 0.0; // c[j - 1 - 2 lane]
+        int32_t v_next = (uint32_t)lane < n ? s[lane] : 0;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+            const bool valid = j0 + lane < n;
+            const int32_t v = v_next;
+            if (j0 + 64 < n)
+                v_next = j0 + 64 + lane < n ? s[j0 + 64 + lane] : 0;
+            const double c_mine = valid ? scale_any(v, small_samples) - mean : 0.0;
+            const uint32_t slab = (j0 >> 6) & 3u;
+            lds.ac.ring[64 * slab + lane] = c_mine;
+            if (slab == 0)
+                lds.ac.ring[kGenRing + lane] = c_mine;
+            wave_sync();
+            const LdsDoubles rl = (LdsDoubles)lds.ac.ring + ((j0 - 2u * (uint32_t)lane) & (uint32_t)(kGenRing - 1)); // c[j0 - 2 lane]
+            if (n - j0 >= 64u) {
+#pragma unroll
+                for (int t = 0; t < 64; t++) {
+                    const double cj = read_lane(c_mine, t);
+                    const double A = rl[t];
+                    const double pe = cj * A, po = cj * B;
+                    acc_e += pe;
+                    acc_o += po;
+                    B = A;
+                }
+            } else {
+                const int cnt = (int)(n - j0);
+                for (int t = 0; t < cnt; t++) {
+                    const double cj = read_lane(c_mine, t);
+                    const double A = rl[t];
+                    const double pe = cj * A, po = cj * B;
+                    acc_e += pe;
+                    acc_o += po;
+                    B = A;
+                }
+            }
+            wave_sync();
+        }
+    }
+
+    // ---- normalise (:41-44), Schur recursion (:47-68), always 100 stages ------------------------------------------------------
+    // gen0 = gen1 = ac[1 .. 100]: lane L holds columns 2L (= ac[2L + 1], its own odd lag) and 2L + 1 (= ac[2L + 2], the next
+    // lane's even lag).  A stage: gen1'[j] = gen1[j + 1] + k gen0[j]; gen0'[j] = gen1[j + 1] k + gen0[j] for the columns still
+    // alive (what lies beyond them is never read by a live column).
+    {
+        const double ac0 = read_lane(acc_e, 0);
+        const double n_e = acc_e / ac0, n_o = acc_o / ac0;
+        double g1a = n_o, g1b = wave_shl1(0.0, n_e);
+        double g0a = g1a, g0b = g1b;
+        double err = 1.0;
+        double g = read_lane(g1a, 0);
+        double k = -g / err;
+        err += g * k;
         if (lane == 0)
-            kk[0] = k0;
-        double kprev = k0;
+            lds.kk[0] = k;
+#pragma unroll 1
         for (int i = 1; i < kMaxOrder; i++) {
-            const int count = kMaxOrder - i;
-            double n1_lo = 0, n0_lo = 0, n1_hi = 0, n0_hi = 0;
-            if (lane < count) {
-                const double a = g1[lane + 1], c = g0[lane];
-                n1_lo = a + kprev * c;
-                n0_lo = a * kprev + c;
-            }
-            if (lane + 64 < count) {
-                const double a = g1[lane + 65], c = g0[lane + 64];
-                n1_hi = a + kprev * c;
-                n0_hi = a * kprev + c;
-            }
-            wave_sync();
-            if (lane < count)
-                g1[lane] = n1_lo, g0[lane] = n0_lo;
-            if (lane + 64 < count)
-                g1[lane + 64] = n1_hi, g0[lane + 64] = n0_hi;
-            wave_sync();
-            const double ki = -g1[0] / err;
-            err += g1[0] * ki;
+            const double next = wave_shl1(0.0, g1a); // gen1[2L + 2]
+            const double n1a = g1b + k * g0a, n0a = g1b * k + g0a;
+            const double n1b = next + k * g0b, n0b = next * k + g0b;
+            g1a = n1a, g0a = n0a, g1b = n1b, g0b = n0b;
+            g = read_lane(g1a, 0);
+            k = -g / err;
+            err += g * k;
             if (lane == 0)
-                kk[i] = ki;
-            kprev = ki;
+                lds.kk[i] = k;
         }
     }
     wave_sync();
-    const double k_lo = kk[lane];
-    const double k_hi = lane + 64 < kMaxOrder ? kk[lane + 64] : 0.0;
+    const double k_lo = lds.kk[lane];
+    const double k_hi = lane + 64 < kMaxOrder ? lds.kk[lane + 64] : 0.0;
+    wave_sync();
 
     // ---- order (:70-78), quantise (:80-96) ----------------------------------------------------------------------------------
     int order;
@@ -305,26 +402,98 @@ __global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__
         const int32_t q_lo = isnan(v_lo) ? 0 : trunc_to_i32(v_lo);
         const int32_t q_hi = isnan(v_hi) ? 0 : trunc_to_i32(v_hi);
         if (lane < order) {
-            q_lds[lane] = q_lo;
-            kk[lane] = order <= 1 ? 0.0 : dequant(lane, q_lo, flags);
+            lds.q[lane] = q_lo;
+            lds.kk[lane] = order <= 1 ? 0.0 : dequant(lane, q_lo, flags);
         }
         if (lane + 64 < order) {
-            q_lds[lane + 64] = q_hi;
-            kk[lane + 64] = dequant(lane + 64, q_hi, flags);
+            lds.q[lane + 64] = q_hi;
+            lds.kk[lane + 64] = dequant(lane + 64, q_hi, flags);
         }
     }
     wave_sync();
-    step_up(kk, a_lds, order, lane, flags);
+    step_up(lds.kk, lds.a, order, lane, flags);
     for (int i = lane; i < kMaxOrder; i += 64)
-        q_ws[(size_t)b * kMaxOrder + i] = i < order ? q_lds[i] : 0;
+        q_ws[(size_t)b * kMaxOrder + i] = i < order ? lds.q[i] : 0;
 
     // ---- residues (:98-119): r[0] = s[0]; r[i] = s[i] - (int32)((2^34 + sum_{j=1..min(i,order)} a[j] s[i-j]) >> 35) ----------
     if ((uint32_t)order >= n)
         flags |= SELA_HIP_FLAG_SHORT_BLOCK; // the reference's warm-up loop reads samples[1 .. order] (:104-110): past its vector
-    // In registers as well: a round's 64 samples, the 64 before them and the 64 before those; tap j wants sample i - j = the
-    // value j lanes down, so a window starts as the round's own samples and moves up one lane per tap, lane 0 fed from the
-    // rounds before (zero before the block: a tap that reaches there adds 0, which is what "taps = min(i, order)" means).
+    // which form: FP64 taps are exact while 2^34 + sum |a[j]| x max |s| < 2^53
+    bool fp64_taps;
     {
+        bool modest = true; // every |a[j]| below 2^39: their sum fits 2^46 and each is two exact FP64 halves
+        uint64_t a_abs = 0;
+        for (int j = 1 + lane; j <= order; j += 64) {
+            const int64_t aj = lds.a[j];
+            const uint64_t mag = aj < 0 ? 0 - (uint64_t)aj : (uint64_t)aj;
+            modest &= mag < ((uint64_t)1 << 39);
+            a_abs += modest ? mag : 0u;
+            const int64_t top = aj >> 20;
+            lds.af[j] = ((double)(int32_t)(top >> 16) * 65536.0 + (double)(uint32_t)((uint64_t)top & 0xFFFFu)) * 1048576.0 + (double)(uint32_t)((uint64_t)aj & 0xFFFFFu);
+        }
+        const uint64_t a_sum = wave_sum_wrap(a_abs);
+        const uint64_t room = ((uint64_t)1 << 53) - ((uint64_t)1 << (SELA_Q_SHIFT - 1));
+        fp64_taps = !__any(!modest) && (a_sum == 0 || (uint64_t)s_mag < room / a_sum) && !force_wrap_taps;
+        wave_sync();
+    }
+    uint64_t t0_lane = 0; // sum of this lane's zig-zagged residues
+    bool wide = false;
+    if (fp64_taps) {
+        int32_t* const sT = lds.st;
+        for (int m = lane; m < kGenPad; m += 64)
+            sT[m + (m >> 5)] = 0;
+        for (uint32_t i0 = 0; i0 < n; i0 += kGenStretch) {
+            if (i0) { // the stretch before this one left its last 128 samples behind: they become this one's history
+                int32_t keep[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int e = kGenStretch + lane + 64 * h; // = kGenPad + (kGenStretch - kGenPad) + ...
+                    keep[h] = sT[e + (e >> 5)];
+                }
+                wave_sync();
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int e = lane + 64 * h;
+                    sT[e + (e >> 5)] = keep[h];
+                }
+            }
+#pragma unroll 8
+            for (int t = 0; t < kGenPerLane; t++) {
+                const uint32_t i = i0 + lane + 64 * t;
+                const int e = kGenPad + lane + 64 * t;
+                sT[e + (e >> 5)] = i < n ? s[i] : 0;
+            }
+            wave_sync();
+            const int32_t* mine_s = sT + (kGenPad + 32 * lane) + ((kGenPad + 32 * lane) >> 5); // &s[i0 + 32 lane], 32 words without a pad inside
+            double win_f[kGenPerLane], acc_f[kGenPerLane];
+#pragma unroll
+            for (int t = 0; t < kGenPerLane; t++) {
+                acc_f[t] = (double)((int64_t)1 << (SELA_Q_SHIFT - 1));
+                win_f[t] = (double)mine_s[t];
+            }
+#pragma unroll 1
+            for (int j0 = 0; j0 < order; j0 += 32)
+                gen_taps_f64<0>(j0, order, lane, sT, lds.af, win_f, acc_f);
+            int32_t rr[kGenPerLane];
+#pragma unroll
+            for (int t = 0; t < kGenPerLane; t++) { // floor(sum / 2^35): |.| < 2^18
+                const int32_t pred = (int32_t)__builtin_floor(acc_f[t] * (1.0 / (double)((int64_t)1 << SELA_Q_SHIFT)));
+                rr[t] = (int32_t)((uint32_t)mine_s[t] - (uint32_t)pred);
+            }
+            const uint32_t first = i0 + 32 * (uint32_t)lane;
+#pragma unroll
+            for (int t = 0; t < kGenPerLane; t++)
+                if (first + t < n) {
+                    r[first + t] = rr[t];
+                    t0_lane += zigzag32(rr[t]);
+                    wide |= (rr[t] >= (1 << 30)) || (rr[t] < -(1 << 30));
+                }
+            wave_sync(); // (the samples are re-staged by the next stretch)
+        }
+    } else {
+        // 64-bit wrap-around taps: a round's 64 samples, the 64 before them and the 64 before those in registers; tap j wants
+        // sample i - j = the value j lanes down, so a window starts as the round's own samples and moves up one lane per tap,
+        // lane 0 fed from the rounds before (zero before the block: a tap that reaches there adds 0).
         const uint32_t o = (uint32_t)order;
         int32_t before1 = 0, before2 = 0; // samples i0 - 64 + lane, i0 - 128 + lane
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
@@ -334,26 +503,36 @@ __global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__
             int32_t win = mine;
 #pragma unroll 4
             for (uint32_t j = 1; j <= o; j++) {
-                // lane 0's tap j is sample i0 - j: lane 64 - j of the round before, lane 128 - j of the one before that
                 const int32_t feed = j <= 64u ? __builtin_amdgcn_readlane(before1, (int)(64u - j)) : __builtin_amdgcn_readlane(before2, (int)(128u - j));
                 win = __builtin_amdgcn_update_dpp(feed, win, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                temp += (uint64_t)a_lds[j] * (uint64_t)(int64_t)win;
+                temp += (uint64_t)lds.a[j] * (uint64_t)(int64_t)win;
             }
-            if (valid)
-                r[i0 + lane] = (int32_t)((uint32_t)mine - (uint32_t)(int32_t)((int64_t)temp >> SELA_Q_SHIFT));
+            if (valid) {
+                const int32_t rt = (int32_t)((uint32_t)mine - (uint32_t)(int32_t)((int64_t)temp >> SELA_Q_SHIFT));
+                r[i0 + lane] = rt;
+                t0_lane += zigzag32(rt);
+                wide |= (rt >= (1 << 30)) || (rt < -(1 << 30));
+            }
             before2 = before1;
             before1 = mine;
         }
     }
-    __threadfence();
+    // the lanes read each other's residues back for the Rice plan
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
     // ---- the two Rice plans -------------------------------------------------------------------------------------------------
     uint32_t ck, rk;
     uint64_t cbits, rbits;
-    bool cwide, rwide;
-    rice_plan_stream(q_ws + (size_t)b * kMaxOrder, (uint32_t)order, lane, ck, cbits, cwide);
-    rice_plan_stream(r, n, lane, rk, rbits, rwide);
-    if (cwide || rwide)
+    {
+        const int32_t* const q = lds.q;
+        uint64_t c0 = 0;
+        for (int i = lane; i < order; i += 64)
+            c0 += zigzag32(q[i]);
+        rice_plan_convex([&](uint32_t i) { return q[i]; }, (uint32_t)order, lane, wave_sum_wrap(c0), ck, cbits);
+        rice_plan_convex([&](uint32_t i) { return r[i]; }, n, lane, wave_sum_wrap(t0_lane), rk, rbits);
+    }
+    if (__any(wide))
         flags |= SELA_HIP_FLAG_RICE_RANGE;
     // requiredInts = ceil((float)bits / 32) (rice_encoder.cpp:37,63): exact below 2^24 bits, and a count the u16 field of the
     // subframe can carry (65535 words = 2,097,120 bits) is far below that
@@ -364,7 +543,7 @@ __global__ __launch_bounds__(64) void k_generic_analyse(const void* __restrict__
     flags = wave_or(flags);
     if (lane == 0) {
         GenericMeta m;
-        m.order = (uint32_t)order, m.coef_k = ck, m.coef_words = cwords, m.res_k = rk, m.res_words = rwords, m.flags = flags;
+        m.order = (uint32_t)order, m.coef_k = ck, m.coef_words = cwords, m.res_k = rk, m.res_words = rwords, m.flags = flags, m.form = fp64_taps ? 0u : 1u;
         meta[b] = m;
     }
 }
@@ -738,10 +917,15 @@ __global__ __launch_bounds__(64) void k_generic_decode(const uint8_t* __restrict
     }
 }
 
-// ---- combine: src/frame/frame_decoder.cpp:17-69 over the decoded subframes of a frame, one workgroup per frame ----------------
+// ---- combine: src/frame/frame_decoder.cpp:17-69 over the decoded subframes of a frame ----------------------------------------
+// One workgroup per (frame, slice of kCombineSlice samples): every slice walks the frame's subframes in the reference's order --
+// independent ones first, then dependent ones IN SUBFRAME ORDER, a later subframe of a channel overwriting an earlier one, an
+// unknown type skipped -- and moves its own samples only (a thread meets the same samples in every pass: the passes need no
+// barrier for the data, only for the channels' counts).  A frame of 65535 samples is 16 workgroups instead of one.
 // kOut16: interleaved int16 at sample_offsets[f] (src/file/wav_file.cpp:244-266 narrows so); every channel of the frame must
 // have come out with the first one's length, or the frame counts as malformed.
 constexpr int kCombineThreads = 256;
+constexpr uint32_t kCombineSlice = 4096;
 template <bool kOut16>
 __global__ __launch_bounds__(kCombineThreads) void k_generic_combine(const int32_t* __restrict__ dec_ws, const GenericSubInfo* __restrict__ info, uint32_t n_frames,
     uint32_t channels, uint32_t stride, int32_t* __restrict__ all /* [n_frames][channels][stride] by channel */, uint32_t* __restrict__ counts,
@@ -752,6 +936,8 @@ __global__ __launch_bounds__(kCombineThreads) void k_generic_combine(const int32
     if (f >= n_frames)
         return;
     const uint32_t t = threadIdx.x;
+    const uint32_t lo = blockIdx.y * kCombineSlice, hi = lo + kCombineSlice; // this workgroup's samples
+    const bool first_slice = blockIdx.y == 0;
     const GenericSubInfo* const inf = info + (size_t)f * channels;
     int32_t* const fa = all + (size_t)f * channels * stride;
     const int32_t* const fd = dec_ws + (size_t)f * channels * stride;
@@ -767,7 +953,8 @@ __global__ __launch_bounds__(kCombineThreads) void k_generic_combine(const int32
             bad = true;
             continue;
         }
-        for (uint32_t i = t; i < si.n; i += kCombineThreads)
+        const uint32_t end = min(si.n, hi);
+        for (uint32_t i = lo + t; i < end; i += kCombineThreads)
             fa[(size_t)si.channel * stride + i] = fd[(size_t)c * stride + i];
         __syncthreads();
         if (t == 0)
@@ -782,7 +969,8 @@ __global__ __launch_bounds__(kCombineThreads) void k_generic_combine(const int32
             bad = true;
             continue;
         }
-        for (uint32_t i = t; i < si.n; i += kCombineThreads)
+        const uint32_t end = min(si.n, hi);
+        for (uint32_t i = lo + t; i < end; i += kCombineThreads)
             fa[(size_t)si.channel * stride + i] = (int32_t)((uint32_t)fa[(size_t)si.parent * stride + i] - (uint32_t)fd[(size_t)c * stride + i]);
         __syncthreads();
         if (t == 0)
@@ -793,18 +981,28 @@ __global__ __launch_bounds__(kCombineThreads) void k_generic_combine(const int32
         const uint32_t n = (uint32_t)(sample_offsets[f + 1] - sample_offsets[f]);
         for (uint32_t c = 0; c < channels; c++)
             bad |= cnt[c] != n;
-        if (!bad) {
+        if (!bad && lo < n) {
+            const uint32_t end = min(n, hi);
             int16_t* const o = pcm_out + sample_offsets[f] * channels;
-            for (size_t i = t; i < (size_t)n * channels; i += kCombineThreads) {
-                const uint32_t smp = (uint32_t)(i / channels), c = (uint32_t)(i % channels);
-                o[i] = (int16_t)(uint16_t)fa[(size_t)c * stride + smp];
+            if (channels == 1) {
+                for (uint32_t i = lo + t; i < end; i += kCombineThreads)
+                    o[i] = (int16_t)(uint16_t)fa[i];
+            } else if (channels == 2) { // (a sample pair per thread: one 32-bit store)
+                uint32_t* const o2 = reinterpret_cast<uint32_t*>(o);
+                for (uint32_t i = lo + t; i < end; i += kCombineThreads)
+                    o2[i] = ((uint32_t)fa[i] & 0xFFFFu) | ((uint32_t)fa[(size_t)stride + i] << 16);
+            } else {
+                for (size_t i = (size_t)lo * channels + t; i < (size_t)end * channels; i += kCombineThreads) {
+                    const uint32_t smp = (uint32_t)(i / channels), c = (uint32_t)(i % channels);
+                    o[i] = (int16_t)(uint16_t)fa[(size_t)c * stride + smp];
+                }
             }
         }
-    } else {
+    } else if (first_slice) {
         for (uint32_t c = t; c < channels; c += kCombineThreads)
             counts[(size_t)f * channels + c] = cnt[c];
     }
-    if (bad && t == 0) {
+    if (bad && t == 0 && first_slice) {
         atomicOr(&status[0], (uint32_t)SELA_HIP_FLAG_BAD_FRAME);
         atomicAdd(&status[1], 1u);
     }
@@ -817,16 +1015,20 @@ size_t generic_encode_workspace_bytes(uint32_t n_frames, uint32_t channels, uint
     return blocks * n * (4 + 4) + blocks * kMaxOrder * 4 + blocks * sizeof(GenericMeta) + ((size_t)n_frames * channels + 1) * (8 + 4) + 1024;
 }
 
+static std::atomic<int> g_force_wrap_taps{0};
+void set_generic_wrap_taps(int on) { g_force_wrap_taps.store(on, std::memory_order_relaxed); }
+
 hipError_t launch_generic_analyse(const void* d_input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, int32_t* d_sig,
     int32_t* d_res, int32_t* d_q, GenericMeta* d_meta, hipStream_t stream)
 {
     const uint32_t blocks = n_frames * n_sig;
     if (blocks == 0)
         return hipSuccess;
+    const uint32_t wrap = g_force_wrap_taps.load(std::memory_order_relaxed) ? 1u : 0u;
     if (in16)
-        hipLaunchKernelGGL(k_generic_analyse<true>, dim3(blocks), dim3(64), 0, stream, d_input, n_frames, channels, n_sig, n, d_sig, d_res, d_q, d_meta);
+        hipLaunchKernelGGL(k_generic_analyse<true>, dim3(blocks), dim3(64), 0, stream, d_input, n_frames, channels, n_sig, n, d_sig, d_res, d_q, d_meta, wrap);
     else
-        hipLaunchKernelGGL(k_generic_analyse<false>, dim3(blocks), dim3(64), 0, stream, d_input, n_frames, channels, n_sig, n, d_sig, d_res, d_q, d_meta);
+        hipLaunchKernelGGL(k_generic_analyse<false>, dim3(blocks), dim3(64), 0, stream, d_input, n_frames, channels, n_sig, n, d_sig, d_res, d_q, d_meta, wrap);
     return hipGetLastError();
 }
 
@@ -864,11 +1066,12 @@ hipError_t launch_generic_decode(const uint8_t* d_frames, const uint64_t* d_fram
             return e;
     } else
         hipLaunchKernelGGL(k_generic_decode, dim3(subs), dim3(64), 0, stream, d_frames, d_frame_offsets, base_bytes, n_frames, channels, stride, d_dec, d_info, d_status);
+    const dim3 grid(n_frames, (stride + kCombineSlice - 1) / kCombineSlice);
     if (d_pcm_out)
-        hipLaunchKernelGGL(k_generic_combine<true>, dim3(n_frames), dim3(kCombineThreads), 0, stream, d_dec, d_info, n_frames, channels, stride, d_all, d_counts,
+        hipLaunchKernelGGL(k_generic_combine<true>, grid, dim3(kCombineThreads), 0, stream, d_dec, d_info, n_frames, channels, stride, d_all, d_counts,
             d_sample_offsets, d_pcm_out, d_status);
     else
-        hipLaunchKernelGGL(k_generic_combine<false>, dim3(n_frames), dim3(kCombineThreads), 0, stream, d_dec, d_info, n_frames, channels, stride, d_all, d_counts,
+        hipLaunchKernelGGL(k_generic_combine<false>, grid, dim3(kCombineThreads), 0, stream, d_dec, d_info, n_frames, channels, stride, d_all, d_counts,
             d_sample_offsets, d_pcm_out, d_status);
     return hipGetLastError();
 }
