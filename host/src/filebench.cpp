@@ -76,20 +76,23 @@ int main(int argc, char** argv)
         return 2;
     }
     if (std::string(argv[1]) == "frames") {
-        // sela_filebench frames <threads> <frames per thread>: the reference's own fan-out (src/sela/encoder.cpp:58-73: T threads,
-        // each constructing a frame::FrameEncoder per frame of its share) on the host classes, then the decoders the same way
+        // sela_filebench frames <threads> <frames per thread> [samples per channel = 2048] [bits = 16]: the reference's own fan-out
+        // (src/sela/encoder.cpp:58-73: T threads, each constructing a frame::FrameEncoder per frame of its share) on the host
+        // classes, then the decoders the same way.  Another length, or 17 bits, is the any-length route's business.
         const int threads = std::max(1, std::atoi(argv[2])), per = argc > 3 ? std::max(1, std::atoi(argv[3])) : 16;
+        const int len = argc > 4 ? std::min(65535, std::max(128, std::atoi(argv[4]))) : 2048, bits = argc > 5 ? std::atoi(argv[5]) : 16;
+        const int top = bits > 16 ? 60000 : 30000, step = bits > 16 ? 1201 : 601;
         using clock = std::chrono::steady_clock;
         std::vector<data::WavFrame> in;
         uint32_t x = 2463534242u;
         for (int i = 0; i < threads * per; i++) {
-            std::vector<std::vector<int32_t>> ch(2, std::vector<int32_t>(2048));
+            std::vector<std::vector<int32_t>> ch(2, std::vector<int32_t>((size_t)len));
             int v[2] = { 0, 0 };
-            for (int j = 0; j < 2048; j++)
+            for (int j = 0; j < len; j++)
                 for (int c = 0; c < 2; c++) {
                     x ^= x << 13, x ^= x >> 17, x ^= x << 5;
-                    v[c] += (int)(x % 601) - 300;
-                    v[c] = std::min(30000, std::max(-30000, v[c]));
+                    v[c] += (int)(x % (uint32_t)step) - step / 2;
+                    v[c] = std::min(top, std::max(-top, v[c]));
                     ch[c][j] = v[c];
                 }
             in.emplace_back(16, std::move(ch));
@@ -130,8 +133,8 @@ int main(int argc, char** argv)
                 return 1;
             }
         const double encMs = std::chrono::duration<double, std::milli>(t1 - t0).count(), decMs = std::chrono::duration<double, std::milli>(t2 - t1).count();
-        std::printf("{\"threads\": %d, \"frames\": %zu, \"encode_ms\": %.3f, \"decode_ms\": %.3f, \"encode_msps\": %.1f, \"decode_msps\": %.1f, \"frames_not_lossless\": %zu}\n",
-            threads, in.size(), encMs, decMs, in.size() * 2048.0 / encMs / 1e3, in.size() * 2048.0 / decMs / 1e3, differing);
+        std::printf("{\"threads\": %d, \"frames\": %zu, \"samples_per_channel\": %d, \"bits\": %d, \"encode_ms\": %.3f, \"decode_ms\": %.3f, \"encode_msps\": %.1f, \"decode_msps\": %.1f, \"frames_not_lossless\": %zu}\n",
+            threads, in.size(), len, bits, encMs, decMs, in.size() * (double)len / encMs / 1e3, in.size() * (double)len / decMs / 1e3, differing);
         return 0;
     }
     if (std::string(argv[1]) == "batch") {

@@ -101,17 +101,41 @@ data::SelaFrame FrameEncoder::process()
     // The reference takes a data::WavFrame as it is: int32 samples, as many per channel as the vectors hold
     // (src/frame/frame_encoder.cpp:11-102 never looks at a length; only its WAV reader cuts 2048-sample frames).  The shape that
     // reader produces -- 2048 samples within 16 bits -- goes to the fast kernels (and is coalesced with other threads' frames);
-    // anything else to the any-length kernels (sela_hip_encode_i32).  What stays refused: channels of different lengths (the
-    // reference's stereo difference indexes the shorter one out of bounds, :22-24), more than 65535 samples (the subframe's
-    // u16 field) and a block not longer than its own predictor order (the reference reads past its vector; SELA_HIP_ERANGE).
+    // anything else to the any-length kernels (sela_hip_encode_i32), channels of different lengths included: every channel is
+    // analysed at its own length (:73-98), the second channel of an exactly-stereo frame against channel 0 - channel 1 over
+    // its own length (:20-24; sela_hip_encode_ragged_i32).  What stays refused is what the reference itself cannot answer: an
+    // exactly-stereo frame whose first channel is the shorter one (its difference signal indexes that channel out of bounds,
+    // :22-24), more than 65535 samples (the subframe's u16 field) and a block not longer than its own predictor order (the
+    // reference reads past its vector; SELA_HIP_ERANGE).
     const size_t n = wavFrame.samples[0].size();
-    bool narrow = n == kBlock;
+    bool narrow = n == kBlock, ragged = false;
     for (size_t c = 0; c < channels; c++) {
-        if (wavFrame.samples[c].size() != n)
-            throw data::Exception("FrameEncoder: the channels of a frame must have one length");
+        ragged = ragged || wavFrame.samples[c].size() != n;
+        if (wavFrame.samples[c].size() == 0 || wavFrame.samples[c].size() > 65535)
+            throw data::Exception("FrameEncoder: a channel holds 1..65535 samples (the subframe's count is 16 bits wide)");
+    }
+    if (ragged) {
+        if (channels == 2 && wavFrame.samples[0].size() < wavFrame.samples[1].size())
+            throw data::Exception("FrameEncoder: the first channel of a stereo frame must not be the shorter one (the reference's difference signal reads it past its end)");
+        std::vector<int32_t> flat;
+        std::vector<uint32_t> lengths(channels);
+        size_t cap = 4;
+        for (size_t c = 0; c < channels; c++) {
+            lengths[c] = (uint32_t)wavFrame.samples[c].size();
+            flat.insert(flat.end(), wavFrame.samples[c].begin(), wavFrame.samples[c].end());
+            cap += sela_hip_encode_bound_bytes_n(1, 1, lengths[c]);
+        }
+        std::vector<uint8_t> bytes(cap);
+        size_t used = 0;
+        if (sela_hip_encode_ragged_i32(flat.data(), lengths.data(), (uint32_t)channels, bytes.data(), bytes.size(), &used) != SELA_HIP_OK)
+            throw data::Exception(std::string("FrameEncoder: ") + sela_hip_last_error());
+        data::SelaFrame frame(wavFrame.bitsPerSample);
+        parseFrame(bytes.data(), used, (uint8_t)channels, wavFrame.bitsPerSample, frame);
+        return frame;
+    }
+    for (size_t c = 0; c < channels; c++)
         for (size_t i = 0; narrow && i < n; i++)
             narrow = wavFrame.samples[c][i] >= INT16_MIN && wavFrame.samples[c][i] <= INT16_MAX;
-    }
     if (n == 0 || n > 65535)
         throw data::Exception("FrameEncoder: a channel holds 1..65535 samples (the subframe's count is 16 bits wide)");
     uint64_t offsets[2] = { 0, 0 };
@@ -128,8 +152,15 @@ data::SelaFrame FrameEncoder::process()
         std::vector<int32_t> planar(n * channels);
         for (size_t c = 0; c < channels; c++)
             std::memcpy(planar.data() + c * n, wavFrame.samples[c].data(), n * sizeof(int32_t));
-        bytes.resize(sela_hip_encode_bound_bytes_n(1, (uint32_t)channels, (uint32_t)n));
+        // room for six bytes per sample first (24-bit audio needs three): the format's own bound -- 65535 words per subframe, a
+        // quarter of a megabyte per channel -- only for the frame that asks for it
+        const size_t bound = sela_hip_encode_bound_bytes_n(1, (uint32_t)channels, (uint32_t)n);
+        bytes.resize(std::min(bound, 4 + channels * (12 + 128 + 6 * n)));
         rc = sela_hip_encode_i32(planar.data(), 1, (uint32_t)channels, (uint32_t)n, bytes.data(), bytes.size(), offsets);
+        if (rc == SELA_HIP_ECAPACITY && bytes.size() < bound) {
+            bytes.resize(bound);
+            rc = sela_hip_encode_i32(planar.data(), 1, (uint32_t)channels, (uint32_t)n, bytes.data(), bytes.size(), offsets);
+        }
     }
     if (rc != SELA_HIP_OK)
         throw data::Exception(std::string("FrameEncoder: ") + sela_hip_last_error());

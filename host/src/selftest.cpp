@@ -339,7 +339,25 @@ int main(int argc, char** argv)
                 CHECK(predictor.reflectionCoefficients.size() == std::max<size_t>(1, enc.optimalLpcOrder > 1 ? enc.optimalLpcOrder : 1));
                 CHECK(enc.optimalLpcOrder <= 1 || (predictor.reflectionCoefficients[0] >= -1.0 && predictor.reflectionCoefficients[0] <= 1.0));
 
-                // channels of different lengths, and a block shorter than its order, stay refused (undefined in the reference)
+                // channels of different lengths (round 6; src/frame/frame_encoder.cpp:20-24,73-98): every channel at its own length,
+                // the second channel of a stereo frame against the difference over ITS length
+                f = frame::FrameEncoder(data::WavFrame(16, { wide, right })).process();
+                CHECK(f.subFrames.size() == 2 && f.subFrames[0].samplesPerChannel == 2048 && f.subFrames[1].samplesPerChannel == 1000);
+                back = frame::FrameDecoder(f).process();
+                CHECK(back.samples.size() == 2 && back.samples[0] == wide && back.samples[1] == right);
+                std::vector<int32_t> near(left.begin(), left.begin() + 700);
+                for (int i = 0; i < 700; i++)
+                    near[i] -= i % 3;
+                f = frame::FrameEncoder(data::WavFrame(16, { left, near })).process();
+                CHECK(f.subFrames.size() == 2 && f.subFrames[1].subFrameType == 1 && f.subFrames[1].parentChannelNumber == 0 && f.subFrames[1].samplesPerChannel == 700);
+                back = frame::FrameDecoder(f).process();
+                CHECK(back.samples.size() == 2 && back.samples[0] == left && back.samples[1] == near);
+                f = frame::FrameEncoder(data::WavFrame(16, { right, three[0], wide })).process();
+                CHECK(f.subFrames.size() == 3 && f.subFrames[0].samplesPerChannel == 1000 && f.subFrames[1].samplesPerChannel == 5000 && f.subFrames[2].samplesPerChannel == 2048);
+                back = frame::FrameDecoder(f).process();
+                CHECK(back.samples.size() == 3 && back.samples[0] == right && back.samples[1] == three[0] && back.samples[2] == wide);
+                // a stereo frame whose FIRST channel is the shorter one, and a block shorter than its order, stay refused (the
+                // reference reads past its vectors there)
                 bool threw = false;
                 try {
                     frame::FrameEncoder(data::WavFrame(16, { left, wide })).process();

@@ -175,10 +175,11 @@ uint32_t sela_hip_index_samples(const uint8_t* frames, const uint64_t* frame_off
  * frame::FrameEncoder(const data::WavFrame&).process() and frame::FrameDecoder(const data::SelaFrame&).process()
  * (src/include/frame.hpp:8-24) on what they really take and return: data::WavFrame = int32 samples per channel
  * (src/include/data/wav_frame.hpp:8-16), nothing narrowed (src/frame/frame_decoder.cpp:64-71; only file::WavFile::writeToFile
- * truncates to 16 bits).  The encoder always runs the any-length kernels; the decoder offers its subframes to the fast kernels'
- * parse and synthesis first (k_decode_subframes32: subframes of 2048 samples that fit the parser's plan -- every stream an
- * encoder writes -- with the samples kept in 32 bits) and runs the any-length kernel on a chunk of frames in which anything
- * else turns up.  Results identical to the calls above wherever both apply.
+ * truncates to 16 bits).  The encoder always runs the any-length kernels (sela_generic.hip: the fast kernels' loops with a
+ * run-time length); the decoder runs the fast decoder's lane-parallel parse and tuned synthesis with 32-bit samples and a
+ * run-time length (k_decode_subframes32: one piece for 2048-sample subframes that fit the parser's plan, segments for
+ * everything else) and leaves to a serial kernel only the streams it will not judge (frames that are not whole words, malformed
+ * headers, Rice streams that run dry, coefficients outside the tables).  Results identical to the calls above wherever both apply.
  *   samples      [n_frames][channels][samples_per_channel] (planar per frame: WavFrame.samples[c][i]), 1 .. 65535 per channel.
  *   samples_out  [n_frames][channels][stride]: channel c of frame f at ((f * channels) + c) * stride, counts_out[f * channels + c]
  *                of them valid (0 for a channel no subframe of the frame names; what lies behind a channel's count is not
@@ -191,6 +192,20 @@ int sela_hip_encode_i32(const int32_t* samples, uint32_t n_frames, uint32_t chan
     uint8_t* frames_out, size_t frames_cap, uint64_t* frame_offsets_out /* [n_frames+1] */);
 int sela_hip_decode_i32(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels,
     int32_t* samples_out, uint32_t stride, uint32_t* counts_out /* [n_frames * channels] */);
+/* ONE frame whose channels differ in length, as frame::FrameEncoder::process codes it (src/frame/frame_encoder.cpp:11-102):
+ * every channel is analysed at its own samples[i].size() (:73-98) and its subframe carries that as samplesPerChannel
+ * (src/include/data/sela_sub_frame.hpp:41); the second channel of an exactly-stereo frame is also tried as the difference
+ * channel 0 - channel 1 over ITS OWN length (:20-24), so channel 0 must be at least as long -- where it is shorter the
+ * reference indexes past its vector, and this call returns SELA_HIP_EINVAL.  The decoder has always taken such frames
+ * (sela_hip_decode_i32).
+ *   samples      the channels back to back: lengths[0] samples of channel 0, then lengths[1] of channel 1, ...
+ *   lengths      [channels], each 1 .. 65535
+ *   frame_out    the frame's bytes (sync word + subframes); 4 + the sum over the channels of
+ *                sela_hip_encode_bound_bytes_n(1, 1, lengths[c]) holds any frame of samples within 17 bits (SELA_HIP_ECAPACITY
+ *                when a frame does not fit); *frame_bytes receives the size.
+ * Errors as sela_hip_encode_i32. */
+int sela_hip_encode_ragged_i32(const int32_t* samples, const uint32_t* lengths, uint32_t channels, uint8_t* frame_out, size_t frame_cap,
+    size_t* frame_bytes);
 
 /* ---- streaming jobs (host pointers) -------------------------------------------------------------------
  * For callers that produce their input piece by piece (a file being read): feed() enqueues a piece and

@@ -177,6 +177,22 @@ size_t ref_frame_encode_i32(const int32_t* planar, uint32_t channels, uint32_t n
     return put_frame(sf, out);
 }
 
+// ... and on a data::WavFrame whose channels differ in length (samples = the channels back to back).  The caller keeps to frames
+// on which the reference is defined: an exactly-stereo frame with channel 0 the shorter indexes past its vector
+// (src/frame/frame_encoder.cpp:22-24).
+size_t ref_frame_encode_ragged(const int32_t* samples, const uint32_t* lengths, uint32_t channels, uint8_t* out)
+{
+    std::vector<std::vector<int32_t>> s(channels);
+    const int32_t* cur = samples;
+    for (uint32_t c = 0; c < channels; c++) {
+        s[c].assign(cur, cur + lengths[c]);
+        cur += lengths[c];
+    }
+    data::WavFrame wf((uint8_t)16, std::move(s));
+    data::SelaFrame sf = frame::FrameEncoder(wf).process();
+    return put_frame(sf, out);
+}
+
 // out[c][0 .. counts[c]) = WavFrame.samples[c] exactly as frame::FrameDecoder::process returns them (32-bit, every
 // channel with its own length); out is [channels][stride].  Returns bytes consumed.
 size_t ref_frame_decode_i32(const uint8_t* in, uint32_t channels, int32_t* out, uint32_t stride, uint32_t* counts)

@@ -395,6 +395,45 @@ size_t sela_oracle_frame_encode_i32(const int32_t* planar, uint32_t channels, ui
     return (size_t)(p - out);
 }
 
+size_t sela_oracle_frame_encode_ragged(const int32_t* samples, const uint32_t* lengths, uint32_t channels, uint8_t* out, uint32_t* flags)
+{
+    /* src/frame/frame_encoder.cpp:11-102 on a data::WavFrame whose channels differ in length: every channel is analysed at
+     * its own samples[i].size() (:73-98); the second channel of an exactly-stereo frame takes the difference over ITS OWN
+     * length, reading channel 0 up to there (:20-24) -- so channel 0 must be at least as long (the reference indexes past
+     * its vector otherwise: the caller's business).  Every subframe carries its own samplesPerChannel (residueData.dataCount,
+     * src/include/data/sela_sub_frame.hpp:41).  samples = the channels back to back. */
+    uint8_t* p = out;
+    const uint32_t sync = SELA_SYNC_WORD;
+    memcpy(p, &sync, 4), p += 4;
+    const int32_t* cur = samples;
+    const int32_t* first = samples;
+    for (uint32_t c = 0; c < channels; c++) {
+        const uint32_t n = lengths[c];
+        coded_block act;
+        code_block(cur, (int)n, &act, flags);
+        if (c == 1 && channels == 2) {
+            int32_t* dif = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+            for (uint32_t j = 0; j < n; j++)
+                dif[j] = (int32_t)((uint32_t)first[j] - (uint32_t)cur[j]);
+            coded_block dc;
+            code_block(dif, (int)n, &dc, flags);
+            if ((size_t)dc.cwords + (size_t)dc.rwords < (size_t)act.cwords + (size_t)act.rwords)
+                p = put_subframe(p, (uint8_t)c, 1, (uint8_t)(c - 1), &dc, (int)n);
+            else
+                p = put_subframe(p, (uint8_t)c, 0, (uint8_t)c, &act, (int)n);
+            free(dc.cw);
+            free(dc.rw);
+            free(dif);
+        } else {
+            p = put_subframe(p, (uint8_t)c, 0, (uint8_t)c, &act, (int)n);
+        }
+        free(act.cw);
+        free(act.rw);
+        cur += n;
+    }
+    return (size_t)(p - out);
+}
+
 size_t sela_oracle_frame_encode(const int16_t* pcm, uint32_t channels, uint32_t n, uint8_t* out, uint32_t* flags)
 {
     /* the demux of src/file/wav_file.cpp:194-200, then the frame encoder */

@@ -62,6 +62,11 @@ size_t sela_oracle_frame_encode(const int16_t* pcm, uint32_t channels, uint32_t 
  * (src/include/data/wav_frame.hpp:8-16).  planar = [channels][n]. */
 size_t sela_oracle_frame_encode_i32(const int32_t* planar, uint32_t channels, uint32_t n, uint8_t* out, uint32_t* flags);
 
+/* The same on a frame whose channels differ in length (src/frame/frame_encoder.cpp:20-24,73-98): samples = the channels back to
+ * back, lengths[c] samples each; an exactly-stereo frame needs lengths[0] >= lengths[1] (the reference reads channel 0 up to
+ * channel 1's length). */
+size_t sela_oracle_frame_encode_ragged(const int32_t* samples, const uint32_t* lengths, uint32_t channels, uint8_t* out, uint32_t* flags);
+
 /* frame::FrameDecoder::process as the reference returns it: out[c][0 .. counts[c]) = WavFrame.samples[c], 32-bit,
  * every subframe with its own samplesPerChannel; out is [channels][stride].  Returns bytes consumed. */
 size_t sela_oracle_frame_decode_i32(const uint8_t* in, uint32_t channels, int32_t* out, uint32_t stride, uint32_t* counts, uint32_t* flags);

@@ -28,7 +28,7 @@ EXPORTS = [
     "sela_hip_host_alloc", "sela_hip_host_free", "sela_hip_decode_max_channels",
     "sela_hip_encode_begin", "sela_hip_encode_feed", "sela_hip_encode_end",
     "sela_hip_decode_begin", "sela_hip_decode_feed", "sela_hip_decode_end",
-    "sela_hip_encode_bound_bytes_n", "sela_hip_index_samples", "sela_hip_encode_i32", "sela_hip_decode_i32",
+    "sela_hip_encode_bound_bytes_n", "sela_hip_index_samples", "sela_hip_encode_i32", "sela_hip_decode_i32", "sela_hip_encode_ragged_i32",
     "sela_hip_lpc_encode_n", "sela_hip_lpc_decode_n",
 ]
 
@@ -116,9 +116,10 @@ def lib() -> C.CDLL:
     L.sela_hip_index_samples.restype = u32
     L.sela_hip_encode_i32.argtypes = [vp, u32, u32, u32, vp, sz, vp]
     L.sela_hip_decode_i32.argtypes = [vp, vp, u32, u32, vp, u32, vp]
+    L.sela_hip_encode_ragged_i32.argtypes = [vp, vp, u32, vp, sz, vp]
     L.sela_hip_lpc_encode_n.argtypes = [vp, u32, u32, vp, vp, vp]
     L.sela_hip_lpc_decode_n.argtypes = [vp, vp, vp, u32, u32, vp, vp]
-    for name in ("sela_hip_encode_i32", "sela_hip_decode_i32", "sela_hip_lpc_encode_n", "sela_hip_lpc_decode_n"):
+    for name in ("sela_hip_encode_i32", "sela_hip_decode_i32", "sela_hip_encode_ragged_i32", "sela_hip_lpc_encode_n", "sela_hip_lpc_decode_n"):
         getattr(L, name).restype = C.c_int
     L.sela_hip_debug_phase_buffer.argtypes = [C.c_void_p]
     L.sela_hip_debug_phase_buffer.restype = None

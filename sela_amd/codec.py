@@ -168,6 +168,19 @@ def encode_i32(samples: np.ndarray):
     return frames[: int(offs[n_frames])].copy(), offs
 
 
+def encode_ragged(channels) -> bytes:
+    """frame::FrameEncoder on a data::WavFrame whose channels differ in length: list of int32 arrays -> the frame's bytes."""
+    lib = capi.lib()
+    chans = [np.ascontiguousarray(c, dtype=np.int32).ravel() for c in channels]
+    flat = np.concatenate(chans)
+    lengths = np.array([len(c) for c in chans], np.uint32)
+    cap = 4 + sum(int(lib.sela_hip_encode_bound_bytes_n(1, 1, len(c))) for c in chans)
+    out = np.empty(cap, np.uint8)
+    used = C.c_size_t(0)
+    capi.check(lib.sela_hip_encode_ragged_i32(flat.ctypes.data, lengths.ctypes.data, len(chans), out.ctypes.data, cap, C.byref(used)))
+    return out[: used.value].tobytes()
+
+
 def decode_i32(frames: np.ndarray, offsets: np.ndarray, channels: int, stride=None):
     """frame::FrameDecoder as it returns: -> list (per frame) of lists (per channel) of int32 arrays."""
     lib = capi.lib()

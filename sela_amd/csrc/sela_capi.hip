@@ -1437,7 +1437,12 @@ struct HipBackend {
     {
         return sela::generic_decode(frames, offsets, n_frames, channels, samples_out, stride, counts_out, nullptr, nullptr);
     }
+    static int encode_i32_now(const int32_t* samples, uint32_t n_frames, uint32_t channels, uint32_t n, uint8_t* frames_out, size_t frames_cap, uint64_t* offsets_out)
+    {
+        return sela::generic_encode(samples, false, n_frames, channels, n, frames_out, frames_cap, offsets_out);
+    }
     static size_t encode_bound_bytes(uint32_t n_frames, uint32_t channels) { return sela_hip_encode_bound_bytes(n_frames, channels); }
+    static size_t encode_i32_bound_bytes(uint32_t n_frames, uint32_t channels, uint32_t n) { return sela::generic_encode_bound_bytes(n_frames, channels, n); }
     static void* take(size_t bytes) { return pool().take(bytes); }
     static void give(void* p) { pool().give(p); }
     static std::string last_error() { return sela_hip_last_error(); }
@@ -1456,7 +1461,7 @@ typedef sela::CallCoalescer<HipBackend> Coalescer;
 Coalescer* coalescer(Coalescer::Kind kind, int device)
 {
     static std::mutex mu;
-    static Coalescer* table[3][64] = {};
+    static Coalescer* table[4][64] = {};
     const int d = device >= 0 && device < 64 ? device : 0;
     std::lock_guard<std::mutex> lock(mu);
     Coalescer*& c = table[(int)kind][d];
@@ -1561,7 +1566,78 @@ int sela_hip_encode_i32(const int32_t* samples, uint32_t n_frames, uint32_t chan
         return fail(SELA_HIP_EINVAL, "samples_per_channel must be 1 .. 65535 (the subframe's field is 16 bits wide)");
     if (channels == 0 || channels > 255 || !frame_offsets_out || (n_frames && (!samples || !frames_out)))
         return fail(SELA_HIP_EINVAL, "bad argument");
-    return sela::generic_encode(samples, false, n_frames, channels, samples_per_channel, frames_out, frames_cap, frame_offsets_out);
+    // Small calls from many threads -- the reference's thread loop over frame::FrameEncoder (src/sela/encoder.cpp:58-73) on frames
+    // that are not the CLI's shape -- go to the device together, like the one-shot calls of the fast path (sela_coalescer.h):
+    // calls of one shape (channels, samples per channel) share a job, every call gets its own bytes and its own error.
+    SmallCall call;
+    if (n_frames == 0 || n_frames > kCoalesceFrames || (size_t)n_frames * channels * samples_per_channel > ((size_t)1 << 20) || hipGetDevice(&call.device) != hipSuccess)
+        return sela::generic_encode(samples, false, n_frames, channels, samples_per_channel, frames_out, frames_cap, frame_offsets_out);
+    call.channels = channels, call.n_frames = n_frames, call.shape = samples_per_channel;
+    call.samples = samples, call.frames_out = frames_out, call.frames_cap = frames_cap, call.offsets_out = frame_offsets_out;
+    return submit_small(Coalescer::kEncode32, call);
+}
+
+// One frame whose channels differ in length (src/frame/frame_encoder.cpp:11-102): every channel is a block of its own -- coded
+// as a one-channel frame of its own length by the any-length kernels -- and the frame is their subframes, renamed, behind one
+// sync word; the second channel of an exactly-stereo frame against the difference channel 0 - channel 1 over its own length.
+int sela_hip_encode_ragged_i32(const int32_t* samples, const uint32_t* lengths, uint32_t channels, uint8_t* frame_out, size_t frame_cap, size_t* frame_bytes)
+{
+    if (channels == 0 || channels > 255 || !samples || !lengths || !frame_out || !frame_bytes)
+        return fail(SELA_HIP_EINVAL, "bad argument");
+    for (uint32_t c = 0; c < channels; c++)
+        if (lengths[c] == 0 || lengths[c] > 65535)
+            return fail(SELA_HIP_EINVAL, "every channel holds 1 .. 65535 samples (the subframe's field is 16 bits wide)");
+    if (channels == 2 && lengths[0] < lengths[1])
+        return fail(SELA_HIP_EINVAL, "an exactly-stereo frame whose first channel is the shorter one: the reference's difference signal reads it past its end (src/frame/frame_encoder.cpp:22-24)");
+    if (frame_cap < 4)
+        return fail(SELA_HIP_ECAPACITY, "frame_out too small");
+    // a one-channel frame: sync word (4) | channel, type, parent | k, words (u16), order | words | k, words (u16), n (u16) | words
+    auto mono = [&](const int32_t* x, uint32_t n, std::vector<uint8_t>& bytes, uint32_t& words) -> int {
+        bytes.resize(sela::generic_encode_bound_bytes(1, 1, n));
+        uint64_t offs[2] = { 0, 0 };
+        const int rc = sela::generic_encode(x, false, 1, 1, n, bytes.data(), bytes.size(), offs);
+        if (rc != SELA_HIP_OK)
+            return rc;
+        bytes.resize((size_t)offs[1]);
+        const uint32_t cw = bytes[8] | ((uint32_t)bytes[9] << 8);
+        const size_t p2 = 4 + 7 + 4 * (size_t)cw;
+        words = cw + (bytes[p2 + 1] | ((uint32_t)bytes[p2 + 2] << 8));
+        return SELA_HIP_OK;
+    };
+    const uint32_t sync = SELA_SYNC_WORD;
+    std::memcpy(frame_out, &sync, 4);
+    size_t at = 4;
+    const int32_t* cur = samples;
+    std::vector<uint8_t> own, dif;
+    std::vector<int32_t> d;
+    for (uint32_t c = 0; c < channels; c++) {
+        const uint32_t n = lengths[c];
+        uint32_t own_words = 0, dif_words = 0;
+        int rc = mono(cur, n, own, own_words);
+        if (rc != SELA_HIP_OK)
+            return rc;
+        const std::vector<uint8_t>* take = &own;
+        uint8_t type = 0, parent = (uint8_t)c;
+        if (channels == 2 && c == 1) { // :18-72
+            d.resize(n);
+            for (uint32_t j = 0; j < n; j++)
+                d[j] = (int32_t)((uint32_t)samples[j] - (uint32_t)cur[j]);
+            rc = mono(d.data(), n, dif, dif_words);
+            if (rc != SELA_HIP_OK)
+                return rc;
+            if (dif_words < own_words) // :64-66: strictly fewer words
+                take = &dif, type = 1, parent = 0;
+        }
+        const size_t sub = take->size() - 4;
+        if (at + sub > frame_cap)
+            return fail(SELA_HIP_ECAPACITY, "frame_out too small (4 + the sum over the channels of sela_hip_encode_bound_bytes_n(1, 1, lengths[c]) holds any frame of 17-bit samples)");
+        std::memcpy(frame_out + at, take->data() + 4, sub);
+        frame_out[at] = (uint8_t)c, frame_out[at + 1] = type, frame_out[at + 2] = parent;
+        at += sub;
+        cur += n;
+    }
+    *frame_bytes = at;
+    return SELA_HIP_OK;
 }
 
 int sela_hip_decode_i32(const uint8_t* frames, const uint64_t* frame_offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out, uint32_t stride,

@@ -67,10 +67,35 @@ struct Arena { // one device allocation, handed out in aligned pieces for the le
 // frame classes run side by side on the device instead of taking turns on the default stream).  Leased like the fast path's
 // contexts (sela_capi.hip): a thread that ends -- programs start threads per job -- parks its set for the next thread on
 // that device instead of paying a stream and an allocation again; sela_hip_shutdown() frees the parked ones.
+struct PinnedScratch { // page-locked host memory for what a call reads back first (status words, offsets, a small call's whole output)
+    uint8_t* base = nullptr;
+    size_t cap = 0;
+    void release()
+    {
+        if (base)
+            (void)hipHostFree(base);
+        base = nullptr, cap = 0;
+    }
+    uint8_t* reserve(size_t bytes) // null when the runtime has none to give: the caller copies into its own (pageable) memory then
+    {
+        if (base && bytes <= cap)
+            return base;
+        release();
+        const size_t want = std::max<size_t>(bytes + (bytes >> 2), 1 << 16);
+        if (hipHostMalloc(reinterpret_cast<void**>(&base), want, hipHostMallocDefault) != hipSuccess) {
+            base = nullptr;
+            return nullptr;
+        }
+        cap = want;
+        return base;
+    }
+};
+
 struct GenericContext {
     int device = -1;
     hipStream_t stream = nullptr;
     Arena arena;
+    PinnedScratch pinned;
     void destroy()
     {
         int before = -1;
@@ -78,6 +103,7 @@ struct GenericContext {
         if (device >= 0 && before != device)
             (void)hipSetDevice(device);
         arena.release();
+        pinned.release();
         if (stream)
             (void)hipStreamDestroy(stream);
         stream = nullptr;
@@ -202,6 +228,13 @@ size_t generic_encode_bound_bytes(uint32_t n_frames, uint32_t channels, uint32_t
 }
 
 // input: int16 [n_frames][n][channels] (in16) or int32 [n_frames][channels][n]
+// One submission per chunk of frames: copy in, analyse, plan, pack, assemble, copy out -- the Rice words and the frame bytes go
+// to scratch sized by an ESTIMATE (4.5 bytes per sample: what 32-bit noise costs; 16-bit audio needs half), the kernels stay
+// inside it whatever the data, and only a chunk whose plan turns out larger is packed and assembled again at its exact size
+// (round 5 waited for the plan before it sized anything: two trips to the device per call).  What the host reads back first --
+// status, sizes, offsets, and a small call's frames -- lands in page-locked memory of the calling thread's context.
+constexpr size_t kEagerBytes = (size_t)4 << 20;
+
 int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t channels, uint32_t n, uint8_t* frames_out, size_t frames_cap,
     uint64_t* frame_offsets_out)
 {
@@ -214,7 +247,9 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
     Arena& g_arena = ctx->arena;
     const uint32_t n_sig = channels == 2 ? 3u : channels;
     const size_t in_frame_bytes = (size_t)n * channels * (in16 ? 2 : 4);
-    const size_t per_frame = (size_t)n_sig * n * 8 + (size_t)n_sig * (kMaxOrder * 4 + sizeof(GenericMeta) + 2 * kPiece) + in_frame_bytes + (size_t)channels * 12 + 8;
+    const size_t est_frame_bytes = ((size_t)n * channels * 9) / 2 + (size_t)channels * 64 + 64; // words and frame bytes, each
+    const size_t per_frame = (size_t)n_sig * n * 8 + (size_t)n_sig * (kMaxOrder * 4 + sizeof(GenericMeta) + 2 * kPiece) + in_frame_bytes + (size_t)channels * 12 + 8
+        + 2 * est_frame_bytes;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
     uint64_t base_bytes = 0;
     frame_offsets_out[0] = 0;
@@ -222,7 +257,9 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
     for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const uint32_t cf = std::min(chunk, n_frames - f0);
         const size_t blocks = (size_t)cf * n_sig, subs = (size_t)cf * channels;
-        const size_t fixed = blocks * n * 8 + blocks * (kMaxOrder * 4 + sizeof(GenericMeta)) + cf * in_frame_bytes + (subs + 1) * 12 + ((size_t)cf + 1) * 8 + 64 + 12 * kPiece;
+        const size_t est_words = ((size_t)cf * est_frame_bytes + 3) / 4, est_bytes = est_words * 4;
+        const size_t fixed = blocks * n * 8 + blocks * (kMaxOrder * 4 + sizeof(GenericMeta)) + cf * in_frame_bytes + (subs + 1) * 12 + ((size_t)cf + 1) * 8 + 64 + 16 * kPiece
+            + est_words * 4 + 8 + est_bytes;
         hipError_t e = g_arena.reserve(fixed);
         if (e != hipSuccess)
             return report_hip_error(e, "generic encode: scratch");
@@ -231,66 +268,79 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
         int32_t* d_res = g_arena.take<int32_t>(blocks * n);
         int32_t* d_q = g_arena.take<int32_t>(blocks * kMaxOrder);
         GenericMeta* d_meta = g_arena.take<GenericMeta>(blocks);
-        // what the host reads back after the plan, in one piece: status (4 x u32) | total words | frame offsets
-        uint64_t* d_head = g_arena.take<uint64_t>(3 + (size_t)cf + 1);
+        // what the host reads back first, in one piece: status (4 x u32) | total words | frame offsets
+        const size_t head_words = 3 + (size_t)cf + 1;
+        uint64_t* d_head = g_arena.take<uint64_t>(head_words);
         uint32_t* d_status = reinterpret_cast<uint32_t*>(d_head);
         uint64_t* d_offsets = d_head + 3;
         uint64_t* d_word_base = g_arena.take<uint64_t>(subs + 1);
         uint32_t* d_chosen = g_arena.take<uint32_t>(subs);
+        uint32_t* d_words = g_arena.take<uint32_t>(est_words + 2);
+        uint8_t* d_frames = g_arena.take<uint8_t>(est_bytes);
         if (!g_arena.fits())
             return report_error(SELA_HIP_ENOMEM, "generic encode: internal scratch estimate too small");
+        const bool eager = est_bytes <= kEagerBytes;
+        uint8_t* const pin = ctx->pinned.reserve(head_words * 8 + (eager ? est_bytes : 0));
+        std::vector<uint64_t> head_pageable;
+        uint64_t* head = reinterpret_cast<uint64_t*>(pin);
+        if (!pin) {
+            head_pageable.resize(head_words);
+            head = head_pageable.data();
+        }
+        uint8_t* const eager_frames = pin && eager ? pin + head_words * 8 : nullptr;
         e = hipMemcpyAsync(d_in, static_cast<const uint8_t*>(input) + (size_t)f0 * in_frame_bytes, cf * in_frame_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
             e = hipMemsetAsync(d_head, 0, 24, st);
         if (e == hipSuccess)
+            e = hipMemsetAsync(d_words, 0, (est_words + 2) * 4, st);
+        if (e == hipSuccess)
             e = launch_generic_analyse(d_in, in16, cf, channels, n_sig, n, d_sig, d_res, d_q, d_meta, st);
         if (e == hipSuccess)
             e = launch_generic_plan(d_meta, cf, channels, n_sig, base_bytes, d_offsets, d_word_base, d_chosen, d_status, d_head + 2, st);
-        std::vector<uint64_t> head(3 + (size_t)cf + 1);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(head.data(), d_head, head.size() * 8, hipMemcpyDeviceToHost, st);
+            e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, est_words, d_offsets, base_bytes, d_frames, est_bytes, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(head, d_head, head_words * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && eager_frames)
+            e = hipMemcpyAsync(eager_frames, d_frames, est_bytes, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess)
             e = hipStreamSynchronize(st);
         if (e != hipSuccess)
-            return report_hip_error(e, "generic encode: analysis");
+            return report_hip_error(e, "generic encode");
         uint32_t status[4];
-        std::memcpy(status, head.data(), 16);
+        std::memcpy(status, head, 16);
         const uint64_t total_words = head[2];
-        std::memcpy(frame_offsets_out + f0, head.data() + 3, ((size_t)cf + 1) * 8);
+        std::memcpy(frame_offsets_out + f0, head + 3, ((size_t)cf + 1) * 8);
         const int rc = flags_error(status[0], "encode");
         if (rc != SELA_HIP_OK)
             return rc;
         const uint64_t chunk_bytes = frame_offsets_out[f0 + cf] - base_bytes;
         if (frame_offsets_out[f0 + cf] > frames_cap)
             return report_error(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes_n)");
-        // the second half's pieces live behind the first half's (which pack and assemble still read)
-        const size_t used_so_far = g_arena.used;
-        const size_t more = (size_t)total_words * 4 + chunk_bytes + 4 * kPiece;
-        if (used_so_far + more > g_arena.cap) { // (rare: a second allocation for this call only)
+        if (total_words <= est_words && chunk_bytes <= est_bytes) {
+            if (eager_frames) {
+                std::memcpy(frames_out + base_bytes, eager_frames, (size_t)chunk_bytes);
+            } else {
+                e = hipMemcpyAsync(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess)
+                    e = hipStreamSynchronize(st);
+            }
+        } else { // (rare: data that codes to more than 4.5 bytes per sample) pack and assemble again, at the plan's exact sizes
             uint8_t* extra = nullptr;
-            e = hipMalloc(reinterpret_cast<void**>(&extra), more);
+            const size_t words_bytes = (((size_t)total_words + 2) * 4 + 255) & ~(size_t)255;
+            e = hipMalloc(reinterpret_cast<void**>(&extra), words_bytes + chunk_bytes + 256);
             if (e != hipSuccess)
                 return report_hip_error(e, "generic encode: stream scratch");
-            uint32_t* d_words = reinterpret_cast<uint32_t*>(extra);
-            uint8_t* d_frames = extra + (((size_t)total_words * 4 + 255) & ~(size_t)255);
-            e = hipMemsetAsync(d_words, 0, (size_t)total_words * 4 + 4, st);
+            uint32_t* d_words2 = reinterpret_cast<uint32_t*>(extra);
+            uint8_t* d_frames2 = extra + words_bytes;
+            e = hipMemsetAsync(d_words2, 0, ((size_t)total_words + 2) * 4, st);
             if (e == hipSuccess)
-                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, d_offsets, base_bytes, d_frames, chunk_bytes, st);
+                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words2, total_words, d_offsets, base_bytes, d_frames2, chunk_bytes, st);
             if (e == hipSuccess)
-                e = hipMemcpyAsync(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost, st);
+                e = hipMemcpyAsync(frames_out + base_bytes, d_frames2, chunk_bytes, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess)
                 e = hipStreamSynchronize(st);
             (void)hipFree(extra);
-        } else {
-            uint32_t* d_words = g_arena.take<uint32_t>((size_t)total_words + 1);
-            uint8_t* d_frames = g_arena.take<uint8_t>(chunk_bytes);
-            e = hipMemsetAsync(d_words, 0, (size_t)total_words * 4 + 4, st);
-            if (e == hipSuccess)
-                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, d_offsets, base_bytes, d_frames, chunk_bytes, st);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess)
-                e = hipStreamSynchronize(st);
         }
         if (e != hipSuccess)
             return report_hip_error(e, "generic encode: emit");
@@ -403,19 +453,26 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
                 local[i] = sample_offsets[f0 + i] - s0;
             e = hipMemcpyAsync(d_sample_offsets, local.data(), local.size() * 8, hipMemcpyHostToDevice, st);
         }
-        std::vector<uint32_t> tail(4 + subs);
         const int mode = g_standard_first_mode.load(std::memory_order_relaxed); // -1: the product; 0: the serial kernel alone; 1: as -1; 2: offered, every subframe by segments
         const bool offer = mode != 0, standard_path = mode != 2;
         // A small chunk's samples travel with the status, one wait for the device instead of two (a call of one frame -- the
-        // frame classes' kind -- is mostly waits); what they are worth is known when both have arrived.
+        // frame classes' kind -- is mostly waits); what they are worth is known when both have arrived.  Both land in
+        // page-locked memory of the calling thread's context (a copy into pageable memory is staged by the runtime, and waits).
         const size_t out_bytes = pcm_out ? (size_t)chunk_samples * channels * 2 : subs * stride * sizeof(int32_t);
-        const bool eager = out_bytes <= ((size_t)4 << 20);
-        auto copy_out = [&]() {
-            // samples_out and the device's channel-major array have one layout ([frame][channel][stride]): ONE copy (a copy per
-            // channel cost 13 us each: 7 ms for 256 stereo frames).  What lies behind a channel's count is not defined.
-            return pcm_out ? hipMemcpyAsync(pcm_out + s0 * channels, d_pcm, out_bytes, hipMemcpyDeviceToHost, st)
-                           : hipMemcpyAsync(samples_out + (size_t)f0 * channels * stride, d_all, out_bytes, hipMemcpyDeviceToHost, st);
-        };
+        const bool eager = out_bytes <= kEagerBytes;
+        const size_t tail_bytes = ((4 + subs) * 4 + 15) & ~(size_t)15;
+        uint8_t* const pin = ctx->pinned.reserve(tail_bytes + (eager ? out_bytes : 0));
+        std::vector<uint32_t> tail_pageable;
+        uint32_t* tail = reinterpret_cast<uint32_t*>(pin);
+        if (!pin) {
+            tail_pageable.resize(4 + subs);
+            tail = tail_pageable.data();
+        }
+        uint8_t* const eager_out = pin && eager ? pin + tail_bytes : nullptr;
+        uint8_t* const user_out = pcm_out ? reinterpret_cast<uint8_t*>(pcm_out + s0 * channels) : reinterpret_cast<uint8_t*>(samples_out + (size_t)f0 * channels * stride);
+        const void* const device_out = pcm_out ? static_cast<const void*>(d_pcm) : static_cast<const void*>(d_all);
+        // samples_out and the device's channel-major array have one layout ([frame][channel][stride]): ONE copy (a copy per
+        // channel cost 13 us each: 7 ms for 256 stereo frames).  What lies behind a channel's count is not defined.
         for (int attempt = offer ? 0 : 1; attempt < 2; attempt++) {
             if (e == hipSuccess)
                 e = hipMemsetAsync(d_tail, 0, (4 + subs) * 4, st);
@@ -423,9 +480,9 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
                 e = launch_generic_decode(d_frames, d_offsets, base_bytes, cf, channels, stride, d_dec, d_info, d_all, d_counts, d_sample_offsets, d_pcm, d_status,
                     attempt == 0, standard_path, st);
             if (e == hipSuccess)
-                e = hipMemcpyAsync(tail.data(), d_tail, tail.size() * 4, hipMemcpyDeviceToHost, st);
+                e = hipMemcpyAsync(tail, d_tail, (4 + subs) * 4, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess && eager)
-                e = copy_out();
+                e = hipMemcpyAsync(eager_out ? eager_out : user_out, device_out, out_bytes, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess)
                 e = hipStreamSynchronize(st);
             if (e != hipSuccess)
@@ -436,7 +493,7 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
                 break;
             }
         }
-        const uint32_t* const status = tail.data();
+        const uint32_t* const status = tail;
         if (status[0] & SELA_HIP_FLAG_BAD_FRAME)
             return report_error(SELA_HIP_EFORMAT, "malformed frame (sync word, sizes, an order above 100, a Rice parameter above 31, a channel or parent that does not exist, or channels of different lengths)");
         if (status[0] & SELA_HIP_FLAG_RICE_OVERRUN)
@@ -444,9 +501,11 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
         if (status[0] & SELA_HIP_FLAG_COEF_OVERFLOW)
             return report_error(SELA_HIP_ERANGE, "decode: a predictor coefficient left the int64 range");
         if (!pcm_out)
-            std::memcpy(counts_out + (size_t)f0 * channels, tail.data() + 4, subs * 4);
-        if (!eager) {
-            e = copy_out();
+            std::memcpy(counts_out + (size_t)f0 * channels, tail + 4, subs * 4);
+        if (eager_out) {
+            std::memcpy(user_out, eager_out, out_bytes);
+        } else if (!eager) {
+            e = hipMemcpyAsync(user_out, device_out, out_bytes, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess)
                 e = hipStreamSynchronize(st);
         }

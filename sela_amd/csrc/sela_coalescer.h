@@ -9,7 +9,10 @@
 //       static int decode_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int16_t* pcm_out);
 //       static int decode_i32_now(const uint8_t* frames, const uint64_t* offsets, uint32_t n_frames, uint32_t channels, int32_t* samples_out,
 //                                 uint32_t stride, uint32_t* counts_out);   // sela_hip_decode_i32: [frame][channel][stride] + a count per row
+//       static int encode_i32_now(const int32_t* samples, uint32_t n_frames, uint32_t channels, uint32_t n, uint8_t* frames_out, size_t frames_cap,
+//                                 uint64_t* offsets_out);                      // sela_hip_encode_i32: [frame][channel][n]
 //       static size_t encode_bound_bytes(uint32_t n_frames, uint32_t channels);
+//       static size_t encode_i32_bound_bytes(uint32_t n_frames, uint32_t channels, uint32_t n);
 //       static void* take(size_t bytes);  static void give(void* p);      // staging memory of a batch
 //       static std::string last_error();                                  // of the calling thread's last *_now
 //       static void after_batch();                                        // the leader is through with the device
@@ -17,6 +20,7 @@
 #ifndef SELA_COALESCER_H_
 #define SELA_COALESCER_H_
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -54,6 +58,8 @@ struct SmallCall {
     int32_t* samples_out = nullptr; // decode to 32-bit channels (sela_hip_decode_i32): [n_frames][channels][stride], counts_out[n_frames * channels]
     uint32_t stride = 0;
     uint32_t* counts_out = nullptr;
+    const int32_t* samples = nullptr; // encode from 32-bit channels (sela_hip_encode_i32): [n_frames][channels][shape], shape = samples per channel
+    uint32_t shape = 0;               // (calls only share a batch with calls of the same shape; 0 for the other kinds)
     int rc = SELA_HIP_OK;
     std::string error;
     bool done = false, lead = false;
@@ -62,7 +68,7 @@ struct SmallCall {
 template <class Backend>
 class CallCoalescer {
 public:
-    enum Kind { kDecode = 0, kEncode = 1, kDecode32 = 2 };
+    enum Kind { kDecode = 0, kEncode = 1, kDecode32 = 2, kEncode32 = 3 };
 
 private:
     const Kind kind;
@@ -77,6 +83,7 @@ private:
     void run_one(SmallCall& c)
     {
         c.rc = encode ? Backend::encode_now(c.pcm, c.n_frames, c.channels, c.frames_out, c.frames_cap, c.offsets_out)
+            : kind == kEncode32 ? Backend::encode_i32_now(c.samples, c.n_frames, c.channels, c.shape, c.frames_out, c.frames_cap, c.offsets_out)
             : kind == kDecode32 ? Backend::decode_i32_now(c.frames, c.offsets_in, c.n_frames, c.channels, c.samples_out, c.stride, c.counts_out)
                                 : Backend::decode_now(c.frames, c.offsets_in, c.n_frames, c.channels, c.pcm_out);
         if (c.rc != SELA_HIP_OK)
@@ -137,6 +144,47 @@ private:
                         c->offsets_out[f] = offsets[at + f] - base;
                 }
                 at += c->n_frames;
+            }
+        } else if (kind == kEncode32) {
+            // data::WavFrame values of ONE shape (submit() batches by channels and samples per channel): one job, every call its own bytes
+            const uint32_t n = batch[0]->shape;
+            const size_t frame_in = (size_t)n * channels * sizeof(int32_t);
+            // room for what the callers have room for (the bound of a frame is the format's worst case, 65535 words per subframe:
+            // half a megabyte per stereo frame; callers size their buffers for their data and are told when that was too little)
+            size_t cap = 0;
+            for (const SmallCall* c : batch)
+                cap += std::min(c->frames_cap, Backend::encode_i32_bound_bytes(c->n_frames, channels, n));
+            in = Backend::take(total * frame_in);
+            out = Backend::take(cap);
+            if (!in.p || !out.p) {
+                rc = SELA_HIP_ENOMEM, oom = true;
+            } else {
+                size_t at = 0;
+                for (const SmallCall* c : batch) {
+                    std::memcpy(static_cast<uint8_t*>(in.p) + at * frame_in, c->samples, c->n_frames * frame_in);
+                    at += c->n_frames;
+                }
+                rc = Backend::encode_i32_now(static_cast<const int32_t*>(in.p), (uint32_t)total, channels, n, static_cast<uint8_t*>(out.p), cap, offsets.data());
+            }
+            if (rc == SELA_HIP_ERANGE || rc == SELA_HIP_ECAPACITY) {
+                for (SmallCall* c : batch) // a block the reference cannot answer must not fail its neighbours' calls: everyone on their own
+                    run_one(*c);
+            } else {
+                const std::string msg = rc == SELA_HIP_OK ? std::string() : (oom ? std::string("no page-locked memory for a coalesced batch") : Backend::last_error());
+                size_t at = 0;
+                for (SmallCall* c : batch) {
+                    const uint64_t base = offsets[at], bytes = offsets[at + c->n_frames] - base;
+                    if (rc != SELA_HIP_OK) {
+                        c->rc = rc, c->error = msg;
+                    } else if (bytes > c->frames_cap) {
+                        c->rc = SELA_HIP_ECAPACITY, c->error = "frames_out too small (see sela_hip_encode_bound_bytes_n)";
+                    } else {
+                        std::memcpy(c->frames_out, static_cast<const uint8_t*>(out.p) + base, (size_t)bytes);
+                        for (uint32_t f = 0; f <= c->n_frames; f++)
+                            c->offsets_out[f] = offsets[at + f] - base;
+                    }
+                    at += c->n_frames;
+                }
             }
         } else if (kind == kDecode32) {
             // frames of any shape to 32-bit channels: one job with the widest caller's stride, every call handed its own rows
@@ -258,9 +306,9 @@ public:
                         break;
                 }
             }
-            std::vector<SmallCall*> batch; // everything that waits for this device with this channel count, this call included
+            std::vector<SmallCall*> batch; // everything that waits for this device with this channel count (and shape), this call included
             for (auto it = queue.begin(); it != queue.end() && batch.size() < kMaxCalls;) {
-                if ((*it)->channels == call.channels && (*it)->device == call.device) {
+                if ((*it)->channels == call.channels && (*it)->device == call.device && (*it)->shape == call.shape) {
                     batch.push_back(*it);
                     it = queue.erase(it);
                 } else {

@@ -23,8 +23,8 @@ hipError_t launch_generic_analyse(const void* d_input, bool in16, uint32_t n_fra
 hipError_t launch_generic_plan(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint64_t base_bytes, uint64_t* d_frame_offsets,
     uint64_t* d_word_base, uint32_t* d_chosen, uint32_t* d_status, uint64_t* d_total_words, hipStream_t stream);
 hipError_t launch_generic_emit(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, const int32_t* d_res, const int32_t* d_q,
-    const uint32_t* d_chosen, const uint64_t* d_word_base, uint32_t* d_words /* zeroed */, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint8_t* d_frames,
-    uint64_t frames_cap, hipStream_t stream);
+    const uint32_t* d_chosen, const uint64_t* d_word_base, uint32_t* d_words /* zeroed */, uint64_t words_cap /* a subframe whose words would reach beyond is left out */,
+    const uint64_t* d_frame_offsets, uint64_t base_bytes, uint8_t* d_frames, uint64_t frames_cap, hipStream_t stream);
 // fast_first: the subframes go to k_decode_subframes32 (sela_decode32.hip: the fast decoder's lane-parallel parse and tuned
 // synthesis, any length) instead of k_generic_decode (the serial walk); d_status[2] then counts the subframes that kernel left
 // alone -- not zero: run the launch again without fast_first -- and d_status[3] those it parsed by segments (standard_path:

@@ -70,53 +70,128 @@ __device__ inline void put_codeword(uint32_t* buf, uint64_t pos, uint32_t u, uin
         or_bits(buf, pos, rem, k);
 }
 
-// pack the stream v[0..n) with parameter k into zeroed words.  The 64 codewords of a round are OR-ed together in an LDS window
-// (`win`, kPackWindow words) and go out as whole words: plain stores, but for the round's first and last word, which the
-// rounds before and behind it share (an atomic OR each; first version: every codeword piece an atomic OR in global memory,
-// 0.85 ms of a 3.6 ms encode at 3875 stereo frames).  A round longer than the window (unary runs of thousands of bits) goes
-// piece by piece as before.
-constexpr uint32_t kPackWindow = 512; // words: 16,384 bits for 64 codewords
+// pack the stream v[0..n) with parameter k into zeroed words (src/rice/rice_encoder.cpp:35-71).
+// Round 6: 2048 values at a time, lane L owning 32 CONSECUTIVE values (staged through LDS so that the loads are coalesced and the
+// lanes' reads fall on different banks) -- ONE scan of the lanes' bit counts per stretch, every codeword of at most 32 bits OR-ed
+// into the LDS window without a branch -- and the window leaves as whole words: plain stores, but for the stretch's first and
+// last word, which its neighbours share (an atomic OR each).  A stretch whose quotients are long (a lane's bits beyond 2^26) or
+// whose bits do not fit the window goes 64 codewords at a time as the first version did for every round (rice_pack_round).
+constexpr uint32_t kPackWindow = 2304;  // words: 73,728 bits for 2048 codewords (36 bits each), and room for the 2048 staged values (2112 words)
+constexpr uint32_t kPackStretch = 2048;
+
+// 64 codewords at bit position `base` of the stream: lane = codeword
+__device__ inline uint64_t rice_pack_round(uint32_t u, bool valid, uint32_t k, uint32_t* out, uint64_t base, int lane, uint32_t* win)
+{
+    const uint64_t len = valid ? (uint64_t)(u >> k) + 1 + k : 0;
+    uint64_t incl = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, d, 64);
+        const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d, 64);
+        if (lane >= d)
+            incl += ((uint64_t)hi << 32) | lo;
+    }
+    const uint32_t tlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)incl, 63);
+    const uint32_t thi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(incl >> 32), 63);
+    const uint64_t total = ((uint64_t)thi << 32) | tlo; // the round's bits (wave-uniform)
+    const uint64_t first_word = base >> 5, span = ((base + total + 31) >> 5) - first_word;
+    if (span <= kPackWindow) {
+        for (uint32_t w = lane; w < (uint32_t)span; w += 64)
+            win[w] = 0;
+        wave_sync();
+        if (valid)
+            put_codeword(win, (base & 31) + incl - len, u, k);
+        wave_sync();
+        for (uint32_t w = lane; w < (uint32_t)span; w += 64) {
+            const uint32_t x = win[w];
+            if (x == 0)
+                continue; // (the words are zeroed)
+            if (w == 0 || w + 1 == (uint32_t)span)
+                atomicOr(&out[first_word + w], x);
+            else
+                out[first_word + w] = x;
+        }
+        wave_sync();
+    } else if (valid) {
+        put_codeword(out, base + incl - len, u, k); // piece by piece, straight into memory
+    }
+    return total;
+}
+
 __device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k, uint32_t* out, int lane, uint32_t* win)
 {
     uint64_t base = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        const bool valid = i0 + lane < n;
-        const uint32_t u = valid ? zigzag32(v[i0 + lane]) : 0u;
-        const uint64_t len = valid ? (uint64_t)(u >> k) + 1 + k : 0;
-        // exclusive scan of 64-bit lengths over the lanes
-        uint64_t incl = len;
+    for (uint32_t i0 = 0; i0 < n; i0 += kPackStretch) {
+        const uint32_t in_stretch = min(kPackStretch, n - i0);
+        // stage: value i of the stretch at word i + i / 32
+        for (uint32_t i = lane; i < in_stretch; i += 64)
+            win[i + (i >> 5)] = zigzag32(v[i0 + i]);
+        wave_sync();
+        uint32_t u[32];
+        const uint32_t mine = in_stretch > 32u * (uint32_t)lane ? min(32u, in_stretch - 32u * (uint32_t)lane) : 0u;
+        uint32_t bits = 0, longest = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, d, 64);
-            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d, 64);
-            if (lane >= d)
-                incl += ((uint64_t)hi << 32) | lo;
+        for (int t = 0; t < 32; t++) {
+            u[t] = (uint32_t)t < mine ? win[33 * lane + t] : 0u;
+            const uint32_t q = u[t] >> k;
+            longest = max(longest, q);
+            bits += (uint32_t)t < mine ? q + 1 + k : 0u; // (may wrap when a quotient is long: then `longest` says so)
         }
-        const uint32_t tlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)incl, 63);
-        const uint32_t thi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(incl >> 32), 63);
-        const uint64_t total = ((uint64_t)thi << 32) | tlo; // the round's bits (wave-uniform)
-        const uint64_t first_word = base >> 5, span = ((base + total + 31) >> 5) - first_word;
-        if (span <= kPackWindow) {
-            for (uint32_t w = lane; w < (uint32_t)span; w += 64)
+        wave_sync(); // the staged values are in registers: the window is free
+        const bool easy = !__any(longest >= (1u << 20)); // a lane's bits below 2^26, the stretch's below 2^32
+        uint32_t at = 0, total = 0;
+        if (easy) {
+            at = wave_exclusive_scan(bits, lane);
+            total = (uint32_t)__builtin_amdgcn_readlane((int)(at + bits), 63);
+        }
+        const uint64_t first_word = base >> 5;
+        const uint32_t span = easy ? (uint32_t)((((base & 31) + total + 31) >> 5)) : 0u;
+        if (easy && span + 1 <= kPackWindow) {
+            for (uint32_t w = lane; w <= span; w += 64) // (one word to spare: or_bits_both touches the word behind a codeword's last)
                 win[w] = 0;
             wave_sync();
-            if (valid)
-                put_codeword(win, (base & 31) + incl - len, u, k);
+            uint32_t pos = (uint32_t)(base & 31) + at;
+#pragma unroll
+            for (int t = 0; t < 32; t++) {
+                if ((uint32_t)t < mine) {
+                    const uint32_t ones = u[t] >> k, len = ones + 1 + k;
+                    if (len <= 32) {
+                        const uint32_t rem = __builtin_amdgcn_ubfe(__brev(u[t]), 32 - k, k); // the low k bits, the first one the most significant
+                        const uint64_t wide = (uint64_t)(((1u << ones) - 1u) | (rem << ((ones + 1) & 31))) << (pos & 31);
+                        atomicOr(&win[pos >> 5], (uint32_t)wide);
+                        atomicOr(&win[(pos >> 5) + 1], (uint32_t)(wide >> 32));
+                    } else {
+                        put_codeword(win, pos, u[t], k);
+                    }
+                    pos += len;
+                }
+            }
             wave_sync();
-            for (uint32_t w = lane; w < (uint32_t)span; w += 64) {
+            for (uint32_t w = lane; w < span; w += 64) {
                 const uint32_t x = win[w];
                 if (x == 0)
                     continue; // (the words are zeroed)
-                if (w == 0 || w + 1 == (uint32_t)span)
+                if (w == 0 || w + 1 == span)
                     atomicOr(&out[first_word + w], x);
                 else
                     out[first_word + w] = x;
             }
             wave_sync();
-        } else if (valid) {
-            put_codeword(out, base + incl - len, u, k);
+            base += total;
+        } else { // long quotients, or more bits than the window holds: 64 codewords at a time, codeword i of the stretch in lane i % 64
+            // (the values go back through the window's first 2112 words: rice_pack_round uses the window too, so round by round from registers)
+            for (uint32_t r0 = 0; r0 < in_stretch; r0 += 64) {
+                // codeword r0 + lane lives in lane (r0 + lane) / 32's register (r0 + lane) % 32
+                const uint32_t src_lane = (r0 + (uint32_t)lane) >> 5;
+                uint32_t mine_u = 0;
+#pragma unroll
+                for (int t = 0; t < 32; t++) {
+                    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * src_lane), (int)u[t]);
+                    mine_u = (((r0 + (uint32_t)lane) & 31u) == (uint32_t)t) ? got : mine_u;
+                }
+                base += rice_pack_round(mine_u, r0 + lane < in_stretch, k, out, base, lane, win);
+            }
         }
-        base += total;
     }
 }
 
@@ -325,14 +400,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             wave_sync();
             const LdsDoubles rl = (LdsDoubles)lds.ac.ring + ((j0 - 2u * (uint32_t)lane) & (uint32_t)(kGenRing - 1)); // c[j0 - 2 lane]
             if (n - j0 >= 64u) {
+                // (the window values are fetched kAcAhead steps ahead of their use: a ds_read_b64 takes ~100 cycles to come back)
+                constexpr int kAcAhead = 8;
+                double ahead[kAcAhead];
+#pragma unroll
+                for (int t = 0; t < kAcAhead; t++)
+                    ahead[t] = rl[t];
 #pragma unroll
                 for (int t = 0; t < 64; t++) {
                     const double cj = read_lane(c_mine, t);
-                    const double A = rl[t];
+                    const double A = ahead[t % kAcAhead];
+                    if (t + kAcAhead < 64)
+                        ahead[t % kAcAhead] = rl[t + kAcAhead];
                     const double pe = cj * A, po = cj * B;
                     acc_e += pe;
                     acc_o += po;
                     B = A;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 const int cnt = (int)(n - j0);
@@ -550,14 +634,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
 // ---- plan: the stereo decision, frame sizes, offsets -- one workgroup -----------------------------------------------------
 // src/frame/frame_encoder.cpp:64-72: the difference candidate wins iff its words (coefficients + residues) are FEWER.
-constexpr int kPlanThreads = 256;
+// 1024 threads, a contiguous range of frames each; the ranges' sums are scanned across the workgroup (shuffles within a wave,
+// the sixteen waves' totals through LDS -- the first version's single thread walked 256 partial sums: 40 of its 60 us).
+constexpr int kPlanThreads = 1024;
 __global__ __launch_bounds__(kPlanThreads) void k_generic_plan(const GenericMeta* __restrict__ meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig,
     uint64_t base_bytes, uint64_t* __restrict__ frame_offsets /* [n_frames + 1], absolute */, uint64_t* __restrict__ word_base /* [n_frames * channels + 1] */,
     uint32_t* __restrict__ chosen /* [n_frames * channels]: signal index */, uint32_t* __restrict__ status, uint64_t* __restrict__ total_words_out)
 {
-    __shared__ uint64_t part_bytes[kPlanThreads], part_words[kPlanThreads];
-    __shared__ uint32_t part_flags[kPlanThreads];
+    constexpr int kWaves = kPlanThreads / 64;
+    __shared__ uint64_t wave_bytes[kWaves], wave_words[kWaves];
+    __shared__ uint32_t wave_flags[kWaves];
     const uint32_t t = threadIdx.x;
+    const int lane = t % 64, wave = t / 64;
     const uint32_t per = (n_frames + kPlanThreads - 1) / kPlanThreads;
     const uint32_t f_begin = min(t * per, n_frames), f_end = min(f_begin + per, n_frames);
     auto frame_plan = [&](uint32_t f, uint64_t& bytes, uint64_t& words, uint32_t& flags, bool write, uint64_t words_before) {
@@ -589,29 +677,44 @@ __global__ __launch_bounds__(kPlanThreads) void k_generic_plan(const GenericMeta
         frame_plan(f, bt, w, my_flags, false, 0);
         my_bytes += bt, my_words += w;
     }
-    part_bytes[t] = my_bytes, part_words[t] = my_words, part_flags[t] = my_flags;
-    __syncthreads();
-    if (t == 0) {
-        uint64_t run_b = 0, run_w = 0;
-        uint32_t fl = 0;
-        for (int i = 0; i < kPlanThreads; i++) {
-            const uint64_t pb = part_bytes[i], pw = part_words[i];
-            part_bytes[i] = run_b, part_words[i] = run_w;
-            run_b += pb, run_w += pw;
-            fl |= part_flags[i];
+    // exclusive scan of (bytes, words) over the threads
+    auto scan64 = [&](uint64_t v) -> uint64_t { // inclusive, within the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
+            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+            if (lane >= d)
+                v += ((uint64_t)hi << 32) | lo;
         }
-        frame_offsets[n_frames] = base_bytes + run_b;
-        word_base[(size_t)n_frames * channels] = run_w;
-        *total_words_out = run_w;
-        atomicOr(&status[0], fl);
-    }
+        return v;
+    };
+    const uint64_t incl_b = scan64(my_bytes), incl_w = scan64(my_words);
+    const uint32_t fl = wave_or(my_flags);
+    if (lane == 63)
+        wave_bytes[wave] = incl_b, wave_words[wave] = incl_w;
+    if (lane == 0)
+        wave_flags[wave] = fl;
     __syncthreads();
-    uint64_t at_b = part_bytes[t], at_w = part_words[t];
+    uint64_t at_b = incl_b - my_bytes, at_w = incl_w - my_words, all_b = 0, all_w = 0;
+    uint32_t all_fl = 0;
+    for (int w = 0; w < kWaves; w++) {
+        const uint64_t wb = wave_bytes[w], ww = wave_words[w];
+        if (w < wave)
+            at_b += wb, at_w += ww;
+        all_b += wb, all_w += ww;
+        all_fl |= wave_flags[w];
+    }
+    if (t == 0) {
+        frame_offsets[n_frames] = base_bytes + all_b;
+        word_base[(size_t)n_frames * channels] = all_w;
+        *total_words_out = all_w;
+        atomicOr(&status[0], all_fl);
+    }
     for (uint32_t f = f_begin; f < f_end; f++) {
         uint64_t bt, w;
-        uint32_t fl = 0;
+        uint32_t fl2 = 0;
         frame_offsets[f] = base_bytes + at_b;
-        frame_plan(f, bt, w, fl, true, at_w);
+        frame_plan(f, bt, w, fl2, true, at_w);
         at_b += bt, at_w += w;
     }
 }
@@ -619,7 +722,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_generic_plan(const GenericMeta
 // ---- pack: the chosen candidates' two Rice streams, one wave per subframe ---------------------------------------------------
 __global__ __launch_bounds__(64) void k_generic_pack(const GenericMeta* __restrict__ meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n,
     const int32_t* __restrict__ res_ws, const int32_t* __restrict__ q_ws, const uint32_t* __restrict__ chosen, const uint64_t* __restrict__ word_base,
-    uint32_t* __restrict__ words /* zeroed */)
+    uint32_t* __restrict__ words /* zeroed */, uint64_t words_cap)
 {
     const uint32_t sub = blockIdx.x;
     if (sub >= n_frames * channels)
@@ -629,6 +732,8 @@ __global__ __launch_bounds__(64) void k_generic_pack(const GenericMeta* __restri
     const size_t b = (size_t)f * n_sig + chosen[sub];
     const GenericMeta m = meta[b];
     if (m.flags & (SELA_HIP_FLAG_WORDS_CAP | SELA_HIP_FLAG_RICE_RANGE))
+        return;
+    if (word_base[sub] + m.coef_words + m.res_words > words_cap) // (the host sized the words by an estimate: it packs again at the plan's size)
         return;
     __shared__ uint32_t win[kPackWindow];
     uint32_t* const out = words + word_base[sub];
@@ -1041,13 +1146,13 @@ hipError_t launch_generic_plan(const GenericMeta* d_meta, uint32_t n_frames, uin
 }
 
 hipError_t launch_generic_emit(const GenericMeta* d_meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig, uint32_t n, const int32_t* d_res, const int32_t* d_q,
-    const uint32_t* d_chosen, const uint64_t* d_word_base, uint32_t* d_words /* zeroed */, const uint64_t* d_frame_offsets, uint64_t base_bytes, uint8_t* d_frames,
-    uint64_t frames_cap, hipStream_t stream)
+    const uint32_t* d_chosen, const uint64_t* d_word_base, uint32_t* d_words /* zeroed */, uint64_t words_cap, const uint64_t* d_frame_offsets, uint64_t base_bytes,
+    uint8_t* d_frames, uint64_t frames_cap, hipStream_t stream)
 {
     const uint32_t subs = n_frames * channels;
     if (subs == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_generic_pack, dim3(subs), dim3(64), 0, stream, d_meta, n_frames, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words);
+    hipLaunchKernelGGL(k_generic_pack, dim3(subs), dim3(64), 0, stream, d_meta, n_frames, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, words_cap);
     hipLaunchKernelGGL(k_generic_assemble, dim3(subs), dim3(kAsmThreads), 0, stream, d_meta, n_frames, channels, n_sig, n, d_chosen, d_word_base, d_words,
         d_frame_offsets, base_bytes, d_frames, frames_cap);
     return hipGetLastError();

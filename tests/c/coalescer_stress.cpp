@@ -85,6 +85,33 @@ struct StubBackend {
         std::this_thread::sleep_for(std::chrono::microseconds(30));
         return SELA_HIP_OK;
     }
+    // "encoding 32-bit channels": 8 bytes per frame -- its first sample | channels << 16 | n << 24, and a checksum
+    static size_t encode_i32_bound_bytes(uint32_t n_frames, uint32_t, uint32_t) { return (size_t)n_frames * 8; }
+    static int encode_i32_now(const int32_t* samples, uint32_t n_frames, uint32_t channels, uint32_t n, uint8_t* out, size_t cap, uint64_t* offsets)
+    {
+        g_jobs++, g_frames += (int)n_frames;
+        if (cap < (size_t)n_frames * 8) {
+            t_error = "frames_out too small";
+            return SELA_HIP_ECAPACITY;
+        }
+        for (uint32_t f = 0; f < n_frames; f++) {
+            const int32_t* p = samples + (size_t)f * n * channels;
+            if (p[0] == -777) {
+                t_error = "a block the reference cannot answer";
+                return SELA_HIP_ERANGE;
+            }
+            uint32_t sum = 0;
+            for (size_t i = 0; i < (size_t)n * channels; i++)
+                sum = sum * 31u + (uint32_t)p[i];
+            const uint32_t first = ((uint32_t)p[0] & 0xFFFFu) | (channels << 16) | (n << 24);
+            std::memcpy(out + 8 * f, &first, 4);
+            std::memcpy(out + 8 * f + 4, &sum, 4);
+            offsets[f] = 8 * (uint64_t)f;
+        }
+        offsets[n_frames] = 8 * (uint64_t)n_frames;
+        std::this_thread::sleep_for(std::chrono::microseconds(30));
+        return SELA_HIP_OK;
+    }
     static void* take(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
     static void give(void* p) { std::free(p); }
     static std::string last_error() { return t_error; }
@@ -93,7 +120,7 @@ struct StubBackend {
 
 typedef sela::CallCoalescer<StubBackend> Coalescer;
 
-int worker(Coalescer& enc, Coalescer& dec, Coalescer& dec32, int id, int rounds, std::atomic<int>& failures)
+int worker(Coalescer& enc, Coalescer& dec, Coalescer& dec32, Coalescer& enc32, int id, int rounds, std::atomic<int>& failures)
 {
     std::mt19937 rng(1000 + id);
     for (int r = 0; r < rounds; r++) {
@@ -162,6 +189,30 @@ int worker(Coalescer& enc, Coalescer& dec, Coalescer& dec32, int id, int rounds,
                         failures++, std::fprintf(stderr, "thread %d round %d: decode32 row %zu came back as somebody else's\n", id, r, row);
                 }
         }
+        // 32-bit channels of a shape of the thread's own (three shapes among the threads: only equal shapes may share a job); every
+        // 19th call holds a block "the reference cannot answer": the batch is retried call by call, only this caller hears of it
+        const uint32_t shape = 40u + 10u * (uint32_t)(id % 3);
+        const bool refused = r % 19 == 4;
+        std::vector<int32_t> planar((size_t)n * channels * shape);
+        for (uint32_t f = 0; f < n; f++)
+            for (size_t i = 0; i < (size_t)shape * channels; i++)
+                planar[(size_t)f * shape * channels + i] = (refused && f == n - 1) ? -777 : (int32_t)(id * 1000 + r * 3 + (int)f);
+        std::vector<uint8_t> bytes32((size_t)n * 8);
+        std::vector<uint64_t> offsets32(n + 1, ~0ull);
+        sela::SmallCall x;
+        x.device = e.device, x.channels = channels, x.n_frames = n, x.shape = shape;
+        x.samples = planar.data(), x.frames_out = bytes32.data(), x.frames_cap = bytes32.size(), x.offsets_out = offsets32.data();
+        const int rx = enc32.submit(x);
+        if (refused ? rx != SELA_HIP_ERANGE : (rx != SELA_HIP_OK || offsets32[n] != 8ull * n)) {
+            failures++, std::fprintf(stderr, "thread %d round %d: encode32 rc %d (refused: %d)\n", id, r, rx, (int)refused);
+        } else if (!refused) {
+            for (uint32_t f = 0; f < n; f++) {
+                uint32_t first;
+                std::memcpy(&first, bytes32.data() + offsets32[f], 4);
+                if ((first & 0xFFFFu) != ((uint32_t)planar[(size_t)f * shape * channels] & 0xFFFFu) || ((first >> 16) & 0xFF) != channels || (first >> 24) != shape)
+                    failures++, std::fprintf(stderr, "thread %d round %d: encode32 frame %u came back as somebody else's\n", id, r, f);
+            }
+        }
     }
     return 0;
 }
@@ -171,11 +222,11 @@ int worker(Coalescer& enc, Coalescer& dec, Coalescer& dec32, int id, int rounds,
 int main(int argc, char** argv)
 {
     const int threads = argc > 1 ? std::atoi(argv[1]) : 16, rounds = argc > 2 ? std::atoi(argv[2]) : 120;
-    Coalescer enc(true), dec(false), dec32(Coalescer::kDecode32);
+    Coalescer enc(true), dec(false), dec32(Coalescer::kDecode32), enc32(Coalescer::kEncode32);
     std::atomic<int> failures{ 0 };
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; t++)
-        pool.emplace_back(worker, std::ref(enc), std::ref(dec), std::ref(dec32), t, rounds, std::ref(failures));
+        pool.emplace_back(worker, std::ref(enc), std::ref(dec), std::ref(dec32), std::ref(enc32), t, rounds, std::ref(failures));
     for (std::thread& t : pool)
         t.join();
     std::printf("%d threads x %d rounds: %d device jobs for %d frames, %d batches led, %d failures\n", threads, rounds, g_jobs.load(), g_frames.load(),

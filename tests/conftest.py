@@ -74,3 +74,16 @@ def generic_kats():
     import numpy as np
 
     return np.load(os.path.join(ROOT, "tests", "golden", "generic_kats.npz"))
+
+
+@pytest.fixture(scope="session")
+def ragged_digests():
+    """Frames whose channels differ in length through the reference's frame::FrameEncoder (make_golden.py ragged)."""
+    return _load_json("ragged.json")
+
+
+@pytest.fixture(scope="session")
+def ragged_kats():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "ragged_kats.npz"))

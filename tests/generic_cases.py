@@ -70,6 +70,27 @@ def retag(sub: bytearray, channel: int, type_: int, parent: int) -> bytearray:
     return s
 
 
+# ---- frames whose channels differ in length, through frame::FrameEncoder (src/frame/frame_encoder.cpp:20-24,73-98) -----------
+def ragged_cases():
+    """(label, [int32 array per channel]).  Every channel at its own length; the second channel of an exactly-stereo frame against
+    channel 0 - channel 1 over ITS length (channel 0 the longer one: where it is shorter the reference reads past its vector)."""
+    def chan(n, track, c=0, wide=False):
+        x = synth_pcm(4000 + n, 2, track)[4000:, c].astype(np.int32)
+        if wide:
+            x = np.clip(2 * x + ((x >> 3) & 1), -65535, 65535)
+        return np.ascontiguousarray(x.astype(np.int32))
+
+    left = chan(1500, 70)
+    near = left[:1000] - (synth_pcm(5000, 1, 77, noise_shift=6)[4000:, 0].astype(np.int32) >> 9)  # a near copy: the difference wins
+    yield "stereo_long_short_diff", [left, near.astype(np.int32)]
+    yield "stereo_long_short_indep", [chan(2048, 71), chan(777, 72, 1)]
+    yield "stereo_one_sample_apart_i17", [chan(2049, 73, 0, True), chan(2048, 73, 1, True)]
+    yield "three_ragged", [chan(300, 74), chan(2048, 75, 1), chan(777, 76)]
+    yield "three_short_first_i17", [chan(150, 78, 0, True), chan(5000, 79, 1, True), chan(4096, 80)]
+    yield "five_ragged", [chan(128 + 333 * i, 81 + i, i & 1) for i in range(5)]
+    yield "stereo_long_65535", [chan(65535, 87), chan(30000, 88, 1)]
+
+
 # ---- a hand-made .sela FILE whose frames have different lengths (stereo; every length <= 5000: the reference's stereo WAV
 #      writer keeps a 10000-sample buffer, src/file/wav_file.cpp:245-255) --------------------------------------------------
 ODD_FILE_LENGTHS = (2048, 2048, 1000, 1000, 3000, 2048, 777, 3000)

@@ -6,7 +6,7 @@ which compiles the unmodified reference from /root/reference).  The fixtures are
 inputs and the reference's outputs.  Commit the resulting .npz / .json files; the GPU box
 and CI only ever read them.
 
-    python tests/golden/make_golden.py [kats] [configs] [files] [album] [generic]     (default: all five sections)
+    python tests/golden/make_golden.py [kats] [configs] [files] [album] [generic] [ragged]     (default: all six sections)
 """
 import ctypes as C
 import hashlib
@@ -120,9 +120,11 @@ def album_digests(ref, threads=8):
 def main():
     ref = reference()
     assert ref is not None, "build oracle/_ref first: make -C oracle ref"
-    sections = set(sys.argv[1:]) or {"kats", "configs", "files", "album", "generic"}
+    sections = set(sys.argv[1:]) or {"kats", "configs", "files", "album", "generic", "ragged"}
     if "generic" in sections:
         generic(ref)
+    if "ragged" in sections:
+        ragged(ref)
     if "files" in sections:
         with open(os.path.join(HERE, "file_digests.json"), "w") as f:
             json.dump(file_digests(ref), f, indent=1, sort_keys=True)
@@ -133,6 +135,29 @@ def main():
         kats(ref)
     if "configs" in sections:
         config_digests(ref)
+
+
+def ragged(ref):
+    """Frames whose channels differ in length through the reference's frame::FrameEncoder (oracle/ref_shim.cpp
+    ref_frame_encode_ragged) and back through its frame::FrameDecoder: digests of the inputs (regenerated by
+    tests/generic_cases.py), the frame bytes (whole, for the short ones) and the decoded channels -> ragged.json, ragged_kats.npz."""
+    import generic_cases as gc
+
+    table, arrays = {}, {}
+    for label, chans in gc.ragged_cases():
+        blob = ref.frame_encode_ragged(chans)
+        dec, used = ref.frame_decode_i32(blob, len(chans))
+        assert used == len(blob)
+        table[label] = {"lengths": [int(len(c)) for c in chans], "input_sha256": gc.sha_channels(chans), "frame_bytes": len(blob),
+                        "frame_sha256": hashlib.sha256(blob).hexdigest(), "decoded_sha256": gc.sha_channels(dec),
+                        "subframe_types": [int(s[1]) for s in gc.subframes_of(blob, len(chans))],
+                        "lossless": bool(all(np.array_equal(a, b) for a, b in zip(dec, chans)))}
+        if len(blob) < 20000:
+            arrays[f"{label}/bytes"] = np.frombuffer(blob, np.uint8)
+        print(label, table[label], flush=True)
+    with open(os.path.join(HERE, "ragged.json"), "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "ragged_kats.npz"), **arrays)
 
 
 def generic(ref):

@@ -77,6 +77,9 @@ class Oracle:
         self._fenc32 = f("frame_encode_i32")
         self._fenc32.restype = C.c_size_t
         self._fenc32.argtypes = [_i32p, C.c_uint32, C.c_uint32, _u8p] + flags
+        self._fencr = f("frame_encode_ragged")
+        self._fencr.restype = C.c_size_t
+        self._fencr.argtypes = [_i32p, _u32p, C.c_uint32, _u8p] + flags
         self._fdec32 = f("frame_decode_i32")
         self._fdec32.restype = C.c_size_t
         self._fdec32.argtypes = [_u8p, C.c_uint32, _i32p, C.c_uint32, _u32p] + flags
@@ -161,6 +164,15 @@ class Oracle:
         ch, n = p.shape
         out = np.zeros(4 + ch * (12 + 4 * 128 + 16 * n + 256), np.uint8)
         used = self._fenc32(p, ch, n, out, *self._fl())
+        return out[:used].tobytes()
+
+    def frame_encode_ragged(self, channels):
+        """channels: list of int32 arrays of different lengths (data::WavFrame.samples) -> bytes of the on-disk frame."""
+        chans = [np.ascontiguousarray(c, dtype=np.int32).ravel() for c in channels]
+        flat = np.concatenate(chans) if chans else np.zeros(0, np.int32)
+        lengths = np.array([len(c) for c in chans], np.uint32)
+        out = np.zeros(4 + sum(12 + 4 * 128 + 16 * len(c) + 256 for c in chans), np.uint8)
+        used = self._fencr(flat, lengths, len(chans), out, *self._fl())
         return out[:used].tobytes()
 
     def frame_decode_i32(self, blob, channels, stride=65535):

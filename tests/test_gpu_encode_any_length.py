@@ -94,3 +94,31 @@ def test_a_batch_of_frames_equals_frame_by_frame(gpu):  # noqa: F811
         assert frames[int(offs[f]):int(offs[f + 1])].tobytes() == o.frame_encode_i32(planar[f]), f
     f16, o16 = codec.encode_host(pcm)
     assert np.array_equal(o16, offs) and np.array_equal(f16, frames)
+
+
+def test_frames_whose_channels_differ_in_length_equal_the_references_bytes(gpu, ragged_digests, ragged_kats):  # noqa: F811
+    """frame::FrameEncoder on channels of different lengths (src/frame/frame_encoder.cpp:20-24,73-98: every channel at its own
+    samples[i].size(), the stereo difference over channel 1's length): the frame bytes the unmodified reference wrote
+    (tests/golden/ragged.json, ragged_kats.npz), decoded back to the reference's channels; and the one shape on which the
+    reference indexes past its vector -- stereo, channel 0 the shorter -- refused."""
+    import hashlib
+
+    import generic_cases as gc
+    from sela_amd import capi, codec
+
+    for label, chans in gc.ragged_cases():
+        g = ragged_digests[label]
+        assert gc.sha_channels(chans) == g["input_sha256"], label
+        blob = codec.encode_ragged(chans)
+        assert len(blob) == g["frame_bytes"] and hashlib.sha256(blob).hexdigest() == g["frame_sha256"], label
+        if f"{label}/bytes" in ragged_kats:
+            assert blob == ragged_kats[f"{label}/bytes"].tobytes(), label
+        dec = codec.decode_i32(np.frombuffer(blob, np.uint8), np.array([0, len(blob)], np.uint64), len(chans))[0]
+        assert gc.sha_channels(dec) == g["decoded_sha256"], label
+    short_first = [np.arange(500, dtype=np.int32), np.arange(900, dtype=np.int32)]
+    with pytest.raises(capi.SelaHipError) as err:
+        codec.encode_ragged(short_first)
+    assert err.value.code == -2  # SELA_HIP_EINVAL
+    # equal lengths through the same entry = sela_hip_encode_i32
+    x = gc.case_input(1000, "stereo_diff", False)
+    assert codec.encode_ragged([x[0], x[1]]) == codec.encode_i32(x[None])[0].tobytes()

@@ -39,6 +39,42 @@ def test_crafted_frames_decode_like_the_reference(generic_kats):
             assert np.array_equal(dec[c], generic_kats[f"crafted/{name}/decoded{c}"]), (name, c)
 
 
+def test_frames_whose_channels_differ_in_length_against_the_reference_fixtures(ragged_digests, ragged_kats):
+    """src/frame/frame_encoder.cpp:20-24,73-98: every channel at its own length, the stereo difference over channel 1's."""
+    o = oracle()
+    for label, chans in gc.ragged_cases():
+        g = ragged_digests[label]
+        assert gc.sha_channels(chans) == g["input_sha256"] and [len(c) for c in chans] == g["lengths"], label
+        blob = o.frame_encode_ragged(chans)
+        assert len(blob) == g["frame_bytes"] and hashlib.sha256(blob).hexdigest() == g["frame_sha256"], label
+        if f"{label}/bytes" in ragged_kats:
+            assert blob == ragged_kats[f"{label}/bytes"].tobytes(), label
+        assert [s[1] for s in gc.subframes_of(blob, len(chans))] == g["subframe_types"], label
+        dec, used = o.frame_decode_i32(blob, len(chans))
+        assert used == len(blob) and gc.sha_channels(dec) == g["decoded_sha256"], label
+
+
+def test_oracle_against_the_reference_on_ragged_frames():
+    ref = reference()
+    if ref is None:
+        pytest.skip("oracle/_ref/libsela_ref.so not built (needs /root/reference)")
+    o = oracle()
+    rng = np.random.default_rng(12)
+    for trial in range(40):
+        ch = int(rng.integers(2, 6))
+        lengths = [int(rng.integers(101, 3000)) for _ in range(ch)]
+        if ch == 2:
+            lengths.sort(reverse=True)  # (channel 0 the longer one: the reference reads it up to channel 1's length)
+        amp = int(rng.choice([300, 32767, 65535]))
+        chans = []
+        for c, n in enumerate(lengths):
+            t = np.arange(n)
+            chans.append(np.clip(np.round(amp * 0.5 * np.sin(t * 0.03 * (c + 1)) + rng.normal(0, amp * 0.02 + 1, n)), -amp, amp).astype(np.int32))
+        if ch == 2 and trial % 2:
+            chans[1] = (chans[0][: lengths[1]] - rng.integers(-2, 3, lengths[1])).astype(np.int32)
+        assert o.frame_encode_ragged(chans) == ref.frame_encode_ragged(chans), (trial, lengths, amp)
+
+
 def test_oracle_against_the_reference_on_odd_shapes():
     ref = reference()
     if ref is None:
