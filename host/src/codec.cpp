@@ -418,33 +418,27 @@ size_t decodeFile(std::ifstream& in, std::ofstream& out)
     if (channels == 0)
         throw data::Exception("Decoder: unsupported channel count");
     const size_t announced = std::min<size_t>(sela.selaHeader.numFrames, payload / (4 + 12 * (size_t)channels));
-    file::WavFile::writeHeader(out, sela.selaHeader.sampleRate, (uint16_t)channels, 16, (uint32_t)(announced * kBlock * channels * 2));
+    // Nothing goes to `out` before the stream's verdict is in: the streaming job reports a frame that does not say 2048 samples
+    // only at its end (such frames decode to silence until then), and a std::ofstream cannot be cut back -- a fallback that
+    // finds fewer samples than were already written would leave the stale ones behind the data chunk.  (The variant by path,
+    // which can truncate its file, writes while it decodes.)
     sela_host::PinnedBuffer<int16_t> pcm;
-    size_t written = 0;
     try {
-        streamDecode(StreamFetcher{ in, sela }, sela, payload, pcm, [&](const int16_t* p, size_t done) {
-            if (done > written) {
-                out.write(reinterpret_cast<const char*>(p + written), (std::streamsize)((done - written) * 2));
-                written = done;
-            }
-        });
+        streamDecode(StreamFetcher{ in, sela }, sela, payload, pcm, [](const int16_t*, size_t) {});
     } catch (const data::Exception&) { // frames that do not say 2048?  (decodeOddStream)
         in.clear();
         in.seekg(SELA_FILE_HEADER_BYTES, std::ios::beg);
         sela.frameBytes.resize(payload);
         if (!readExact(in, sela.frameBytes.data(), payload) || !decodeOddStream(sela, payload, pcm))
             throw;
-        out.seekp(0, std::ios::beg);
         file::WavFile::writeHeader(out, sela.selaHeader.sampleRate, (uint16_t)channels, 16, (uint32_t)(pcm.size() * 2));
         out.write(reinterpret_cast<const char*>(pcm.data()), (std::streamsize)(pcm.size() * 2));
         return sela.frameCount();
     }
-    const size_t frames = sela.frameCount();
-    if (frames != announced) { // the stream ended early (bad sync word): the header sizes follow what was decoded
-        out.seekp(0, std::ios::beg);
-        file::WavFile::writeHeader(out, sela.selaHeader.sampleRate, (uint16_t)channels, 16, (uint32_t)(frames * kBlock * channels * 2));
-        out.seekp(0, std::ios::end);
-    }
+    const size_t frames = sela.frameCount(); // (fewer than announced when the stream ended early: a bad sync word)
+    (void)announced;
+    file::WavFile::writeHeader(out, sela.selaHeader.sampleRate, (uint16_t)channels, 16, (uint32_t)(frames * kBlock * channels * 2));
+    out.write(reinterpret_cast<const char*>(pcm.data()), (std::streamsize)(frames * kBlock * channels * 2));
     return frames;
 }
 

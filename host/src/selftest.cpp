@@ -441,6 +441,38 @@ int main(int argc, char** argv)
             CHECK(sela::decodeFile(dir + "/forms_obj.sela", dir + "/forms_path.wav") == 2300);
             const std::string wa = slurp(dir + "/forms_obj.wav"), wb = slurp(dir + "/forms_stream.wav"), wc = slurp(dir + "/forms_path.wav");
             CHECK(wa.size() == 44 + (size_t)2300 * 2048 * ch * 2 && wa == wb && wa == wc);
+            // a hand-made file whose frames say 2048, 700, 3000 and 700 samples (fewer per frame than 2048 on average: a decoder
+            // that wrote 2048-sample frames before it found out has written too much): the stream variant of decodeFile must
+            // leave exactly what the variant by path and the object path leave
+            {
+                std::vector<data::SelaFrame> odd;
+                const size_t lens[4] = { 2048, 700, 3000, 700 };
+                std::vector<int16_t> want;
+                for (size_t f = 0; f < 4; f++) {
+                    std::vector<std::vector<int32_t>> chans(2, std::vector<int32_t>(lens[f]));
+                    for (size_t i = 0; i < lens[f]; i++) {
+                        chans[0][i] = (int32_t)(9000 * std::sin((double)(i + 100 * f) * 0.02)) + (int32_t)((i * 7919 + f) % 11);
+                        chans[1][i] = chans[0][i] / 2 + (int32_t)(i % 5);
+                        want.push_back((int16_t)chans[0][i]);
+                        want.push_back((int16_t)chans[1][i]);
+                    }
+                    odd.push_back(frame::FrameEncoder(data::WavFrame(16, chans)).process());
+                }
+                file::SelaFile of(44100, 16, 2, std::move(odd));
+                {
+                    std::ofstream out(dir + "/odd.sela", std::ios::binary);
+                    of.writeToFile(out);
+                }
+                {
+                    std::ifstream in(dir + "/odd.sela", std::ios::binary);
+                    std::ofstream out(dir + "/odd_stream.wav", std::ios::binary);
+                    CHECK(sela::decodeFile(in, out) == 4);
+                }
+                CHECK(sela::decodeFile(dir + "/odd.sela", dir + "/odd_path.wav") == 4);
+                const std::string os = slurp(dir + "/odd_stream.wav"), op = slurp(dir + "/odd_path.wav");
+                CHECK(os.size() == 44 + want.size() * 2 && os == op);
+                CHECK(os.size() >= 44 && std::memcmp(os.data() + 44, want.data(), std::min(os.size() - 44, want.size() * 2)) == 0);
+            }
             size_t differing = 0; // (the codec is the reference's: off by one in a handful of frames at most)
             for (size_t i = 0; i < (size_t)2300 * 2048 * ch; i++)
                 differing += std::memcmp(&wa[44 + 2 * i], &pcm[i], 2) != 0;

@@ -480,6 +480,8 @@ static void decode_sub(const sub_view* v, int32_t* s, uint32_t* flags)
     int32_t* r = (int32_t*)malloc(4 * (size_t)v->n + 4);
     memcpy(cw, v->cw, 4 * (size_t)v->cwords);
     memcpy(rw, v->rw, 4 * (size_t)v->rwords);
+    if (v->n == 0 || v->n <= v->order) /* samples[0] = residues[0]; samples[1 .. order] (src/lpc/sample_generator.cpp:14-22): past the vectors */
+        raise_flag(flags, SELA_ORACLE_FLAG_SHORT_BLOCK);
     sela_oracle_rice_decode(cw, v->cwords, v->order, v->ck, q, flags);
     sela_oracle_rice_decode(rw, v->rwords, v->n, v->rk, r, flags);
     int order = v->order > SELA_MAX_LPC_ORDER ? SELA_MAX_LPC_ORDER : v->order;

@@ -29,6 +29,7 @@ extern "C" {
 #define SELA_ORACLE_FLAG_COEF_OVERFLOW 2u /* |2^35*coef| >= 2^63 in the step-up output */
 #define SELA_ORACLE_FLAG_RICE_RANGE 4u   /* zig-zag value does not fit 32 bits */
 #define SELA_ORACLE_FLAG_RICE_OVERRUN 8u /* Rice decoder ran past the end of its words */
+#define SELA_ORACLE_FLAG_SHORT_BLOCK 128u /* decoder: a subframe with no samples, or not longer than its order (sample_generator.cpp:14-22 writes past its vector) */
 #define SELA_ORACLE_FLAG_BAD_FRAME 32u   /* a subframe names a channel / parent that does not exist, or a parent shorter than itself */
 
 /* FP64 intermediates of one analysis, exposed so that GPU kernels can be compared stage by

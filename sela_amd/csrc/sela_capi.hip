@@ -972,6 +972,11 @@ int job_end(sela_hip_job* job, uint32_t* frames_final, uint64_t* bytes_final)
         return fail(SELA_HIP_EFORMAT, "malformed frame stream (bad sync word or subframe header)");
     if (seen_flags & SELA_HIP_FLAG_RICE_OVERRUN)
         return fail(SELA_HIP_EFORMAT, "a Rice stream ended before all its values were read");
+    // (the same policy as the any-length route, sela_capi_generic.hip: what the reference leaves undefined is reported)
+    if (seen_flags & SELA_HIP_FLAG_COEF_OVERFLOW)
+        return fail(SELA_HIP_ERANGE, "decode: a predictor coefficient left the int64 range");
+    if (seen_flags & SELA_HIP_FLAG_Q_RANGE)
+        return fail(SELA_HIP_ERANGE, "decode: a quantised reflection coefficient outside [-64, 63] (the reference indexes past its tables, src/lpc/linear_predictor.cpp:23-26)");
     return SELA_HIP_OK;
 }
 
@@ -1025,7 +1030,30 @@ struct Flights {
         }
         (void)hipEventRecord(mine->done, stream);
     }
+    void release_all() // sela_hip_shutdown: the events go back to the runtime, each on its device
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        int before = -1;
+        (void)hipGetDevice(&before);
+        for (int dev = 0; dev < 64; dev++) {
+            if (entries[dev].empty())
+                continue;
+            (void)hipSetDevice(dev);
+            for (Entry& e : entries[dev])
+                (void)hipEventDestroy(e.done);
+            entries[dev].clear();
+        }
+        if (before >= 0)
+            (void)hipSetDevice(before);
+    }
 };
+// A stream that is being captured into a graph must not be touched by the bookkeeping: the event record would be captured too,
+// and a query of that event afterwards fails.  Such a launch counts as having neighbours (no schedule) and leaves no mark.
+bool stream_is_capturing(hipStream_t stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return stream && hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
 Flights& flights()
 {
     static Flights* f = new Flights; // (never destroyed: events outlive the statics' teardown)
@@ -1046,7 +1074,7 @@ uint32_t launch_priorities(hipStream_t stream, int& dev)
     const int64_t forced = g_forced_priorities.load(std::memory_order_relaxed);
     if (forced >= 0)
         return (uint32_t)forced;
-    if (flights().others_pending(dev, stream))
+    if (stream_is_capturing(stream) || flights().others_pending(dev, stream))
         return 0;
     g_launches_alone.fetch_add(1, std::memory_order_relaxed);
     return kFallingPriorities;
@@ -1148,6 +1176,7 @@ void sela_hip_shutdown(void)
     }
     if (before >= 0)
         (void)hipSetDevice(before);
+    flights().release_all();
     pool().trim();
 }
 
@@ -1250,7 +1279,8 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
     if (e != hipSuccess)
         return fail_hip(e, "encode launch");
     if (dev >= 0 && n_frames)
-        flights().note(dev, static_cast<hipStream_t>(stream));
+        if (!stream_is_capturing(static_cast<hipStream_t>(stream)))
+            flights().note(dev, static_cast<hipStream_t>(stream));
     return SELA_HIP_OK;
 }
 
@@ -1283,7 +1313,8 @@ int sela_hip_decode_device(const uint8_t* d_frames, const uint64_t* d_frame_offs
     if (e != hipSuccess)
         return fail_hip(e, "decode launch");
     if (dev >= 0)
-        flights().note(dev, static_cast<hipStream_t>(stream));
+        if (!stream_is_capturing(static_cast<hipStream_t>(stream)))
+            flights().note(dev, static_cast<hipStream_t>(stream));
     return SELA_HIP_OK;
 }
 
@@ -1523,10 +1554,21 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
     // track, a tenth of the whole call).  They refuse a subframe that does not say 2048 (SELA_HIP_EFORMAT, nothing written
     // beyond [n_frames][2048][channels], which is why pcm_out must hold that much, sela_hip.h); only then are the headers
     // walked, and a stream that turns out to be of the other kind goes, whole, down the any-length route.
-    const int rc = decode_standard(frames, frame_offsets, n_frames, channels, pcm_out);
+    // (One look is free: the first subframe of the first frame.  A stream that says another length there is not offered to
+    // the fast kernels at all -- they would write 2048-sample frames of silence into a pcm_out its caller sized from
+    // sela_hip_index_samples().  A stream that turns odd LATER still needs the room the header asks for.)
+    bool first_is_standard = true;
+    if (n_frames && frame_offsets[1] >= frame_offsets[0] + 16) {
+        const uint8_t* fb = frames + frame_offsets[0];
+        const uint64_t fbytes = frame_offsets[1] - frame_offsets[0];
+        const uint64_t cw = (uint64_t)fb[8] | ((uint64_t)fb[9] << 8), p2 = 4 + 7 + 4 * cw;
+        if (p2 + 5 <= fbytes)
+            first_is_standard = ((uint32_t)fb[p2 + 3] | ((uint32_t)fb[p2 + 4] << 8)) == SELA_HIP_SAMPLES_PER_FRAME;
+    }
+    const int rc = first_is_standard ? decode_standard(frames, frame_offsets, n_frames, channels, pcm_out) : SELA_HIP_EFORMAT;
     if (rc != SELA_HIP_EFORMAT || n_frames == 0)
         return rc;
-    const std::string first_error = sela_hip_last_error();
+    const std::string first_error = first_is_standard ? std::string(sela_hip_last_error()) : std::string("malformed frame stream");
     for (uint32_t f = 0; f < n_frames; f++)
         if (frame_offsets[f + 1] < frame_offsets[f])
             return rc;
@@ -1778,6 +1820,8 @@ int sela_hip_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* r
         return fail(SELA_HIP_EINVAL, "lpc_decode: order outside 0..100");
     if (status[0] & SELA_HIP_FLAG_COEF_OVERFLOW)
         return fail(SELA_HIP_ERANGE, "lpc_decode: a predictor coefficient left the int64 range");
+    if (status[0] & SELA_HIP_FLAG_Q_RANGE)
+        return fail(SELA_HIP_ERANGE, "lpc_decode: a quantised reflection coefficient outside [-64, 63] (the reference indexes past its tables, src/lpc/linear_predictor.cpp:23-26)");
     return SELA_HIP_OK;
 }
 

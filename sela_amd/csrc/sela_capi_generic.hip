@@ -498,8 +498,14 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
             return report_error(SELA_HIP_EFORMAT, "malformed frame (sync word, sizes, an order above 100, a Rice parameter above 31, a channel or parent that does not exist, or channels of different lengths)");
         if (status[0] & SELA_HIP_FLAG_RICE_OVERRUN)
             return report_error(SELA_HIP_EFORMAT, "a Rice stream ended before all its values were read");
+        // what the reference itself leaves undefined is reported, never decoded silently (one policy: here, in the streaming
+        // jobs' sela_hip_decode_end and in sela_hip_lpc_decode[_n])
         if (status[0] & SELA_HIP_FLAG_COEF_OVERFLOW)
             return report_error(SELA_HIP_ERANGE, "decode: a predictor coefficient left the int64 range");
+        if (status[0] & SELA_HIP_FLAG_Q_RANGE)
+            return report_error(SELA_HIP_ERANGE, "decode: a quantised reflection coefficient outside [-64, 63] (the reference indexes past its tables, src/lpc/linear_predictor.cpp:23-26)");
+        if (status[0] & SELA_HIP_FLAG_SHORT_BLOCK)
+            return report_error(SELA_HIP_ERANGE, "decode: a subframe without samples or not longer than its predictor order (the reference writes past its vector, src/lpc/sample_generator.cpp:14-22)");
         if (!pcm_out)
             std::memcpy(counts_out + (size_t)f0 * channels, tail + 4, subs * 4);
         if (eager_out) {
@@ -619,6 +625,10 @@ int generic_lpc_decode(const int32_t* order, const int32_t* q, const int32_t* re
             return report_error(SELA_HIP_EINVAL, "lpc_decode: order outside 0..100");
         if (status[0] & SELA_HIP_FLAG_COEF_OVERFLOW)
             return report_error(SELA_HIP_ERANGE, "lpc_decode: a predictor coefficient left the int64 range");
+        if (status[0] & SELA_HIP_FLAG_Q_RANGE)
+            return report_error(SELA_HIP_ERANGE, "lpc_decode: a quantised reflection coefficient outside [-64, 63] (the reference indexes past its tables, src/lpc/linear_predictor.cpp:23-26)");
+        if (status[0] & SELA_HIP_FLAG_SHORT_BLOCK)
+            return report_error(SELA_HIP_ERANGE, "lpc_decode: a block without samples or not longer than its predictor order (the reference writes past its vector, src/lpc/sample_generator.cpp:14-22)");
     }
     return SELA_HIP_OK;
 }

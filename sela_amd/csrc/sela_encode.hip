@@ -1776,7 +1776,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // 0.65 .. 0.86 M cycles, and a 3875-frame launch ON ITS OWN takes 0.396 ms instead of 0.427 (12.25 G samples/s
         // strictly serial instead of 11.65) -- but beside another stream's kernels, which is how throughput is had, the same
         // priorities starve the other kernel's waves: 14.97 G samples/s with two batches in flight against 15.71 without
-        // (raising the decoder's priority as well: 15.26; milder schedules: 15.3 .. 15.6).  Off.
+        // (raising the decoder's priority as well: 15.26; milder schedules: 15.3 .. 15.6).  So the schedule is decided per launch
+        // (round 5): sela_hip_encode_device passes it when no other stream of the library has work pending, 0 otherwise
+        // (sela_capi.hip, "does a device-pointer launch have the device to itself?").
         constexpr int kPrio2From = (int)(0.27 * kChunks), kPrio1From = (int)(0.71 * kChunks);
 #pragma unroll 1
         for (int c = 0; c < kChunks; c++) { // (the PCM of a chunk is fetched two chunks ahead)

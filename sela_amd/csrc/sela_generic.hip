@@ -954,6 +954,8 @@ __global__ __launch_bounds__(64) void k_generic_decode(const uint8_t* __restrict
         return;
     }
     si.n = n, si.ok = 1;
+    if (n == 0 || n <= order) // lpc::SampleGenerator writes samples[0] and samples[1 .. order] whatever the length (src/lpc/sample_generator.cpp:14-22): past its vector
+        flags |= SELA_HIP_FLAG_SHORT_BLOCK;
     const uint32_t* const fw = reinterpret_cast<const uint32_t*>(fb); // (frames are whole words at word-aligned offsets)
     const uint32_t n_fw = (uint32_t)(fbytes >> 2);
     bool overrun = false;

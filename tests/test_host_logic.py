@@ -343,7 +343,7 @@ def test_reference_binding_is_built_and_fails_loudly_without_a_gpu(tmp_path):
             pytest.skip("no reference checkout here: the binding is built in the build container")
         subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "bound"])
     if torch.cuda.is_available():
-        pytest.skip("a GPU is visible: tests/test_gpu_round4.py runs the binding for real")
+        pytest.skip("a GPU is visible: tests/test_gpu_host_and_files.py runs the binding for real")
     wav = tmp_path / "in.wav"
     _write_wav(wav, synth_pcm(5000, 2, 1), 44100)
     r = subprocess.run([exe, "-e", str(wav), str(tmp_path / "out.sela")], capture_output=True, text=True)

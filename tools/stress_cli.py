@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sela_amd.synth import synth_pcm  # noqa: E402
-from test_gpu_round2 import _write_wav  # noqa: E402
+from test_host_cpp import _write_wav  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 limit = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
