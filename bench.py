@@ -315,6 +315,7 @@ class Bench:
         self.lib.sela_hip_debug_encode_fused(1 if getattr(args, "encode_fused", False) else 0)
         if getattr(args, "priorities", None):
             self.lib.sela_hip_debug_priorities(int(args.priorities.split(":")[0], 16))
+        self.lib.sela_hip_debug_encode_split(max(0, getattr(args, "encode_split", 0)))
         self.exchange = torch.cuda.Stream() if self.dist is not None else None
         self.lanes_forced = args.lanes is not None  # (also --lanes=N and abbreviations: argparse's own answer)
         self.n_lanes = max(1, args.lanes if self.lanes_forced else 2)
@@ -614,6 +615,9 @@ def lanes_block(job: ChainJob, m, samples, steps):
             "wave_priorities": ("forced " + forced) if forced else "by the library: an encode launch gets the falling schedule when no other stream has library work pending "
                                                                    "(the strictly serial leg), none beside a neighbour (the lanes)",
             "launches_given_the_falling_schedule": int(job.b.lib.sela_hip_debug_launches_alone()),
+            "encode_split": {"mode": getattr(job.b.args, "encode_split", 0), "launches_cut_in_two": int(job.b.lib.sela_hip_debug_launches_split()),
+                             "what": "experiment (--encode-split N): an encode launch as two halves on two streams, the first half's plan + assemble under the second "
+                                     "half's tail; measured slower than the whole launch (DESIGN.md 9), so the library never does it by itself"},
             "what": "consecutive batches are independent encode->decode chains on alternating HIP streams; one lane = strictly serial"}
 
 
@@ -941,6 +945,8 @@ def main():
                     help="experiments only: force the encoder's block kernel (0: k_encode_blocks, 8 / 16: k_encode_teams); -1: the library's own choice by launch size")
     ap.add_argument("--priorities", type=str, default=None,
                     help="experiments only: the team kernel's wave priorities by quarters of a wave's work (hex, e.g. 00010203: falling from 3 to 0)")
+    ap.add_argument("--encode-split", type=int, default=0,
+                    help="experiments only: 1..999 cuts every encode launch of teams of 16 in two (that share per mille to the first half); 0 (default): never")
     ap.add_argument("--encode-fused", action="store_true",
                     help="experiments only: the encoder's one-launch form (the host pipeline's) on device pointers, no plan / assemble kernels")
     args = ap.parse_args()

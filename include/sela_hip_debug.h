@@ -82,6 +82,13 @@ void sela_hip_debug_encode_hashes(int on);
  * loudest sample; the product kernels leave the choice in two spare bits of their per-block records, which this reads back.
  * Synchronises the device.  Returns SELA_HIP_OK or an error code. */
 int sela_hip_debug_block_forms(const void* d_workspace, uint32_t n_frames, uint32_t channels, uint32_t* counts_out, uint8_t* forms_out);
+/* Debug hook (tests, bench.py --encode-split; process-wide): an encode launch on device pointers that the library gives to teams of
+ * 16 is cut in two -- the halves on two streams, the first half's plan + assemble under the second half's tail (sela_capi.hip,
+ * Splitter).  Built and measured in round 6: slower than the whole launch, so the library never does it by itself.  0: never
+ * (the product); 1 .. 999: every such launch, with that share (per mille) of its frames in the first half.
+ * sela_hip_debug_launches_split(): how many launches were. */
+void sela_hip_debug_encode_split(int mode);
+int sela_hip_debug_launches_split(void);
 /* Debug hook (tests; process-wide): the any-length decoder (sela_hip_decode_i32 -- frame::FrameDecoder behind it -- and
  * sela_hip_decode on streams that are not 2048 samples per frame) offers its subframes to k_decode_subframes32 first (the fast
  * decoder's lane-parallel parse and tuned synthesis with 32-bit samples: one piece for 2048-sample subframes that fit the

@@ -35,7 +35,7 @@ EXPORTS = [
 
 # the test hooks include/sela_hip_debug.h declares (not part of the boundary)
 DEBUG_EXPORTS = [
-    "sela_hip_debug_phase_buffer", "sela_hip_debug_force_plain_fir", "sela_hip_debug_mean_workers", "sela_hip_debug_encode_teams", "sela_hip_debug_encode_kernel", "sela_hip_debug_encode_fused", "sela_hip_debug_priorities", "sela_hip_debug_priorities_adaptive", "sela_hip_debug_launches_alone", "sela_hip_debug_block_forms", "sela_hip_debug_encode_hashes", "sela_hip_debug_standard_first", "sela_hip_debug_standard_chunks", "sela_hip_debug_segment_subframes", "sela_hip_debug_generic_wrap_taps", "sela_hip_debug_keep_both_candidates", "sela_hip_debug_stage_wait",
+    "sela_hip_debug_phase_buffer", "sela_hip_debug_force_plain_fir", "sela_hip_debug_mean_workers", "sela_hip_debug_encode_teams", "sela_hip_debug_encode_kernel", "sela_hip_debug_encode_fused", "sela_hip_debug_priorities", "sela_hip_debug_priorities_adaptive", "sela_hip_debug_launches_alone", "sela_hip_debug_block_forms", "sela_hip_debug_encode_hashes", "sela_hip_debug_standard_first", "sela_hip_debug_standard_chunks", "sela_hip_debug_segment_subframes", "sela_hip_debug_generic_wrap_taps", "sela_hip_debug_encode_split", "sela_hip_debug_launches_split", "sela_hip_debug_keep_both_candidates", "sela_hip_debug_stage_wait",
     "sela_hip_debug_reissued_feeds", "sela_hip_debug_contexts_created", "sela_hip_debug_decode_recurrence",
 ]
 
@@ -147,6 +147,10 @@ def lib() -> C.CDLL:
     L.sela_hip_debug_segment_subframes.restype = C.c_longlong
     L.sela_hip_debug_generic_wrap_taps.argtypes = [C.c_int]
     L.sela_hip_debug_generic_wrap_taps.restype = None
+    L.sela_hip_debug_encode_split.argtypes = [C.c_int]
+    L.sela_hip_debug_encode_split.restype = None
+    L.sela_hip_debug_launches_split.argtypes = []
+    L.sela_hip_debug_launches_split.restype = C.c_int
     L.sela_hip_debug_block_forms.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.sela_hip_debug_block_forms.restype = C.c_int
     L.sela_hip_debug_keep_both_candidates.argtypes = [C.c_int]

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -31,7 +32,8 @@ void set_encode_hashes(int on);
 hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t channels, uint8_t* d_frames, size_t frames_cap,
     uint64_t* d_frame_offsets, uint32_t* d_status, void* d_workspace, sela_hip_trace* d_trace, hipStream_t stream,
     hipEvent_t* ev, uint64_t* d_phase_cycles, const EncodeHostLink* link, int force_plain_fir, int self_blocks_override, int team_lanes,
-    int32_t* d_trace_residues = nullptr, uint32_t priorities = 0);
+    int32_t* d_trace_residues = nullptr, uint32_t priorities = 0, int phase = 0, const uint64_t* plan_base = nullptr, bool plan_accumulate = false);
+uint32_t encode_split_frames(uint32_t n_frames, uint32_t channels, int permille);
 hipError_t launch_stage_rice_encode(const int32_t* d_values, const uint64_t* d_value_offsets, uint32_t n_streams, uint32_t* d_k, uint32_t* d_word_counts,
     uint32_t* d_words, const uint64_t* d_word_offsets, uint32_t* d_status, hipStream_t stream);
 hipError_t launch_stage_lpc_decode(const int32_t* d_order, const int32_t* d_q, const int32_t* d_residues, uint32_t n_blocks, int32_t* d_samples,
@@ -1080,6 +1082,71 @@ uint32_t launch_priorities(hipStream_t stream, int& dev)
     return kFallingPriorities;
 }
 
+// ---- an encode launch cut in two (round 6: built, measured, OFF) ------------------------------------------------------------------
+// One fill of team waves ends in a tail: the last waves walk alone while most SIMDs idle, and plan + assemble -- 30 us during which
+// one CU works -- wait behind it.  Round 5 measured from outside that two encoders on two streams, each on its share of the track,
+// finish 6 % sooner than one launch (tools/split_probe.py: 0.434 -> 0.408 ms per call).  Round 6 built it inside the call -- a launch
+// the library gives to teams of 16 runs as two halves on the caller's stream and a side stream of the device, the first half's
+// plan + assemble under the second half's tail, the second half's frames placed behind the first's by its plan kernel
+// (k_plan_frames' base); same bytes, offsets and status words (tests) -- and it is SLOWER: one lane 12.16-12.20 G samples/s at every
+// share from 40 to 70 % against 12.48 uncut (profiles/r06/split_sweep.txt): the two event hand-overs between the streams cost more
+// than the 15 us of plan + assemble they hide.  So the library never cuts by itself; the form stays behind
+// sela_hip_debug_encode_split (bench.py --encode-split N) for the comparison.  Never while kernel timing is on, with a trace or phase
+// buffer, with a kernel forced by a debug hook, or into a stream that is being captured.
+struct Splitter {
+    std::mutex mu;
+    hipStream_t side[64] = {};
+    hipEvent_t begun[64] = {}, half_done[64] = {};
+    std::map<const void*, std::pair<uint32_t, uint32_t>> last; // workspace -> (frames of the launch, frames of its first half; 0: whole)
+    bool ready(int dev)
+    {
+        if (side[dev])
+            return true;
+        if (hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) {
+            side[dev] = nullptr;
+            return false;
+        }
+        if (hipEventCreateWithFlags(&begun[dev], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&half_done[dev], hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(side[dev]);
+            side[dev] = nullptr;
+            return false;
+        }
+        return true;
+    }
+    void release_all()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        int before = -1;
+        (void)hipGetDevice(&before);
+        for (int dev = 0; dev < 64; dev++)
+            if (side[dev]) {
+                (void)hipSetDevice(dev);
+                (void)hipStreamSynchronize(side[dev]);
+                (void)hipEventDestroy(begun[dev]);
+                (void)hipEventDestroy(half_done[dev]);
+                (void)hipStreamDestroy(side[dev]);
+                side[dev] = nullptr;
+            }
+        last.clear();
+        if (before >= 0)
+            (void)hipSetDevice(before);
+    }
+};
+Splitter& splitter()
+{
+    static Splitter* s = new Splitter; // (never destroyed: streams outlive the statics' teardown)
+    return *s;
+}
+std::atomic<int> g_encode_split{ 0 };    // debug (sela_hip_debug_encode_split): 0 never (the product), 1..999: every launch of teams of 16, that share to the first half
+std::atomic<int> g_launches_split{ 0 };
+size_t second_half_offset(uint32_t first, uint32_t channels) { return (sela::encode_workspace_bytes(first, channels) + 255) & ~(size_t)255; }
+uint32_t split_of_last_launch(const void* d_workspace, uint32_t n_frames)
+{
+    std::lock_guard<std::mutex> lock(splitter().mu);
+    const auto it = splitter().last.find(d_workspace);
+    return it != splitter().last.end() && it->second.first == n_frames ? it->second.second : 0u;
+}
+
 } // namespace
 
 // ---- the stages on their own (sela_hip.h): plain synchronous calls, device buffers of their own -----------------------------
@@ -1177,6 +1244,7 @@ void sela_hip_shutdown(void)
     if (before >= 0)
         (void)hipSetDevice(before);
     flights().release_all();
+    splitter().release_all();
     pool().trim();
 }
 
@@ -1206,8 +1274,17 @@ int sela_hip_debug_block_forms(const void* d_workspace, uint32_t n_frames, uint3
     const size_t blocks = (size_t)n_frames * sela_hip_signals_per_frame(channels);
     std::vector<sela::BlockMeta> meta(blocks);
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess && blocks) // (the records open the workspace, launch_encode)
-        e = hipMemcpy(meta.data(), reinterpret_cast<const void*>(((uintptr_t)d_workspace + 255) & ~(uintptr_t)255), blocks * sizeof(sela::BlockMeta), hipMemcpyDeviceToHost);
+    // (the records open the workspace, launch_encode -- or, after a launch that was cut in two, each half's workspace)
+    const uint32_t first = split_of_last_launch(d_workspace, n_frames);
+    const size_t n_sig = sela_hip_signals_per_frame(channels);
+    if (e == hipSuccess && blocks) {
+        const size_t head = first ? (size_t)first * n_sig : blocks;
+        e = hipMemcpy(meta.data(), reinterpret_cast<const void*>(((uintptr_t)d_workspace + 255) & ~(uintptr_t)255), head * sizeof(sela::BlockMeta), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && first) {
+            const uint8_t* second = static_cast<const uint8_t*>(d_workspace) + second_half_offset(first, channels);
+            e = hipMemcpy(meta.data() + head, reinterpret_cast<const void*>(((uintptr_t)second + 255) & ~(uintptr_t)255), (blocks - head) * sizeof(sela::BlockMeta), hipMemcpyDeviceToHost);
+        }
+    }
     if (e != hipSuccess)
         return fail_hip(e, "block forms");
     for (size_t b = 0; b < blocks; b++) {
@@ -1219,6 +1296,8 @@ int sela_hip_debug_block_forms(const void* d_workspace, uint32_t n_frames, uint3
     return SELA_HIP_OK;
 }
 void sela_hip_debug_keep_both_candidates(int on) { sela::set_keep_both_candidates(on); }
+void sela_hip_debug_encode_split(int mode) { g_encode_split.store(mode < 0 || mode > 999 ? 0 : mode, std::memory_order_relaxed); }
+int sela_hip_debug_launches_split(void) { return g_launches_split.load(std::memory_order_relaxed); }
 void sela_hip_debug_encode_hashes(int on) { sela::set_encode_hashes(on); }
 int sela_hip_debug_encode_kernel(uint32_t n_frames, uint32_t channels) { return sela::encode_team_lanes(n_frames, channels, g_team_lanes); }
 
@@ -1242,7 +1321,12 @@ int sela_hip_kernel_times(float* ms_out, int capacity)
 
 uint32_t sela_hip_signals_per_frame(uint32_t channels) { return channels == 2 ? 3u : channels; }
 
-size_t sela_hip_encode_workspace_bytes(uint32_t n_frames, uint32_t channels) { return sela::encode_workspace_bytes(n_frames, channels); }
+size_t sela_hip_encode_workspace_bytes(uint32_t n_frames, uint32_t channels)
+{
+    // (room for the two workspaces of a launch that the debug hook cuts in two, at any share: the fixed parts -- the rings -- twice)
+    const size_t whole = sela::encode_workspace_bytes(n_frames, channels);
+    return sela::encode_split_frames(n_frames, channels, 500) ? whole + sela::encode_workspace_bytes(0, channels) + 65536 : whole;
+}
 
 size_t sela_hip_decode_workspace_bytes(uint32_t n_frames, uint32_t channels) { return sela::decode_workspace_bytes(n_frames, channels); }
 
@@ -1272,10 +1356,61 @@ int sela_hip_encode_device(const int16_t* d_pcm, uint32_t n_frames, uint32_t cha
     if (use_fused)
         g_timing.recorded = ev ? 1 : 0;
     int dev = -1;
-    const uint32_t priorities = launch_priorities(static_cast<hipStream_t>(stream), dev);
-    hipError_t e = sela::launch_encode(d_pcm, n_frames, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace,
-        d_trace, static_cast<hipStream_t>(stream), ev, g_phase_cycles, use_fused ? &fused : nullptr, g_force_plain_fir, g_self_blocks, g_team_lanes, nullptr,
-        priorities);
+    const hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint32_t priorities = launch_priorities(st, dev);
+    // cut in two?  (see Splitter)
+    uint32_t first = 0;
+    const int split_mode = g_encode_split.load(std::memory_order_relaxed);
+    if (dev >= 0 && n_frames && split_mode > 0 && !ev && !d_trace && !g_phase_cycles && !use_fused && g_team_lanes < 0 && !stream_is_capturing(st)) {
+        first = sela::encode_split_frames(n_frames, channels, split_mode);
+        if (first && second_half_offset(first, channels) + sela::encode_workspace_bytes(n_frames - first, channels) > workspace_bytes)
+            first = 0;
+    }
+    hipError_t e = hipSuccess;
+    bool split_done = false;
+    if (first) {
+        Splitter& sp = splitter();
+        std::unique_lock<std::mutex> lock(sp.mu, std::try_to_lock); // (one split launch at a time per process: a second caller is not alone anyway)
+        if (lock.owns_lock() && sp.ready(dev)) {
+            const uint32_t rest = n_frames - first;
+            void* const ws2 = static_cast<uint8_t*>(d_workspace) + second_half_offset(first, channels);
+            const int16_t* const pcm2 = d_pcm + (size_t)first * SELA_HIP_SAMPLES_PER_FRAME * channels;
+            const hipStream_t side = sp.side[dev];
+            e = hipEventRecord(sp.begun[dev], st);
+            if (e == hipSuccess)
+                e = hipStreamWaitEvent(side, sp.begun[dev], 0);
+            if (e == hipSuccess) // the first half's blocks, on the caller's stream
+                e = sela::launch_encode(d_pcm, first, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace, nullptr, st, nullptr, nullptr, nullptr,
+                    g_force_plain_fir, g_self_blocks, 16, nullptr, priorities, 1);
+            if (e == hipSuccess) // the second half's, beside them
+                e = sela::launch_encode(pcm2, rest, channels, d_frames, frames_cap, d_frame_offsets + first, d_status, ws2, nullptr, side, nullptr, nullptr, nullptr,
+                    g_force_plain_fir, g_self_blocks, 16, nullptr, priorities, 1);
+            if (e == hipSuccess)
+                e = hipEventRecord(sp.half_done[dev], side);
+            if (e == hipSuccess) // the first half's plan + assemble, under the second half's tail
+                e = sela::launch_encode(d_pcm, first, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace, nullptr, st, nullptr, nullptr, nullptr,
+                    g_force_plain_fir, g_self_blocks, 16, nullptr, priorities, 2);
+            if (e == hipSuccess)
+                e = hipStreamWaitEvent(st, sp.half_done[dev], 0);
+            if (e == hipSuccess) // the second half's frames behind the first's
+                e = sela::launch_encode(pcm2, rest, channels, d_frames, frames_cap, d_frame_offsets + first, d_status, ws2, nullptr, st, nullptr, nullptr, nullptr,
+                    g_force_plain_fir, g_self_blocks, 16, nullptr, priorities, 2, d_frame_offsets + first, true);
+            sp.last[d_workspace] = std::make_pair(n_frames, first);
+            g_launches_split.fetch_add(1, std::memory_order_relaxed);
+            split_done = true;
+        }
+    }
+    if (!split_done) {
+        e = sela::launch_encode(d_pcm, n_frames, channels, d_frames, frames_cap, d_frame_offsets, d_status, d_workspace,
+            d_trace, st, ev, g_phase_cycles, use_fused ? &fused : nullptr, g_force_plain_fir, g_self_blocks, g_team_lanes, nullptr,
+            priorities);
+        if (n_frames) {
+            std::lock_guard<std::mutex> lock(splitter().mu);
+            const auto it = splitter().last.find(d_workspace);
+            if (it != splitter().last.end())
+                it->second = std::make_pair(n_frames, 0u);
+        }
+    }
     if (e != hipSuccess)
         return fail_hip(e, "encode launch");
     if (dev >= 0 && n_frames)

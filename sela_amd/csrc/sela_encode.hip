@@ -2015,16 +2015,22 @@ constexpr int kPlanThreadsSmall = 256, kPlanFramesSmall = 4096; // up to 4096 fr
 
 template <int kPlanThreads, int kPlanLdsFrames>
 __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* __restrict__ meta, uint32_t n_frames,
-    uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* __restrict__ frame_offsets,
-    uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status)
+    uint32_t channels, uint32_t n_sig, size_t frames_cap, uint64_t* frame_offsets,
+    uint8_t* __restrict__ choice_out, uint32_t* __restrict__ status,
+    const uint64_t* base_in /* null: the stream starts at 0; else where the frames before these end (may BE frame_offsets: the second half of a split launch) */,
+    uint32_t accumulate /* the status words already hold the first half's */)
 {
     __shared__ uint64_t part[kPlanThreads / kWave]; // the waves' totals of one tile
     __shared__ uint32_t frame_size[kPlanLdsFrames]; // bytes of the frames of one tile
     __shared__ uint32_t acc[2];                      // flags, frames that do not fit frames_cap
+    __shared__ uint64_t start;
     const uint32_t tid = threadIdx.x;
     if (tid < 2)
         acc[tid] = 0;
-    uint64_t base = 0; // bytes of the tiles before this one (the same value in every thread)
+    if (tid == 0)
+        start = base_in ? *base_in : 0;
+    __syncthreads(); // (read before any thread writes frame_offsets[0], which may be the same word)
+    uint64_t base = start; // bytes of the frames and tiles before this one (the same value in every thread)
     uint32_t flags = 0, overflow = 0;
     // Tiles of kPlanLdsFrames frames.  Within a tile, frame f is sized by thread f mod 1024: the metadata loads of
     // one pass are independent and coalesced, and the passes do not depend on each other (a thread that walks
@@ -2083,9 +2089,14 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_frames(const BlockMeta* _
         atomicAdd(&acc[1], overflow);
     __syncthreads();
     if (tid == 0) { // this single workgroup is the only writer of the encode status words
-        status[0] = acc[0];
-        status[1] = acc[1];
-        status[2] = status[3] = 0;
+        if (accumulate) {
+            status[0] |= acc[0];
+            status[1] += acc[1];
+        } else {
+            status[0] = acc[0];
+            status[1] = acc[1];
+            status[2] = status[3] = 0;
+        }
     }
 }
 
@@ -2311,6 +2322,19 @@ static int team_lanes_for(size_t blocks)
     return s8 <= s16 ? 8 : 16;
 }
 
+// Where a launch that has the device to itself is cut in two (sela_capi.hip: the halves run on two streams, the first half's plan +
+// assemble under the second half's tail): only launches the library gives to teams of 16 as a whole -- both halves then run
+// teams of 16 as well -- and at a multiple of 32 frames (eight waves of four frames: a half's grid stays whole).  0: not split.
+uint32_t encode_split_frames(uint32_t n_frames, uint32_t channels, int permille /* of the frames to the first half; < 0: the default */)
+{
+    const size_t blocks = (size_t)n_frames * sela_hip_signals_per_frame(channels);
+    if (n_frames < 2048 || team_lanes_for(blocks) != 16)
+        return 0;
+    const uint32_t share = permille < 0 ? 520u : (uint32_t)permille;
+    const uint32_t first = (uint32_t)((uint64_t)n_frames * share / 1000 + 16) / 32 * 32;
+    return first >= 32 && first + 32 <= n_frames ? first : 0;
+}
+
 // debug (sela_hip_debug_keep_both_candidates): write both stereo candidates' slots as round 3 did -- for the comparison of
 // the traffic and for the tests, which check that the bytes do not depend on it
 static std::atomic<int> g_keep_both_candidates{0};
@@ -2332,7 +2356,9 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
     const EncodeHostLink* link /* the host pipeline's one-launch form; nullptr: three kernels */,
     int force_plain_fir, int self_blocks_override, int team_lanes /* -1: by launch size; 0: k_encode_blocks; 8, 16: k_encode_teams<P> */,
     int32_t* d_trace_residues /* with d_trace and team_lanes 0: every block's residues, [block][2048]; or nullptr */,
-    uint32_t priorities /* wave priorities by quarters of a wave's work, e.g. 0x00010203 falling; 0: none (the caller knows whether the launch has the device to itself) */)
+    uint32_t priorities /* wave priorities by quarters of a wave's work, e.g. 0x00010203 falling; 0: none (the caller knows whether the launch has the device to itself) */,
+    int phase /* 0: everything; 1: the blocks only; 2: plan + assemble only (a launch split over two streams, sela_capi.hip) */,
+    const uint64_t* plan_base /* phase 2: where the frames before these end (device), or null */, bool plan_accumulate)
 {
     const uint32_t n_sig = sela_hip_signals_per_frame(channels);
     const size_t blocks = (size_t)n_frames * n_sig;
@@ -2360,6 +2386,9 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
 
     if (link && (d_trace || d_phase_cycles))
         return hipErrorInvalidValue; // (the analysis trace and the phase counts are the device-pointer path's)
+    if (phase != 0 && (link || n_frames == 0))
+        return hipErrorInvalidValue;
+    if (phase != 2) {
     if (n_frames == 0) { // (nothing to launch; a job's stream position stays where it is)
         hipError_t err = hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream);
         if (err == hipSuccess && d_frame_offsets)
@@ -2488,7 +2517,8 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         hipLaunchKernelGGL((k_encode_blocks<0, false>), grid, wg, 0, stream, d_pcm, n_frames, channels, n_sig, meta, slots, rings, ring_owner, ticket, d_trace, d_phase_cycles, force_plain_fir, mean_out, mean_ready, n_workers, self_blocks, total_e, fa);
     if (ev)
         (void)hipEventRecord(ev[1], stream);
-    if (!link) {
+    } // (phase != 2)
+    if (!link && phase != 1) {
         uint8_t* const choice = reinterpret_cast<uint8_t*>(group_state); // (the look-back cells' space: five bytes per frame, unused on this path)
         // (the small plan exists for launches with a neighbour, whose resident workgroups leave no CU sixteen free wave slots
         // and 57 KB; a launch that is alone -- the caller says so with its priorities -- finds them at once, and sixteen waves
@@ -2496,10 +2526,10 @@ hipError_t launch_encode(const int16_t* d_pcm, uint32_t n_frames, uint32_t chann
         // samples/s, two lanes unchanged, A/B on one box)
         if (n_frames <= (uint32_t)kPlanFramesSmall && !(priorities != 0 && n_frames >= 2048u))
             hipLaunchKernelGGL((k_plan_frames<kPlanThreadsSmall, kPlanFramesSmall>), dim3(1), dim3(kPlanThreadsSmall), 0, stream, meta, n_frames, channels, n_sig,
-                frames_cap, d_frame_offsets, choice, d_status);
+                frames_cap, d_frame_offsets, choice, d_status, plan_base, plan_accumulate ? 1u : 0u);
         else
             hipLaunchKernelGGL((k_plan_frames<kPlanThreadsBig, kPlanFramesBig>), dim3(1), dim3(kPlanThreadsBig), 0, stream, meta, n_frames, channels, n_sig,
-                frames_cap, d_frame_offsets, choice, d_status);
+                frames_cap, d_frame_offsets, choice, d_status, plan_base, plan_accumulate ? 1u : 0u);
         if (ev)
             (void)hipEventRecord(ev[2], stream);
         hipLaunchKernelGGL(k_assemble_frames, dim3(n_frames), dim3(kAsmThreads), 0, stream, meta, slots, choice, d_frame_offsets, n_frames, channels,

@@ -759,3 +759,57 @@ def test_wave_priorities_follow_the_neighbours(gpu):  # noqa: F811
     gpu.cuda.synchronize()
     frames, offs = out.to_host()
     assert np.array_equal(frames, want[0]) and np.array_equal(offs, want[1])
+
+
+@pytest.mark.parametrize("share", [300, 520, 800])
+def test_a_launch_cut_in_two_gives_the_same_bytes(gpu, share):  # noqa: F811
+    """The form of sela_hip_encode_device that cuts a launch in two halves on two streams (sela_capi.hip, Splitter; an experiment
+    behind a debug hook: measured slower, never taken by the library itself): frame bytes, offsets, status words and the
+    per-block records are those of the whole launch and of the oracle; a launch that is not teams of 16 is never cut."""
+    from sela_amd import capi, codec
+
+    lib = capi.lib()
+    o = oracle()
+    pcm = synth_frames(3875, 2, 11)
+    pcm[100:108, :, 1] = pcm[100:108, :, 0] // 2  # (some frames whose difference wins)
+    ref_frames, ref_offsets, _ = o.encode_frames(pcm, threads=8)
+    d_pcm = gpu.from_numpy(pcm).cuda()
+    enc = codec.Encoder(3875, 2)
+    try:
+        lib.sela_hip_debug_encode_split(0)
+        whole = enc.encode(d_pcm)
+        gpu.cuda.synchronize()
+        f0, o0 = whole.to_host()
+        forms0 = np.zeros(3875 * 3, np.uint8)
+        counts0 = np.zeros(3, np.uint32)
+        capi.check(lib.sela_hip_debug_block_forms(C.c_void_p(enc.workspace.data_ptr()), 3875, 2, C.c_void_p(counts0.ctypes.data), C.c_void_p(forms0.ctypes.data)))
+        before = lib.sela_hip_debug_launches_split()
+        lib.sela_hip_debug_encode_split(share)
+        gpu.cuda.synchronize()  # (alone: nothing else pending)
+        cut = enc.encode(d_pcm)
+        gpu.cuda.synchronize()
+        assert lib.sela_hip_debug_launches_split() == before + 1
+        f1, o1 = cut.to_host()
+        forms1 = np.zeros(3875 * 3, np.uint8)
+        counts1 = np.zeros(3, np.uint32)
+        capi.check(lib.sela_hip_debug_block_forms(C.c_void_p(enc.workspace.data_ptr()), 3875, 2, C.c_void_p(counts1.ctypes.data), C.c_void_p(forms1.ctypes.data)))
+        assert np.array_equal(o1, o0) and np.array_equal(f1, f0)
+        assert np.array_equal(o1, ref_offsets) and np.array_equal(f1, ref_frames)
+        assert np.array_equal(forms1, forms0) and np.array_equal(counts1, counts0)
+        # decode what the cut launch wrote
+        dec = codec.Decoder(3875, 2)
+        back = dec.decode(cut.frames, cut.offsets, 3875)
+        gpu.cuda.synchronize()
+        dec.check()
+        ref_back, _ = o.decode_frames(ref_frames, ref_offsets, 2, threads=8)
+        assert np.array_equal(back.cpu().numpy(), ref_back)
+        # a small launch (k_encode_blocks) is never cut
+        small = codec.Encoder(1000, 2)
+        n_before = lib.sela_hip_debug_launches_split()
+        out = small.encode(d_pcm[:1000])
+        gpu.cuda.synchronize()
+        assert lib.sela_hip_debug_launches_split() == n_before
+        fs, os_ = out.to_host()
+        assert np.array_equal(os_, ref_offsets[:1001]) and np.array_equal(fs, ref_frames[: int(ref_offsets[1000])])
+    finally:
+        lib.sela_hip_debug_encode_split(0)
