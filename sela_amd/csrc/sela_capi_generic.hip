@@ -14,7 +14,6 @@
 #include <cstring>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "sela_device.h"
@@ -92,40 +91,22 @@ struct PinnedScratch { // page-locked host memory for what a call reads back fir
     }
 };
 
-// A large call is cut into pieces that alternate between two LANES -- a stream, device scratch and page-locked staging each --
-// so that one piece's copies (host memory -> staging by the calling thread, staging <-> device by the copy engines) run beside
-// the other piece's kernels.  A small call uses the first lane only.
-struct Lane {
+struct GenericContext {
+    int device = -1;
     hipStream_t stream = nullptr;
     Arena arena;
     PinnedScratch pinned;
-};
-struct GenericContext {
-    int device = -1;
-    Lane lane[2];
-    hipStream_t& stream = lane[0].stream;
-    Arena& arena = lane[0].arena;
-    PinnedScratch& pinned = lane[0].pinned;
-    Lane* second(hipError_t& err) // (its stream is made when a call first needs it)
-    {
-        err = hipSuccess;
-        if (!lane[1].stream)
-            err = hipStreamCreateWithFlags(&lane[1].stream, hipStreamNonBlocking);
-        return err == hipSuccess ? &lane[1] : nullptr;
-    }
     void destroy()
     {
         int before = -1;
         (void)hipGetDevice(&before);
         if (device >= 0 && before != device)
             (void)hipSetDevice(device);
-        for (Lane& l : lane) {
-            l.arena.release();
-            l.pinned.release();
-            if (l.stream)
-                (void)hipStreamDestroy(l.stream);
-            l.stream = nullptr;
-        }
+        arena.release();
+        pinned.release();
+        if (stream)
+            (void)hipStreamDestroy(stream);
+        stream = nullptr;
         if (before >= 0 && before != device)
             (void)hipSetDevice(before);
     }
@@ -197,28 +178,6 @@ std::atomic<long long> g_segment_subframes{0}; // subframes k_decode_subframes32
 
 constexpr size_t kPiece = 256; // what take() may add per piece
 constexpr size_t kChunkBudget = (size_t)768 << 20; // device scratch per chunk of frames
-constexpr size_t kPipelinePiece = (size_t)6 << 20; // host bytes (in + out) of one piece of a call that is cut up for the two lanes
-
-// host memory to host memory, by up to four threads when it is worth their start (a core copies ~10 GB/s; the staging of a large
-// call would otherwise be what the call waits for)
-void copy_bytes(void* dst, const void* src, size_t bytes)
-{
-    constexpr size_t kPerThread = (size_t)2 << 20;
-    const size_t parts = std::min<size_t>(4, bytes / kPerThread);
-    if (parts < 2) {
-        std::memcpy(dst, src, bytes);
-        return;
-    }
-    std::vector<std::thread> helpers;
-    const size_t step = (bytes / parts + 63) & ~(size_t)63;
-    for (size_t i = 1; i < parts; i++) {
-        const size_t at = i * step, len = i + 1 == parts ? bytes - at : step;
-        helpers.emplace_back([=] { std::memcpy(static_cast<uint8_t*>(dst) + at, static_cast<const uint8_t*>(src) + at, len); });
-    }
-    std::memcpy(dst, src, step);
-    for (std::thread& t : helpers)
-        t.join();
-}
 
 int device_ready()
 {
@@ -285,128 +244,84 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
     GenericContext* const ctx = g_lease.get(ctx_err);
     if (!ctx)
         return report_hip_error(ctx_err, "the calling thread's scratch and stream");
+    Arena& g_arena = ctx->arena;
     const uint32_t n_sig = channels == 2 ? 3u : channels;
     const size_t in_frame_bytes = (size_t)n * channels * (in16 ? 2 : 4);
     const size_t est_frame_bytes = ((size_t)n * channels * 9) / 2 + (size_t)channels * 64 + 64; // words and frame bytes, each
     const size_t per_frame = (size_t)n_sig * n * 8 + (size_t)n_sig * (kMaxOrder * 4 + sizeof(GenericMeta) + 2 * kPiece) + in_frame_bytes + (size_t)channels * 12 + 8
         + 2 * est_frame_bytes;
-    uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
+    uint64_t base_bytes = 0;
     frame_offsets_out[0] = 0;
-    if (n_frames == 0)
-        return SELA_HIP_OK;
-    // pieces: the whole call when it is small; pieces of about kPipelinePiece bytes of input, alternating between two lanes, when
-    // it is large -- a piece's frames land where the piece before it ended, which the host knows when that piece is finished
-    // (its offsets are relative until then: the plan kernel starts every piece at 0)
-    Lane* lanes[2] = { &ctx->lane[0], &ctx->lane[0] };
-    if ((size_t)n_frames * in_frame_bytes > 2 * kPipelinePiece && n_frames > 1) {
-        hipError_t e2 = hipSuccess;
-        if (Lane* l = ctx->second(e2)) {
-            lanes[1] = l;
-            chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(chunk, kPipelinePiece / in_frame_bytes));
-        }
-    }
-    const bool piped = lanes[1] != lanes[0];
-
-    struct Piece {
-        uint32_t f0 = 0, cf = 0;
-        Lane* lane = nullptr;
-        size_t blocks = 0, subs = 0, est_words = 0, est_bytes = 0, head_words = 0;
-        int32_t *d_res = nullptr, *d_q = nullptr;
-        GenericMeta* d_meta = nullptr;
-        uint64_t *d_head = nullptr, *d_word_base = nullptr;
-        uint32_t* d_chosen = nullptr;
-        uint8_t* d_frames = nullptr;
-        uint64_t* head = nullptr;        // host: status (4 x u32) | total words | frame offsets (relative to the piece)
-        uint8_t* staged_frames = nullptr; // host, page-locked: the piece's frames at their estimated size (null: copied when the size is known)
-        std::vector<uint64_t> head_pageable;
-        bool live = false;
-    } piece[2];
-    uint64_t base_bytes = 0; // where the next piece to FINISH starts in frames_out
-
-    auto begin = [&](Piece& p, uint32_t f0, uint32_t cf, Lane* lane) -> int {
-        p.f0 = f0, p.cf = cf, p.lane = lane;
-        p.blocks = (size_t)cf * n_sig, p.subs = (size_t)cf * channels;
-        p.est_words = ((size_t)cf * est_frame_bytes + 3) / 4, p.est_bytes = p.est_words * 4;
-        Arena& arena = lane->arena;
-        const size_t fixed = p.blocks * n * 8 + p.blocks * (kMaxOrder * 4 + sizeof(GenericMeta)) + cf * in_frame_bytes + (p.subs + 1) * 12 + ((size_t)cf + 1) * 8 + 64 + 16 * kPiece
-            + p.est_words * 4 + 8 + p.est_bytes;
-        hipError_t e = arena.reserve(fixed);
+    const hipStream_t st = ctx->stream;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const uint32_t cf = std::min(chunk, n_frames - f0);
+        const size_t blocks = (size_t)cf * n_sig, subs = (size_t)cf * channels;
+        const size_t est_words = ((size_t)cf * est_frame_bytes + 3) / 4, est_bytes = est_words * 4;
+        const size_t fixed = blocks * n * 8 + blocks * (kMaxOrder * 4 + sizeof(GenericMeta)) + cf * in_frame_bytes + (subs + 1) * 12 + ((size_t)cf + 1) * 8 + 64 + 16 * kPiece
+            + est_words * 4 + 8 + est_bytes;
+        hipError_t e = g_arena.reserve(fixed);
         if (e != hipSuccess)
             return report_hip_error(e, "generic encode: scratch");
-        void* d_in = arena.take<uint8_t>(cf * in_frame_bytes);
-        int32_t* d_sig = arena.take<int32_t>(p.blocks * n);
-        p.d_res = arena.take<int32_t>(p.blocks * n);
-        p.d_q = arena.take<int32_t>(p.blocks * kMaxOrder);
-        p.d_meta = arena.take<GenericMeta>(p.blocks);
-        p.head_words = 3 + (size_t)cf + 1;
-        p.d_head = arena.take<uint64_t>(p.head_words);
-        p.d_word_base = arena.take<uint64_t>(p.subs + 1);
-        p.d_chosen = arena.take<uint32_t>(p.subs);
-        uint32_t* d_words = arena.take<uint32_t>(p.est_words + 2);
-        p.d_frames = arena.take<uint8_t>(p.est_bytes);
-        if (!arena.fits())
+        void* d_in = g_arena.take<uint8_t>(cf * in_frame_bytes);
+        int32_t* d_sig = g_arena.take<int32_t>(blocks * n);
+        int32_t* d_res = g_arena.take<int32_t>(blocks * n);
+        int32_t* d_q = g_arena.take<int32_t>(blocks * kMaxOrder);
+        GenericMeta* d_meta = g_arena.take<GenericMeta>(blocks);
+        // what the host reads back first, in one piece: status (4 x u32) | total words | frame offsets
+        const size_t head_words = 3 + (size_t)cf + 1;
+        uint64_t* d_head = g_arena.take<uint64_t>(head_words);
+        uint32_t* d_status = reinterpret_cast<uint32_t*>(d_head);
+        uint64_t* d_offsets = d_head + 3;
+        uint64_t* d_word_base = g_arena.take<uint64_t>(subs + 1);
+        uint32_t* d_chosen = g_arena.take<uint32_t>(subs);
+        uint32_t* d_words = g_arena.take<uint32_t>(est_words + 2);
+        uint8_t* d_frames = g_arena.take<uint8_t>(est_bytes);
+        if (!g_arena.fits())
             return report_error(SELA_HIP_ENOMEM, "generic encode: internal scratch estimate too small");
-        // page-locked staging of this lane: head | frames out | (a piece of a large call:) samples in
-        const bool stage_out = p.est_bytes <= kEagerBytes || piped;
-        const size_t head_bytes = (p.head_words * 8 + 63) & ~(size_t)63;
-        uint8_t* const pin = lane->pinned.reserve(head_bytes + (stage_out ? p.est_bytes : 0) + (piped ? cf * in_frame_bytes : 0) + 64);
-        p.head = reinterpret_cast<uint64_t*>(pin);
+        const bool eager = est_bytes <= kEagerBytes;
+        uint8_t* const pin = ctx->pinned.reserve(head_words * 8 + (eager ? est_bytes : 0));
+        std::vector<uint64_t> head_pageable;
+        uint64_t* head = reinterpret_cast<uint64_t*>(pin);
         if (!pin) {
-            p.head_pageable.resize(p.head_words);
-            p.head = p.head_pageable.data();
+            head_pageable.resize(head_words);
+            head = head_pageable.data();
         }
-        p.staged_frames = pin && stage_out ? pin + head_bytes : nullptr;
-        const hipStream_t st = lane->stream;
-        const uint8_t* src = static_cast<const uint8_t*>(input) + (size_t)f0 * in_frame_bytes;
-        if (pin && piped) { // (from staging the copy is asynchronous: the calling thread goes on to the other lane's piece)
-            uint8_t* const staged_in = pin + head_bytes + (stage_out ? p.est_bytes : 0);
-            copy_bytes(staged_in, src, cf * in_frame_bytes);
-            src = staged_in;
-        }
-        e = hipMemcpyAsync(d_in, src, cf * in_frame_bytes, hipMemcpyHostToDevice, st);
+        uint8_t* const eager_frames = pin && eager ? pin + head_words * 8 : nullptr;
+        e = hipMemcpyAsync(d_in, static_cast<const uint8_t*>(input) + (size_t)f0 * in_frame_bytes, cf * in_frame_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
-            e = hipMemsetAsync(p.d_head, 0, 24, st);
+            e = hipMemsetAsync(d_head, 0, 24, st);
         if (e == hipSuccess)
-            e = hipMemsetAsync(d_words, 0, (p.est_words + 2) * 4, st);
+            e = hipMemsetAsync(d_words, 0, (est_words + 2) * 4, st);
         if (e == hipSuccess)
-            e = launch_generic_analyse(d_in, in16, cf, channels, n_sig, n, d_sig, p.d_res, p.d_q, p.d_meta, st);
+            e = launch_generic_analyse(d_in, in16, cf, channels, n_sig, n, d_sig, d_res, d_q, d_meta, st);
         if (e == hipSuccess)
-            e = launch_generic_plan(p.d_meta, cf, channels, n_sig, 0, p.d_head + 3, p.d_word_base, p.d_chosen, reinterpret_cast<uint32_t*>(p.d_head), p.d_head + 2, st);
+            e = launch_generic_plan(d_meta, cf, channels, n_sig, base_bytes, d_offsets, d_word_base, d_chosen, d_status, d_head + 2, st);
         if (e == hipSuccess)
-            e = launch_generic_emit(p.d_meta, cf, channels, n_sig, n, p.d_res, p.d_q, p.d_chosen, p.d_word_base, d_words, p.est_words, p.d_head + 3, 0, p.d_frames, p.est_bytes, st);
+            e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words, est_words, d_offsets, base_bytes, d_frames, est_bytes, st);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(p.head, p.d_head, p.head_words * 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && p.staged_frames)
-            e = hipMemcpyAsync(p.staged_frames, p.d_frames, p.est_bytes, hipMemcpyDeviceToHost, st);
-        if (e != hipSuccess)
-            return report_hip_error(e, "generic encode");
-        p.live = true;
-        return SELA_HIP_OK;
-    };
-    auto finish = [&](Piece& p) -> int {
-        if (!p.live)
-            return SELA_HIP_OK;
-        p.live = false;
-        const hipStream_t st = p.lane->stream;
-        hipError_t e = hipStreamSynchronize(st);
+            e = hipMemcpyAsync(head, d_head, head_words * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && eager_frames)
+            e = hipMemcpyAsync(eager_frames, d_frames, est_bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
         if (e != hipSuccess)
             return report_hip_error(e, "generic encode");
         uint32_t status[4];
-        std::memcpy(status, p.head, 16);
-        const uint64_t total_words = p.head[2];
-        for (uint32_t i = 0; i <= p.cf; i++)
-            frame_offsets_out[p.f0 + i] = base_bytes + p.head[3 + i];
+        std::memcpy(status, head, 16);
+        const uint64_t total_words = head[2];
+        std::memcpy(frame_offsets_out + f0, head + 3, ((size_t)cf + 1) * 8);
         const int rc = flags_error(status[0], "encode");
         if (rc != SELA_HIP_OK)
             return rc;
-        const uint64_t chunk_bytes = p.head[3 + p.cf];
-        if (base_bytes + chunk_bytes > frames_cap)
+        const uint64_t chunk_bytes = frame_offsets_out[f0 + cf] - base_bytes;
+        if (frame_offsets_out[f0 + cf] > frames_cap)
             return report_error(SELA_HIP_ECAPACITY, "frames_out too small (see sela_hip_encode_bound_bytes_n)");
-        if (total_words <= p.est_words && chunk_bytes <= p.est_bytes) {
-            if (p.staged_frames) {
-                copy_bytes(frames_out + base_bytes, p.staged_frames, (size_t)chunk_bytes);
+        if (total_words <= est_words && chunk_bytes <= est_bytes) {
+            if (eager_frames) {
+                std::memcpy(frames_out + base_bytes, eager_frames, (size_t)chunk_bytes);
             } else {
-                e = hipMemcpyAsync(frames_out + base_bytes, p.d_frames, chunk_bytes, hipMemcpyDeviceToHost, st);
+                e = hipMemcpyAsync(frames_out + base_bytes, d_frames, chunk_bytes, hipMemcpyDeviceToHost, st);
                 if (e == hipSuccess)
                     e = hipStreamSynchronize(st);
             }
@@ -420,7 +335,7 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
             uint8_t* d_frames2 = extra + words_bytes;
             e = hipMemsetAsync(d_words2, 0, ((size_t)total_words + 2) * 4, st);
             if (e == hipSuccess)
-                e = launch_generic_emit(p.d_meta, p.cf, channels, n_sig, n, p.d_res, p.d_q, p.d_chosen, p.d_word_base, d_words2, total_words, p.d_head + 3, 0, d_frames2, chunk_bytes, st);
+                e = launch_generic_emit(d_meta, cf, channels, n_sig, n, d_res, d_q, d_chosen, d_word_base, d_words2, total_words, d_offsets, base_bytes, d_frames2, chunk_bytes, st);
             if (e == hipSuccess)
                 e = hipMemcpyAsync(frames_out + base_bytes, d_frames2, chunk_bytes, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess)
@@ -430,35 +345,6 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
         if (e != hipSuccess)
             return report_hip_error(e, "generic encode: emit");
         base_bytes += chunk_bytes;
-        return SELA_HIP_OK;
-    };
-    auto drain = [&]() {
-        for (Piece& p : piece)
-            if (p.live)
-                (void)hipStreamSynchronize(p.lane->stream), p.live = false;
-    };
-    int k = 0;
-    for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk, k++) {
-        Piece& p = piece[k & 1];
-        int rc = finish(p); // (the piece that used this lane before: pieces finish in the order they began)
-        if (rc == SELA_HIP_OK)
-            rc = begin(p, f0, std::min(chunk, n_frames - f0), lanes[k & 1]);
-        if (rc != SELA_HIP_OK) {
-            drain();
-            return rc;
-        }
-        if (!piped) {
-            rc = finish(p);
-            if (rc != SELA_HIP_OK)
-                return rc;
-        }
-    }
-    for (int i = 0; i < 2; i++) {
-        const int rc = finish(piece[(k + i) & 1]);
-        if (rc != SELA_HIP_OK) {
-            drain();
-            return rc;
-        }
     }
     return SELA_HIP_OK;
 }
@@ -525,155 +411,89 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
     GenericContext* const ctx = g_lease.get(ctx_err);
     if (!ctx)
         return report_hip_error(ctx_err, "the calling thread's scratch and stream");
+    Arena& g_arena = ctx->arena;
     for (uint32_t f = 0; f < n_frames; f++)
         if (frame_offsets[f + 1] < frame_offsets[f])
             return report_error(SELA_HIP_EFORMAT, "frame offsets must not decrease");
     if (stride == 0)
         stride = 1;
-    if (n_frames == 0)
-        return SELA_HIP_OK;
-    const int mode = g_standard_first_mode.load(std::memory_order_relaxed); // -1: the product; 0: the serial kernel alone; 1: as -1; 2: offered, every subframe by segments
-    const bool offer = mode != 0, standard_path = mode != 2;
-    // ---- pieces: the whole call when it is small (its samples then travel with the status: one wait for the device -- a call of
-    //      one frame, the frame classes' kind, is mostly waits); pieces of about kPipelinePiece host bytes, alternating between two
-    //      lanes, when it is large ----
-    const size_t out_per_frame = pcm_out ? 0 : (size_t)channels * stride * sizeof(int32_t);
-    const size_t total_out = pcm_out ? (size_t)(sample_offsets[n_frames] - sample_offsets[0]) * channels * 2 : (size_t)n_frames * out_per_frame;
-    const size_t total_host = total_out + (size_t)(frame_offsets[n_frames] - frame_offsets[0]);
-    const size_t per_frame_device = (size_t)channels * stride * 8 + (size_t)channels * (sizeof(GenericSubInfo) + 4) + 16 + (size_t)channels * stride * (pcm_out ? 2 : 0);
-    uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame_device));
-    Lane* lanes[2] = { &ctx->lane[0], &ctx->lane[0] };
-    if (total_host > 2 * kPipelinePiece && n_frames > 1) {
-        hipError_t e2 = hipSuccess;
-        if (Lane* l = ctx->second(e2)) {
-            lanes[1] = l;
-            const size_t per_frame_host = std::max<size_t>(1, total_host / n_frames);
-            chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(chunk, kPipelinePiece / per_frame_host));
-        }
-    }
-    const bool piped = lanes[1] != lanes[0];
-
-    struct Piece {
-        uint32_t f0 = 0, cf = 0;
-        Lane* lane = nullptr;
-        size_t subs = 0, out_bytes = 0;
-        uint64_t base_bytes = 0, s0 = 0;
-        uint8_t* d_frames = nullptr;
-        uint64_t* d_offsets = nullptr;
-        int32_t *d_dec = nullptr, *d_all = nullptr;
-        GenericSubInfo* d_info = nullptr;
-        uint32_t* d_tail = nullptr;
-        uint64_t* d_sample_offsets = nullptr;
-        int16_t* d_pcm = nullptr;
-        uint32_t* tail = nullptr;       // host: status (4 x u32) | a count per (frame, channel)
-        uint8_t* staged_out = nullptr;  // host, page-locked: the piece's samples (null: they go straight to the caller's memory)
-        std::vector<uint32_t> tail_pageable;
-        std::vector<uint64_t> offsets_pageable; // (without page-locked staging: must outlive the copy that reads it)
-        bool live = false;
-    } piece[2];
-
-    auto user_out_of = [&](const Piece& p) -> uint8_t* {
-        return pcm_out ? reinterpret_cast<uint8_t*>(pcm_out + p.s0 * channels) : reinterpret_cast<uint8_t*>(samples_out + (size_t)p.f0 * channels * stride);
-    };
-    auto launch = [&](Piece& p, bool fast_first) -> hipError_t {
-        const hipStream_t st = p.lane->stream;
-        hipError_t e = hipMemsetAsync(p.d_tail, 0, (4 + p.subs) * 4, st);
-        if (e == hipSuccess)
-            e = launch_generic_decode(p.d_frames, p.d_offsets, p.base_bytes, p.cf, channels, stride, p.d_dec, p.d_info, p.d_all, p.d_tail + 4, p.d_sample_offsets, p.d_pcm,
-                p.d_tail, fast_first, standard_path, st);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(p.tail, p.d_tail, (4 + p.subs) * 4, hipMemcpyDeviceToHost, st);
-        const void* const device_out = pcm_out ? static_cast<const void*>(p.d_pcm) : static_cast<const void*>(p.d_all);
-        // samples_out and the device's channel-major array have one layout ([frame][channel][stride]): ONE copy
-        if (e == hipSuccess && (p.staged_out || p.out_bytes <= kEagerBytes))
-            e = hipMemcpyAsync(p.staged_out ? p.staged_out : user_out_of(p), device_out, p.out_bytes, hipMemcpyDeviceToHost, st);
-        return e;
-    };
-    auto begin = [&](Piece& p, uint32_t f0, uint32_t cf, Lane* lane) -> int {
-        p.f0 = f0, p.cf = cf, p.lane = lane, p.subs = (size_t)cf * channels;
-        p.base_bytes = frame_offsets[f0];
-        const uint64_t in_bytes = frame_offsets[f0 + cf] - p.base_bytes;
-        p.s0 = pcm_out ? sample_offsets[f0] : 0;
-        const uint64_t chunk_samples = pcm_out ? sample_offsets[f0 + cf] - p.s0 : 0;
-        p.out_bytes = pcm_out ? (size_t)chunk_samples * channels * 2 : p.subs * stride * sizeof(int32_t);
-        Arena& arena = lane->arena;
-        const size_t need = in_bytes + 8 + ((size_t)cf + 1) * 16 + p.subs * stride * 8 + p.subs * (sizeof(GenericSubInfo) + 4) + (size_t)chunk_samples * channels * 2 + 64 + 12 * kPiece;
-        hipError_t e = arena.reserve(need);
+    const size_t per_frame = (size_t)channels * stride * 8 + (size_t)channels * (sizeof(GenericSubInfo) + 4) + 16 + (size_t)channels * stride * (pcm_out ? 2 : 0);
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));
+    const hipStream_t st = ctx->stream;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const uint32_t cf = std::min(chunk, n_frames - f0);
+        const size_t subs = (size_t)cf * channels;
+        const uint64_t base_bytes = frame_offsets[f0], in_bytes = frame_offsets[f0 + cf] - base_bytes;
+        const uint64_t s0 = pcm_out ? sample_offsets[f0] : 0, chunk_samples = pcm_out ? sample_offsets[f0 + cf] - s0 : 0;
+        const size_t need = in_bytes + 8 + ((size_t)cf + 1) * 16 + subs * stride * 8 + subs * (sizeof(GenericSubInfo) + 4) + (size_t)chunk_samples * channels * 2 + 64
+            + 12 * kPiece;
+        hipError_t e = g_arena.reserve(need);
         if (e != hipSuccess)
             return report_hip_error(e, "generic decode: scratch");
-        p.d_frames = arena.take<uint8_t>(in_bytes + 8);
-        p.d_offsets = arena.take<uint64_t>((size_t)cf + 1);
-        p.d_dec = arena.take<int32_t>(p.subs * stride);
-        p.d_all = arena.take<int32_t>(p.subs * stride);
-        p.d_info = arena.take<GenericSubInfo>(p.subs);
-        p.d_tail = arena.take<uint32_t>(4 + p.subs);
-        p.d_sample_offsets = pcm_out ? arena.take<uint64_t>((size_t)cf + 1) : nullptr;
-        p.d_pcm = pcm_out ? arena.take<int16_t>((size_t)chunk_samples * channels) : nullptr;
-        if (!arena.fits())
+        uint8_t* d_frames = g_arena.take<uint8_t>(in_bytes + 8);
+        uint64_t* d_offsets = g_arena.take<uint64_t>((size_t)cf + 1);
+        int32_t* d_dec = g_arena.take<int32_t>(subs * stride);
+        int32_t* d_all = g_arena.take<int32_t>(subs * stride);
+        GenericSubInfo* d_info = g_arena.take<GenericSubInfo>(subs);
+        // what the host reads back first, in one piece: status (4 x u32) | a count per (frame, channel)
+        uint32_t* d_tail = g_arena.take<uint32_t>(4 + subs);
+        uint32_t* d_status = d_tail;
+        uint32_t* d_counts = d_tail + 4;
+        uint64_t* d_sample_offsets = pcm_out ? g_arena.take<uint64_t>((size_t)cf + 1) : nullptr;
+        int16_t* d_pcm = pcm_out ? g_arena.take<int16_t>((size_t)chunk_samples * channels) : nullptr;
+        if (!g_arena.fits())
             return report_error(SELA_HIP_ENOMEM, "generic decode: internal scratch estimate too small");
-        // page-locked staging of this lane: tail | offsets | samples out | (a piece of a large call:) frames in
-        const size_t tail_bytes = ((4 + p.subs) * 4 + 15) & ~(size_t)15, offs_bytes = 2 * ((size_t)cf + 1) * 8;
-        const bool stage_out = p.out_bytes <= kEagerBytes || piped;
-        uint8_t* const pin = lane->pinned.reserve(tail_bytes + offs_bytes + (stage_out ? p.out_bytes : 0) + (piped ? (size_t)in_bytes : 0) + 64);
-        p.tail = reinterpret_cast<uint32_t*>(pin);
-        p.staged_out = pin && stage_out ? pin + tail_bytes + offs_bytes : nullptr;
-        if (!pin) {
-            p.tail_pageable.resize(4 + p.subs);
-            p.tail = p.tail_pageable.data();
-        }
-        const hipStream_t st = lane->stream;
-        const uint8_t* src_frames = frames + p.base_bytes;
-        if (pin && piped) { // (from staging the copy is asynchronous: the calling thread goes on to the other lane's piece)
-            uint8_t* const staged_in = pin + tail_bytes + offs_bytes + (stage_out ? p.out_bytes : 0);
-            copy_bytes(staged_in, src_frames, (size_t)in_bytes);
-            src_frames = staged_in;
-        }
-        e = hipMemcpyAsync(p.d_frames, src_frames, in_bytes, hipMemcpyHostToDevice, st);
-        uint64_t* const offs_host = pin ? reinterpret_cast<uint64_t*>(pin + tail_bytes) : nullptr;
-        if (e == hipSuccess) {
-            if (offs_host) {
-                std::memcpy(offs_host, frame_offsets + f0, ((size_t)cf + 1) * 8);
-                e = hipMemcpyAsync(p.d_offsets, offs_host, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice, st);
-            } else {
-                e = hipMemcpyAsync(p.d_offsets, frame_offsets + f0, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice, st);
-            }
-        }
-        if (e == hipSuccess && pcm_out) { // positions relative to the piece's first sample
-            uint64_t* local = offs_host ? offs_host + cf + 1 : nullptr;
-            if (!local) {
-                p.offsets_pageable.resize((size_t)cf + 1);
-                local = p.offsets_pageable.data();
-            }
-            for (uint32_t i = 0; i <= cf; i++)
-                local[i] = sample_offsets[f0 + i] - p.s0;
-            e = hipMemcpyAsync(p.d_sample_offsets, local, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice, st);
-        }
+        e = hipMemcpyAsync(d_frames, frames + base_bytes, in_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
-            e = launch(p, offer);
-        if (e != hipSuccess)
-            return report_hip_error(e, "generic decode");
-        p.live = true;
-        return SELA_HIP_OK;
-    };
-    auto finish = [&](Piece& p) -> int {
-        if (!p.live)
-            return SELA_HIP_OK;
-        p.live = false;
-        const hipStream_t st = p.lane->stream;
-        hipError_t e = hipStreamSynchronize(st);
-        if (e == hipSuccess && offer) {
-            if (p.tail[2] == 0) { // (the fast kernel took every subframe and every one came out clean)
+            e = hipMemcpyAsync(d_offsets, frame_offsets + f0, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice, st);
+        std::vector<uint64_t> local;
+        if (e == hipSuccess && pcm_out) { // positions relative to the chunk's first sample
+            local.resize((size_t)cf + 1);
+            for (uint32_t i = 0; i <= cf; i++)
+                local[i] = sample_offsets[f0 + i] - s0;
+            e = hipMemcpyAsync(d_sample_offsets, local.data(), local.size() * 8, hipMemcpyHostToDevice, st);
+        }
+        const int mode = g_standard_first_mode.load(std::memory_order_relaxed); // -1: the product; 0: the serial kernel alone; 1: as -1; 2: offered, every subframe by segments
+        const bool offer = mode != 0, standard_path = mode != 2;
+        // A small chunk's samples travel with the status, one wait for the device instead of two (a call of one frame -- the
+        // frame classes' kind -- is mostly waits); what they are worth is known when both have arrived.  Both land in
+        // page-locked memory of the calling thread's context (a copy into pageable memory is staged by the runtime, and waits).
+        const size_t out_bytes = pcm_out ? (size_t)chunk_samples * channels * 2 : subs * stride * sizeof(int32_t);
+        const bool eager = out_bytes <= kEagerBytes;
+        const size_t tail_bytes = ((4 + subs) * 4 + 15) & ~(size_t)15;
+        uint8_t* const pin = ctx->pinned.reserve(tail_bytes + (eager ? out_bytes : 0));
+        std::vector<uint32_t> tail_pageable;
+        uint32_t* tail = reinterpret_cast<uint32_t*>(pin);
+        if (!pin) {
+            tail_pageable.resize(4 + subs);
+            tail = tail_pageable.data();
+        }
+        uint8_t* const eager_out = pin && eager ? pin + tail_bytes : nullptr;
+        uint8_t* const user_out = pcm_out ? reinterpret_cast<uint8_t*>(pcm_out + s0 * channels) : reinterpret_cast<uint8_t*>(samples_out + (size_t)f0 * channels * stride);
+        const void* const device_out = pcm_out ? static_cast<const void*>(d_pcm) : static_cast<const void*>(d_all);
+        // samples_out and the device's channel-major array have one layout ([frame][channel][stride]): ONE copy (a copy per
+        // channel cost 13 us each: 7 ms for 256 stereo frames).  What lies behind a channel's count is not defined.
+        for (int attempt = offer ? 0 : 1; attempt < 2; attempt++) {
+            if (e == hipSuccess)
+                e = hipMemsetAsync(d_tail, 0, (4 + subs) * 4, st);
+            if (e == hipSuccess)
+                e = launch_generic_decode(d_frames, d_offsets, base_bytes, cf, channels, stride, d_dec, d_info, d_all, d_counts, d_sample_offsets, d_pcm, d_status,
+                    attempt == 0, standard_path, st);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(tail, d_tail, (4 + subs) * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && eager)
+                e = hipMemcpyAsync(eager_out ? eager_out : user_out, device_out, out_bytes, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(st);
+            if (e != hipSuccess)
+                return report_hip_error(e, "generic decode");
+            if (attempt == 0 && tail[2] == 0) { // (the fast kernel took every subframe and every one came out clean)
                 g_standard_chunks.fetch_add(1, std::memory_order_relaxed);
-                g_segment_subframes.fetch_add(p.tail[3], std::memory_order_relaxed);
-            } else { // something the fast kernel will not judge: the piece again on the serial kernel
-                e = launch(p, false);
-                if (e == hipSuccess)
-                    e = hipStreamSynchronize(st);
+                g_segment_subframes.fetch_add(tail[3], std::memory_order_relaxed);
+                break;
             }
         }
-        if (e != hipSuccess)
-            return report_hip_error(e, "generic decode");
-        const uint32_t* const status = p.tail;
+        const uint32_t* const status = tail;
         if (status[0] & SELA_HIP_FLAG_BAD_FRAME)
             return report_error(SELA_HIP_EFORMAT, "malformed frame (sync word, sizes, an order above 100, a Rice parameter above 31, a channel or parent that does not exist, or channels of different lengths)");
         if (status[0] & SELA_HIP_FLAG_RICE_OVERRUN)
@@ -687,45 +507,16 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
         if (status[0] & SELA_HIP_FLAG_SHORT_BLOCK)
             return report_error(SELA_HIP_ERANGE, "decode: a subframe without samples or not longer than its predictor order (the reference writes past its vector, src/lpc/sample_generator.cpp:14-22)");
         if (!pcm_out)
-            std::memcpy(counts_out + (size_t)p.f0 * channels, p.tail + 4, p.subs * 4);
-        if (p.staged_out) {
-            copy_bytes(user_out_of(p), p.staged_out, p.out_bytes);
-        } else if (p.out_bytes > kEagerBytes) { // (no staging: a large piece straight into the caller's memory, once its verdict is in)
-            e = hipMemcpyAsync(user_out_of(p), pcm_out ? static_cast<const void*>(p.d_pcm) : static_cast<const void*>(p.d_all), p.out_bytes, hipMemcpyDeviceToHost, st);
+            std::memcpy(counts_out + (size_t)f0 * channels, tail + 4, subs * 4);
+        if (eager_out) {
+            std::memcpy(user_out, eager_out, out_bytes);
+        } else if (!eager) {
+            e = hipMemcpyAsync(user_out, device_out, out_bytes, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess)
                 e = hipStreamSynchronize(st);
-            if (e != hipSuccess)
-                return report_hip_error(e, "generic decode: copy out");
         }
-        return SELA_HIP_OK;
-    };
-    auto drain = [&]() { // after an error: nothing of this call may still be running when its buffers go back
-        for (Piece& p : piece)
-            if (p.live)
-                (void)hipStreamSynchronize(p.lane->stream), p.live = false;
-    };
-    int k = 0;
-    for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk, k++) {
-        Piece& p = piece[k & 1];
-        int rc = finish(p); // (the piece that used this lane before)
-        if (rc == SELA_HIP_OK)
-            rc = begin(p, f0, std::min(chunk, n_frames - f0), lanes[k & 1]);
-        if (rc != SELA_HIP_OK) {
-            drain();
-            return rc;
-        }
-        if (!piped) { // one lane: a piece is finished before the next begins
-            rc = finish(p);
-            if (rc != SELA_HIP_OK)
-                return rc;
-        }
-    }
-    for (int i = 0; i < 2; i++) { // in the order they were begun
-        const int rc = finish(piece[(k + i) & 1]);
-        if (rc != SELA_HIP_OK) {
-            drain();
-            return rc;
-        }
+        if (e != hipSuccess)
+            return report_hip_error(e, "generic decode: copy out");
     }
     return SELA_HIP_OK;
 }

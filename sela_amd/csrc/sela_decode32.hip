@@ -299,9 +299,9 @@ __device__ inline AnyHeader walk_headers_any(const uint8_t* fb, uint64_t fbytes,
 // frame::FrameDecoder returns what the synthesis produces, untruncated (src/frame/frame_decoder.cpp:24-25,64-71), at each
 // subframe's own samplesPerChannel, so the class -- and sela_hip_decode_i32 behind it -- cannot use k_decode_frames, whose
 // samples pass through int16 and whose plan is 2048 samples.  One wave per subframe here:
-//   * a subframe of 2048 samples whose words fit the parser's plan (every subframe the reference's CLI writes) runs the very
-//     parse and synthesis of k_decode_frames -- positions in LDS, residues decoded just in time;
-//   * any other length, or a stream beyond the plan, is parsed segment by segment (parse_segment above), the residues parked
+//   * a subframe of at most 2048 samples whose words fit the parser's plan (every subframe the reference's CLI writes, and every
+//     shorter one) runs the very parse and synthesis of k_decode_frames -- positions in LDS, residues decoded just in time;
+//   * a longer one, or a stream beyond the plan, is parsed segment by segment (parse_segment above), the residues parked
 //     where the samples will lie (dec_ws), and synthesised in place by the same recurrence with the length a run-time value.
 // The samples land where k_generic_decode would have left them (dec_ws, info: k_generic_combine follows either).  The kernel
 // takes a subframe or leaves it alone: anything it would have to judge -- a frame that is not whole words at an aligned
@@ -336,14 +336,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
         SynthTables* const tables = &scratch.t;
         const uint32_t order = hd.order;
         int32_t* const samples = dec_ws + (size_t)sub * stride;
-        const bool standard = standard_path && hd.n == (uint32_t)kBlock && nw <= (uint32_t)kStreamCap;
+        // (in one piece: up to 2048 samples whose words fit the parser's plan -- its positions are one 16-bit word per codeword)
+        const bool standard = standard_path && hd.n <= (uint32_t)kBlock && nw <= (uint32_t)kStreamCap;
         if (standard) {
             for (uint32_t w = lane; w < nw + kStreamMargin; w += kWave) // the start bitmap
                 sl.marks[w] = 0;
             wave_sync();
             ParseProfile pp;
             const StreamWords sw = { gw, nw };
-            flags |= parse_subframe<false>(sw, sl.marks, sl.pos, reinterpret_cast<uint16_t*>(tables), coef_values(&scratch), hd.cw, hd.rw, hd.ck, hd.rk, order, lane, pp);
+            flags |= parse_subframe<false>(sw, sl.marks, sl.pos, reinterpret_cast<uint16_t*>(tables), coef_values(&scratch), hd.cw, hd.rw, hd.ck, hd.rk, order, lane, pp, hd.n);
         } else {
             // the coefficients (src/frame/frame_decoder.cpp:19-23): bits [24, 24 + 32 cw) of the aligned words
             if (order)
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
         if (!si.ok) {
             si.channel = si.type = si.parent = 0, si.n = 0;
             atomicAdd(&status[2], 1u);
-        } else if (!(hd.n == (uint32_t)kBlock && hd.cw + 2 + hd.rw <= (uint32_t)kStreamCap && standard_path))
+        } else if (!(hd.n <= (uint32_t)kBlock && hd.cw + 2 + hd.rw <= (uint32_t)kStreamCap && standard_path))
             atomicAdd(&status[3], 1u); // (subframes that went by segments: tests and the probes ask)
         info[sub] = si;
     }

@@ -634,88 +634,113 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
 // ---- plan: the stereo decision, frame sizes, offsets -- one workgroup -----------------------------------------------------
 // src/frame/frame_encoder.cpp:64-72: the difference candidate wins iff its words (coefficients + residues) are FEWER.
-// 1024 threads, a contiguous range of frames each; the ranges' sums are scanned across the workgroup (shuffles within a wave,
-// the sixteen waves' totals through LDS -- the first version's single thread walked 256 partial sums: 40 of its 60 us).
-constexpr int kPlanThreads = 1024;
+// 1024 threads over tiles of 4096 frames.  Within a tile frame f is sized by thread f mod 1024 -- the records' loads of one pass
+// are independent and coalesced (a thread that walks consecutive frames waits for memory once per frame: the second version,
+// 46 us at 3875 frames; the first version's single thread walking 256 partial sums: 60) -- its subframes' word counts go to LDS;
+// then every thread sums a contiguous run of the tile's frames, the runs are scanned across the workgroup (shuffles within a
+// wave, the sixteen waves' totals through LDS), and the offsets and the subframes' word bases are written frame by frame again.
+constexpr int kPlanThreads = 1024, kPlanTile = 4096;
 __global__ __launch_bounds__(kPlanThreads) void k_generic_plan(const GenericMeta* __restrict__ meta, uint32_t n_frames, uint32_t channels, uint32_t n_sig,
     uint64_t base_bytes, uint64_t* __restrict__ frame_offsets /* [n_frames + 1], absolute */, uint64_t* __restrict__ word_base /* [n_frames * channels + 1] */,
     uint32_t* __restrict__ chosen /* [n_frames * channels]: signal index */, uint32_t* __restrict__ status, uint64_t* __restrict__ total_words_out)
 {
     constexpr int kWaves = kPlanThreads / 64;
     __shared__ uint64_t wave_bytes[kWaves], wave_words[kWaves];
-    __shared__ uint32_t wave_flags[kWaves];
+    __shared__ uint32_t frame_words[kPlanTile]; // words of the frames of one tile (their bytes follow: 4 + 12 channels + 4 words)
+    __shared__ uint32_t frame_first_hi[kPlanTile];
+    __shared__ uint32_t all_flags;
     const uint32_t t = threadIdx.x;
     const int lane = t % 64, wave = t / 64;
-    const uint32_t per = (n_frames + kPlanThreads - 1) / kPlanThreads;
-    const uint32_t f_begin = min(t * per, n_frames), f_end = min(f_begin + per, n_frames);
-    auto frame_plan = [&](uint32_t f, uint64_t& bytes, uint64_t& words, uint32_t& flags, bool write, uint64_t words_before) {
-        bytes = 4;
-        words = 0;
-        for (uint32_t c = 0; c < channels; c++) {
-            uint32_t sgn = c;
-            const GenericMeta* m = meta + (size_t)f * n_sig + c;
-            if (channels == 2 && c == 1) {
-                const GenericMeta* d = meta + (size_t)f * n_sig + 2;
-                flags |= d->flags; // (both candidates were computed by the reference too: either's trouble is the frame's)
-                if ((uint64_t)d->coef_words + d->res_words < (uint64_t)m->coef_words + m->res_words)
-                    sgn = 2, m = d;
-            }
-            flags |= m->flags;
-            if (write) {
-                chosen[(size_t)f * channels + c] = sgn;
-                word_base[(size_t)f * channels + c] = words_before + words;
-            }
-            const uint64_t w = (m->flags & SELA_HIP_FLAG_WORDS_CAP) ? 0 : (uint64_t)m->coef_words + m->res_words;
-            words += w;
-            bytes += SELA_SUBFRAME_HEADER_BYTES + 4 * w;
-        }
-    };
-    uint64_t my_bytes = 0, my_words = 0;
+    if (t == 0)
+        all_flags = 0;
+    uint64_t base_b = 0, base_w = 0; // bytes / words of the tiles before this one (the same in every thread)
     uint32_t my_flags = 0;
-    for (uint32_t f = f_begin; f < f_end; f++) {
-        uint64_t bt, w;
-        frame_plan(f, bt, w, my_flags, false, 0);
-        my_bytes += bt, my_words += w;
-    }
-    // exclusive scan of (bytes, words) over the threads
-    auto scan64 = [&](uint64_t v) -> uint64_t { // inclusive, within the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
-            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
-            if (lane >= d)
-                v += ((uint64_t)hi << 32) | lo;
+    for (uint32_t tile0 = 0; tile0 < n_frames; tile0 += kPlanTile) {
+        const uint32_t tile_n = min((uint32_t)kPlanTile, n_frames - tile0);
+        __syncthreads(); // (the tile before has been read)
+        for (uint32_t i = t; i < tile_n; i += kPlanThreads) {
+            const uint32_t f = tile0 + i;
+            uint32_t words = 0;
+            for (uint32_t c = 0; c < channels; c++) {
+                uint32_t sgn = c;
+                const GenericMeta* m = meta + (size_t)f * n_sig + c;
+                if (channels == 2 && c == 1) {
+                    const GenericMeta* d = meta + (size_t)f * n_sig + 2;
+                    my_flags |= d->flags; // (both candidates were computed by the reference too: either's trouble is the frame's)
+                    if ((uint64_t)d->coef_words + d->res_words < (uint64_t)m->coef_words + m->res_words)
+                        sgn = 2, m = d;
+                }
+                my_flags |= m->flags;
+                chosen[(size_t)f * channels + c] = sgn;
+                words += (m->flags & SELA_HIP_FLAG_WORDS_CAP) ? 0u : m->coef_words + m->res_words; // (<= 255 x 131,070 words: fits)
+            }
+            frame_words[i] = words;
         }
-        return v;
-    };
-    const uint64_t incl_b = scan64(my_bytes), incl_w = scan64(my_words);
-    const uint32_t fl = wave_or(my_flags);
-    if (lane == 63)
-        wave_bytes[wave] = incl_b, wave_words[wave] = incl_w;
-    if (lane == 0)
-        wave_flags[wave] = fl;
+        __syncthreads();
+        const uint32_t per = (tile_n + kPlanThreads - 1) / kPlanThreads;
+        const uint32_t begin = min(t * per, tile_n), end = min(begin + per, tile_n);
+        uint64_t my_words = 0;
+        for (uint32_t i = begin; i < end; i++)
+            my_words += frame_words[i];
+        const uint64_t my_bytes = (uint64_t)(end - begin) * (4 + (uint64_t)channels * SELA_SUBFRAME_HEADER_BYTES) + 4 * my_words;
+        auto scan64 = [&](uint64_t v) -> uint64_t { // inclusive, within the wave
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
+                const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+                if (lane >= d)
+                    v += ((uint64_t)hi << 32) | lo;
+            }
+            return v;
+        };
+        const uint64_t incl_b = scan64(my_bytes), incl_w = scan64(my_words);
+        if (lane == 63)
+            wave_bytes[wave] = incl_b, wave_words[wave] = incl_w;
+        __syncthreads();
+        uint64_t at_w = base_w + incl_w - my_words, tile_b = 0, tile_w = 0;
+        for (int w = 0; w < kWaves; w++) {
+            const uint64_t wb = wave_bytes[w], ww = wave_words[w];
+            if (w < wave)
+                at_w += ww;
+            tile_b += wb, tile_w += ww;
+        }
+        // every frame's first word: an exclusive scan of the run in place (frame_words[i] <- words before frame i in the stream) ...
+        for (uint32_t i = begin; i < end; i++) {
+            const uint32_t w = frame_words[i];
+            frame_words[i] = (uint32_t)(at_w - base_w); // (relative to the tile: 4096 frames x 255 x 131,070 words fit 2^32 only just -- kept in 64 bits below)
+            frame_first_hi[i] = (uint32_t)((at_w - base_w) >> 32);
+            at_w += w;
+        }
+        __syncthreads();
+        // ... and then frame by frame again as in the first pass -- thread f mod 1024, independent loads (the third version: the
+        // run's owner walked its frames' subframes through `chosen`, a chain of dependent loads: 38 us at 3875 frames)
+        for (uint32_t i = t; i < tile_n; i += kPlanThreads) {
+            const uint32_t f = tile0 + i;
+            const uint64_t first = base_w + (((uint64_t)frame_first_hi[i] << 32) | frame_words[i]);
+            uint64_t w_at = first;
+            for (uint32_t c = 0; c < channels; c++) {
+                const GenericMeta* m = meta + (size_t)f * n_sig + c;
+                if (channels == 2 && c == 1) {
+                    const GenericMeta* d = meta + (size_t)f * n_sig + 2;
+                    if ((uint64_t)d->coef_words + d->res_words < (uint64_t)m->coef_words + m->res_words)
+                        m = d;
+                }
+                word_base[(size_t)f * channels + c] = w_at;
+                w_at += (m->flags & SELA_HIP_FLAG_WORDS_CAP) ? 0u : m->coef_words + m->res_words;
+            }
+            // bytes before frame f = (frames before it) x (4 + 12 channels) + 4 x (words before it)
+            frame_offsets[f] = base_bytes + (uint64_t)f * (4 + (uint64_t)channels * SELA_SUBFRAME_HEADER_BYTES) + 4 * first;
+        }
+        base_b += tile_b, base_w += tile_w;
+    }
+    if (my_flags)
+        atomicOr(&all_flags, my_flags);
     __syncthreads();
-    uint64_t at_b = incl_b - my_bytes, at_w = incl_w - my_words, all_b = 0, all_w = 0;
-    uint32_t all_fl = 0;
-    for (int w = 0; w < kWaves; w++) {
-        const uint64_t wb = wave_bytes[w], ww = wave_words[w];
-        if (w < wave)
-            at_b += wb, at_w += ww;
-        all_b += wb, all_w += ww;
-        all_fl |= wave_flags[w];
-    }
     if (t == 0) {
-        frame_offsets[n_frames] = base_bytes + all_b;
-        word_base[(size_t)n_frames * channels] = all_w;
-        *total_words_out = all_w;
-        atomicOr(&status[0], all_fl);
-    }
-    for (uint32_t f = f_begin; f < f_end; f++) {
-        uint64_t bt, w;
-        uint32_t fl2 = 0;
-        frame_offsets[f] = base_bytes + at_b;
-        frame_plan(f, bt, w, fl2, true, at_w);
-        at_b += bt, at_w += w;
+        frame_offsets[n_frames] = base_bytes + base_b;
+        word_base[(size_t)n_frames * channels] = base_w;
+        *total_words_out = base_w;
+        atomicOr(&status[0], all_flags);
     }
 }
 
