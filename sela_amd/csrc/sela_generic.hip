@@ -208,9 +208,9 @@ __device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k
 //   mean            a chunk of 64 quotients goes to LDS and comes back by same-address reads: one v_add_f64 per sample.
 //   autocorrelation lane L owns lags 2L and 2L + 1 (51 lanes): its two window values are c[j - 2L] and the one before, so a
 //                   step needs ONE new value per lane -- from a ring of 256 centred samples in LDS (+ 64 mirrored behind its
-//                   end: the 64 reads of a chunk have compile-time offsets) -- the wave-uniform c[j] as a scalar operand
-//                   (v_readlane of the register that holds the chunk), two multiplies and two adds: every product rounded
-//                   before it is added, every accumulator in ascending j.
+//                   end: the 64 reads of a chunk have compile-time offsets) -- the wave-uniform c[j] by a same-address read of
+//                   the same ring, two multiplies and two adds: every product rounded before it is added, every accumulator
+//                   in ascending j.
 //   Schur           in registers: lane L holds columns 2L, 2L + 1 of gen0 / gen1; gen1[j + 1] of the odd column is the next
 //                   lane's register (one DPP move of 64 bits per stage).
 //   residues        2048 samples at a time, lane L owning 32 CONSECUTIVE samples and sliding a statically addressed window of
@@ -406,9 +406,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
                 for (int t = 0; t < kAcAhead; t++)
                     ahead[t] = rl[t];
+                // the wave-uniform multiplier c[j] comes by a same-address LDS read as well (two v_readlane of the register that holds the
+                // chunk cost 4.1 k of the block's 23.3 k vector instructions: 0.775 -> 0.756 ms at 11,625 blocks; the phase is then bound
+                // by the LDS -- 2 reads per step and wave against 4 vector instructions)
+                const LdsDoubles cu = (LdsDoubles)lds.ac.ring + (j0 & (uint32_t)(kGenRing - 1));
+                double mult[kAcAhead];
+#pragma unroll
+                for (int t = 0; t < kAcAhead; t++)
+                    mult[t] = cu[t];
 #pragma unroll
                 for (int t = 0; t < 64; t++) {
-                    const double cj = read_lane(c_mine, t);
+                    const double cj = mult[t % kAcAhead];
+                    if (t + kAcAhead < 64)
+                        mult[t % kAcAhead] = cu[t + kAcAhead];
                     const double A = ahead[t % kAcAhead];
                     if (t + kAcAhead < 64)
                         ahead[t % kAcAhead] = rl[t + kAcAhead];

@@ -333,7 +333,10 @@ def test_hostile_streams_of_any_length_through_the_segment_parser(gpu, shape):  
 
     o = oracle()
     rng = np.random.default_rng(2024 if shape == "short" else 4048)
-    trials, n_lo, n_hi = (200, 1, 700) if shape == "short" else (60, 3000, 30000)
+    import os
+
+    scale = int(os.environ.get("SELA_HOSTILE_SCALE", "1"))  # (a long soak: SELA_HOSTILE_SCALE=20)
+    trials, n_lo, n_hi = (200 * scale, 1, 700) if shape == "short" else (60 * scale, 3000, 30000)
     same = failed = 0
     for trial in range(trials):
         ch = int(rng.integers(1, 4))
