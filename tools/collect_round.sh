@@ -34,10 +34,14 @@ for (name, grid), d in groups.items():
     print(f"{name:48s} workgroups {grid:7d}  launches {len(d):3d}  min {min(d):10.1f} us  mean {sum(d)/len(d):10.1f} us")
 PY
 # 5. the frame classes from many threads (the reference's own loop, src/sela/encoder.cpp:58-73): the CLI's shape and odd shapes
-{ for shape in "2048 16" "1000 17" "4096 16"; do for T in 1 4 16 64; do echo -n "shape $shape: "; host/sela_filebench frames $T 16 $shape 2>&1 | tail -1; done; done; } > "$OUT/frame_classes_fanout.txt" 2>&1
+{ for R in 1 2 3; do for shape in "2048 16" "1000 17" "4096 16"; do for T in 1 4 16 64; do echo -n "run $R shape $shape: "; host/sela_filebench frames $T 16 $shape 2>&1 | tail -1; done; done; done; } > "$OUT/frame_classes_fanout.txt" 2>&1
 # 6. BASELINE configs[2] (1000 frames) and configs[3] (the album's launches) under rocprofv3 with the PMC passes
 bash tools/config2_profile.sh > /dev/null 2>&1; cp "$ROOT/gpurun_out/config2_1000_frames.txt" "$OUT/config2_1000_frames.txt" 2>/dev/null
 bash tools/album_profile.sh > "$OUT/album_kernels.txt" 2>&1
+# 6b. an encode launch cut in two inside the library (an experiment behind --encode-split), one lane
+for S in 0 400 500 520 600 700; do
+  python bench.py --no-cpu-baseline --no-host-legs --no-extra-legs --lanes 1 --encode-split $S 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print('--lanes 1 --encode-split %-5s %6.0f M samples/s  %.4f ms/step  launches cut %s' % ('$S', d['value'], d['ms_per_step'], d['lanes']['encode_split']['launches_cut_in_two']))"
+done > "$OUT/split_sweep.txt" 2>&1
 # 7. the FP64 matrix pipe beside the vector pipe (the gate of VERDICT r5 item 3), the differential corpus' summary
 [ -x tools/mfma_overlap ] && tools/mfma_overlap > "$OUT/mfma_overlap.txt" 2>&1
 python -m pytest tests/test_gpu_encode_parity.py -q -s -k corpus -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -6 > "$OUT/corpus.txt"
