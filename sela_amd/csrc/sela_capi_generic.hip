@@ -45,7 +45,9 @@ struct Arena { // one device allocation, handed out in aligned pieces for the le
         if (base && bytes <= cap)
             return hipSuccess;
         release();
-        const size_t want = std::max<size_t>(bytes + (bytes >> 2), 1 << 20);
+        // (grow-only, and from a size that the batches of frame-at-a-time callers do not outgrow call after call: a regrowth is a
+        // hipFree + hipMalloc, hundreds of microseconds in the middle of a batch)
+        const size_t want = std::max<size_t>(bytes + (bytes >> 1), (size_t)16 << 20);
         const hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), want);
         if (e != hipSuccess) {
             base = nullptr;
@@ -81,7 +83,7 @@ struct PinnedScratch { // page-locked host memory for what a call reads back fir
         if (base && bytes <= cap)
             return base;
         release();
-        const size_t want = std::max<size_t>(bytes + (bytes >> 2), 1 << 16);
+        const size_t want = std::max<size_t>(bytes + (bytes >> 1), (size_t)3 << 20); // (grow-only; a regrowth is a hipHostFree + hipHostMalloc: milliseconds)
         if (hipHostMalloc(reinterpret_cast<void**>(&base), want, hipHostMallocDefault) != hipSuccess) {
             base = nullptr;
             return nullptr;

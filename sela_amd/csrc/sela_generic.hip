@@ -71,13 +71,16 @@ __device__ inline void put_codeword(uint32_t* buf, uint64_t pos, uint32_t u, uin
 }
 
 // pack the stream v[0..n) with parameter k into zeroed words (src/rice/rice_encoder.cpp:35-71).
-// Round 6: 2048 values at a time, lane L owning 32 CONSECUTIVE values (staged through LDS so that the loads are coalesced and the
+// Round 6: 1024 values at a time, lane L owning 16 CONSECUTIVE values (staged through LDS so that the loads are coalesced and the
 // lanes' reads fall on different banks) -- ONE scan of the lanes' bit counts per stretch, every codeword of at most 32 bits OR-ed
 // into the LDS window without a branch -- and the window leaves as whole words: plain stores, but for the stretch's first and
 // last word, which its neighbours share (an atomic OR each).  A stretch whose quotients are long (a lane's bits beyond 2^26) or
 // whose bits do not fit the window goes 64 codewords at a time as the first version did for every round (rice_pack_round).
-constexpr uint32_t kPackWindow = 2304;  // words: 73,728 bits for 2048 codewords (36 bits each), and room for the 2048 staged values (2112 words)
-constexpr uint32_t kPackStretch = 2048;
+constexpr uint32_t kPackPerLane = 16;                         // consecutive values a lane owns in a stretch
+constexpr uint32_t kPackStretch = 64 * kPackPerLane;         // 1024 values
+constexpr uint32_t kPackWindow = 1152;  // words: 36,864 bits for 1024 codewords (36 bits each), and room for the 1024 staged values
+                                        // (1088 words: one pad word per 16).  4.6 KB per wave: eight waves per SIMD (a stretch of 2048
+                                        // values in a window of 9.2 KB, four waves per SIMD: 110 us for 7750 subframes of 2048 samples)
 
 // 64 codewords at bit position `base` of the stream: lane = codeword
 __device__ inline uint64_t rice_pack_round(uint32_t u, bool valid, uint32_t k, uint32_t* out, uint64_t base, int lane, uint32_t* win)
@@ -123,22 +126,22 @@ __device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k
     uint64_t base = 0;
     for (uint32_t i0 = 0; i0 < n; i0 += kPackStretch) {
         const uint32_t in_stretch = min(kPackStretch, n - i0);
-        // stage: value i of the stretch at word i + i / 32
+        // stage: value i of the stretch at word i + i / 16
         for (uint32_t i = lane; i < in_stretch; i += 64)
-            win[i + (i >> 5)] = zigzag32(v[i0 + i]);
+            win[i + (i >> 4)] = zigzag32(v[i0 + i]);
         wave_sync();
-        uint32_t u[32];
-        const uint32_t mine = in_stretch > 32u * (uint32_t)lane ? min(32u, in_stretch - 32u * (uint32_t)lane) : 0u;
+        uint32_t u[kPackPerLane];
+        const uint32_t mine = in_stretch > kPackPerLane * (uint32_t)lane ? min(kPackPerLane, in_stretch - kPackPerLane * (uint32_t)lane) : 0u;
         uint32_t bits = 0, longest = 0;
 #pragma unroll
-        for (int t = 0; t < 32; t++) {
-            u[t] = (uint32_t)t < mine ? win[33 * lane + t] : 0u;
+        for (int t = 0; t < (int)kPackPerLane; t++) {
+            u[t] = (uint32_t)t < mine ? win[(kPackPerLane + 1) * lane + t] : 0u;
             const uint32_t q = u[t] >> k;
             longest = max(longest, q);
             bits += (uint32_t)t < mine ? q + 1 + k : 0u; // (may wrap when a quotient is long: then `longest` says so)
         }
         wave_sync(); // the staged values are in registers: the window is free
-        const bool easy = !__any(longest >= (1u << 20)); // a lane's bits below 2^26, the stretch's below 2^32
+        const bool easy = !__any(longest >= (1u << 20)); // a lane's bits below 2^25, the stretch's below 2^32
         uint32_t at = 0, total = 0;
         if (easy) {
             at = wave_exclusive_scan(bits, lane);
@@ -152,7 +155,7 @@ __device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k
             wave_sync();
             uint32_t pos = (uint32_t)(base & 31) + at;
 #pragma unroll
-            for (int t = 0; t < 32; t++) {
+            for (int t = 0; t < (int)kPackPerLane; t++) {
                 if ((uint32_t)t < mine) {
                     const uint32_t ones = u[t] >> k, len = ones + 1 + k;
                     if (len <= 32) {
@@ -179,15 +182,15 @@ __device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k
             wave_sync();
             base += total;
         } else { // long quotients, or more bits than the window holds: 64 codewords at a time, codeword i of the stretch in lane i % 64
-            // (the values go back through the window's first 2112 words: rice_pack_round uses the window too, so round by round from registers)
+            // (rice_pack_round uses the window too, so round by round from the registers)
             for (uint32_t r0 = 0; r0 < in_stretch; r0 += 64) {
-                // codeword r0 + lane lives in lane (r0 + lane) / 32's register (r0 + lane) % 32
-                const uint32_t src_lane = (r0 + (uint32_t)lane) >> 5;
+                // codeword r0 + lane lives in lane (r0 + lane) / 16's register (r0 + lane) % 16
+                const uint32_t src_lane = (r0 + (uint32_t)lane) / kPackPerLane;
                 uint32_t mine_u = 0;
 #pragma unroll
-                for (int t = 0; t < 32; t++) {
+                for (int t = 0; t < (int)kPackPerLane; t++) {
                     const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * src_lane), (int)u[t]);
-                    mine_u = (((r0 + (uint32_t)lane) & 31u) == (uint32_t)t) ? got : mine_u;
+                    mine_u = (((r0 + (uint32_t)lane) % kPackPerLane) == (uint32_t)t) ? got : mine_u;
                 }
                 base += rice_pack_round(mine_u, r0 + lane < in_stretch, k, out, base, lane, win);
             }
@@ -671,18 +674,25 @@ __global__ __launch_bounds__(kPlanThreads) void k_generic_plan(const GenericMeta
         for (uint32_t i = t; i < tile_n; i += kPlanThreads) {
             const uint32_t f = tile0 + i;
             uint32_t words = 0;
-            for (uint32_t c = 0; c < channels; c++) {
-                uint32_t sgn = c;
-                const GenericMeta* m = meta + (size_t)f * n_sig + c;
-                if (channels == 2 && c == 1) {
-                    const GenericMeta* d = meta + (size_t)f * n_sig + 2;
-                    my_flags |= d->flags; // (both candidates were computed by the reference too: either's trouble is the frame's)
-                    if ((uint64_t)d->coef_words + d->res_words < (uint64_t)m->coef_words + m->res_words)
-                        sgn = 2, m = d;
+            // (values, not pointers, are selected: a record chosen by pointer is loaded again through it -- a chain of dependent
+            // loads, 32 us for 3875 frames)
+            const GenericMeta* const fm = meta + (size_t)f * n_sig;
+            if (channels == 2) {
+                const uint32_t w0 = fm[0].coef_words + fm[0].res_words, w1 = fm[1].coef_words + fm[1].res_words, w2 = fm[2].coef_words + fm[2].res_words;
+                const uint32_t f0 = fm[0].flags, f1 = fm[1].flags, f2 = fm[2].flags;
+                const bool diff = (uint64_t)fm[2].coef_words + fm[2].res_words < (uint64_t)fm[1].coef_words + fm[1].res_words;
+                my_flags |= f0 | f1 | f2; // (both candidates were computed by the reference too: either's trouble is the frame's)
+                chosen[(size_t)f * 2] = 0;
+                chosen[(size_t)f * 2 + 1] = diff ? 2u : 1u;
+                const uint32_t fs = diff ? f2 : f1, ws = diff ? w2 : w1;
+                words = ((f0 & SELA_HIP_FLAG_WORDS_CAP) ? 0u : w0) + ((fs & SELA_HIP_FLAG_WORDS_CAP) ? 0u : ws);
+            } else {
+                for (uint32_t c = 0; c < channels; c++) {
+                    const uint32_t fl = fm[c].flags, w = fm[c].coef_words + fm[c].res_words;
+                    my_flags |= fl;
+                    chosen[(size_t)f * channels + c] = c;
+                    words += (fl & SELA_HIP_FLAG_WORDS_CAP) ? 0u : w; // (<= 255 x 131,070 words: fits)
                 }
-                my_flags |= m->flags;
-                chosen[(size_t)f * channels + c] = sgn;
-                words += (m->flags & SELA_HIP_FLAG_WORDS_CAP) ? 0u : m->coef_words + m->res_words; // (<= 255 x 131,070 words: fits)
             }
             frame_words[i] = words;
         }
@@ -728,15 +738,17 @@ __global__ __launch_bounds__(kPlanThreads) void k_generic_plan(const GenericMeta
             const uint32_t f = tile0 + i;
             const uint64_t first = base_w + (((uint64_t)frame_first_hi[i] << 32) | frame_words[i]);
             uint64_t w_at = first;
-            for (uint32_t c = 0; c < channels; c++) {
-                const GenericMeta* m = meta + (size_t)f * n_sig + c;
-                if (channels == 2 && c == 1) {
-                    const GenericMeta* d = meta + (size_t)f * n_sig + 2;
-                    if ((uint64_t)d->coef_words + d->res_words < (uint64_t)m->coef_words + m->res_words)
-                        m = d;
+            const GenericMeta* const fm = meta + (size_t)f * n_sig;
+            if (channels == 2) {
+                const uint32_t w0 = fm[0].coef_words + fm[0].res_words, f0 = fm[0].flags;
+                word_base[(size_t)f * 2] = w_at;
+                word_base[(size_t)f * 2 + 1] = w_at + ((f0 & SELA_HIP_FLAG_WORDS_CAP) ? 0u : w0);
+            } else {
+                for (uint32_t c = 0; c < channels; c++) {
+                    const uint32_t fl = fm[c].flags, w = fm[c].coef_words + fm[c].res_words;
+                    word_base[(size_t)f * channels + c] = w_at;
+                    w_at += (fl & SELA_HIP_FLAG_WORDS_CAP) ? 0u : w;
                 }
-                word_base[(size_t)f * channels + c] = w_at;
-                w_at += (m->flags & SELA_HIP_FLAG_WORDS_CAP) ? 0u : m->coef_words + m->res_words;
             }
             // bytes before frame f = (frames before it) x (4 + 12 channels) + 4 x (words before it)
             frame_offsets[f] = base_bytes + (uint64_t)f * (4 + (uint64_t)channels * SELA_SUBFRAME_HEADER_BYTES) + 4 * first;
