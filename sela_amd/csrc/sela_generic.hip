@@ -216,16 +216,23 @@ __device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k
 //                   in ascending j.
 //   Schur           in registers: lane L holds columns 2L, 2L + 1 of gen0 / gen1; gen1[j + 1] of the odd column is the next
 //                   lane's register (one DPP move of 64 bits per stage).
-//   residues        2048 samples at a time, lane L owning 32 CONSECUTIVE samples and sliding a statically addressed window of
-//                   32 registers over its history (one new LDS word and 32 multiply-adds per tap) -- in FP64 (v_fma_f64, full
+//   residues        1024 samples at a time, lane L owning 16 CONSECUTIVE samples and sliding a statically addressed window of
+//                   16 registers over its history (one new LDS word and 16 multiply-adds per tap) -- in FP64 (v_fma_f64, full
 //                   rate) where that is exact: 2^34 + sum |a[j]| x max |s| < 2^53 bounds every partial sum of integers, in any
 //                   order.  A block beyond that bound (21-bit noise with a long predictor; nothing 16-bit) takes the 64-bit
 //                   wrap-around taps in a window that moves one lane per tap, as the first version did for every block.
 //   Rice parameter  by convexity (rice_plan_convex), not by all twenty sums.
-constexpr int kGenPad = 128;                                   // "no sample" / the samples before a stretch of 2048, in front of it
-constexpr int kGenStretch = 2048;                              // samples per pass of the residue filter
-constexpr int kGenPerLane = kGenStretch / kWave;               // 32
-constexpr int kGenSBufWords = (kGenPad + kGenStretch) / 32 * 33; // index i stored at i + i / 32: 32-word strides fall on different banks
+// Occupancy is what this kernel lives on -- its mean, its Schur stages and its accumulators are dependent chains -- and the residue
+// filter's register window is what bounds it: 32 samples per lane (128 VGPRs of window and sums, 168 in all, 12 KB of LDS) allow three
+// waves per SIMD, 16 per lane (125 / 7.9 KB) four or, with 16 registers spilled outside the loops, five: 763 / 667 / 655 us for 11,625
+// blocks of 2048 samples.
+#define SELA_GEN_WAVES 5
+constexpr int kGenPad = 128;                                   // "no sample" / the samples before a stretch, in front of it
+constexpr int kGenPerLane = 16;                                // consecutive samples a lane owns in a stretch of the residue filter
+constexpr int kGenPadShift = kGenPerLane == 32 ? 5 : 4;        // index i stored at i + (i >> shift): the lanes' strides fall on different banks
+constexpr int kGenStretch = kGenPerLane * kWave;               // samples per pass of the residue filter
+constexpr int kGenSBufWords = (kGenPad + kGenStretch) + ((kGenPad + kGenStretch) >> kGenPadShift);
+static_assert(kGenPerLane == 16 || kGenPerLane == 32, "the window is a power of two of registers");
 constexpr int kGenRing = 256, kGenMirror = 64;
 
 struct AnalyseLds {
@@ -258,8 +265,8 @@ __device__ __forceinline__ double scale_any(int32_t v, bool small /* wave-unifor
     return (double)v / SELA_SAMPLE_SCALE;
 }
 
-// Taps j0 + JJ + 1 .. j0 + 32 of the residue filter in FP64 (the window of sela_encode.hip's fir_taps_f64): tap j uses
-// win[(t - j) mod 32] = s[32 lane + t - j] and loads the one new element s[32 lane - j].
+// Taps j0 + JJ + 1 .. j0 + kGenPerLane of the residue filter in FP64 (the window of sela_encode.hip's fir_taps_f64): tap j uses
+// win[(t - j) mod kGenPerLane] = s[kGenPerLane lane + t - j] and loads the one new element s[kGenPerLane lane - j].
 template <int JJ>
 __device__ __forceinline__ void gen_taps_f64(int j0, int order, int lane, const int32_t* sT, const double* a_f, double (&win)[kGenPerLane], double (&acc)[kGenPerLane])
 {
@@ -267,13 +274,13 @@ __device__ __forceinline__ void gen_taps_f64(int j0, int order, int lane, const 
     if (j > order)
         return;
     const double aj = read_first_lane(a_f[j]);
-    const int e = kGenPad + 32 * lane - j;
-    win[(32 - JJ - 1) & 31] = (double)sT[e + (e >> 5)];
+    const int e = kGenPad + kGenPerLane * lane - j;
+    win[(kGenPerLane - JJ - 1) & (kGenPerLane - 1)] = (double)sT[e + (e >> kGenPadShift)];
 #pragma unroll
     for (int t = 0; t < kGenPerLane; t++)
-        acc[t] = __builtin_fma(aj, win[(t - JJ - 1) & 31], acc[t]);
+        acc[t] = __builtin_fma(aj, win[(t - JJ - 1) & (kGenPerLane - 1)], acc[t]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (JJ < 31)
+    if constexpr (JJ < kGenPerLane - 1)
         gen_taps_f64<JJ + 1>(j0, order, lane, sT, a_f, win, acc);
 }
 
@@ -322,7 +329,7 @@ __device__ __forceinline__ void rice_plan_convex(Load load, uint32_t n, int lane
 }
 
 template <bool kIn16>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_generic_analyse(const void* __restrict__ input, uint32_t n_frames, uint32_t channels,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SELA_GEN_WAVES, SELA_GEN_WAVES))) void k_generic_analyse(const void* __restrict__ input, uint32_t n_frames, uint32_t channels,
     uint32_t n_sig, uint32_t n, int32_t* __restrict__ sig_ws, int32_t* __restrict__ res_ws, int32_t* __restrict__ q_ws, GenericMeta* __restrict__ meta, uint32_t force_wrap_taps /* tests: every block on the 64-bit wrap-around taps */)
 {
     __shared__ __attribute__((aligned(16))) AnalyseLds lds;
@@ -538,30 +545,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (fp64_taps) {
         int32_t* const sT = lds.st;
         for (int m = lane; m < kGenPad; m += 64)
-            sT[m + (m >> 5)] = 0;
+            sT[m + (m >> kGenPadShift)] = 0;
         for (uint32_t i0 = 0; i0 < n; i0 += kGenStretch) {
             if (i0) { // the stretch before this one left its last 128 samples behind: they become this one's history
                 int32_t keep[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int e = kGenStretch + lane + 64 * h; // = kGenPad + (kGenStretch - kGenPad) + ...
-                    keep[h] = sT[e + (e >> 5)];
+                    keep[h] = sT[e + (e >> kGenPadShift)];
                 }
                 wave_sync();
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int e = lane + 64 * h;
-                    sT[e + (e >> 5)] = keep[h];
+                    sT[e + (e >> kGenPadShift)] = keep[h];
                 }
             }
 #pragma unroll 8
             for (int t = 0; t < kGenPerLane; t++) {
                 const uint32_t i = i0 + lane + 64 * t;
                 const int e = kGenPad + lane + 64 * t;
-                sT[e + (e >> 5)] = i < n ? s[i] : 0;
+                sT[e + (e >> kGenPadShift)] = i < n ? s[i] : 0;
             }
             wave_sync();
-            const int32_t* mine_s = sT + (kGenPad + 32 * lane) + ((kGenPad + 32 * lane) >> 5); // &s[i0 + 32 lane], 32 words without a pad inside
+            const int32_t* mine_s = sT + (kGenPad + kGenPerLane * lane) + ((kGenPad + kGenPerLane * lane) >> kGenPadShift); // &s[i0 + kGenPerLane lane]: no pad word inside
             double win_f[kGenPerLane], acc_f[kGenPerLane];
 #pragma unroll
             for (int t = 0; t < kGenPerLane; t++) {
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 win_f[t] = (double)mine_s[t];
             }
 #pragma unroll 1
-            for (int j0 = 0; j0 < order; j0 += 32)
+            for (int j0 = 0; j0 < order; j0 += kGenPerLane)
                 gen_taps_f64<0>(j0, order, lane, sT, lds.af, win_f, acc_f);
             int32_t rr[kGenPerLane];
 #pragma unroll
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 const int32_t pred = (int32_t)__builtin_floor(acc_f[t] * (1.0 / (double)((int64_t)1 << SELA_Q_SHIFT)));
                 rr[t] = (int32_t)((uint32_t)mine_s[t] - (uint32_t)pred);
             }
-            const uint32_t first = i0 + 32 * (uint32_t)lane;
+            const uint32_t first = i0 + (uint32_t)kGenPerLane * (uint32_t)lane;
 #pragma unroll
             for (int t = 0; t < kGenPerLane; t++)
                 if (first + t < n) {

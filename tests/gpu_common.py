@@ -229,7 +229,7 @@ def _both_decoders(blob, offs, ch):
     return offered, alone, took
 
 
-ENCODE_LENGTHS = [2, 63, 64, 65, 101, 127, 128, 129, 191, 255, 256, 257, 300, 1000, 2047, 2048, 2049, 2175, 2176, 2177, 4095, 4096, 4097, 6144, 20000, 65535]
+ENCODE_LENGTHS = [2, 63, 64, 65, 101, 127, 128, 129, 191, 255, 256, 257, 300, 1000, 1023, 1024, 1025, 1151, 1152, 1153, 2047, 2048, 2049, 2175, 2176, 2177, 3071, 3072, 3073, 4095, 4096, 4097, 6144, 20000, 65535]
 
 
 def _wrap_taps(on):

@@ -219,7 +219,7 @@ def test_random_shapes_against_the_oracle(gpu):  # noqa: F811
 
 @pytest.mark.parametrize("n", ENCODE_LENGTHS)
 def test_frames_of_any_length_equal_the_oracles_bytes_in_both_forms_of_the_residue_filter(gpu, n):  # noqa: F811
-    """Lengths on both sides of every boundary the kernel has (chunks of 64, the ring of 256, stretches of 2048 with 128 samples
+    """Lengths on both sides of every boundary the kernel has (chunks of 64, the ring of 256, stretches of 1024 with 128 samples
     of history), mono / stereo / three channels, silence, DC, tones, clicks, noise, 16- and 21-bit: the frame bytes are the
     oracle's with the residue filter chosen by the block's bound (FP64 taps where exact) and forced onto the 64-bit taps."""
     from sela_amd import codec
