@@ -245,6 +245,49 @@ def test_segment_parallel_parse_model():
         _model_case(o, [1], rng.integers(-40, 40, n))
 
 
+def test_segmented_parse_model_on_streams_of_any_length():
+    """tools/parse_model.py parse_segments -- the algorithm of k_decode_subframes32's parse by segments (sela_decode32.hip: an entry
+    anywhere in a word, a limit behind which a codeword is the next segment's, a cap on the codewords listed, segments sized by
+    the stream's own words per value) -- against the oracle's encoder and decoder: long noise (segments cut by their words),
+    silence (cut by their codeword count), clicks whose unary runs span zones and segments, and tiny segments that put every
+    boundary case on every few codewords."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from oracle_lib import oracle
+    from parse_model import parse_segments
+
+    o = oracle()
+    rng = np.random.default_rng(8)
+
+    def check(values, seg_words=1072, seg_values=2048, min_segments=1):
+        v = np.asarray(values, np.int32)
+        k, words = o.rice_encode(v)
+        got, over, segs = parse_segments(words, 0, 32 * len(words), k, len(v), seg_words, seg_values)
+        assert not over and np.array_equal(got, v), (len(v), k, seg_words, seg_values)
+        assert segs >= min_segments, (segs, min_segments)
+        # ... and from an entry in the middle of a word: the same stream behind 24 junk bits (how the coefficient stream lies)
+        shifted = np.zeros(len(words) + 1, np.uint64)
+        shifted[:-1] |= (words.astype(np.uint64) << np.uint64(24)) & np.uint64(0xFFFFFFFF)
+        shifted[1:] |= words.astype(np.uint64) >> np.uint64(8)
+        shifted[0] |= np.uint64(0x00ABCDEF)
+        got2, over2, _ = parse_segments(shifted.astype(np.uint32), 24, 24 + 32 * len(words), k, len(v), seg_words, seg_values)
+        assert not over2 and np.array_equal(got2, v)
+
+    check(rng.integers(-20000, 20000, 9000), min_segments=3)               # ~17 bits per value: several segments' words
+    check(np.zeros(10000), min_segments=4)                                   # k = 0, a bit per value: cut by the 2048-codeword cap
+    check(np.where(rng.random(6000) < 0.004, rng.integers(-(1 << 17), 1 << 17, 6000), rng.integers(-2, 3, 6000)))  # long unary runs
+    for seg_words, seg_values in ((3, 5), (1, 1), (2, 64), (7, 3), (64, 2048)):
+        check(rng.integers(-300, 300, 700), seg_words, seg_values, min_segments=2)
+        check(np.where(rng.random(500) < 0.05, 5000, 0), seg_words, seg_values, min_segments=2)  # runs longer than a whole segment
+    # a stream that runs dry: what is missing reads as zeros and the overrun is reported
+    v = rng.integers(-300, 300, 3000).astype(np.int32)
+    k, words = o.rice_encode(v)
+    got, over, _ = parse_segments(words[: len(words) // 2], 0, 32 * (len(words) // 2), k, 3000)
+    n_ok = int((got == v).cumprod().sum())
+    assert over and n_ok > 1300 and np.all(got[n_ok + 1:] == 0)
+
+
 def test_parse_model_reports_truncated_streams():
     """A residue stream cut short decodes zeros behind its end and raises the overrun flag -- the behaviour
     of the kernel (reads beyond the stream are zero), which the reference leaves undefined."""

@@ -188,6 +188,150 @@ def parse(words, cw, rw, ck, rk, order, n_values=2048, n_coef_lanes=4, stats=Non
     return out_q, out_r, overrun[0], overrun[1]
 
 
+# ---- any stream length: the same walks, segment by segment (sela_decode32.hip: parse_segment / parse_stream_segments) ----------
+def parse_segment(words, w0, entry, n_seg_words, stream_end, k, need):
+    """One segment: the words [w0, w0 + n_seg_words) of `words`, the true trajectory entering at bit `entry` (0..31) of word w0;
+    positions are relative to bit 32 * w0.  A codeword that STARTS in front of the limit min(32 n_seg_words, stream_end) is this
+    segment's however far it reaches.  -> (starts listed (<= need), the bit behind the last of them, overrun)."""
+    W = n_seg_words
+    zr = -(-W // WAVE)
+    limit = min(32 * W, stream_end)
+    base = 32 * w0
+
+    def word_at(w):
+        return int(words[w0 + w]) if w0 + w < len(words) else 0
+
+    def bits_at(pos):
+        w, sh = pos >> 5, pos & 31
+        return ((word_at(w) | (word_at(w + 1) << 32)) >> sh) & 0xFFFFFFFF
+
+    class L:
+        pass
+
+    lanes = []
+    for i in range(WAVE):
+        ln = L()
+        first, end = min(i * zr, W), min((i + 1) * zr, W)
+        ln.first_word, ln.end_word = first, end
+        ln.pos = entry if i == 0 else 32 * first
+        ln.zone_end = min(32 * end, limit)
+        ln.in_run, ln.nB, ln.m = False, 0, None
+        lanes.append(ln)
+
+    def step(ln):
+        x = bits_at(ln.pos)
+        if x == 0xFFFFFFFF:
+            ln.pos += 32
+            ln.in_run = True
+            return
+        t = (~x & (x + 1)).bit_length() - 1
+        ln.pos += t + 1 + k
+        ln.in_run = False
+
+    marks = set()
+    for ln in lanes:  # phase A
+        while ln.pos < ln.zone_end:
+            if not ln.in_run:
+                marks.add(ln.pos)
+            step(ln)
+    for ln in lanes:  # phase B (a lane's walk depends on the marks alone: lane by lane is the same as in lock step)
+        while ln.m is None:
+            if not ln.in_run:
+                if ln.pos >= limit:
+                    ln.m = -1
+                    break
+                if ln.pos in marks:
+                    ln.m = ln.pos
+                    break
+                ln.nB += 1
+            step(ln)
+    # the chain from lane 0, every chain lane's codewords from its true entry
+    starts, cur, e = [], 0, entry
+    while True:
+        ln = lanes[cur]
+        own = sorted(p for p in marks if e <= p < 32 * ln.end_word and p >= 32 * ln.first_word) if e < 32 * ln.end_word else []
+        pos = e
+        walked = []
+        for _ in range(len(own) + ln.nB):  # pass 2: the lane walks its codewords again and lists their starts
+            walked.append(pos)
+            while True:
+                x = bits_at(pos)
+                if x != 0xFFFFFFFF:
+                    break
+                pos += 32
+            pos += (~x & (x + 1)).bit_length() - 1 + 1 + k
+        assert walked[: len(own)] == own, "the marks behind a lane's true entry are its own trajectory"
+        starts += [(p, cur) for p in walked]
+        if ln.m < 0:
+            end_of_last = pos
+            break
+        assert pos == ln.m and (ln.m >> 5) // zr > cur
+        cur, e = (ln.m >> 5) // zr, ln.m
+    listed = starts[:need]
+    # the bit behind the last listed codeword
+    p = listed[-1][0]
+    while True:
+        x = bits_at(p)
+        if x != 0xFFFFFFFF:
+            break
+        p += 32
+    nxt = p + (~x & (x + 1)).bit_length() - 1 + 1 + k
+    overrun = nxt > stream_end  # (the listed codewords are in order: the last one decides whether any reaches beyond the stream's end)
+    return [q for q, _ in listed], nxt, overrun, base
+
+
+def parse_segments(words, first_bit, stream_end, k, count, seg_words=1072, seg_values=2048):
+    """rice::RiceDecoder on `count` values of the stream in bits [first_bit, stream_end) of `words`, by segments of at most
+    seg_words words and seg_values codewords sized by the stream's own words per value -> (values, overrun, segments)."""
+    words = np.asarray(words, np.uint32)
+    end_word = (stream_end + 31) >> 5
+    n_stream_words = max(1, end_word - (first_bit >> 5))
+    per_value_x256 = (256 * n_stream_words + count - 1) // max(count, 1) + 1
+    out = np.zeros(count, np.int32)
+    done, entry, boost, overrun, segments = 0, first_bit, 0, False, 0
+    while done < count:
+        if entry >= stream_end:
+            overrun = True
+            break
+        need = min(count - done, seg_values)
+        w0 = entry >> 5
+        guess = (need * per_value_x256) >> 8
+        W = max(1, min(min(seg_words, end_word - w0), (guess + (guess >> 4) + 2) << boost))
+        starts, nxt, over, base = parse_segment(words, w0, entry & 31, W, stream_end - 32 * w0, k, need)
+        assert starts, "a segment whose entry lies in front of its limit lists at least that codeword"
+        for i, p in enumerate(starts):
+            pos, ones = base + p, 0
+            while True:
+                x = _bits(words, pos)
+                if x != 0xFFFFFFFF:
+                    break
+                ones += 32
+                pos += 32
+            t = (~x & (x + 1)).bit_length() - 1
+            ones += t
+            pos += t + 1
+            field = _bits(words, pos) & ((1 << k) - 1) if k else 0
+            rem = 0
+            for b in range(k):
+                rem = (rem << 1) | ((field >> b) & 1)
+            u = ((ones << k) | rem) & 0xFFFFFFFF
+            v = unzigzag(u)
+            out[done + i] = np.int32(v) if v < (1 << 31) else np.int32(v - (1 << 32))
+        done += len(starts)
+        entry = 32 * w0 + nxt
+        overrun |= over
+        boost = boost + 1 if len(starts) < need and boost < 12 else boost
+        segments += 1
+    return out, overrun, segments
+
+
+def _bits(words, pos):
+    w, sh = pos >> 5, pos & 31
+    lo = int(words[w]) if w < len(words) else 0
+    hi = int(words[w + 1]) if w + 1 < len(words) else 0
+    return ((lo | (hi << 32)) >> sh) & 0xFFFFFFFF
+
+
 def subframe_words(coef_words, res_words):
     """The aligned words of one subframe from the word holding [coef word count u16 | order u8 | first
     coefficient byte]: coefficient words sit 3 bytes in (src/file/sela_file.cpp:121-129)."""
