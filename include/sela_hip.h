@@ -177,7 +177,7 @@ uint32_t sela_hip_index_samples(const uint8_t* frames, const uint64_t* frame_off
  * (src/include/data/wav_frame.hpp:8-16), nothing narrowed (src/frame/frame_decoder.cpp:64-71; only file::WavFile::writeToFile
  * truncates to 16 bits).  The encoder always runs the any-length kernels (sela_generic.hip: the fast kernels' loops with a
  * run-time length); the decoder runs the fast decoder's lane-parallel parse and tuned synthesis with 32-bit samples and a
- * run-time length (k_decode_subframes32: one piece for 2048-sample subframes that fit the parser's plan, segments for
+ * run-time length (k_decode_subframes32: one piece for subframes of at most 2048 samples that fit the parser's plan, segments for
  * everything else) and leaves to a serial kernel only the streams it will not judge (frames that are not whole words, malformed
  * headers, Rice streams that run dry, coefficients outside the tables).  Results identical to the calls above wherever both apply.
  *   samples      [n_frames][channels][samples_per_channel] (planar per frame: WavFrame.samples[c][i]), 1 .. 65535 per channel.

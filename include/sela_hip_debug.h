@@ -91,8 +91,8 @@ void sela_hip_debug_encode_split(int mode);
 int sela_hip_debug_launches_split(void);
 /* Debug hook (tests; process-wide): the any-length decoder (sela_hip_decode_i32 -- frame::FrameDecoder behind it -- and
  * sela_hip_decode on streams that are not 2048 samples per frame) offers its subframes to k_decode_subframes32 first (the fast
- * decoder's lane-parallel parse and tuned synthesis with 32-bit samples: one piece for 2048-sample subframes that fit the
- * parser's plan, segments for everything else) and decodes again on the serial kernel k_generic_decode when that kernel left
+ * decoder's lane-parallel parse and tuned synthesis with 32-bit samples: one piece for subframes of at most 2048 samples that
+ * fit the parser's plan, segments for everything else) and decodes again on the serial kernel k_generic_decode when that kernel left
  * anything alone.  -1 / 1: the product; 0: never offer (the serial kernel alone); 2: offer, but every subframe by segments.
  * sela_hip_debug_standard_chunks(): how many chunks of frames the fast kernel has decoded, alone, so far;
  * sela_hip_debug_segment_subframes(): how many subframes of those chunks it parsed by segments. */

@@ -249,7 +249,7 @@ int generic_encode(const void* input, bool in16, uint32_t n_frames, uint32_t cha
     Arena& g_arena = ctx->arena;
     const uint32_t n_sig = channels == 2 ? 3u : channels;
     const size_t in_frame_bytes = (size_t)n * channels * (in16 ? 2 : 4);
-    const size_t est_frame_bytes = ((size_t)n * channels * 9) / 2 + (size_t)channels * 64 + 64; // words and frame bytes, each
+    const size_t est_frame_bytes = ((size_t)n * channels * 9) / 2 + (size_t)channels * 192 + 64; // words and frame bytes, each (a subframe: 12 bytes of header, up to 32 coefficient words)
     const size_t per_frame = (size_t)n_sig * n * 8 + (size_t)n_sig * (kMaxOrder * 4 + sizeof(GenericMeta) + 2 * kPiece) + in_frame_bytes + (size_t)channels * 12 + 8
         + 2 * est_frame_bytes;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, kChunkBudget / per_frame));

@@ -230,8 +230,9 @@ __device__ __forceinline__ uint32_t parse_stream_segments(const uint32_t* gw, ui
         // as many words as `need` codewords of the stream's average length take (+ 1/16 + 2): a segment that finds fewer simply
         // hands the rest to the next one (and makes that one twice as long: a stream whose codewords grow must not be walked
         // a few codewords at a time), one that covers many more than it may list parses them for nothing
-        const uint32_t guess = (uint32_t)(((uint64_t)need * words_per_value_x256) >> 8);
-        const uint32_t W = max(1u, min(min((uint32_t)kSegWords, end_word - w0), (guess + (guess >> 4) + 2) << boost));
+        const uint64_t guess = ((uint64_t)need * words_per_value_x256) >> 8;
+        const uint64_t wanted = (guess + (guess >> 4) + 2) << boost; // (< 2^28 x 2^12: no wrap in 64 bits)
+        const uint32_t W = max(1u, min(min((uint32_t)kSegWords, end_word - w0), (uint32_t)min(wanted, (uint64_t)kSegWords)));
         for (uint32_t w = lane; w < W + kStreamMargin; w += kWave)
             sl->marks[w] = 0;
         wave_sync();
