@@ -1,5 +1,5 @@
 #!/bin/bash
-# (one gpurun call) smoke, the whole GPU suite, then the round's profile collection
+# tools/gpu_suite_and_collect.sh  (one gpurun call): smoke, the whole GPU suite, then tools/collect_round.sh r06 -- what every refresh of profiles/r06 ran
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r06
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2
