@@ -897,8 +897,8 @@ def any_length_leg(np):
     from sela_amd.synth import synth_pcm
 
     out = {"what": "host pointers in and out, synchronous calls, best of 3 (the first call of a kind also loads its kernels and grows the thread's "
-                   "scratch); the any-length kernels (one wave per block), and for the 2048-sample 17-bit frames' decode the fast parse and "
-                   "synthesis with 32-bit samples (k_decode_subframes32); checked against the oracle"}
+                   "scratch); the any-length kernels -- the fast kernels' loops with a run-time length, one wave per block (sela_generic.hip) and the fast "
+                   "decoder's lane-parallel parse and synthesis with 32-bit samples, by segments beyond 2048 samples (k_decode_subframes32); checked against the oracle"}
     o = oracle()
 
     def best(fn):
