@@ -160,8 +160,9 @@ int sela_hip_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32
  *     sample_offsets[] as sela_hip_index_samples() reports them (for 2048 everywhere that is f * 2048, the layout above), and
  *     a frame whose channels disagree about the length is malformed (SELA_HIP_EFORMAT; the reference's WAV writer indexes
  *     past the shorter ones, src/file/wav_file.cpp:248-262).  The fast kernels are tried first, unasked (a stream of
- *     2048-sample frames pays nothing for the other kind), and they may write up to [n_frames][2048][channels] before they
- *     find the odd frame: pcm_out must hold max(n_frames * 2048, sample_offsets[n_frames]) * channels samples.
+ *     2048-sample frames pays nothing for the other kind) -- unless the stream's FIRST frame already says another length --
+ *     and they may write up to [n_frames][2048][channels] before they find an odd frame further on: pcm_out must hold
+ *     max(n_frames * 2048, sample_offsets[n_frames]) * channels samples.
  * The streaming jobs and the device-pointer calls below stay what they are: the fast path for what the reference's CLI writes
  * (2048 everywhere); a stream with another length gets SELA_HIP_EFORMAT from them, and the caller comes here. */
 size_t sela_hip_encode_bound_bytes_n(uint32_t n_frames, uint32_t channels, uint32_t samples_per_channel);

@@ -3,10 +3,11 @@
 //
 // Plain synchronous calls on the calling thread's current device and a stream of the calling thread's own (GenericContext below:
 // threads that code a frame at a time through the frame classes run side by side on the device instead of taking turns on
-// the default stream): copy in, kernels, copy out, in chunks of frames that keep the device scratch bounded, with as few
-// waits for the device as the data flow allows (an encode: two; a decode: two).  The scratch is one grow-only device allocation per thread (a frame at a time through
-// frame::FrameEncoder must not pay a hipMalloc / hipFree pair per call); sela_hip_thread_release() / sela_hip_shutdown() and
-// the thread's end give it back.
+// the default stream): copy in, kernels, copy out, in chunks of frames that keep the device scratch bounded, ONE wait for the
+// device per chunk (round 6: the encoder sizes its Rice words and frame bytes by an estimate instead of waiting for its plan,
+// and what the host reads first lands in page-locked memory of the context).  The scratch is one grow-only device allocation
+// per thread (a frame at a time through frame::FrameEncoder must not pay a hipMalloc / hipFree pair per call);
+// sela_hip_thread_release() / sela_hip_shutdown() and the thread's end give it back.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

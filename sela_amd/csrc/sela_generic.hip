@@ -6,14 +6,15 @@
 // src/frame/frame_decoder.cpp:24-25,48-49) and frame::FrameDecoder returns untruncated int32 (frame_decoder.cpp:64-71).
 // The fast kernels (sela_encode.hip, sela_decode.hip) are built around the one shape the reference's CLI produces --
 // 2048 samples of 16-bit PCM -- and everything else comes here: the same arithmetic, bit for bit, with the length a run-time
-// value (1 .. 65535: the u16 field) and nothing assumed about the samples.  One wave per block / subframe, register
-// windows and global-memory scratch instead of an LDS plan: the route for callers of the frame classes with odd shapes, not
-// the one bench.py times.
+// value (1 .. 65535: the u16 field) and nothing assumed about the samples.  One wave per block / subframe: the fast kernels'
+// loops with a run-time length (round 6), global-memory scratch between the kernels; the route for callers of the frame classes
+// with other shapes, not the one bench.py's headline times.
 //
 // Encode: k_generic_analyse (samples -> order, q[], residues, the two Rice plans) -> k_generic_plan (stereo decision, frame
 // sizes, offsets) -> k_generic_pack (the chosen candidates' Rice streams) -> k_generic_assemble (on-disk bytes).
-// Decode: k_generic_decode (one wave per subframe: headers, Rice parse, synthesis, 32-bit) -> k_generic_combine
-// (independent subframes first, then dependent ones in subframe order: src/frame/frame_decoder.cpp:17-69).
+// Decode: k_decode_subframes32 (sela_decode32.hip: the fast decoder's lane-parallel parse and tuned synthesis, any length, 32-bit)
+// or, for what that kernel will not judge, k_generic_decode (one wave per subframe: headers, a serial Rice walk, synthesis)
+// -> k_generic_combine (independent subframes first, then dependent ones in subframe order: src/frame/frame_decoder.cpp:17-69).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
