@@ -234,8 +234,8 @@ def test_the_timed_kernels_keep_their_registers_and_occupancy():
     for parts in (("k_encode_teamsILi0ELi16E",), ("k_encode_blocksILi0ELb0E",)):
         r = one(*parts)
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 168 and r["lds"] <= 160 * 1024 // 12, (parts, r)
-    r = one("k_encode_teamsILi0ELi8E")
-    assert r["vgpr_spill"] <= 12 and r["vgpr"] <= 168 and r["lds"] <= 160 * 1024 // 12, r
+    r = one("k_encode_teamsILi0ELi8E")  # (10 spilled: 16 scratch instructions, three of them in a loop -- once per mean chunk / per block's tail)
+    assert r["vgpr_spill"] <= 10 and r["vgpr"] <= 168 and r["lds"] <= 160 * 1024 // 12, r
     r = one("k_encode_blocksILi0ELb1E") # the host pipeline's one-launch form
     assert r["vgpr_spill"] <= 4 and r["vgpr"] <= 168, r
     r = one("k_decode_framesILb0E")
@@ -243,3 +243,25 @@ def test_the_timed_kernels_keep_their_registers_and_occupancy():
     for parts in (("k_plan_framesILi256E",), ("k_assemble_frames",)):
         r = one(*parts)
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (parts, r)
+
+
+def test_the_any_length_kernels_keep_the_occupancy_they_live_on():
+    """Round 6 put the any-length route on the fast kernels' loops, and what its kernels cost is decided by how many waves a SIMD
+    holds (k_generic_analyse: 763 / 667 / 655 us for 11,625 blocks at three / four / five): the shipped code object is asked for
+    the budgets -- analysis: 102 VGPRs and 8 KB of LDS for five waves per SIMD (its 16 spilled registers lie outside the loops);
+    the decoder of any length: 72 VGPRs, no spill, 5.8 KB for seven; the pack: 4.7 KB for eight."""
+    res = _kernel_resources()
+
+    def all_of(*parts):
+        names = [n for n in res if all(p in n for p in parts)]
+        assert names, parts
+        return [res[n] for n in names]
+
+    for r in all_of("k_generic_analyse"):
+        assert r["vgpr"] <= 102 and r["vgpr_spill"] <= 16 and r["lds"] <= 160 * 1024 // 20, r
+    for r in all_of("k_decode_subframes32"):
+        assert r["vgpr"] <= 72 and r["vgpr_spill"] == 0 and r["lds"] <= 160 * 1024 // 28, r
+    for r in all_of("k_generic_pack"):
+        assert r["vgpr_spill"] == 0 and r["lds"] <= 160 * 1024 // 32, r
+    for r in all_of("k_lpc_decode_any"):
+        assert r["vgpr"] <= 72 and r["vgpr_spill"] == 0, r
