@@ -1484,7 +1484,7 @@ struct TeamPlan {
     // share with the smallest chunk, one 16-step trip
     static constexpr int kChunk = P == 8 ? 16 : 64;
     static constexpr int kRing = P == 8 ? 160 : 256;
-    static constexpr int kStride = kRing + kTeamMirror;        // doubles; 184 and 280 are 24 mod 32: consecutive rings start 48 banks apart (team_ac_steps)
+    static constexpr int kStride = P == 8 ? kRing + kTeamMirror : kRing + 48; // doubles; 184 is 24 mod 32, 304 is 16 mod 32: consecutive rings start 48 / 32 banks apart (team_ac_steps)
     static constexpr int kPer = kChunk / P;                    // samples a lane stages per chunk
     static constexpr int kMeanPer = kTeamMeanChunk / P;
     static constexpr int kRingBytes = B * kStride * 8;
@@ -1493,7 +1493,7 @@ struct TeamPlan {
     static constexpr int kQBase = kSmallBase;                  // the quantised coefficients of the wave's blocks wait for their tails where the tail's plan keeps
     static constexpr int kQStride = 104;                       //   ac[] for k_encode_blocks (832 bytes it does not use here): 100 x int8, the order, an escape mark
     static constexpr int kLdsBytes = kRingBytes > kCwBase + kCoefWordsCap * 4 ? kRingBytes : kCwBase + kCoefWordsCap * 4;
-    static_assert(G + kTeamAhead <= kTeamWin && kChunk % kTeamWin == 0 && kRing % kChunk == 0 && kStride % 32 == 24, "team plan");
+    static_assert(G + kTeamAhead <= kTeamWin && kChunk % kTeamWin == 0 && kRing % kChunk == 0 && kStride % 32 == (P == 8 ? 24 : 16) && kStride >= kRing + kTeamMirror, "team plan");
     static_assert((G * P - 1) + kChunk + kChunk <= kRing && 2 * kTeamMeanChunk <= kRing, "the ring must hold the lags' reach, the chunk in use and the chunk being written");
     static_assert(kLdsBytes * 12 <= 160 * 1024, "twelve waves per CU");
     static_assert(B * kKStride * 8 <= kQBase && B * kKStride * 8 <= kRingBytes && B * kQStride <= 104 * 8, "k[] in the dead rings below the q store; the q store inside SmallArrays::ac");
@@ -1518,21 +1518,25 @@ __device__ __forceinline__ double team_first(double v)
     return __builtin_bit_cast(double, ((uint64_t)team_first<P>((uint32_t)(x >> 32)) << 32) | team_first<P>((uint32_t)x));
 }
 
-// the samples first .. first + kPer - 1 of signal `sig` of the frame at fp, as the integers the reference analyses
-// (src/frame/frame_encoder.cpp:22-24 for the difference signal)
-template <int kPer>
+// the samples first, first + kStep, .. (kPer of them) of signal `sig` of the frame at fp, as the integers the reference analyses
+// (src/frame/frame_encoder.cpp:22-24 for the difference signal).  kStep = P (teams of 16): the lanes of a team take neighbouring samples, so
+// their ds_write_b64 into the ring fall on 16 different bank pairs (with kPer consecutive samples per lane, a stride of 2 kPer
+// dwords, a 16-lane store group is 4-way conflicted: SQ_LDS_BANK_CONFLICT, 3072 of the 7168 extra LDS cycles per wave of P = 16).
+// Teams of 8 keep kStep = 1 and their vector loads (two teams to a store group, 2-way at worst; the strided form costs that
+// kernel three more spilled registers).
+template <int kPer, int kStep>
 __device__ __forceinline__ void team_load_raw(const int16_t* __restrict__ fp, uint32_t channels, uint32_t sig, int first, int32_t (&raw)[kPer])
 {
     if (channels == 2) {
-        const uint32_t* pw = reinterpret_cast<const uint32_t*>(fp) + first; // (dword-aligned: unaligned vector loads are fine)
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(fp) + first;
         uint32_t w[kPer];
-        if constexpr (kPer % 4 == 0) {
+        if constexpr (kStep == 1 && kPer % 4 == 0) { // (dword-aligned: unaligned vector loads are fine)
 #pragma unroll
             for (int u = 0; u < kPer / 4; u++) {
                 const uint4 v = reinterpret_cast<const uint4*>(pw)[u];
                 w[4 * u] = v.x, w[4 * u + 1] = v.y, w[4 * u + 2] = v.z, w[4 * u + 3] = v.w;
             }
-        } else if constexpr (kPer % 2 == 0) {
+        } else if constexpr (kStep == 1 && kPer % 2 == 0) {
 #pragma unroll
             for (int u = 0; u < kPer / 2; u++) {
                 const uint2 v = reinterpret_cast<const uint2*>(pw)[u];
@@ -1541,7 +1545,7 @@ __device__ __forceinline__ void team_load_raw(const int16_t* __restrict__ fp, ui
         } else {
 #pragma unroll
             for (int u = 0; u < kPer; u++)
-                w[u] = pw[u];
+                w[u] = pw[u * kStep];
         }
         const uint32_t first_shift = sig == 1 ? 16u : 0u;     // signal 0: l, 1: r, 2: l - r  as  a - (b & mask)
         const uint32_t second_mask = sig == 2 ? 0xFFFFFFFFu : 0u;
@@ -1553,22 +1557,22 @@ __device__ __forceinline__ void team_load_raw(const int16_t* __restrict__ fp, ui
     } else {
 #pragma unroll
         for (int i = 0; i < kPer; i++)
-            raw[i] = fp[(size_t)(first + i) * channels + sig];
+            raw[i] = fp[(size_t)(first + i * kStep) * channels + sig];
     }
 }
 
-// x = s / 32767 (kCentre: minus the block's mean) of a lane's kPer samples to ring positions pos ..; kMirror: the ring's
-// first entries also behind its end
-template <int kPer, bool kCentre, bool kMirror, int kRing>
+// x = s / 32767 (kCentre: minus the block's mean) of a lane's kPer samples to ring positions pos, pos + kStep, ..; kMirror: the
+// ring's first entries also behind its end
+template <int kPer, int kStep, bool kCentre, bool kMirror, int kRing>
 __device__ __forceinline__ void team_stage(double* ring_b, int pos, const int32_t (&raw)[kPer], double mean)
 {
 #pragma unroll
     for (int i = 0; i < kPer; i++) {
         const double x = scale_sample(raw[i]);
         const double c = kCentre ? x - mean : x;
-        ring_b[pos + i] = c;
-        if (kMirror && pos + i < kTeamMirror)
-            ring_b[kRing + pos + i] = c;
+        ring_b[pos + i * kStep] = c;
+        if (kMirror && pos + i * kStep < kTeamMirror)
+            ring_b[kRing + pos + i * kStep] = c;
     }
 }
 
@@ -1612,9 +1616,14 @@ __device__ __forceinline__ double team_chain(const double* x, double sum)
 // multiplier: addr_w / addr_m are the LDS addresses of c[j0 - G p] and c[j0]) is issued first and lands -- the LDS
 // returns a wave's reads in order, so "at most six newer ones outstanding" is "the pair of three steps ago is there" --
 // right before its first use.  The compiler sees no load of its own in this loop.
-// Banks: a ds_read_b64 is served in two halves of 32 lanes = 4 teams of 8 (2 of 16); within a team the lanes read G
-// entries apart (26 p dwords mod 64 for G = 13: all different, and 14 p for G = 7), and the rings of consecutive blocks
-// start 48 dwords apart mod 64: the 32 lanes of a half touch 32 different bank pairs.
+// Banks: a ds_read_b64 is served in two halves of 32 lanes = 4 teams of 8 (2 of 16), bank = dword address mod 64.  Within a
+// team the lanes read G entries apart: -26 p dwords mod 64 for G = 13 and -14 p for G = 7, all different bank pairs.  Between
+// the teams of a half, the rings' distance decides: 184 doubles = 48 dwords mod 64 puts the four teams of 8 on 32 different bank
+// pairs; for two teams of 16 the same 48 (a ring of 280) put 8 of the second team's 16 lanes on the first team's pairs -- every
+// window read took 4 LDS cycles instead of 2 (SQ_LDS_BANK_CONFLICT 21.0 M of SQ_LDS_IDX_ACTIVE 70.0 M per 3875-frame launch,
+// round 6) -- while 32 dwords (a ring of 304: {-14 p} and {32 - 14 p} are the two halves of the even residues) leave none:
+// 2.6 M of 51.7 M.  The launch itself went from 362 to 360 us: the LDS was not what it waited for (SQ_WAIT_INST_LDS 3 % of
+// the wave cycles), the cycles are simply no longer spent.
 template <int G, int R0>
 __device__ __forceinline__ void team_ac_steps(double (&W)[kTeamWin], double (&M)[4], double (&acc)[G], uint32_t addr_w, uint32_t addr_m)
 {
@@ -1654,6 +1663,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     constexpr int B = Plan::B, G = Plan::G, kPer = Plan::kPer, kMeanPer = Plan::kMeanPer, kChunk = Plan::kChunk, kRing = Plan::kRing;
     constexpr bool kTrace = kMode == 1;
     constexpr bool kFused = false;
+    constexpr int kStep = P == 16 ? P : 1; // team_load_raw
     __shared__ __attribute__((aligned(32))) unsigned char lds[Plan::kLdsBytes];
     unsigned char* const big = lds; // the tail's LDS plan (k_encode_blocks), over the dead rings
     uint32_t* const cw_buf = reinterpret_cast<uint32_t*>(lds + Plan::kCwBase);
@@ -1689,12 +1699,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     double mean;
     {
         constexpr int kChunks = kBlock / kTeamMeanChunk;
-        const int mine = p * kMeanPer; // this lane's samples of a chunk
+        const int mine = kStep == 1 ? p * kMeanPer : p; // this lane's samples of a chunk: mine + kStep i
         int32_t raw_a[kMeanPer], raw_b[kMeanPer];
-        team_load_raw<kMeanPer>(fp, channels, sig, mine, raw_a);
-        team_stage<kMeanPer, false, false, kRing>(ring_b, mine, raw_a, 0.0);
-        team_load_raw<kMeanPer>(fp, channels, sig, kTeamMeanChunk + mine, raw_a);
-        team_load_raw<kMeanPer>(fp, channels, sig, 2 * kTeamMeanChunk + mine, raw_b);
+        team_load_raw<kMeanPer, kStep>(fp, channels, sig, mine, raw_a);
+        team_stage<kMeanPer, kStep, false, false, kRing>(ring_b, mine, raw_a, 0.0);
+        team_load_raw<kMeanPer, kStep>(fp, channels, sig, kTeamMeanChunk + mine, raw_a);
+        team_load_raw<kMeanPer, kStep>(fp, channels, sig, 2 * kTeamMeanChunk + mine, raw_b);
         double sum = 0.0;
         const uint32_t quarter_priorities = team_priorities;
         set_wave_priority((int)(quarter_priorities & 0xFF)); // (see the note on priorities at the autocorrelation's loop)
@@ -1703,12 +1713,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             // chunk c + 1 -> the place chunk c - 1 was summed from, chunk c is summed from the other one
             const int here = (c & 1) * kTeamMeanChunk, there = kTeamMeanChunk - here;
             if (c + 1 < kChunks)
-                team_stage<kMeanPer, false, false, kRing>(ring_b, there + mine, raw_a, 0.0);
+                team_stage<kMeanPer, kStep, false, false, kRing>(ring_b, there + mine, raw_a, 0.0);
 #pragma unroll
             for (int i = 0; i < kMeanPer; i++)
                 raw_a[i] = raw_b[i];
             if (c + 3 < kChunks)
-                team_load_raw<kMeanPer>(fp, channels, sig, (c + 3) * kTeamMeanChunk + mine, raw_b);
+                team_load_raw<kMeanPer, kStep>(fp, channels, sig, (c + 3) * kTeamMeanChunk + mine, raw_b);
             wave_sync();
             sum = team_chain<kTeamMeanChunk>(ring_b + here, sum);
             wave_sync();
@@ -1727,12 +1737,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // "no sample" before the block: every position but chunk 0's stands for a negative index until its chunk arrives
         for (int i = kChunk + p; i < Plan::kStride; i += P)
             ring_b[i] = 0.0;
-        const int mine = p * kPer; // this lane's samples of a chunk
+        const int mine = kStep == 1 ? p * kPer : p; // this lane's samples of a chunk: mine + kStep i
         int32_t raw_a[kPer], raw_b[kPer];
-        team_load_raw<kPer>(fp, channels, sig, mine, raw_a);
-        team_stage<kPer, true, true, kRing>(ring_b, mine, raw_a, mean);
-        team_load_raw<kPer>(fp, channels, sig, kChunk + mine, raw_a);
-        team_load_raw<kPer>(fp, channels, sig, 2 * kChunk + mine, raw_b);
+        team_load_raw<kPer, kStep>(fp, channels, sig, mine, raw_a);
+        team_stage<kPer, kStep, true, true, kRing>(ring_b, mine, raw_a, mean);
+        team_load_raw<kPer, kStep>(fp, channels, sig, kChunk + mine, raw_a);
+        team_load_raw<kPer, kStep>(fp, channels, sig, 2 * kChunk + mine, raw_b);
         wave_sync();
         const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)ring_b;
         double W[kTeamWin], M[4];
@@ -1764,7 +1774,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             }
         };
         auto stage_next = [&](const int32_t (&raw)[kPer]) { // the next chunk over the oldest one, which no lag reaches any more
-            team_stage<kPer, true, true, kRing>(ring_b, (int)pos_stage + mine, raw, mean);
+            team_stage<kPer, kStep, true, true, kRing>(ring_b, (int)pos_stage + mine, raw, mean);
             pos_stage += kChunk;
             pos_stage = pos_stage >= (uint32_t)kRing ? 0u : pos_stage;
         };
@@ -1792,7 +1802,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for (int i = 0; i < kPer; i++)
                 raw_a[i] = raw_b[i];
             if (c + 3 < kChunks)
-                team_load_raw<kPer>(fp, channels, sig, (c + 3) * kChunk + mine, raw_b);
+                team_load_raw<kPer, kStep>(fp, channels, sig, (c + 3) * kChunk + mine, raw_b);
             trips();
         }
         // (three fetches past the end are in flight: land them before the rings are reused)

@@ -239,8 +239,8 @@ constexpr int kGenRing = 256, kGenMirror = 64;
 struct AnalyseLds {
     union {
         struct {
-            double ring[kGenRing + kGenMirror];
-            double chunk[64];
+            alignas(16) double ring[kGenRing + kGenMirror];
+            alignas(16) double chunk[64];
         } ac;
         int32_t st[kGenSBufWords];
     };
@@ -251,6 +251,11 @@ struct AnalyseLds {
 };
 
 typedef const volatile __attribute__((address_space(3))) double* LdsDoubles; // (volatile: the reads stay ds_read_b64, 2 LDS cycles each)
+// Two neighbours at once.  Lane L's window starts 2 L doubles below lane 0's, a stride of 16 bytes: as ds_read_b64 the two halves
+// of a half-wave fall on the same banks (SQ_LDS_BANK_CONFLICT 23 % of SQ_LDS_IDX_ACTIVE), as ds_read_b128 the 64 lanes read 1 KB
+// of consecutive LDS, four conflict-free passes for two steps' values.
+typedef double __attribute__((ext_vector_type(2))) DoublePair;
+typedef const volatile __attribute__((address_space(3))) DoublePair* LdsPairs;
 
 // x = s / 32767 (src/lpc/residue_generator.cpp:12-18): q0 = s * RN(1/32767), one residual fma, one correction fma equal the
 // correctly rounded quotient for every |s| <= 70000 (exhaustive check: tests/test_host_logic.py); anything larger divides.
@@ -372,9 +377,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SELA_GEN_WAV
             wave_sync();
             const LdsDoubles ch = (LdsDoubles)lds.ac.chunk;
             if (n - j0 >= 64u) {
+                const LdsPairs cp = (LdsPairs)lds.ac.chunk;
 #pragma unroll
-                for (int l = 0; l < 64; l++)
-                    sum += ch[l];
+                for (int l = 0; l < 32; l++) {
+                    const DoublePair two = cp[l];
+                    sum += two.x;
+                    sum += two.y;
+                }
             } else {
                 const int cnt = (int)(n - j0);
                 for (int l = 0; l < cnt; l++)
@@ -411,32 +420,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SELA_GEN_WAV
             wave_sync();
             const LdsDoubles rl = (LdsDoubles)lds.ac.ring + ((j0 - 2u * (uint32_t)lane) & (uint32_t)(kGenRing - 1)); // c[j0 - 2 lane]
             if (n - j0 >= 64u) {
-                // (the window values are fetched kAcAhead steps ahead of their use: a ds_read_b64 takes ~100 cycles to come back)
-                constexpr int kAcAhead = 8;
-                double ahead[kAcAhead];
+                // (the window values are fetched kAcAhead pairs ahead of their use: an LDS read takes ~100 cycles to come back)
+                constexpr int kAcAhead = 4;
+                const LdsPairs rp = (LdsPairs)rl; // j0 and 2 lane are even and the ring is 16-byte aligned
+                DoublePair ahead[kAcAhead];
 #pragma unroll
-                for (int t = 0; t < kAcAhead; t++)
-                    ahead[t] = rl[t];
+                for (int u = 0; u < kAcAhead; u++)
+                    ahead[u] = rp[u];
                 // the wave-uniform multiplier c[j] comes by a same-address LDS read as well (two v_readlane of the register that holds the
-                // chunk cost 4.1 k of the block's 23.3 k vector instructions: 0.775 -> 0.756 ms at 11,625 blocks; the phase is then bound
-                // by the LDS -- 2 reads per step and wave against 4 vector instructions)
-                const LdsDoubles cu = (LdsDoubles)lds.ac.ring + (j0 & (uint32_t)(kGenRing - 1));
-                double mult[kAcAhead];
+                // chunk cost 4.1 k of the block's 23.3 k vector instructions: 0.775 -> 0.756 ms at 11,625 blocks)
+                const LdsPairs cp = (LdsPairs)((LdsDoubles)lds.ac.ring + (j0 & (uint32_t)(kGenRing - 1)));
+                DoublePair mult[kAcAhead];
 #pragma unroll
-                for (int t = 0; t < kAcAhead; t++)
-                    mult[t] = cu[t];
+                for (int u = 0; u < kAcAhead; u++)
+                    mult[u] = cp[u];
 #pragma unroll
-                for (int t = 0; t < 64; t++) {
-                    const double cj = mult[t % kAcAhead];
-                    if (t + kAcAhead < 64)
-                        mult[t % kAcAhead] = cu[t + kAcAhead];
-                    const double A = ahead[t % kAcAhead];
-                    if (t + kAcAhead < 64)
-                        ahead[t % kAcAhead] = rl[t + kAcAhead];
-                    const double pe = cj * A, po = cj * B;
-                    acc_e += pe;
-                    acc_o += po;
-                    B = A;
+                for (int u = 0; u < 32; u++) {
+                    const DoublePair cj = mult[u % kAcAhead];
+                    if (u + kAcAhead < 32)
+                        mult[u % kAcAhead] = cp[u + kAcAhead];
+                    const DoublePair A = ahead[u % kAcAhead];
+                    if (u + kAcAhead < 32)
+                        ahead[u % kAcAhead] = rp[u + kAcAhead];
+                    {
+                        const double pe = cj.x * A.x, po = cj.x * B; // step j0 + 2 u
+                        acc_e += pe;
+                        acc_o += po;
+                    }
+                    {
+                        const double pe = cj.y * A.y, po = cj.y * A.x; // step j0 + 2 u + 1
+                        acc_e += pe;
+                        acc_o += po;
+                    }
+                    B = A.y;
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {

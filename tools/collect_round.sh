@@ -10,6 +10,7 @@ bash tools/collect_profiles.sh "$TAG" > "$OUT/collect.log" 2>&1
 # 2. SQ instruction counters of the bench kernels, and of the any-length route's kernels at the bench's launch size
 bash tools/valu_counters.sh > "$OUT/valu_counters.txt" 2>&1
 bash tools/generic_counters.sh 2>&1 | grep -v amdgpu.ids > "$OUT/generic_counters.txt"
+bash tools/lds_counters.sh 2>&1 | grep "sela::" > "$OUT/lds_counters.txt"
 # 3. what the lanes and the wave priorities do to the headline (the first line is the default: priorities by the library)
 for CFG in "" "--lanes 1" "--priorities 0" "--priorities 0 --lanes 1" "--priorities 00010203" "--priorities 00010203 --lanes 1" "--encode-teams 0 --lanes 1"; do
   python bench.py --no-cpu-baseline --no-host-legs --no-extra-legs $CFG 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print('bench.py %-36s %6.0f M samples/s  %.4f ms/step  one lane %6.0f  kernels %s' % ('$CFG', d['value'], d['ms_per_step'], d['lanes']['value_one_lane'], {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d['kernel_ms'].items()}))"

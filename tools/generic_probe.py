@@ -27,14 +27,15 @@ if "counters" in sys.argv[1:]:
     # for tools/generic_counters.sh; the decode twice: the product (one-piece parse) and every subframe by segments
     from sela_amd import capi
 
-    pcm = synth_pcm(2048 * 3875, 2, 23).reshape(3875, 2048, 2)
+    nf = int(os.environ.get("SELA_PROBE_FRAMES", "3875"))
+    pcm = synth_pcm(2048 * nf, 2, 23).reshape(nf, 2048, 2)
     planar = np.ascontiguousarray(pcm.transpose(0, 2, 1)).astype(np.int32)
     frames, offs = codec.encode_i32(planar)
     for mode in (1, 2):
         capi.lib().sela_hip_debug_standard_first(mode)
         dec = codec.decode_i32(frames, offs, 2)
     capi.lib().sela_hip_debug_standard_first(-1)
-    assert all(np.array_equal(dec[f][c], planar[f, c]) for f in (0, 17, 3874) for c in (0, 1))
+    assert all(np.array_equal(dec[f][c], planar[f, c]) for f in (0, 17, nf - 1) for c in (0, 1))
     sys.exit(0)
 
 for n, nf in ((1000, 256), (2048, 32), (4096, 64), (65535, 4)):
