@@ -173,11 +173,14 @@ def test_random_shapes_against_the_oracle(gpu):  # noqa: F811
     must be refused with SELA_HIP_ERANGE, exactly those."""
     from sela_amd import capi, codec
 
+    import os
+
     o = oracle()
-    rng = np.random.default_rng(77)
+    trials = int(os.environ.get("SELA_SHAPES_TRIALS", "300"))  # (a soak: SELA_SHAPES_TRIALS=6000 SELA_SHAPES_SEED=...)
+    rng = np.random.default_rng(int(os.environ.get("SELA_SHAPES_SEED", "77")))
     landmarks = [1, 2, 3, 31, 63, 64, 65, 100, 101, 102, 103, 127, 128, 129, 2047, 2048, 2049]
     refused = coded = 0
-    for trial in range(300):
+    for trial in range(trials):
         n = int(rng.choice(landmarks)) if trial % 3 == 0 else int(rng.integers(1, 6001))
         ch = int(rng.integers(1, 7))
         amp = int(2 ** rng.uniform(0, 20))
@@ -214,7 +217,7 @@ def test_random_shapes_against_the_oracle(gpu):  # noqa: F811
         for c in range(ch):
             assert np.array_equal(dec[c], ref_dec[c]), (trial, n, ch, c)
         coded += 1
-    assert refused >= 5 and coded >= 200, (refused, coded)
+    assert refused >= 5 and coded >= 2 * trials // 3, (refused, coded)
 
 
 @pytest.mark.parametrize("n", ENCODE_LENGTHS)
