@@ -21,6 +21,7 @@
 #define SELA_COALESCER_H_
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -41,9 +42,20 @@ namespace sela {
 // that finds nobody ahead of it runs at once, as it is; calls that arrive while it is on the device queue up, and when
 // it returns ONE of them takes everything that is waiting for the same device and channel count to the device as a
 // single job, hands every call its part of the result, and parks the streams it used for the next leader.  A lone caller
-// pays nothing; T busy threads end up in batches of about T calls.  A call's own failure (output buffer too small, a
-// malformed frame) stays its own.
+// pays nothing; T busy threads end up in batches of about T / kCoalesceLeaders calls.  A call's own failure (output buffer
+// too small, a malformed frame) stays its own.
+//
+// Up to kCoalesceLeaders batches are on the device at a time (round 6; one until then): a batch of a few dozen frames is a
+// trip of ~0.2 ms that leaves the device and the link nearly idle, and with one batch in flight a call waits out the batch
+// in flight, then rides the next.  Calls still pile up only while every leader's seat is taken, so the batches stay batches:
+// T threads settle into kCoalesceLeaders batches of T / kCoalesceLeaders calls that overlap on the device, each on the
+// streams and buffers its leader leases.  Measured with the reference's thread loop over the frame classes (host/sela_filebench
+// frames T 256, 2048-sample 16-bit stereo frames; encode / decode M samples/s), together with the per-call wake-up
+// (SmallCall::tell): T = 64: 376 / 214 -> 437-496 / 246-265; T = 256 (the GPU box's hardware_concurrency(), what the
+// reference starts): 111 / 111 -> 740-920 / 540-560.  Three to six seats: no better on encode, the same or a little better
+// on decode, within the runs' spread; two it is.
 constexpr uint32_t kCoalesceFrames = 32;
+constexpr int kCoalesceLeaders = 2;
 
 struct SmallCall {
     int device = 0;
@@ -62,7 +74,26 @@ struct SmallCall {
     uint32_t shape = 0;               // (calls only share a batch with calls of the same shape; 0 for the other kinds)
     int rc = SELA_HIP_OK;
     std::string error;
-    bool done = false, lead = false;
+    // How the calling thread hears that it leads, or that its results are there: through its OWN mutex and condition variable
+    // (round 6).  With one condition variable for everybody, the end of a batch of T calls woke T threads that each had to
+    // take the coalescer's mutex to look at their flag, one after the other, while the first ones back were already queueing
+    // for the same mutex with their next frames: at the reference's T = hardware_concurrency() = 256 on the GPU box a batch
+    // took 4.7 ms from end to end, 0.3 of them on the device.
+    std::mutex own;
+    std::condition_variable told;
+    std::atomic<bool> done{false}, lead{false};
+
+    void tell(std::atomic<bool>& what) // (the notify under the lock: the waiter may destroy this object as soon as it has seen the flag)
+    {
+        std::lock_guard<std::mutex> hold(own);
+        what.store(true, std::memory_order_release);
+        told.notify_one();
+    }
+    void wait_to_be_told() // (no looking before going to sleep: 200 / 2000 sched_yield rounds first cost 256 threads a third / nine tenths of their rate)
+    {
+        std::unique_lock<std::mutex> hold(own);
+        told.wait(hold, [&] { return done.load(std::memory_order_acquire) || lead.load(std::memory_order_acquire); });
+    }
 };
 
 template <class Backend>
@@ -74,10 +105,21 @@ private:
     const Kind kind;
     const bool encode; // (kind == kEncode)
     std::mutex mu;
-    std::condition_variable cv;
     std::deque<SmallCall*> queue;
-    bool busy = false;
+    const int max_leaders;
+    int leaders = 0;    // batches between "a call was told to lead" and "its callers have their results"
+    int designated = 0; // of those, the ones still in the queue (lingering for company): arrivals join them instead of leading
     size_t last_batch = 0;
+
+    // a free seat and calls nobody leads: the oldest of them leads (mu held; the caller notifies)
+    bool promote_locked()
+    {
+        if (leaders >= max_leaders || designated != 0 || queue.empty())
+            return false;
+        leaders++, designated++;
+        queue.front()->tell(queue.front()->lead);
+        return true;
+    }
     static constexpr size_t kMaxCalls = 4096;
 
     void run_one(SmallCall& c)
@@ -277,17 +319,18 @@ private:
     }
 
 public:
-    explicit CallCoalescer(bool enc) : kind(enc ? kEncode : kDecode), encode(enc) {}
-    explicit CallCoalescer(Kind k) : kind(k), encode(k == kEncode) {}
+    explicit CallCoalescer(bool enc, int seats = kCoalesceLeaders) : kind(enc ? kEncode : kDecode), encode(enc), max_leaders(seats < 1 ? 1 : seats) {}
+    explicit CallCoalescer(Kind k, int seats = kCoalesceLeaders) : kind(k), encode(k == kEncode), max_leaders(seats < 1 ? 1 : seats) {}
 
     int submit(SmallCall& call)
     {
         std::unique_lock<std::mutex> lock(mu);
         queue.push_back(&call);
-        if (!busy)
-            busy = call.lead = true;
-        cv.wait(lock, [&] { return call.done || call.lead; });
-        if (!call.done) {
+        promote_locked(); // (this call itself, if a seat is free and nobody is gathering; nobody else waits to be told)
+        lock.unlock();
+        call.wait_to_be_told();
+        if (!call.done.load(std::memory_order_acquire)) {
+            lock.lock();
             // this call leads.  If the batch before held several calls, their threads are on their way back with their
             // next frames right now: give them until the queue has stopped growing for a moment (bounded) -- a trip to
             // the device costs more than that
@@ -315,6 +358,8 @@ public:
                     ++it;
                 }
             }
+            designated--;
+            promote_locked(); // (calls of another shape that stay behind, if a seat is free)
             lock.unlock();
             try {
                 run_batch(batch);
@@ -325,15 +370,14 @@ public:
             }
             Backend::after_batch(); // the streams and buffers this thread used go to whoever leads next: any caller may
             lock.lock();
-            for (SmallCall* c : batch)
-                c->done = true;
             last_batch = batch.size();
-            if (queue.empty())
-                busy = false;
-            else
-                queue.front()->lead = true;
+            leaders--;
+            promote_locked();
             lock.unlock();
-            cv.notify_all();
+            for (SmallCall* c : batch) // (this call's own flag last: nothing of it is touched by anybody afterwards)
+                if (c != &call)
+                    c->tell(c->done);
+            call.done.store(true, std::memory_order_release);
         }
         return call.rc; // (call.error says why; the caller turns it into its thread's last error)
     }

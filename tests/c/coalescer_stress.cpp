@@ -222,14 +222,16 @@ int worker(Coalescer& enc, Coalescer& dec, Coalescer& dec32, Coalescer& enc32, i
 int main(int argc, char** argv)
 {
     const int threads = argc > 1 ? std::atoi(argv[1]) : 16, rounds = argc > 2 ? std::atoi(argv[2]) : 120;
-    Coalescer enc(true), dec(false), dec32(Coalescer::kDecode32), enc32(Coalescer::kEncode32);
     std::atomic<int> failures{ 0 };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++)
-        pool.emplace_back(worker, std::ref(enc), std::ref(dec), std::ref(dec32), std::ref(enc32), t, rounds, std::ref(failures));
-    for (std::thread& t : pool)
-        t.join();
-    std::printf("%d threads x %d rounds: %d device jobs for %d frames, %d batches led, %d failures\n", threads, rounds, g_jobs.load(), g_frames.load(),
-        g_leaders_done.load(), failures.load());
+    for (int seats : { sela::kCoalesceLeaders, 1, 3 }) { // the shipped number of batches in flight, the strictly serial form, one more
+        Coalescer enc(true, seats), dec(false, seats), dec32(Coalescer::kDecode32, seats), enc32(Coalescer::kEncode32, seats);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++)
+            pool.emplace_back(worker, std::ref(enc), std::ref(dec), std::ref(dec32), std::ref(enc32), t, rounds, std::ref(failures));
+        for (std::thread& t : pool)
+            t.join();
+        std::printf("%d seats: %d threads x %d rounds: %d device jobs for %d frames so far, %d batches led, %d failures\n", seats, threads, rounds, g_jobs.load(),
+            g_frames.load(), g_leaders_done.load(), failures.load());
+    }
     return failures.load() ? 1 : 0;
 }

@@ -35,7 +35,7 @@ for (name, grid), d in groups.items():
     print(f"{name:48s} workgroups {grid:7d}  launches {len(d):3d}  min {min(d):10.1f} us  mean {sum(d)/len(d):10.1f} us")
 PY
 # 5. the frame classes from many threads (the reference's own loop, src/sela/encoder.cpp:58-73): the CLI's shape and odd shapes
-{ for R in 1 2 3; do for shape in "2048 16" "1000 17" "4096 16"; do for T in 1 4 16 64; do echo -n "run $R shape $shape: "; host/sela_filebench frames $T 16 $shape 2>&1 | tail -1; done; done; done; } > "$OUT/frame_classes_fanout.txt" 2>&1
+{ for R in 1 2 3; do for shape in "2048 16" "1000 17" "4096 16"; do for T in 1 16 64 256; do echo -n "run $R shape $shape: "; host/sela_filebench frames $T 128 $shape 2>&1 | tail -1; done; done; done; } > "$OUT/frame_classes_fanout.txt" 2>&1
 # 6. BASELINE configs[2] (1000 frames) and configs[3] (the album's launches) under rocprofv3 with the PMC passes
 bash tools/config2_profile.sh > /dev/null 2>&1; cp "$ROOT/gpurun_out/config2_1000_frames.txt" "$OUT/config2_1000_frames.txt" 2>/dev/null
 bash tools/album_profile.sh > "$OUT/album_kernels.txt" 2>&1
