@@ -1632,7 +1632,7 @@ Coalescer* coalescer(Coalescer::Kind kind, int device)
     std::lock_guard<std::mutex> lock(mu);
     Coalescer*& c = table[(int)kind][d];
     if (!c)
-        c = new Coalescer(kind); // (never destroyed: calls may outlive the statics)
+        c = new Coalescer(kind, kind == Coalescer::kDecode || kind == Coalescer::kDecode32 ? sela::kCoalesceLeadersDecode : sela::kCoalesceLeaders); // (never destroyed: calls may outlive the statics)
     return c;
 }
 

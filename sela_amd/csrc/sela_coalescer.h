@@ -52,10 +52,14 @@ namespace sela {
 // streams and buffers its leader leases.  Measured with the reference's thread loop over the frame classes (host/sela_filebench
 // frames T 256, 2048-sample 16-bit stereo frames; encode / decode M samples/s), together with the per-call wake-up
 // (SmallCall::tell): T = 64: 376 / 214 -> 437-496 / 246-265; T = 256 (the GPU box's hardware_concurrency(), what the
-// reference starts): 111 / 111 -> 740-920 / 540-560.  Three to six seats: no better on encode, the same or a little better
-// on decode, within the runs' spread; two it is.
+// reference starts): 111 / 111 -> 650-930 / 550-565 with two seats for either direction.  By direction (four runs each,
+// T = 256):
+// encode 650-930 / 590-840 / 470-550 M samples/s with 2 / 3 / 4 seats (its jobs read the caller's samples from host memory
+// inside one launch, sela_capi.hip: more of them at once get in each other's way), decode 550-565 / 640-670 / 630-670 -- two
+// seats for the encoders, three for the decoders (1000-sample 17-bit frames, the any-length kinds: 320-430 / 300-440 encode,
+// 420-425 / 435-460 decode with 2 / 3).
 constexpr uint32_t kCoalesceFrames = 32;
-constexpr int kCoalesceLeaders = 2;
+constexpr int kCoalesceLeaders = 2, kCoalesceLeadersDecode = 3;
 
 struct SmallCall {
     int device = 0;
@@ -106,6 +110,7 @@ private:
     const bool encode; // (kind == kEncode)
     std::mutex mu;
     std::deque<SmallCall*> queue;
+    std::atomic<size_t> waiting{0}; // queue.size(), for a lingering leader to watch without the mutex
     const int max_leaders;
     int leaders = 0;    // batches between "a call was told to lead" and "its callers have their results"
     int designated = 0; // of those, the ones still in the queue (lingering for company): arrivals join them instead of leading
@@ -326,6 +331,7 @@ public:
     {
         std::unique_lock<std::mutex> lock(mu);
         queue.push_back(&call);
+        waiting.store(queue.size(), std::memory_order_relaxed);
         promote_locked(); // (this call itself, if a seat is free and nobody is gathering; nobody else waits to be told)
         lock.unlock();
         call.wait_to_be_told();
@@ -335,19 +341,23 @@ public:
             // next frames right now: give them until the queue has stopped growing for a moment (bounded) -- a trip to
             // the device costs more than that
             if (last_batch > 1) {
+                // (the queue's length is watched without the mutex, which the arriving calls need: polling under it, 256 threads kept
+                // the leader waiting 370 us for its "at most 150")
+                const size_t want = last_batch;
+                lock.unlock();
                 const auto t0 = std::chrono::steady_clock::now();
-                size_t seen = queue.size();
+                size_t seen = waiting.load(std::memory_order_relaxed);
                 auto last_growth = t0;
                 for (;;) {
-                    lock.unlock();
                     std::this_thread::yield();
-                    lock.lock();
                     const auto now = std::chrono::steady_clock::now();
-                    if (queue.size() != seen)
-                        seen = queue.size(), last_growth = now;
-                    if (seen >= last_batch || now - last_growth > std::chrono::microseconds(20) || now - t0 > std::chrono::microseconds(150))
+                    const size_t is = waiting.load(std::memory_order_relaxed);
+                    if (is != seen)
+                        seen = is, last_growth = now;
+                    if (seen >= want || now - last_growth > std::chrono::microseconds(20) || now - t0 > std::chrono::microseconds(150))
                         break;
                 }
+                lock.lock();
             }
             std::vector<SmallCall*> batch; // everything that waits for this device with this channel count (and shape), this call included
             for (auto it = queue.begin(); it != queue.end() && batch.size() < kMaxCalls;) {
@@ -358,6 +368,7 @@ public:
                     ++it;
                 }
             }
+            waiting.store(queue.size(), std::memory_order_relaxed);
             designated--;
             promote_locked(); // (calls of another shape that stay behind, if a seat is free)
             lock.unlock();
