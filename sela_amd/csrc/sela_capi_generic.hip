@@ -124,6 +124,38 @@ ContextPark& park()
     return *p;
 }
 constexpr size_t kParked = 64;
+
+// A context's stream.  The runtime serves all streams through a few hardware queues (four) and gives a new stream the queue with the
+// fewest streams on it at that moment; two contexts whose streams share a queue take turns on the device instead of running side
+// by side.  With three coalesced decode jobs in flight, runs of the reference's thread loop over the frame classes came in two kinds:
+// 280-300 M samples/s at 64 threads, or 180-190 (6 of 16 runs; with GPU_MAX_HW_QUEUES=8 or 16: 0 of 12).  So streams are made four
+// at a time, one after the other, and handed out in that order, and the park hands back the context parked last: the contexts in use
+// together are the ones created in a row, on different queues (2 of 16 runs of the slow kind since; the runtime's placement is
+// not ours to decide, only to make less likely to hurt).
+hipError_t fresh_stream(int dev, hipStream_t* out)
+{
+    static std::mutex mu;
+    static std::vector<hipStream_t> bank[64];
+    const int d = dev >= 0 && dev < 64 ? dev : 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (bank[d].empty()) {
+        for (int i = 0; i < 4; i++) {
+            hipStream_t s = nullptr;
+            const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                if (bank[d].empty())
+                    return e;
+                (void)hipGetLastError();
+                break;
+            }
+            bank[d].insert(bank[d].begin(), s); // (handed out from the back: in the order of creation)
+        }
+    }
+    *out = bank[d].back();
+    bank[d].pop_back();
+    return hipSuccess;
+}
+
 struct Lease {
     GenericContext* held = nullptr;
     ~Lease() { give_back(); }
@@ -154,8 +186,10 @@ struct Lease {
             return held;
         give_back();
         {
+            // the context parked LAST: the few that are in use at a time stay the same few, and those are the ones whose streams were
+            // created one after the other (see fresh_stream)
             std::lock_guard<std::mutex> lock(park().mu);
-            for (size_t i = 0; i < park().idle.size(); i++)
+            for (size_t i = park().idle.size(); i-- > 0;)
                 if (park().idle[i]->device == dev) {
                     held = park().idle[i];
                     park().idle.erase(park().idle.begin() + (ptrdiff_t)i);
@@ -164,7 +198,7 @@ struct Lease {
         }
         GenericContext* c = new GenericContext;
         c->device = dev;
-        err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        err = fresh_stream(dev, &c->stream);
         if (err != hipSuccess) {
             delete c;
             return nullptr;

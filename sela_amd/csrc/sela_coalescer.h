@@ -26,6 +26,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -78,6 +79,24 @@ struct SmallCall {
     uint32_t shape = 0;               // (calls only share a batch with calls of the same shape; 0 for the other kinds)
     int rc = SELA_HIP_OK;
     std::string error;
+    // What a decoded batch's leader leaves to the calling threads (round 6): the copies out of the batch's staging buffer into the
+    // call's own memory -- 16 KB per stereo frame for the 32-bit kinds, a third of the leader's time on the device's behalf when
+    // it made them all itself, one call after the other, before it gave up its seat.  The buffer lives until the last call of the
+    // batch has let go of it.
+    struct Piece {
+        void* to;
+        const void* from;
+        size_t bytes;
+    };
+    std::vector<Piece> pieces;
+    std::shared_ptr<void> pieces_from;
+    void collect()
+    {
+        for (const Piece& p : pieces)
+            std::memcpy(p.to, p.from, p.bytes);
+        pieces.clear();
+        pieces_from.reset();
+    }
     // How the calling thread hears that it leads, or that its results are there: through its OWN mutex and condition variable
     // (round 6).  With one condition variable for everybody, the end of a batch of T calls woke T threads that each had to
     // take the coalescer's mutex to look at their flag, one after the other, while the first ones back were already queueing
@@ -129,12 +148,19 @@ private:
 
     void run_one(SmallCall& c)
     {
+        c.pieces.clear(), c.pieces_from.reset(), c.rc = SELA_HIP_OK, c.error.clear(); // (a call retried on its own after its batch failed)
         c.rc = encode ? Backend::encode_now(c.pcm, c.n_frames, c.channels, c.frames_out, c.frames_cap, c.offsets_out)
             : kind == kEncode32 ? Backend::encode_i32_now(c.samples, c.n_frames, c.channels, c.shape, c.frames_out, c.frames_cap, c.offsets_out)
             : kind == kDecode32 ? Backend::decode_i32_now(c.frames, c.offsets_in, c.n_frames, c.channels, c.samples_out, c.stride, c.counts_out)
                                 : Backend::decode_now(c.frames, c.offsets_in, c.n_frames, c.channels, c.pcm_out);
         if (c.rc != SELA_HIP_OK)
             c.error = Backend::last_error();
+    }
+
+    static std::shared_ptr<void> shared_staging(size_t bytes) // a page-locked buffer that goes back to the pool when its last holder lets go
+    {
+        void* p = Backend::take(bytes);
+        return p ? std::shared_ptr<void>(p, [](void* q) { Backend::give(q); }) : std::shared_ptr<void>();
     }
 
     void run_batch(const std::vector<SmallCall*>& batch)
@@ -243,12 +269,12 @@ private:
             }
             const size_t rows = total * channels;
             in = Backend::take(bytes + 4);
-            out = Backend::take(rows * stride * sizeof(int32_t) + rows * sizeof(uint32_t));
-            if (!in.p || !out.p) {
+            const std::shared_ptr<void> shared_out = shared_staging(rows * stride * sizeof(int32_t) + rows * sizeof(uint32_t));
+            if (!in.p || !shared_out) {
                 rc = SELA_HIP_ENOMEM, oom = true;
             } else {
-                int32_t* const samples = static_cast<int32_t*>(out.p);
-                uint32_t* const counts = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(out.p) + rows * stride * sizeof(int32_t));
+                int32_t* const samples = static_cast<int32_t*>(shared_out.get());
+                uint32_t* const counts = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(shared_out.get()) + rows * stride * sizeof(int32_t));
                 size_t at = 0, pos = 0;
                 for (const SmallCall* c : batch) {
                     const uint64_t first = c->offsets_in[0], len = c->offsets_in[c->n_frames] - first;
@@ -267,11 +293,14 @@ private:
                             const uint32_t cnt = counts[at * channels + r];
                             if (cnt > c->stride) {
                                 c->rc = SELA_HIP_ECAPACITY, c->error = "stride is smaller than a channel of the frame";
+                                c->pieces.clear();
                                 break;
                             }
                             c->counts_out[r] = cnt;
-                            std::memcpy(c->samples_out + r * c->stride, samples + (at * channels + r) * stride, (size_t)cnt * sizeof(int32_t));
+                            c->pieces.push_back({ c->samples_out + r * c->stride, samples + (at * channels + r) * stride, (size_t)cnt * sizeof(int32_t) });
                         }
+                        if (!c->pieces.empty())
+                            c->pieces_from = shared_out;
                         at += c->n_frames;
                     }
                 }
@@ -289,8 +318,8 @@ private:
             for (const SmallCall* c : batch)
                 bytes += (size_t)(c->offsets_in[c->n_frames] - c->offsets_in[0] + 3) & ~(size_t)3;
             in = Backend::take(bytes + 4);
-            out = Backend::take(total * frame_pcm);
-            if (!in.p || !out.p) {
+            const std::shared_ptr<void> shared_out = shared_staging(total * frame_pcm);
+            if (!in.p || !shared_out) {
                 rc = SELA_HIP_ENOMEM, oom = true;
             } else {
                 size_t at = 0, pos = 0;
@@ -303,7 +332,7 @@ private:
                     pos += ((size_t)len + 3) & ~(size_t)3; // (frames are whole words: every call's first frame stays aligned)
                     offsets[at] = pos; // (the padding, if a malformed frame left any, belongs to the call's last frame)
                 }
-                rc = Backend::decode_now(static_cast<const uint8_t*>(in.p), offsets.data(), (uint32_t)total, channels, static_cast<int16_t*>(out.p));
+                rc = Backend::decode_now(static_cast<const uint8_t*>(in.p), offsets.data(), (uint32_t)total, channels, static_cast<int16_t*>(shared_out.get()));
             }
             if (rc == SELA_HIP_EFORMAT) {
                 // somebody's malformed frame must not fail its neighbours' calls: everyone on their own
@@ -316,7 +345,7 @@ private:
                     if (rc != SELA_HIP_OK)
                         c->rc = rc, c->error = msg;
                     else
-                        std::memcpy(c->pcm_out, static_cast<const uint8_t*>(out.p) + at * frame_pcm, c->n_frames * frame_pcm);
+                        c->pieces.push_back({ c->pcm_out, static_cast<const uint8_t*>(shared_out.get()) + at * frame_pcm, c->n_frames * frame_pcm }), c->pieces_from = shared_out;
                     at += c->n_frames;
                 }
             }
@@ -390,6 +419,7 @@ public:
                     c->tell(c->done);
             call.done.store(true, std::memory_order_release);
         }
+        call.collect(); // (this call's share of a decoded batch, by its own thread)
         return call.rc; // (call.error says why; the caller turns it into its thread's last error)
     }
 };
