@@ -480,9 +480,31 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
         int16_t* d_pcm = pcm_out ? g_arena.take<int16_t>((size_t)chunk_samples * channels) : nullptr;
         if (!g_arena.fits())
             return report_error(SELA_HIP_ENOMEM, "generic decode: internal scratch estimate too small");
+        // A small chunk's samples travel with the status, one wait for the device instead of two (a call of one frame -- the
+        // frame classes' kind -- is mostly waits); what they are worth is known when both have arrived.  Both land in
+        // page-locked memory of the calling thread's context (a copy into pageable memory is staged by the runtime, and waits)
+        // -- unless the caller's own buffer is page-locked (a coalesced batch's staging, sela_hip_host_alloc): then the samples
+        // go there at once (through the context's buffer and a memcpy, a batch of 50 stereo frames cost its leader 0.8 MB of
+        // copying more).  The frame offsets take the same way in: from page-locked memory the copy is queued, not staged.
+        const size_t out_bytes = pcm_out ? (size_t)chunk_samples * channels * 2 : subs * stride * sizeof(int32_t);
+        const bool eager = out_bytes <= kEagerBytes;
+        const size_t tail_bytes = ((4 + subs) * 4 + 15) & ~(size_t)15, offsets_bytes = (((size_t)cf + 1) * 8 + 15) & ~(size_t)15;
+        uint8_t* const user_out = pcm_out ? reinterpret_cast<uint8_t*>(pcm_out + s0 * channels) : reinterpret_cast<uint8_t*>(samples_out + (size_t)f0 * channels * stride);
+        bool user_locked = false;
+        if (eager) {
+            hipPointerAttribute_t attr;
+            user_locked = hipPointerGetAttributes(&attr, user_out) == hipSuccess && attr.type == hipMemoryTypeHost;
+            (void)hipGetLastError(); // (ordinary memory is not an error)
+        }
+        uint8_t* const pin = ctx->pinned.reserve(tail_bytes + offsets_bytes + (eager && !user_locked ? out_bytes : 0));
+        const uint64_t* offsets_src = frame_offsets + f0;
+        if (pin) {
+            std::memcpy(pin + tail_bytes, frame_offsets + f0, ((size_t)cf + 1) * 8);
+            offsets_src = reinterpret_cast<const uint64_t*>(pin + tail_bytes);
+        }
         e = hipMemcpyAsync(d_frames, frames + base_bytes, in_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(d_offsets, frame_offsets + f0, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice, st);
+            e = hipMemcpyAsync(d_offsets, offsets_src, ((size_t)cf + 1) * 8, hipMemcpyHostToDevice, st);
         std::vector<uint64_t> local;
         if (e == hipSuccess && pcm_out) { // positions relative to the chunk's first sample
             local.resize((size_t)cf + 1);
@@ -492,21 +514,13 @@ int generic_decode(const uint8_t* frames, const uint64_t* frame_offsets, uint32_
         }
         const int mode = g_standard_first_mode.load(std::memory_order_relaxed); // -1: the product; 0: the serial kernel alone; 1: as -1; 2: offered, every subframe by segments
         const bool offer = mode != 0, standard_path = mode != 2;
-        // A small chunk's samples travel with the status, one wait for the device instead of two (a call of one frame -- the
-        // frame classes' kind -- is mostly waits); what they are worth is known when both have arrived.  Both land in
-        // page-locked memory of the calling thread's context (a copy into pageable memory is staged by the runtime, and waits).
-        const size_t out_bytes = pcm_out ? (size_t)chunk_samples * channels * 2 : subs * stride * sizeof(int32_t);
-        const bool eager = out_bytes <= kEagerBytes;
-        const size_t tail_bytes = ((4 + subs) * 4 + 15) & ~(size_t)15;
-        uint8_t* const pin = ctx->pinned.reserve(tail_bytes + (eager ? out_bytes : 0));
         std::vector<uint32_t> tail_pageable;
         uint32_t* tail = reinterpret_cast<uint32_t*>(pin);
         if (!pin) {
             tail_pageable.resize(4 + subs);
             tail = tail_pageable.data();
         }
-        uint8_t* const eager_out = pin && eager ? pin + tail_bytes : nullptr;
-        uint8_t* const user_out = pcm_out ? reinterpret_cast<uint8_t*>(pcm_out + s0 * channels) : reinterpret_cast<uint8_t*>(samples_out + (size_t)f0 * channels * stride);
+        uint8_t* const eager_out = pin && eager && !user_locked ? pin + tail_bytes + offsets_bytes : nullptr;
         const void* const device_out = pcm_out ? static_cast<const void*>(d_pcm) : static_cast<const void*>(d_all);
         // samples_out and the device's channel-major array have one layout ([frame][channel][stride]): ONE copy (a copy per
         // channel cost 13 us each: 7 ms for 256 stereo frames).  What lies behind a channel's count is not defined.
