@@ -122,14 +122,38 @@ __device__ inline uint64_t rice_pack_round(uint32_t u, bool valid, uint32_t k, u
     return total;
 }
 
-__device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k, uint32_t* out, int lane, uint32_t* win)
+// (a stretch's values as they come from memory: lane L holds values L, L + 64, ..; beyond n: 0)
+__device__ __forceinline__ void pack_fetch(const int32_t* v, uint32_t n, uint32_t i0, int lane, int32_t (&raw)[kPackPerLane])
+{
+#pragma unroll
+    for (int t = 0; t < (int)kPackPerLane; t++) {
+        const uint32_t i = i0 + (uint32_t)lane + 64u * (uint32_t)t;
+        raw[t] = i < n ? v[i] : 0;
+    }
+}
+
+// kFetched: the first stretch's values are in `raw` already.  A wave of k_generic_pack is a chain of trips to memory -- two thousand
+// vector instructions in 27 us, SQ_WAIT_ANY 70 % of its cycles -- and every trip taken early is one less: the kernel asks for the
+// block's record, its coefficients and its first 1024 residues together, and a stretch is asked for before the one in front of it is
+// packed: 80 -> 60 us for 7750 subframes of 2048 (more waves per SIMD do not help it: its 160 registers are live values; forced to
+// 128 it spills 9 and takes 57 us, to 96 it spills 735 and takes 444).
+template <bool kFetched>
+__device__ inline void rice_pack_stream(const int32_t* v, uint32_t n, uint32_t k, uint32_t* out, int lane, uint32_t* win, int32_t (&raw)[kPackPerLane])
 {
     uint64_t base = 0;
+    if (!kFetched)
+        pack_fetch(v, n, 0, lane, raw);
     for (uint32_t i0 = 0; i0 < n; i0 += kPackStretch) {
         const uint32_t in_stretch = min(kPackStretch, n - i0);
         // stage: value i of the stretch at word i + i / 16
-        for (uint32_t i = lane; i < in_stretch; i += 64)
-            win[i + (i >> 4)] = zigzag32(v[i0 + i]);
+#pragma unroll
+        for (int t = 0; t < (int)kPackPerLane; t++) {
+            const uint32_t i = (uint32_t)lane + 64u * (uint32_t)t;
+            if (i < in_stretch)
+                win[i + (i >> 4)] = zigzag32(raw[t]);
+        }
+        if (i0 + kPackStretch < n)
+            pack_fetch(v, n, i0 + kPackStretch, lane, raw);
         wave_sync();
         uint32_t u[kPackPerLane];
         const uint32_t mine = in_stretch > kPackPerLane * (uint32_t)lane ? min(kPackPerLane, in_stretch - kPackPerLane * (uint32_t)lane) : 0u;
@@ -801,6 +825,11 @@ __global__ __launch_bounds__(64) void k_generic_pack(const GenericMeta* __restri
     const int lane = threadIdx.x;
     const uint32_t f = sub / channels;
     const size_t b = (size_t)f * n_sig + chosen[sub];
+    // everything that only needs to know WHICH block is asked for in one go: the block's record, its coefficients (all 100 places of
+    // its row: how many count is in the record), the first stretch of its residues
+    int32_t first[kPackPerLane], coefs[kPackPerLane];
+    pack_fetch(res_ws + b * n, n, 0, lane, first);
+    pack_fetch(q_ws + b * kMaxOrder, kMaxOrder, 0, lane, coefs);
     const GenericMeta m = meta[b];
     if (m.flags & (SELA_HIP_FLAG_WORDS_CAP | SELA_HIP_FLAG_RICE_RANGE))
         return;
@@ -808,8 +837,8 @@ __global__ __launch_bounds__(64) void k_generic_pack(const GenericMeta* __restri
         return;
     __shared__ uint32_t win[kPackWindow];
     uint32_t* const out = words + word_base[sub];
-    rice_pack_stream(q_ws + b * kMaxOrder, m.order, m.coef_k, out, lane, win);
-    rice_pack_stream(res_ws + b * n, n, m.res_k, out + m.coef_words, lane, win);
+    rice_pack_stream<true>(q_ws + b * kMaxOrder, m.order, m.coef_k, out, lane, win, coefs);
+    rice_pack_stream<true>(res_ws + b * n, n, m.res_k, out + m.coef_words, lane, win, first);
 }
 
 // ---- assemble: the on-disk bytes (src/file/sela_file.cpp:115-135), one workgroup per subframe -------------------------------
